@@ -1,0 +1,402 @@
+/* ORACLE -- TEST INFRASTRUCTURE, NOT THE PRODUCT.
+ *
+ * A plain-C, serial, f64 restatement of the algorithm of the C2-Ray evolve hot
+ * path (reference: garrelt/C2-Ray3Dm).  It exists only so that tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg can check (and time a
+ * CPU baseline beside) the HIP path.  Nothing in the product may include, link
+ * or call it.
+ *
+ * Parity status: PINNED.  Every function here is checked in tests/test_oracle.py
+ * against fixtures under tests/golden/ that were produced by the UNMODIFIED
+ * reference compiled with amdflang (oracle/ref_build.sh, oracle/ref_driver.F90,
+ * tests/golden/make_golden.py).
+ *
+ * Each function cites the reference file:line it restates.  Operation order and
+ * operand widths follow the reference statement by statement, because the
+ * fixtures are compared at the 1e-13 level: build with -ffp-contract=off.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/c2ray_constants.h"
+
+typedef struct {
+    int    n[3];              /* mesh(1:3)                       sizes.f90:33           */
+    double dr[3];             /* cell size (cm)                  grid.F90:97-104        */
+    double vol;               /* cell volume                     grid.F90               */
+    double coldensh_LLS;      /* LLS column per cell             LLS.F90:178-182        */
+    double clumping;          /* clumping (f32 in the reference) clumping_module.F90:17 */
+    double temper;            /* isothermal temperature          c2ray_parameters.f90:112 */
+    double S_star;            /* table normalisation             radiation_sed_parameters */
+    const double *thick;      /* stellar_photo_thick_table(0:NumTau,1) */
+    const double *thin;       /* stellar_photo_thin_table(0:NumTau,1)  */
+} oracle_cfg;
+
+static inline int pmod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
+static inline int isign1(int d) { return d < 0 ? -1 : 1; }            /* sign(1,d): +1 for d==0 */
+static inline size_t cidx(const int n[3], int i, int j, int k)        /* 1-based, column-major */
+{ return (size_t)(i - 1) + (size_t)n[0] * ((size_t)(j - 1) + (size_t)n[1] * (size_t)(k - 1)); }
+static inline double dmax(double a, double b) { return a > b ? a : b; }
+static inline double dmin(double a, double b) { return a < b ? a : b; }
+
+/* column_density.f90:276-293  weightf */
+static inline double weightf(double cd) { return 1.0 / dmax(C2R_WEIGHT_FLOOR, cd * C2R_SIGMA_HI); }
+
+/* column_density.f90:29-271  cinterp.  pos/srcpos are unwrapped 1-based mesh positions. */
+void oracle_cinterp(const double *cd, const int n[3], const int pos[3], const int src[3],
+                    double *cdensi, double *path)
+{
+    const int i = pos[0], j = pos[1], k = pos[2], i0 = src[0], j0 = src[1], k0 = src[2];
+    const int idel = i - i0, jdel = j - j0, kdel = k - k0;
+    const int idela = abs(idel), jdela = abs(jdel), kdela = abs(kdel);
+    const int sgni = isign1(idel), sgnj = isign1(jdel), sgnk = isign1(kdel);
+    const int im = i - sgni, jm = j - sgnj, km = k - sgnk;
+    const double di = (double)(float)idel, dj = (double)(float)jdel, dk = (double)(float)kdel;
+    double c1, c2, c3, c4, s1, s2, s3, s4, w1, w2, w3, w4, alam, cdi;
+
+    if (kdela >= jdela && kdela >= idela) {                                   /* :108 */
+        alam = (double)((float)(km - k0) + (float)sgnk * 0.5f) / dk;          /* :112 */
+        const double xc = alam * di + (double)(float)i0;
+        const double yc = alam * dj + (double)(float)j0;
+        const double dx = 2.0 * fabs(xc - (double)((float)im + 0.5f * (float)sgni));
+        const double dy = 2.0 * fabs(yc - (double)((float)jm + 0.5f * (float)sgnj));
+        s1 = (1. - dx) * (1. - dy); s2 = (1. - dy) * dx; s3 = (1. - dx) * dy; s4 = dx * dy;
+        const int ip = pmod(i - 1, n[0]) + 1, imp = pmod(im - 1, n[0]) + 1;
+        const int jp = pmod(j - 1, n[1]) + 1, jmp = pmod(jm - 1, n[1]) + 1;
+        const int kmp = pmod(km - 1, n[2]) + 1;
+        c1 = cd[cidx(n, imp, jmp, kmp)]; c2 = cd[cidx(n, ip, jmp, kmp)];
+        c3 = cd[cidx(n, imp, jp, kmp)];  c4 = cd[cidx(n, ip, jp, kmp)];
+        w1 = s1 * weightf(c1); w2 = s2 * weightf(c2); w3 = s3 * weightf(c3); w4 = s4 * weightf(c4);
+        cdi = (c1 * w1 + c2 * w2 + c3 * w3 + c4 * w4) / (w1 + w2 + w3 + w4);   /* :140 */
+        if (kdela == 1 && (idela == 1 || jdela == 1))                          /* :152-158 */
+            cdi = (idela == 1 && jdela == 1) ? C2R_SQRT3 * cdi : C2R_SQRT2 * cdi;
+        *path = sqrt((di * di + dj * dj) / (dk * dk) + 1.0);                   /* :168 */
+    } else if (jdela >= idela && jdela >= kdela) {                             /* :173 */
+        alam = (double)((float)(jm - j0) + (float)sgnj * 0.5f) / dj;
+        const double zc = alam * dk + (double)(float)k0;
+        const double xc = alam * di + (double)(float)i0;
+        const double dz = 2.0 * fabs(zc - (double)((float)km + 0.5f * (float)sgnk));
+        const double dx = 2.0 * fabs(xc - (double)((float)im + 0.5f * (float)sgni));
+        s1 = (1. - dx) * (1. - dz); s2 = (1. - dz) * dx; s3 = (1. - dx) * dz; s4 = dx * dz;
+        const int ip = pmod(i - 1, n[0]) + 1, imp = pmod(im - 1, n[0]) + 1;
+        const int jmp = pmod(jm - 1, n[1]) + 1;
+        const int kp = pmod(k - 1, n[2]) + 1, kmp = pmod(km - 1, n[2]) + 1;
+        c1 = cd[cidx(n, imp, jmp, kmp)]; c2 = cd[cidx(n, ip, jmp, kmp)];
+        c3 = cd[cidx(n, imp, jmp, kp)];  c4 = cd[cidx(n, ip, jmp, kp)];
+        w1 = s1 * weightf(c1); w2 = s2 * weightf(c2); w3 = s3 * weightf(c3); w4 = s4 * weightf(c4);
+        cdi = (c1 * w1 + c2 * w2 + c3 * w3 + c4 * w4) / (w1 + w2 + w3 + w4);
+        if (jdela == 1 && (idela == 1 || kdela == 1))
+            cdi = (idela == 1 && kdela == 1) ? C2R_SQRT3 * cdi : C2R_SQRT2 * cdi;
+        *path = sqrt((di * di + dk * dk) / (dj * dj) + 1.0);                   /* :221 */
+    } else {                                                                   /* :226 */
+        alam = (double)((float)(im - i0) + (float)sgni * 0.5f) / di;
+        const double zc = alam * dk + (double)(float)k0;
+        const double yc = alam * dj + (double)(float)j0;
+        const double dz = 2.0 * fabs(zc - (double)((float)km + 0.5f * (float)sgnk));
+        const double dy = 2.0 * fabs(yc - (double)((float)jm + 0.5f * (float)sgnj));
+        s1 = (1. - dz) * (1. - dy); s2 = (1. - dz) * dy; s3 = (1. - dy) * dz; s4 = dy * dz;
+        const int imp = pmod(im - 1, n[0]) + 1;
+        const int jp = pmod(j - 1, n[1]) + 1, jmp = pmod(jm - 1, n[1]) + 1;
+        const int kp = pmod(k - 1, n[2]) + 1, kmp = pmod(km - 1, n[2]) + 1;
+        c1 = cd[cidx(n, imp, jmp, kmp)]; c2 = cd[cidx(n, imp, jp, kmp)];
+        c3 = cd[cidx(n, imp, jmp, kp)];  c4 = cd[cidx(n, imp, jp, kp)];
+        w1 = s1 * weightf(c1); w2 = s2 * weightf(c2); w3 = s3 * weightf(c3); w4 = s4 * weightf(c4);
+        cdi = (c1 * w1 + c2 * w2 + c3 * w3 + c4 * w4) / (w1 + w2 + w3 + w4);
+        if (idela == 1 && (jdela == 1 || kdela == 1))
+            cdi = (jdela == 1 && kdela == 1) ? C2R_SQRT3 * cdi : C2R_SQRT2 * cdi;
+        *path = sqrt(1.0 + (dj * dj + dk * dk) / (di * di));                   /* :265 */
+    }
+    *cdensi = cdi;
+}
+
+/* radiation_photoionrates.F90:184-228  set_tau_table_positions + read_table */
+static inline double table_lookup(const double *tab, double tau)
+{
+    const double lt = log10(dmax(1.0e-20, tau));
+    const double od = dmin((double)C2R_NUMTAU, dmax(0.0, 1.0 + (lt - C2R_MINLOGTAU) / C2R_DLOGTAU));
+    const int ip = (int)od;
+    const double res = od - (double)ip;
+    const int ip1 = ip + 1 < C2R_NUMTAU ? ip + 1 : C2R_NUMTAU;
+    return tab[ip] + (tab[ip1] - tab[ip]) * res;
+}
+
+/* radiation_photoionrates.F90:71-179 photoion_rates + :233-317 photo_lookuptable (NumFreqBnd=1,
+ * stellar table only).  out = { photo_cell_HI (= cell/vol), photo_in, photo_out } */
+void oracle_photoion_rates(const double *thick, const double *thin, double cd_in, double cd_out,
+                           double vol, double normflux, double out[3])
+{
+    out[0] = out[1] = out[2] = 0.0;
+    if (!(normflux > 0.0)) return;                                             /* :126 */
+    const double tau_in = cd_in * C2R_SIGMA_HI, tau_out = cd_out * C2R_SIGMA_HI;
+    const double p_in = normflux * table_lookup(thick, tau_in);                /* :281 */
+    double p_out, p_cell;
+    if (fabs(tau_out - tau_in) > C2R_TAU_PHOTO_LIMIT) {                        /* :289 */
+        p_out = normflux * table_lookup(thick, tau_out);
+        p_cell = p_in - p_out;
+    } else {                                                                   /* :299 */
+        p_cell = normflux * (tau_out - tau_in) * table_lookup(thin, tau_in);
+        p_out = p_in - p_cell;
+    }
+    out[0] = p_cell / vol; out[1] = p_in; out[2] = p_out;
+}
+
+/* doric.f90:33-134.  xfh/xfh_av are (0:1) = {neutral, ionized}. */
+void oracle_doric(double dt, double temp0, double rhe, double clumping,
+                  double xfh[2], double xfh_av[2], double phih)
+{
+    const double brech0 = clumping * C2R_BH00 * pow(temp0 / 1e4, C2R_ALBPOW);  /* :73 */
+    const double sqrtt0 = sqrt(temp0);
+    const double acolh0 = C2R_COLH0 * sqrtt0 * exp(-C2R_TEMPH0 / temp0);       /* :78 */
+    const double xfh1old = xfh[1], xfh0old = xfh[0];
+    const double aih0 = phih + rhe * acolh0;
+    const double delth = aih0 + rhe * brech0;
+    const double eqxfh1 = aih0 / delth;
+    const double eqxfh0 = rhe * brech0 / delth;
+    const double deltht = delth * dt;
+    const double ee = exp(-deltht);
+    xfh[1] = (xfh1old - eqxfh1) * ee + eqxfh1;
+    xfh[0] = (xfh0old - eqxfh0) * ee + eqxfh0;
+    if (xfh[0] < C2R_EPSILON) { xfh[0] = C2R_EPSILON; xfh[1] = 1.0 - C2R_EPSILON; }   /* :107 */
+    const double avg = deltht < C2R_DELTHT_SMALL ? 1.0 : (1.0 - ee) / deltht;  /* :119 */
+    xfh_av[1] = eqxfh1 + (xfh1old - eqxfh1) * avg;
+    xfh_av[0] = 1.0 - xfh_av[1];
+    if (xfh_av[0] < C2R_EPSILON) xfh_av[0] = C2R_EPSILON;                      /* :130 */
+}
+
+/* ---- per-source sweep ---------------------------------------------------------------- */
+typedef struct {
+    const oracle_cfg *c;
+    const float  *ndens;
+    const double *xh_av;
+    double *phih;
+    double *cdout;             /* coldensh_out scratch, N^3 */
+    const int *src;            /* unwrapped source position */
+    double normflux;
+    int last_l[3], last_r[3];
+    double loss;               /* photon_loss_src_thread(1) */
+    long   visited;
+} sweep_t;
+
+/* evolve_point.F90:83-299  evolve0D (niter /= -1, isothermal, type_of_LLS=1) */
+static void evolve0d(sweep_t *s, const int rt[3])
+{
+    const oracle_cfg *c = s->c;
+    const int *n = c->n;
+    int pos[3];
+    for (int d = 0; d < 3; ++d) pos[d] = pmod(rt[d] - 1, n[d]) + 1;            /* :122 */
+    const size_t id = cidx(n, pos[0], pos[1], pos[2]);
+    if (s->cdout[id] != 0.0) return;                                           /* :128 */
+    s->visited++;
+    const double xav1 = dmax(s->xh_av[id], C2R_EPSILON);                       /* :137 */
+    const double xav0 = dmax(1.0 - xav1, C2R_EPSILON);                         /* :140 */
+    const double nd = (double)s->ndens[id];
+    double cd_in, path, vol_ph;
+    if (rt[0] == s->src[0] && rt[1] == s->src[1] && rt[2] == s->src[2]) {      /* :151 */
+        cd_in = 0.0;
+        path = 0.5 * c->dr[0];
+        vol_ph = c->dr[0] * c->dr[1] * c->dr[2];
+    } else {
+        oracle_cinterp(s->cdout, n, rt, s->src, &cd_in, &path);
+        path = path * c->dr[0];
+        const double xs = c->dr[0] * (double)(float)(rt[0] - s->src[0]);
+        const double ys = c->dr[1] * (double)(float)(rt[1] - s->src[1]);
+        const double zs = c->dr[2] * (double)(float)(rt[2] - s->src[2]);
+        const double dist2 = xs * xs + ys * ys + zs * zs;
+        vol_ph = 4.0 * C2R_PI * dist2 * path;                                  /* :177 */
+        cd_in = cd_in + c->coldensh_LLS * path / c->dr[0];                     /* :194 */
+    }
+    const int stop = cd_in > C2R_MAX_COLDENSH;                                 /* :201 */
+    const double cd_out = cd_in + xav0 * nd * path;                            /* :247, doric.f90:153 */
+    s->cdout[id] = cd_out;
+    double phi[3] = {0.0, 0.0, 0.0};
+    if (!stop) {
+        oracle_photoion_rates(c->thick, c->thin, cd_in, cd_out, vol_ph, s->normflux, phi);
+        phi[0] = phi[0] / (xav0 * nd);                                         /* :262 */
+    }
+    s->phih[id] = s->phih[id] + phi[0];                                        /* :283 */
+    if (rt[0] == s->last_l[0] || rt[1] == s->last_l[1] || rt[2] == s->last_l[2] ||
+        rt[0] == s->last_r[0] || rt[1] == s->last_r[1] || rt[2] == s->last_r[2])
+        s->loss = s->loss + phi[2] * c->vol / vol_ph;                          /* :290-293 */
+}
+
+/* evolve_source.F90:227-267  evolve2D */
+static void evolve2d(sweep_t *s, int k)
+{
+    int rt[3]; rt[2] = k;
+    for (int j = s->src[1]; j <= s->last_r[1]; ++j) {
+        rt[1] = j;
+        for (int i = s->src[0]; i <= s->last_r[0]; ++i) { rt[0] = i; evolve0d(s, rt); }
+        for (int i = s->src[0] - 1; i >= s->last_l[0]; --i) { rt[0] = i; evolve0d(s, rt); }
+    }
+    for (int j = s->src[1] - 1; j >= s->last_l[1]; --j) {
+        rt[1] = j;
+        for (int i = s->src[0]; i <= s->last_r[0]; ++i) { rt[0] = i; evolve0d(s, rt); }
+        for (int i = s->src[0] - 1; i >= s->last_l[0]; --i) { rt[0] = i; evolve0d(s, rt); }
+    }
+}
+
+/* evolve_source.F90:58-221  do_source, serial branch (:188-208).
+ * Adds this source's rates into phih; returns nbox; *loss_out = final photon_loss_src.
+ * cdout (N^3 scratch) holds coldensh_out of this source on return. */
+int oracle_do_source(const oracle_cfg *c, const float *ndens, const double *xh_av, double *phih,
+                     double *cdout, const int src[3], double normflux,
+                     double *loss_out, long *visited_out)
+{
+    const size_t ncell = (size_t)c->n[0] * c->n[1] * c->n[2];
+    memset(cdout, 0, ncell * sizeof(double));                                  /* :91 */
+    sweep_t s = { c, ndens, xh_av, phih, cdout, src, normflux, {0,0,0}, {0,0,0}, 0.0, 0 };
+    int lastpos_l[3], lastpos_r[3];
+    for (int d = 0; d < 3; ++d) {                                              /* :100-102 */
+        const int hr = c->n[d] / 2 - 1 + c->n[d] % 2, hl = c->n[d] / 2;
+        lastpos_r[d] = src[d] + (C2R_MAX_SUBBOX < hr ? C2R_MAX_SUBBOX : hr);
+        lastpos_l[d] = src[d] - (C2R_MAX_SUBBOX < hl ? C2R_MAX_SUBBOX : hl);
+        s.last_r[d] = src[d]; s.last_l[d] = src[d];
+    }
+    int nbox = 0;
+    const double total_flux = normflux * c->S_star;                            /* :119 */
+    double loss_src = total_flux;
+    while (loss_src > C2R_LOSS_FRACTION * total_flux &&
+           s.last_r[2] < lastpos_r[2] && s.last_l[2] > lastpos_l[2]) {         /* :128-131 */
+        nbox++;
+        s.loss = 0.0;
+        for (int d = 0; d < 3; ++d) {
+            const int r = src[d] + C2R_SUBBOXSIZE * nbox, l = src[d] - C2R_SUBBOXSIZE * nbox;
+            s.last_r[d] = r < lastpos_r[d] ? r : lastpos_r[d];
+            s.last_l[d] = l > lastpos_l[d] ? l : lastpos_l[d];
+        }
+        for (int k = src[2]; k <= s.last_r[2]; ++k) evolve2d(&s, k);           /* :192-195 */
+        for (int k = src[2] - 1; k >= s.last_l[2]; --k) evolve2d(&s, k);       /* :198-201 */
+        loss_src = s.loss;                                                     /* :208 */
+    }
+    *loss_out = loss_src;
+    if (visited_out) *visited_out = s.visited;
+    return nbox;
+}
+
+/* evolve.F90:444-495 pass_all_sources + master_slave.F90:74-96 do_grid_static for one rank:
+ * sources rank+1, rank+1+npr, ... (1-based).  phih must be zeroed by the caller
+ * (set_rates_to_zero, evolve.F90:430).  srcpos is 3 x S (column-major, 1-based positions). */
+void oracle_pass_sources(const oracle_cfg *c, const float *ndens, const double *xh_av, double *phih,
+                         const int *srcpos, const double *normflux, int nsrc, int rank, int npr,
+                         double *photon_loss, long *sum_nbox, long *visited)
+{
+    const size_t ncell = (size_t)c->n[0] * c->n[1] * c->n[2];
+    double *cdout = (double *)malloc(ncell * sizeof(double));
+    double loss_total = 0.0; long nb = 0, vis = 0;
+    for (int ns = rank; ns < nsrc; ns += npr) {
+        double loss; long v;
+        nb += oracle_do_source(c, ndens, xh_av, phih, cdout, srcpos + 3 * ns, normflux[ns], &loss, &v);
+        loss_total = loss_total + loss;                                        /* evolve_source.F90:216 */
+        vis += v;
+    }
+    free(cdout);
+    *photon_loss = loss_total; *sum_nbox = nb; if (visited) *visited = vis;
+}
+
+/* evolve_point.F90:305-406 evolve0D_global + :410-555 do_chemistry(local=.false.) over the
+ * whole mesh in the order of global_pass (evolve.F90:548-555).  Returns conv_flag. */
+long oracle_global_pass(const oracle_cfg *c, double dt, const float *ndens, const double *xh,
+                        double *xh_av, double *xh_intermed, const double *phih)
+{
+    const size_t ncell = (size_t)c->n[0] * c->n[1] * c->n[2];
+    long conv_flag = 0;
+    for (size_t id = 0; id < ncell; ++id) {
+        double h_old[2], h[2], h_av[2];
+        h_old[1] = dmax(C2R_EPSILON, xh[id]);
+        h_av[1] = dmax(C2R_EPSILON, xh_av[id]);
+        h_old[0] = 1.0 - h_old[1];
+        h_av[0] = 1.0 - h_av[1];
+        const double nd = (double)ndens[id];
+        const double gamma = phih[id];
+        int nit = 0;
+        for (;;) {                                                             /* :442 */
+            nit++;
+            const double yh0_av_old = h_av[0];
+            h[0] = h_old[0]; h[1] = h_old[1];                                  /* :463 */
+            const double de = nd * (h_av[1] + C2R_ABU_C);                      /* tped.f90:81 */
+            oracle_doric(dt, c->temper, de, c->clumping, h, h_av, gamma);
+            if (fabs((h_av[0] - yh0_av_old) / h_av[0]) < C2R_MIN_FRACTIONAL_CHANGE ||
+                h_av[0] < C2R_MIN_FRACTION_OF_ATOMS) break;                    /* :531-538 */
+            if (nit > C2R_MAX_CHEM_ITER) break;                                /* :541 */
+        }
+        const double yh1_av_old = dmax(C2R_EPSILON, xh_av[id]);                /* :378 */
+        const double yh0_av_old = 1.0 - yh1_av_old;
+        if (fabs(h_av[0] - yh0_av_old) > C2R_MIN_FRACTIONAL_CHANGE &&
+            fabs((h_av[0] - yh0_av_old) / h_av[0]) > C2R_MIN_FRACTIONAL_CHANGE &&
+            h_av[0] > C2R_MIN_FRACTION_OF_ATOMS) conv_flag++;                  /* :384-391 */
+        xh_intermed[id] = h[1];
+        xh_av[id] = h_av[1];
+    }
+    return conv_flag;
+}
+
+/* SUM() of a real(8) array as the reference build evaluates it (evolve.F90:183): amdflang -O2
+ * inlines the intrinsic as one sequential left-to-right accumulation (checked against the
+ * "Intermediate result for mean H ionization fraction" lines of the reference log, which a
+ * Kahan or pairwise sum does not reproduce in the last digits). */
+double oracle_sum(const double *a, size_t n)
+{
+    double s = 0.0;
+    for (size_t i = 0; i < n; ++i) s = s + a[i];
+    return s;
+}
+
+typedef struct {
+    int    niter;                   /* outer iterations done                       */
+    int    converged;               /* 1 = xh updated (evolve.F90:218), 0 = gave up (:228) */
+    long   conv_flag;               /* last global_pass count                      */
+    double photon_loss_all;
+    long   sum_nbox_all;
+    long   visited;                 /* cell-source pairs executed, all iterations  */
+    /* per outer iteration k (0-based, k < niter): values logged by the reference */
+    long   it_conv_flag[128];       /* "Number of non-converged points"            */
+    double it_rel1[128], it_rel0[128]; /* Test-2 values seen at the TOP of iteration k+1 */
+    long   it_sum_nbox[128];
+    double it_sum_xh1[128];         /* sum(xh_intermed) after global pass k        */
+} oracle_report;
+
+/* evolve.F90:83-281  evolve3D (restart=0), single rank. */
+void oracle_evolve3d(const oracle_cfg *c, double dt, const float *ndens, double *xh,
+                     double *xh_av, double *xh_intermed, double *phih,
+                     const int *srcpos, const double *normflux, int nsrc, oracle_report *rep)
+{
+    const size_t ncell = (size_t)c->n[0] * c->n[1] * c->n[2];
+    memcpy(xh_av, xh, ncell * sizeof(double));                                 /* :145-146 */
+    memcpy(xh_intermed, xh, ncell * sizeof(double));
+    int niter = 0;
+    long conv_flag = (long)ncell;
+    double prev1 = (double)(((2.0f * (float)c->n[0]) * (float)c->n[1]) * (float)c->n[2]);   /* :150-151 */
+    double prev0 = prev1;
+    double rel1 = 1.0, rel0 = 1.0;
+    long c1 = (long)(C2R_CONVERGENCE_FRACTION * c->n[0] * c->n[1] * c->n[2]);  /* :162 */
+    long c2 = (nsrc - 1) / 3;
+    const long conv_criterion = c1 < c2 ? c1 : c2;
+    memset(rep, 0, sizeof(*rep));
+    for (;;) {
+        const double sum1 = oracle_sum(xh_intermed, ncell);                    /* :183 */
+        const double sum0 = (double)(float)ncell - sum1;                       /* :184 */
+        rel1 = sum1 > 0.0 ? fabs(sum1 - prev1) / sum1 : 1.0;
+        rel0 = sum0 > 0.0 ? fabs(sum0 - prev0) / sum0 : 1.0;
+        if (niter > 0 && niter <= 128) { rep->it_rel1[niter - 1] = rel1; rep->it_rel0[niter - 1] = rel0;
+                                         rep->it_sum_xh1[niter - 1] = sum1; }
+        if (conv_flag < conv_criterion ||
+            (rel1 < C2R_CONVERGENCE_FRACTION && rel0 < C2R_CONVERGENCE_FRACTION)) {   /* :212 */
+            memcpy(xh, xh_intermed, ncell * sizeof(double));
+            rep->converged = 1;
+            break;
+        } else if (niter > C2R_MAX_OUTER_ITER) {                               /* :228 */
+            rep->converged = 0;
+            break;
+        }
+        prev1 = sum1; prev0 = sum0;
+        niter++;
+        memset(phih, 0, ncell * sizeof(double));                               /* :243 */
+        double loss; long nb, vis;
+        oracle_pass_sources(c, ndens, xh_av, phih, srcpos, normflux, nsrc, 0, 1, &loss, &nb, &vis);
+        rep->photon_loss_all = loss; rep->sum_nbox_all = nb; rep->visited += vis;
+        conv_flag = oracle_global_pass(c, dt, ndens, xh, xh_av, xh_intermed, phih);   /* :269 */
+        if (niter <= 128) { rep->it_conv_flag[niter - 1] = conv_flag; rep->it_sum_nbox[niter - 1] = nb; }
+    }
+    rep->niter = niter; rep->conv_flag = conv_flag;
+}

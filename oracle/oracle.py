@@ -1,0 +1,126 @@
+"""ORACLE bindings -- TEST INFRASTRUCTURE, NOT THE PRODUCT.
+
+ctypes wrapper over oracle/liboracle.so (the plain-C restatement in
+oracle/c2ray_oracle.c).  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    """Compile liboracle.so (gcc, seconds)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+class Cfg(C.Structure):
+    _fields_ = [("n", C.c_int * 3), ("dr", C.c_double * 3), ("vol", C.c_double),
+                ("coldensh_LLS", C.c_double), ("clumping", C.c_double), ("temper", C.c_double),
+                ("S_star", C.c_double), ("thick", C.c_void_p), ("thin", C.c_void_p)]
+
+
+class Report(C.Structure):
+    _fields_ = [("niter", C.c_int), ("converged", C.c_int), ("conv_flag", C.c_long),
+                ("photon_loss_all", C.c_double), ("sum_nbox_all", C.c_long), ("visited", C.c_long),
+                ("it_conv_flag", C.c_long * 128), ("it_rel1", C.c_double * 128),
+                ("it_rel0", C.c_double * 128), ("it_sum_nbox", C.c_long * 128),
+                ("it_sum_xh1", C.c_double * 128)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.oracle_sum.restype = C.c_double
+        _LIB.oracle_global_pass.restype = C.c_long
+        _LIB.oracle_do_source.restype = C.c_int
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """Holds the per-step scalars and the tables; arrays are passed per call (Fortran order)."""
+
+    def __init__(self, n, dr, vol, coldensh_LLS, thick, thin, clumping=1.0, temper=1e4,
+                 S_star=1.00000000000000004e+48):
+        n = (n, n, n) if np.isscalar(n) else tuple(n)
+        dr = (dr, dr, dr) if np.isscalar(dr) else tuple(dr)
+        self.thick = np.ascontiguousarray(thick, dtype=np.float64)
+        self.thin = np.ascontiguousarray(thin, dtype=np.float64)
+        assert self.thick.size == 2001 and self.thin.size == 2001
+        self.cfg = Cfg((C.c_int * 3)(*n), (C.c_double * 3)(*dr), vol, coldensh_LLS, clumping,
+                       temper, S_star, _p(self.thick), _p(self.thin))
+        self.n = n
+        self.ncell = n[0] * n[1] * n[2]
+
+    # -- point functions ------------------------------------------------------------------
+    def cinterp(self, cdout, pos, src):
+        cd, path = C.c_double(), C.c_double()
+        lib().oracle_cinterp(_p(cdout), (C.c_int * 3)(*self.n), (C.c_int * 3)(*pos),
+                             (C.c_int * 3)(*src), C.byref(cd), C.byref(path))
+        return cd.value, path.value
+
+    def photoion_rates(self, cd_in, cd_out, vol, normflux):
+        out = (C.c_double * 3)()
+        lib().oracle_photoion_rates(_p(self.thick), _p(self.thin), C.c_double(cd_in),
+                                    C.c_double(cd_out), C.c_double(vol), C.c_double(normflux), out)
+        return tuple(out)
+
+    @staticmethod
+    def doric(dt, temp0, rhe, clumping, x1_old, xav1, phih):
+        xf = (C.c_double * 2)(1.0 - x1_old, x1_old)
+        xa = (C.c_double * 2)(1.0 - xav1, xav1)
+        lib().oracle_doric(C.c_double(dt), C.c_double(temp0), C.c_double(rhe), C.c_double(clumping),
+                           xf, xa, C.c_double(phih))
+        return xf[0], xf[1], xa[0], xa[1]
+
+    # -- sweep ----------------------------------------------------------------------------
+    def do_source(self, ndens, xh_av, phih, src, normflux):
+        """One source; adds into phih (in place).  Returns (nbox, loss, visited, coldensh_out)."""
+        cdout = np.zeros(self.ncell, dtype=np.float64)
+        loss, vis = C.c_double(), C.c_long()
+        nbox = lib().oracle_do_source(C.byref(self.cfg), _p(ndens), _p(xh_av), _p(phih), _p(cdout),
+                                      (C.c_int * 3)(*[int(v) for v in src]), C.c_double(normflux),
+                                      C.byref(loss), C.byref(vis))
+        return nbox, loss.value, vis.value, cdout
+
+    def pass_sources(self, ndens, xh_av, phih, srcpos, normflux, rank=0, npr=1):
+        """All sources of one rank (static round-robin, master_slave.F90:85); adds into phih."""
+        srcpos = np.ascontiguousarray(srcpos, dtype=np.int32)       # (S,3)
+        normflux = np.ascontiguousarray(normflux, dtype=np.float64)
+        loss, nb, vis = C.c_double(), C.c_long(), C.c_long()
+        lib().oracle_pass_sources(C.byref(self.cfg), _p(ndens), _p(xh_av), _p(phih), _p(srcpos),
+                                  _p(normflux), C.c_int(len(normflux)), C.c_int(rank), C.c_int(npr),
+                                  C.byref(loss), C.byref(nb), C.byref(vis))
+        return loss.value, nb.value, vis.value
+
+    def global_pass(self, dt, ndens, xh, xh_av, xh_intermed, phih):
+        return lib().oracle_global_pass(C.byref(self.cfg), C.c_double(dt), _p(ndens), _p(xh),
+                                        _p(xh_av), _p(xh_intermed), _p(phih))
+
+    def evolve3d(self, dt, ndens, xh, srcpos, normflux):
+        """Full time step.  xh is updated in place.  Returns (report, xh_av, xh_intermed, phih)."""
+        srcpos = np.ascontiguousarray(srcpos, dtype=np.int32)
+        normflux = np.ascontiguousarray(normflux, dtype=np.float64)
+        xh_av = np.empty(self.ncell); xh_int = np.empty(self.ncell); phih = np.zeros(self.ncell)
+        rep = Report()
+        lib().oracle_evolve3d(C.byref(self.cfg), C.c_double(dt), _p(ndens), _p(xh), _p(xh_av),
+                              _p(xh_int), _p(phih), _p(srcpos), _p(normflux),
+                              C.c_int(len(normflux)), C.byref(rep))
+        return rep, xh_av, xh_int, phih
+
+    @staticmethod
+    def sum(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return lib().oracle_sum(_p(a), C.c_size_t(a.size))

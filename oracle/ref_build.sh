@@ -1,0 +1,61 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE ONLY.  Builds the unmodified reference (garrelt/C2-Ray3Dm)
+# hot path from the sources WHERE THEY LIE under /root/reference, with amdflang,
+# into oracle/_ref/N<mesh>/ (git-ignored).  Nothing from /root/reference is
+# copied into the repository.  The reference fixes the mesh size at compile time
+# (sizes.f90:33; the reference's own CheckList line 2 tells the user to edit it),
+# so the one `mesh=` line is rewritten by sed into the BUILD directory -- that
+# generated sizes.f90 is a build output, never committed.
+#
+# Outputs per mesh N:
+#   oracle/_ref/N<N>/c2ray_test        the reference's own program (C2Ray.F90 + nbody_test)
+#   oracle/_ref/N<N>/ref_driver        OUR driver (oracle/ref_driver.F90) linked against the
+#                                      reference objects; dumps f64 fixtures / times do_source
+#   oracle/_ref/N<N>/ref_driver_omp    same with -fopenmp -DMY_OPENMP (TIMING ONLY: the
+#                                      reference's OpenMP path has a data race)
+# usage: oracle/ref_build.sh <mesh> [more meshes...]
+set -euo pipefail
+REF=${C2RAY_REFERENCE:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+FC=${FC:-/opt/rocm/bin/amdflang}
+[ -d "$REF" ] || { echo "reference not present at $REF: nothing to build" >&2; exit 0; }
+[ -x "$FC" ] || { echo "no Fortran compiler ($FC)" >&2; exit 1; }
+
+# compile order = prerequisite order of the reference's makefile_core:40-45 (test target)
+SRCS="precision.f90 mathconstants.f90 cgsconstants.f90 cgsastroconstants.f90 c2ray_parameters.f90
+ cgsphotoconstants.f90 cosmoparms.f90 abundances.f90 atomic.f90 sed_parameters.f90 mrgrnk.f90
+ ctrper.f90 romberg.f90 report_memory.f90 file_admin.f90 read_sm3d.f90 @sizes.f90 no_mpi.F90
+ clocks.f90 nbody_test.F90 grid.F90 tped.f90 density_module.F90 clumping_module.F90 LLS.F90
+ temperature_module.F90 ionfractions_module.F90 material.F90 cosmology.F90 cooling.f90
+ radiation_sizes.f90 radiation_sed_parameters.F90 radiation_tables.F90 sourceprops.F90
+ radiation_photoionrates.F90 thermal.f90 time_module.F90 doric.f90 photonstatistics.F90
+ evolve_data.F90 column_density.f90 evolve_point.F90 evolve_source.F90 master_slave.F90
+ evolve.F90 output.F90"
+
+build_variant () {   # $1 = mesh, $2 = subdir, $3 = extra flags
+  local N=$1 B=$HERE/_ref/N$1/$2 FLAGS="-DGFORT -O2 $3"
+  mkdir -p "$B"
+  sed "s|^\( *integer,dimension(Ndim),parameter,public :: mesh=\)(/ 300, 300, 300 /)|\1(/ $N, $N, $N /)|" \
+      "$REF/sizes.f90" > "$B/sizes.f90"
+  grep -q "mesh=(/ $N, $N, $N /)" "$B/sizes.f90"
+  local objs=""
+  for s in $SRCS; do
+    local src o
+    if [ "${s#@}" != "$s" ]; then src="$B/${s#@}"; else src="$REF/$s"; fi
+    o="$B/$(basename "${s#@}" | sed 's/\.[fF]90$/.o/')"
+    if [ ! -f "$o" ] || [ "$src" -nt "$o" ]; then
+      ( cd "$B" && $FC $FLAGS -c "$src" -o "$o" 2>>"$B/build.log" )
+    fi
+    objs="$objs $o"
+  done
+  ( cd "$B" && $FC $FLAGS -c "$REF/C2Ray.F90" -o C2Ray.o 2>>build.log \
+      && $FC $FLAGS -o c2ray_test $objs C2Ray.o 2>>build.log )
+  ( cd "$B" && $FC $FLAGS -c "$HERE/ref_driver.F90" -o ref_driver.o 2>>build.log \
+      && $FC $FLAGS -o ref_driver $objs ref_driver.o 2>>build.log )
+}
+
+for N in "$@"; do
+  build_variant "$N" serial ""
+  build_variant "$N" omp "-fopenmp -DMY_OPENMP"
+  echo "built oracle/_ref/N$N/{serial,omp}/{c2ray_test,ref_driver}"
+done

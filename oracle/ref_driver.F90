@@ -1,0 +1,321 @@
+!> TEST INFRASTRUCTURE ONLY -- not part of the product.
+!!
+!! Our own driver program, linked against the UNMODIFIED reference objects built
+!! by oracle/ref_build.sh.  It repeats the reference's start-up order
+!! (C2Ray.F90:108-198) and per-step preparation (C2Ray.F90:264-376), then calls
+!! the reference's own hot-path routines (evolve3D evolve.F90:83, do_source
+!! evolve_source.F90:58, cinterp column_density.f90:29, photoion_rates
+!! radiation_photoionrates.F90:71, doric doric.f90:33) and dumps their inputs
+!! and outputs as raw little-endian f64/f32/i32 streams.  All hot-path state of
+!! the reference is public module data, which is what makes this possible
+!! without touching a reference source file.
+!!
+!! Run in a scratch directory holding: results/ , test_sources.dat
+!! (sourceprops.F90:248), the answers file (inputs/input_example_test format)
+!! and driver.nml:
+!!   &ctl mode='evolve'|'sweep'|'point'|'tables', nsteps=, x_init=, dens_file=,
+!!        x_file=, dump_first=, dump_last=, ns_dump=, nrep=, out_dir= /
+!! usage: ref_driver <answers-file>
+program ref_driver
+
+  use precision, only: dp
+  use clocks, only: setup_clocks
+  use file_admin, only: stdinput, logf, flag_for_file_input
+  use c2ray_parameters, only: cosmological, type_of_clumping, use_LLS, type_of_LLS
+  use my_mpi
+  use output_module, only: setup_output
+  use sizes, only: mesh
+  use grid, only: grid_ini, dr, vol
+  use radiation_tables, only: rad_ini, stellar_photo_thick_table, stellar_photo_thin_table
+  use radiation_sed_parameters, only: S_star
+  use radiation_photoionrates, only: photoion_rates, photrates
+  use nbody, only: nbody_ini, NumZred, zred_array
+  use cosmology, only: cosmology_init, redshift_evol, cosmo_evol, zred
+  use material, only: material_ini
+  use density_module, only: density_init, ndens
+  use ionfractions_module, only: xh
+  use clumping_module, only: set_clumping, load_clumping_model, clumping
+  use lls_module, only: set_LLS, coldensh_LLS
+  use times, only: time_ini, set_timesteps
+  use sourceprops, only: source_properties_ini, source_properties, NumSrc, srcpos, &
+       NormFlux_stellar
+  use photonstatistics, only: photon_loss
+  use evolve_data, only: evolve_ini, phih_grid, xh_av, xh_intermed, coldensh_out, &
+       photon_loss_all
+  use evolve_source, only: do_source, sum_nbox, sum_nbox_all
+  use evolve, only: evolve3D
+  use column_density, only: cinterp
+  use doric_module, only: doric
+
+  implicit none
+
+  character(len=16)  :: mode = 'evolve'
+  integer            :: nsteps = 1, dump_first = 1, dump_last = 1, ns_dump = 1, nrep = 1
+  real(kind=dp)      :: x_init = -1.0_dp
+  character(len=512) :: dens_file = 'none', x_file = 'none', out_dir = './dump/'
+  namelist /ctl/ mode, nsteps, x_init, dens_file, x_file, dump_first, dump_last, &
+       ns_dump, nrep, out_dir
+
+  character(len=512) :: answers
+  integer :: restart = 0, nz0 = 1, ierror = 0, nz, u, istep, ns, irep
+  real(kind=dp) :: end_time, sim_time, output_time, dt, actual_dt
+  real(kind=dp) :: t_sweep
+  integer(kind=8) :: c0, c1, crate
+  real, allocatable :: factor(:,:,:)
+  character(len=8) :: tag
+
+  ! ---- start-up, in the order of C2Ray.F90:108-198 -------------------------
+  call setup_clocks
+  call mpi_setup()
+  call get_command_argument(1, answers)
+  open(unit=stdinput, file=trim(answers))
+  call flag_for_file_input(.true.)
+  open(newunit=u, file='driver.nml', status='old')
+  read(u, nml=ctl)
+  close(u)
+
+  call setup_output()
+  call grid_ini()
+  call rad_ini()
+  call material_ini(restart, nz0, ierror)
+  call nbody_ini(ierror)
+  call source_properties_ini()
+  call time_ini()
+  call evolve_ini()
+  sim_time = 0.0_dp
+  call cosmology_init(zred_array(nz0), sim_time)
+  call load_clumping_model(dr(1))
+
+  if (trim(mode) == 'tables') then
+     call dump_r8_1d('thick_table', stellar_photo_thick_table(:,1), size(stellar_photo_thick_table,1))
+     call dump_r8_1d('thin_table', stellar_photo_thin_table(:,1), size(stellar_photo_thin_table,1))
+     stop
+  endif
+
+  if (trim(mode) == 'point') then
+     call point_tests()
+     stop
+  endif
+
+  ! ---- slices / time steps, in the order of C2Ray.F90:264-427 ---------------
+  istep = 0
+  slices: do nz = nz0, NumZred-1
+     zred = zred_array(nz)
+     call set_timesteps(zred, zred_array(nz+1), end_time, dt, output_time)
+     call source_properties(zred, nz, end_time-sim_time, restart)
+     call density_init(zred, nz)
+     if (trim(dens_file) /= 'none') then
+        ! our perturbation of the test problem's uniform density: ndens *= factor
+        allocate(factor(mesh(1),mesh(2),mesh(3)))
+        open(newunit=u, file=trim(dens_file), access='stream', form='unformatted', status='old')
+        read(u) factor
+        close(u)
+        ndens = ndens*factor
+        deallocate(factor)
+     endif
+     steps: do
+        istep = istep + 1
+        actual_dt = min(end_time-sim_time, dt)
+        if (cosmological) then
+           call redshift_evol(sim_time+0.5*actual_dt)
+           call cosmo_evol()
+        endif
+        if (type_of_clumping /= 5) call set_clumping(zred)
+        if (use_LLS .and. type_of_LLS /= 2) call set_LLS(zred)
+
+        if (istep == 1) then
+           if (x_init >= 0.0_dp) xh = x_init
+           if (trim(x_file) /= 'none') then
+              open(newunit=u, file=trim(x_file), access='stream', form='unformatted', status='old')
+              read(u) xh
+              close(u)
+           endif
+        endif
+
+        write(tag,'(A,I3.3)') 'step', istep
+
+        if (trim(mode) == 'sweep') then
+           ! one pass over all sources, exactly what pass_all_sources (evolve.F90:444)
+           ! does around do_grid, without the chemistry
+           call dump_inputs(tag)
+           xh_av = xh
+           xh_intermed = xh
+           call system_clock(c0, crate)
+           do irep = 1, nrep
+              phih_grid = 0.0
+              photon_loss = 0.0
+              sum_nbox = 0
+              do ns = 1, NumSrc
+                 call do_source(actual_dt, ns, 1)
+                 if (ns == ns_dump .and. irep == 1) &
+                      call dump_r8(trim(tag)//'_coldensh_out', coldensh_out)
+              enddo
+           enddo
+           call system_clock(c1)
+           t_sweep = real(c1-c0,dp)/real(crate,dp)/real(nrep,dp)
+           call dump_r8(trim(tag)//'_phih_grid', phih_grid)
+           open(newunit=u, file=trim(out_dir)//trim(tag)//'_sweep.txt', status='replace')
+           write(u,'(A,1X,ES26.17E3)') 'photon_loss', photon_loss(1)
+           write(u,'(A,1X,I12)') 'sum_nbox', sum_nbox
+           write(u,'(A,1X,ES26.17E3)') 'seconds_per_pass', t_sweep
+           write(u,'(A,1X,I12)') 'nthreads', nthreads
+           close(u)
+           stop
+        endif
+
+        ! mode 'evolve'
+        if (istep >= dump_first .and. istep <= dump_last) call dump_inputs(tag)
+        write(logf,*) 'REFDRIVER step ', istep
+        call evolve3D(sim_time, actual_dt, 0)
+        if (istep >= dump_first .and. istep <= dump_last) then
+           call dump_r8(trim(tag)//'_xh_after', xh)
+           call dump_r8(trim(tag)//'_xh_av', xh_av)
+           call dump_r8(trim(tag)//'_xh_intermed', xh_intermed)
+           call dump_r8(trim(tag)//'_phih_grid', phih_grid)
+           open(newunit=u, file=trim(out_dir)//trim(tag)//'_out.txt', status='replace')
+           write(u,'(A,1X,ES26.17E3)') 'photon_loss_all', photon_loss_all(1)
+           write(u,'(A,1X,I12)') 'sum_nbox_all', sum_nbox_all
+           close(u)
+        endif
+        sim_time = sim_time + actual_dt
+        if (istep >= nsteps) exit slices
+        if (abs(sim_time-end_time) <= 1e-6*end_time) exit steps
+     enddo steps
+     if (cosmological) then
+        call redshift_evol(sim_time)
+        call cosmo_evol()
+     endif
+  enddo slices
+
+contains
+
+  subroutine dump_r8(name, a)
+    character(len=*), intent(in) :: name
+    real(kind=dp), intent(in) :: a(:,:,:)
+    integer :: uu
+    open(newunit=uu, file=trim(out_dir)//trim(name)//'.f64', access='stream', &
+         form='unformatted', status='replace')
+    write(uu) a
+    close(uu)
+  end subroutine dump_r8
+
+  subroutine dump_r8_1d(name, a, n)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: n
+    real(kind=dp), intent(in) :: a(n)
+    integer :: uu
+    open(newunit=uu, file=trim(out_dir)//trim(name)//'.f64', access='stream', &
+         form='unformatted', status='replace')
+    write(uu) a
+    close(uu)
+  end subroutine dump_r8_1d
+
+  !> everything the hot path reads for this step (SURVEY.md s8b "what the GPU box will run")
+  subroutine dump_inputs(tag)
+    character(len=*), intent(in) :: tag
+    integer :: uu, is
+    call dump_r8(trim(tag)//'_xh_before', xh)
+    open(newunit=uu, file=trim(out_dir)//trim(tag)//'_ndens.f32', access='stream', &
+         form='unformatted', status='replace')
+    write(uu) ndens
+    close(uu)
+    open(newunit=uu, file=trim(out_dir)//trim(tag)//'_in.txt', status='replace')
+    write(uu,'(A,1X,I12)') 'mesh', mesh(1)
+    write(uu,'(A,1X,ES26.17E3)') 'dt', actual_dt
+    write(uu,'(A,1X,ES26.17E3)') 'dr1', dr(1)
+    write(uu,'(A,1X,ES26.17E3)') 'dr2', dr(2)
+    write(uu,'(A,1X,ES26.17E3)') 'dr3', dr(3)
+    write(uu,'(A,1X,ES26.17E3)') 'vol', vol
+    write(uu,'(A,1X,ES26.17E3)') 'coldensh_LLS', coldensh_LLS
+    write(uu,'(A,1X,ES26.17E3)') 'clumping', real(clumping,dp)
+    write(uu,'(A,1X,ES26.17E3)') 'S_star', S_star
+    write(uu,'(A,1X,ES26.17E3)') 'zred', zred
+    write(uu,'(A,1X,I12)') 'NumSrc', NumSrc
+    do is = 1, NumSrc
+       write(uu,'(A,1X,3(I8,1X),ES26.17E3)') 'src', srcpos(1,is), srcpos(2,is), srcpos(3,is), &
+            NormFlux_stellar(is)
+    enddo
+    close(uu)
+  end subroutine dump_inputs
+
+  !> point-level known answers: cinterp on a filled cube, photoion_rates and doric on
+  !! tabulated arguments.  Inputs come from files written by tests/golden/make_golden.py
+  subroutine point_tests()
+    integer :: uu, n, m, ii, jj, kk, r, cnt
+    integer :: sp(3), pp(3)
+    real(kind=dp), allocatable :: args(:,:), res(:,:)
+    real(kind=dp) :: cd, path, xf(0:1), xfav(0:1), rhe
+    type(photrates) :: phi
+
+    ! --- cinterp: coldensh_out filled from file, all cells within radius r of the source
+    open(newunit=uu, file='point_coldens.f64', access='stream', form='unformatted', status='old')
+    read(uu) coldensh_out
+    close(uu)
+    open(newunit=uu, file='point_cinterp.txt', status='old')
+    read(uu,*) sp(1), sp(2), sp(3), r
+    close(uu)
+    n = (2*r+1)**3 - 1
+    allocate(res(2,n))
+    cnt = 0
+    do kk = -r, r
+       do jj = -r, r
+          do ii = -r, r
+             if (ii == 0 .and. jj == 0 .and. kk == 0) cycle
+             cnt = cnt + 1
+             pp = sp + (/ ii, jj, kk /)
+             call cinterp(pp, sp, cd, path)
+             res(1,cnt) = cd
+             res(2,cnt) = path
+          enddo
+       enddo
+    enddo
+    open(newunit=uu, file=trim(out_dir)//'point_cinterp_out.f64', access='stream', &
+         form='unformatted', status='replace')
+    write(uu) res
+    close(uu)
+    deallocate(res)
+
+    ! --- photoion_rates: rows of (colum_in, colum_out, vol); needs NormFlux_stellar(1)
+    !     from the source list, so load the sources of slice nz0 first
+    zred = zred_array(nz0)
+    call set_timesteps(zred, zred_array(nz0+1), end_time, dt, output_time)
+    call source_properties(zred, nz0, end_time-sim_time, restart)
+    open(newunit=uu, file='point_photo.f64', access='stream', form='unformatted', status='old')
+    read(uu) m
+    allocate(args(3,m), res(3,m))
+    read(uu) args
+    close(uu)
+    do ii = 1, m
+       phi = photoion_rates(args(1,ii), args(2,ii), args(3,ii), 1, 0.5_dp)
+       res(1,ii) = phi%photo_cell_HI
+       res(2,ii) = phi%photo_in
+       res(3,ii) = phi%photo_out
+    enddo
+    open(newunit=uu, file=trim(out_dir)//'point_photo_out.f64', access='stream', &
+         form='unformatted', status='replace')
+    write(uu) NormFlux_stellar(1)
+    write(uu) res
+    close(uu)
+    deallocate(args, res)
+
+    ! --- doric: rows of (dt, temp0, rhe, rhh, xfh1_old, xfh_av1, phih); clumping set as in a step
+    call set_clumping(zred)
+    open(newunit=uu, file='point_doric.f64', access='stream', form='unformatted', status='old')
+    read(uu) m
+    allocate(args(7,m), res(4,m))
+    read(uu) args
+    close(uu)
+    do ii = 1, m
+       xf(1) = args(5,ii); xf(0) = 1.0_dp - xf(1)
+       xfav(1) = args(6,ii); xfav(0) = 1.0_dp - xfav(1)
+       rhe = args(3,ii)
+       call doric(args(1,ii), args(2,ii), rhe, args(4,ii), xf, xfav, args(7,ii))
+       res(1,ii) = xf(0); res(2,ii) = xf(1); res(3,ii) = xfav(0); res(4,ii) = xfav(1)
+    enddo
+    open(newunit=uu, file=trim(out_dir)//'point_doric_out.f64', access='stream', &
+         form='unformatted', status='replace')
+    write(uu) res
+    close(uu)
+  end subroutine point_tests
+
+end program ref_driver

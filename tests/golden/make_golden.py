@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the UNMODIFIED reference.
+
+Runs only in the build container (needs /root/reference and amdflang):
+    oracle/ref_build.sh 32 33 64          # compile the reference per mesh size
+    python tests/golden/make_golden.py     # run it, collect inputs + outputs
+
+Every fixture is DATA: inputs handed to the reference's hot path and the values the
+compiled reference produced (raw arrays + scalars parsed from its own log).  The driver
+that calls the reference routines is oracle/ref_driver.F90 (our code).  Fixtures are always
+generated with the SERIAL build: the reference's OpenMP path has a data race on
+photon_loss_src_thread and is not deterministic.
+"""
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref")
+ANSWERS = "n\nn\n1\n7\n10\n1\n"     # inputs/input_example_test: no restart, slice 1, UV model 7 (Test)
+
+SRC_ONE = [(50, 50, 50, 1e57)]                                  # inputs/test_sources_onesrc.dat
+SRC_STD = [(50, 50, 50, 1e55), (51, 50, 50, 1e55), (52, 50, 50, 1e55), (53, 50, 50, 1e55),
+           (20, 10, 10, 1e57), (70, 70, 50, 1e55), (72, 70, 50, 1e55), (70, 72, 50, 1e55),
+           (72, 72, 50, 1e56), (20, 10, 90, 1e54)]              # inputs/test_sources_standard.dat
+
+
+def density_factor(n, seed, sigma=0.6):
+    """Log-normal multiplicative perturbation of the test problem's uniform density (f32)."""
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal((n, n, n))
+    f = np.exp(sigma * g - 0.5 * sigma * sigma)
+    return f.astype(np.float32)
+
+
+def bubble_xfield(n, centres, radius, x_in=0.9995, x_out=2e-4, seed=7):
+    """Initial ionized-fraction field: ionized spheres (periodic) in neutral gas, with jitter."""
+    rng = np.random.default_rng(seed)
+    ax = np.arange(1, n + 1)
+    x = np.full((n, n, n), x_out)
+    I, J, K = np.meshgrid(ax, ax, ax, indexing="ij")
+    for (ci, cj, ck) in centres:
+        d = [np.minimum(np.abs(A - c), n - np.abs(A - c)) for A, c in ((I, ci), (J, cj), (K, ck))]
+        r2 = d[0] ** 2 + d[1] ** 2 + d[2] ** 2
+        x[r2 <= radius * radius] = x_in
+    x = x * (1.0 + 1e-3 * rng.standard_normal(x.shape))
+    return np.clip(x, 1e-6, 1.0 - 1e-6)
+
+
+def run_driver(n, sources, nml, dens=None, xfield=None, extra_files=None, omp=False, threads=1):
+    d = "/tmp/c2ray_golden_run"
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d + "/results")
+    os.makedirs(d + "/dump")
+    with open(d + "/answers", "w") as f:
+        f.write(ANSWERS)
+    with open(d + "/test_sources.dat", "w") as f:
+        f.write("%d\n" % len(sources))
+        for (i, j, k, flux) in sources:
+            f.write("%d %d %d %.17e 0.0\n" % (i, j, k, flux))
+    nml = dict(nml)
+    if dens is not None:
+        dens.T.tofile(d + "/dens.f32")         # Fortran order on disk
+        nml["dens_file"] = "'dens.f32'"
+    if xfield is not None:
+        xfield.T.tofile(d + "/x.f64")
+        nml["x_file"] = "'x.f64'"
+    for name, writer in (extra_files or {}).items():
+        writer(os.path.join(d, name))
+    with open(d + "/driver.nml", "w") as f:
+        f.write("&ctl " + ", ".join("%s=%s" % kv for kv in nml.items()) + " /\n")
+    exe = os.path.join(REF, "N%d" % n, "omp" if omp else "serial", "ref_driver")
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+    subprocess.check_call([exe, "answers"], cwd=d, env=env, stdout=subprocess.DEVNULL)
+    return d
+
+
+def read_kv(path):
+    out, srcs = {}, []
+    for line in open(path):
+        t = line.split()
+        if t[0] == "src":
+            srcs.append((int(t[1]), int(t[2]), int(t[3]), float(t[4])))
+        else:
+            out[t[0]] = float(t[1]) if ("E" in t[1] or "." in t[1]) else int(t[1])
+    if srcs:
+        out["srcpos"] = [s[:3] for s in srcs]
+        out["normflux"] = [s[3] for s in srcs]
+    return out
+
+
+def rd(d, name, n, dtype=np.float64):
+    return np.fromfile(os.path.join(d, "dump", name), dtype=dtype).reshape((n, n, n), order="F")
+
+
+def parse_log(path):
+    """Per-step, per-iteration values the reference logs (evolve.F90:205-210,249-251,559-566)."""
+    steps, cur = [], None
+    fl = r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[Ee][-+]?\d+)?"
+    for line in open(path):
+        if "REFDRIVER step" in line:
+            cur = {"test1": [], "test2": [], "nonconv": [], "avg_nbox": [], "mean_x": []}
+            steps.append(cur)
+        elif cur is None:
+            continue
+        elif "Test 1 values:" in line:
+            cur["test1"].append([int(v) for v in line.split(":")[1].split()])
+        elif "Test 2 values:" in line:
+            cur["test2"].append([float(v) for v in re.findall(fl, line.split(":")[1])][:2])
+        elif "Number of non-converged points:" in line:
+            cur["nonconv"].append(int(line.split(":")[1]))
+        elif "Average number of subboxes:" in line:
+            cur["avg_nbox"].append(float(re.findall(fl, line.split(":")[1])[0]))
+        elif "Intermediate result for mean H ionization fraction:" in line:
+            cur["mean_x"].append(float(re.findall(fl, line.split(":")[1])[0]))
+    return steps
+
+
+def case_tables():
+    d = run_driver(32, SRC_ONE, {"mode": "'tables'"})
+    thick = np.fromfile(d + "/dump/thick_table.f64")
+    thin = np.fromfile(d + "/dump/thin_table.f64")
+    assert thick.size == 2001 and thin.size == 2001
+    np.savez_compressed(os.path.join(HERE, "tables.npz"), thick=thick, thin=thin)
+    print("tables: thick[0]=%.17g thin[0]=%.17g" % (thick[0], thin[0]))
+
+
+def case_point():
+    n = 32
+    rng = np.random.default_rng(20261003)
+    cd = 10.0 ** rng.uniform(15.0, 21.0, size=(n, n, n))
+    # photoion rows: tau in {0, <1e-20, thin/thick boundary, 1, 1e4, >1e4} x cell widths
+    sig = 6.29999986469627735e-18
+    tin = np.array([0.0, 1e-25, 1e-20, 3e-9, 1e-7, 1e-3, 0.5, 1.0, 37.0, 9.9e3, 1e4, 3e4]) / sig
+    dt_ = np.array([0.0, 1e-9, 0.9e-7, 1.00000001168609742e-07, 1.1e-7, 1e-3, 0.3, 5.0, 2e4]) / sig
+    rows = [(a, a + b, 10.0 ** rng.uniform(70, 76)) for a in tin for b in dt_]
+    photo = np.array(rows, dtype=np.float64)
+    # doric rows: (dt, temp0, rhe, rhh, x1_old, xav1, phih)
+    rows = []
+    for phih in (0.0, 1e-20, 1e-16, 1e-12, 1e-9, 1e-6):
+        for dt in (3.15576e13, 3.15576e9, 1.0e2):
+            for x1 in (2e-4, 0.3, 0.999, 1.0 - 1e-14):
+                nh = 10.0 ** rng.uniform(-5, -2)
+                xav = min(1.0, x1 * (1.0 + 0.1 * rng.uniform()))
+                rows.append((dt, 1e4, nh * (xav + 7.09999994796817191e-07), nh, x1, xav, phih))
+    dor = np.array(rows, dtype=np.float64)
+    out = {"coldens": cd, "photo_in": photo, "doric_in": dor}
+    for tag, (sp, r) in {"a": ((16, 17, 15), 4), "b": ((2, 31, 1), 3)}.items():
+        def w_cd(p): cd.T.tofile(p)
+        def w_ci(p): open(p, "w").write("%d %d %d %d\n" % (sp[0], sp[1], sp[2], r))
+        def w_ph(p):
+            with open(p, "wb") as f:
+                np.int32(len(photo)).tofile(f); photo.tofile(f)
+        def w_do(p):
+            with open(p, "wb") as f:
+                np.int32(len(dor)).tofile(f); dor.tofile(f)
+        d = run_driver(n, SRC_ONE, {"mode": "'point'"},
+                       extra_files={"point_coldens.f64": w_cd, "point_cinterp.txt": w_ci,
+                                    "point_photo.f64": w_ph, "point_doric.f64": w_do})
+        ci = np.fromfile(d + "/dump/point_cinterp_out.f64").reshape(-1, 2)
+        out["cinterp_src_" + tag] = np.array(sp + (r,), dtype=np.int32)
+        out["cinterp_out_" + tag] = ci
+        ph = np.fromfile(d + "/dump/point_photo_out.f64")
+        out["photo_normflux"] = ph[0]
+        out["photo_out"] = ph[1:].reshape(-1, 3)
+        out["doric_out"] = np.fromfile(d + "/dump/point_doric_out.f64").reshape(-1, 4)
+    np.savez_compressed(os.path.join(HERE, "point.npz"), **out)
+    print("point: cinterp %d+%d cells, photo %d rows, doric %d rows" %
+          (len(out["cinterp_out_a"]), len(out["cinterp_out_b"]), len(photo), len(dor)))
+
+
+def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, keep=("xh_after", "phih_grid", "xh_av")):
+    dens = density_factor(n, dens_seed) if dens_seed is not None else None
+    d = run_driver(n, sources, {"mode": "'evolve'", "nsteps": nsteps, "dump_first": dump[0],
+                                "dump_last": dump[-1]}, dens=dens, xfield=xfield)
+    log = parse_log(d + "/results/C2Ray.log")
+    arrays, meta = {}, {"n": n, "steps": {}}
+    for s in dump:
+        tag = "step%03d" % s
+        kv = read_kv("%s/dump/%s_in.txt" % (d, tag))
+        kv.update(read_kv("%s/dump/%s_out.txt" % (d, tag)))
+        kv["log"] = log[s - 1]
+        kv["niter"] = len(log[s - 1]["nonconv"])
+        meta["steps"][tag] = kv
+        arrays[tag + "_xh_before"] = rd(d, tag + "_xh_before.f64", n)
+        arrays[tag + "_ndens"] = rd(d, tag + "_ndens.f32", n, np.float32)
+        for k in keep:
+            arrays[tag + "_" + k] = rd(d, "%s_%s.f64" % (tag, k), n)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    json.dump(meta, open(os.path.join(HERE, name + ".json"), "w"), indent=1)
+    print(name, {t: m["niter"] for t, m in meta["steps"].items()})
+
+
+def case_sweep(name, n, sources, x_init=None, dens_seed=None, xfield=None, ns_dump=1, full=True):
+    dens = density_factor(n, dens_seed) if dens_seed is not None else None
+    nml = {"mode": "'sweep'", "ns_dump": ns_dump}
+    if x_init is not None:
+        nml["x_init"] = "%.17g" % x_init
+    d = run_driver(n, sources, nml, dens=dens, xfield=xfield)
+    tag = "step001"
+    kv = read_kv("%s/dump/%s_in.txt" % (d, tag))
+    kv.update(read_kv("%s/dump/%s_sweep.txt" % (d, tag)))
+    kv["ns_dump"] = ns_dump
+    kv.pop("seconds_per_pass", None)
+    phih = rd(d, tag + "_phih_grid.f64", n)
+    cdo = rd(d, tag + "_coldensh_out.f64", n)
+    arrays = {"xh": rd(d, tag + "_xh_before.f64", n), "ndens": rd(d, tag + "_ndens.f32", n, np.float32)}
+    if full:
+        arrays.update(phih=phih, coldensh_out=cdo)
+    else:   # large grids: three orthogonal planes through source ns_dump + checksums
+        s = [(p - 1) % n for p in kv["srcpos"][ns_dump - 1]]
+        arrays.update(phih_px=phih[s[0]], phih_py=phih[:, s[1]], phih_pz=phih[:, :, s[2]],
+                      cd_px=cdo[s[0]], cd_py=cdo[:, s[1]], cd_pz=cdo[:, :, s[2]])
+        # uniform inputs need not be stored whole
+        for k in ("xh", "ndens"):
+            if np.all(arrays[k] == arrays[k].flat[0]):
+                arrays[k] = arrays[k].flat[0:1].copy()
+    kv["phih_sum"] = float(np.sum(phih, dtype=np.longdouble))
+    kv["phih_max"] = float(phih.max())
+    kv["phih_nonzero"] = int(np.count_nonzero(phih))
+    kv["cd_sum"] = float(np.sum(cdo, dtype=np.longdouble))
+    kv["cd_nonzero"] = int(np.count_nonzero(cdo))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    json.dump({"n": n, **kv}, open(os.path.join(HERE, name + ".json"), "w"), indent=1)
+    print(name, "sum_nbox", kv["sum_nbox"], "loss", kv["photon_loss"], "phih_nonzero", kv["phih_nonzero"])
+
+
+def main():
+    which = set(sys.argv[1:])
+    def want(k): return not which or k in which
+    if want("tables"): case_tables()
+    if want("point"): case_point()
+    # config[0] of BASELINE.json: the reference's own test problem, 32^3, one source, cold start
+    if want("evolve32"): case_evolve("evolve32_onesrc", 32, SRC_ONE, 12, [1, 2, 3, 12])
+    # pre-ionised gas, the 10-source list (positions wrap periodically): sub-box growth to the limit
+    if want("sweep32"): case_sweep("sweep32_std_x999", 32, SRC_STD, x_init=0.999)
+    if want("sweep33"): case_sweep("sweep33_std_x999", 33, SRC_STD, x_init=0.999, dens_seed=33)
+    # perturbed density + ionized bubbles: exercises max_coldensh stop, thin/thick cells, clipping
+    if want("sweep32b"):
+        x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 7.0)
+        case_sweep("sweep32_bubbles", 32, SRC_STD, dens_seed=5, xfield=x, ns_dump=5)
+    if want("evolve32b"):
+        x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 6.0)
+        case_evolve("evolve32_std_bubbles", 32, SRC_STD, 3, [1, 3], dens_seed=11, xfield=x)
+    if want("sweep64"):
+        x = bubble_xfield(64, [(50, 50, 50), (20, 10, 10), (6, 8, 50), (20, 10, 26)], 14.0)
+        srcs = SRC_STD[:8] + [(72, 72, 50, 1e58), (20, 10, 90, 1e54)]
+        case_sweep("sweep64_bubbles", 64, srcs, dens_seed=64, xfield=x, ns_dump=9, full=False)
+    if want("evolve64"):
+        x = bubble_xfield(64, [(50, 50, 50), (20, 10, 10), (6, 8, 50), (20, 10, 26)], 12.0)
+        case_evolve("evolve64_std_bubbles", 64, SRC_STD, 1, [1], dens_seed=65, xfield=x,
+                    keep=("xh_after",))
+
+
+if __name__ == "__main__":
+    main()

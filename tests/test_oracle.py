@@ -1,0 +1,144 @@
+"""CPU tests: the oracle (oracle/c2ray_oracle.c) against fixtures recorded from the compiled,
+unmodified reference (tests/golden/make_golden.py).  The oracle is bit-exact with the reference
+on every fixture, so these tests demand equality, not a tolerance."""
+import numpy as np
+import pytest
+from tests._util import F, load_case, oracle_for, expand, relerr, GOLDEN
+
+
+def test_tables_known_answers(tables):
+    thick, thin = tables
+    # values the reference logs at start-up (radiation_tables.F90:212-215)
+    assert thick.shape == (2001,) and thin.shape == (2001,)
+    assert abs(thick[0] - 9.999999999999995e47) < 1e33
+    assert abs(thin[0] - 4.567323859246105e47) < 1e33
+    assert np.all(np.diff(thick[1:]) <= 0) and np.all(thick >= 0)
+
+
+def test_constants_match_reference_prints():
+    """include/c2ray_constants.h against the widened-f32 semantics of the reference literals."""
+    import re, os
+    txt = open(os.path.join(GOLDEN, "..", "..", "include", "c2ray_constants.h")).read()
+    val = {m.group(1): float(m.group(2).strip("()")) for m in
+           re.finditer(r"#define\s+(C2R_\w+)\s+(\(?-?[0-9.]+(?:[eE][-+]?\d+)?\)?)", txt)}
+    f32 = lambda x: float(np.float32(x))
+    assert val["C2R_PI"] == f32(3.141592654)
+    assert val["C2R_SIGMA_HI"] == f32(6.30e-18)
+    assert val["C2R_CONVERGENCE_FRACTION"] == f32(1.0e-4)
+    assert val["C2R_MIN_FRACTIONAL_CHANGE"] == f32(1.0e-3)
+    assert val["C2R_MIN_FRACTION_OF_ATOMS"] == f32(1.0e-8) == val["C2R_DELTHT_SMALL"]
+    assert val["C2R_MAX_COLDENSH"] == f32(2e19)
+    assert val["C2R_TAU_PHOTO_LIMIT"] == f32(1.0e-7)
+    assert val["C2R_SQRT3"] == float(np.sqrt(np.float32(3.0)))
+    assert val["C2R_SQRT2"] == float(np.sqrt(np.float32(2.0)))
+    assert val["C2R_ABU_C"] == f32(7.1e-7)
+    assert val["C2R_DLOGTAU"] == 24.0 / 2000.0
+    # cgsconstants.f90:39,76,80,86: temph0 = eth0*ev2k, colh0 = 1.3e-8*fh0*xih0/(eth0*eth0)
+    eth0 = f32(13.598)
+    assert val["C2R_TEMPH0"] == eth0 * float(np.float32(1.0) / np.float32(8.617e-05))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_cinterp_points(tables, tag):
+    from oracle.oracle import Oracle
+    pt = np.load(GOLDEN + "/point.npz")
+    o = Oracle(32, 1.0, 1.0, 0.0, *tables)
+    cd = F(pt["coldens"])
+    sp = pt["cinterp_src_" + tag]; r = int(sp[3]); sp = [int(v) for v in sp[:3]]
+    ref = pt["cinterp_out_" + tag]
+    cnt = 0
+    for kk in range(-r, r + 1):
+        for jj in range(-r, r + 1):
+            for ii in range(-r, r + 1):
+                if ii == jj == kk == 0:
+                    continue
+                c, p = o.cinterp(cd, (sp[0] + ii, sp[1] + jj, sp[2] + kk), sp)
+                assert c == ref[cnt, 0] and p == ref[cnt, 1], (ii, jj, kk)
+                cnt += 1
+    assert cnt == len(ref)
+
+
+def test_photoion_rates_points(tables):
+    from oracle.oracle import Oracle
+    pt = np.load(GOLDEN + "/point.npz")
+    o = Oracle(32, 1.0, 1.0, 0.0, *tables)
+    nf = float(pt["photo_normflux"])
+    for row, ref in zip(pt["photo_in"], pt["photo_out"]):
+        assert o.photoion_rates(row[0], row[1], row[2], nf) == tuple(ref)
+    # a source with zero flux contributes nothing (radiation_photoionrates.F90:126)
+    assert o.photoion_rates(1e17, 2e17, 1e72, 0.0) == (0.0, 0.0, 0.0)
+
+
+def test_doric_points():
+    from oracle.oracle import Oracle
+    pt = np.load(GOLDEN + "/point.npz")
+    for row, ref in zip(pt["doric_in"], pt["doric_out"]):
+        assert Oracle.doric(row[0], row[1], row[2], 1.0, row[4], row[5], row[6]) == tuple(ref)
+
+
+@pytest.mark.parametrize("name", ["sweep32_std_x999", "sweep33_std_x999", "sweep32_bubbles"])
+def test_sweep_full_grid(tables, name):
+    m, a = load_case(name)
+    n = m["n"]
+    o = oracle_for(m, tables, n)
+    nd, xh = F(expand(a["ndens"], n)), F(expand(a["xh"], n))
+    phih = np.zeros(o.ncell)
+    loss, nb, vis = o.pass_sources(nd, xh, phih, m["srcpos"], m["normflux"])
+    assert nb == m["sum_nbox"]
+    assert loss == m["photon_loss"]
+    assert np.array_equal(phih, F(a["phih"]))
+    assert np.count_nonzero(phih) == m["phih_nonzero"]
+    ns = m["ns_dump"] - 1
+    _, _, _, cdo = o.do_source(nd, xh, np.zeros(o.ncell), m["srcpos"][ns], m["normflux"][ns])
+    assert np.array_equal(cdo, F(a["coldensh_out"]))
+
+
+def test_sweep32_known_answers(tables):
+    """The numbers SURVEY.md s8a records for this case (independent of our fixture files)."""
+    m, _ = load_case("sweep32_std_x999")
+    assert m["sum_nbox"] == 30 and m["phih_nonzero"] == 32705
+    assert abs(m["photon_loss"] / 7.62318326526291e54 - 1) < 1e-14
+
+
+def test_sweep64_planes(tables):
+    m, a = load_case("sweep64_bubbles")
+    n = m["n"]
+    o = oracle_for(m, tables, n)
+    nd, xh = F(expand(a["ndens"], n)), F(expand(a["xh"], n))
+    phih = np.zeros(o.ncell)
+    loss, nb, vis = o.pass_sources(nd, xh, phih, m["srcpos"], m["normflux"])
+    assert nb == m["sum_nbox"] and loss == m["photon_loss"]
+    p3 = phih.reshape((n, n, n), order="F")
+    s = [(p - 1) % n for p in m["srcpos"][m["ns_dump"] - 1]]
+    assert np.array_equal(p3[s[0]], a["phih_px"])
+    assert np.array_equal(p3[:, s[1]], a["phih_py"])
+    assert np.array_equal(p3[:, :, s[2]], a["phih_pz"])
+    assert np.count_nonzero(phih) == m["phih_nonzero"]
+    assert abs(float(np.sum(phih, dtype=np.longdouble)) / m["phih_sum"] - 1) < 1e-15
+
+
+@pytest.mark.parametrize("name", ["evolve32_onesrc", "evolve32_std_bubbles", "evolve64_std_bubbles"])
+def test_evolve3d_steps(tables, name):
+    m, a = load_case(name)
+    n = m["n"]
+    for tag, s in m["steps"].items():
+        o = oracle_for(s, tables, n)
+        xh = F(a[tag + "_xh_before"]); nd = F(a[tag + "_ndens"])
+        rep, xav, xint, phih = o.evolve3d(s["dt"], nd, xh, s["srcpos"], s["normflux"])
+        assert rep.niter == s["niter"] and rep.converged == 1
+        assert list(rep.it_conv_flag[:rep.niter]) == s["log"]["nonconv"]
+        assert np.array_equal(xh, F(a[tag + "_xh_after"]))
+        if tag + "_phih_grid" in a:
+            assert np.array_equal(phih, F(a[tag + "_phih_grid"]))
+            assert np.array_equal(xav, F(a[tag + "_xh_av"]))
+        assert rep.sum_nbox_all == s["sum_nbox_all"]
+        assert rep.photon_loss_all == s["photon_loss_all"]
+        # logged Test-2 values and mean x (printed with 16-17 digits by the reference)
+        t2 = np.array(s["log"]["test2"][1:])
+        mine = np.array([rep.it_rel1[:rep.niter], rep.it_rel0[:rep.niter]]).T
+        assert relerr(mine, t2) < 1e-13
+        meanx = np.array(rep.it_sum_xh1[:rep.niter]) / float(np.float32(n ** 3))
+        assert relerr(meanx, s["log"]["mean_x"]) < 1e-15
+        # average sub-boxes per source line (evolve.F90:249)
+        avg = np.array(rep.it_sum_nbox[:rep.niter]) / np.float32(len(s["normflux"]))
+        assert relerr(avg, s["log"]["avg_nbox"]) < 1e-6
