@@ -1,0 +1,108 @@
+"""ctypes view of the C ABI in include/c2ray_hip.h (libc2ray_hip.so, built by csrc/Makefile).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present, loading or
+creating a context fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libc2ray_hip.so")
+MAX_ITER_LOG = 128
+
+GRID_NDENS, GRID_XH, GRID_XH_AV, GRID_XH_INTERMED, GRID_PHIH = range(5)
+
+
+class Params(C.Structure):
+    _fields_ = [("mesh", C.c_int32 * 3), ("device", C.c_int32), ("subboxsize", C.c_int32),
+                ("max_subbox", C.c_int32), ("numtau", C.c_int32), ("max_outer_iter", C.c_int32),
+                ("max_chem_iter", C.c_int32), ("reserved0", C.c_int32),
+                ("epsilon", C.c_double), ("convergence_fraction", C.c_double),
+                ("minimum_fractional_change", C.c_double), ("minimum_fraction_of_atoms", C.c_double),
+                ("loss_fraction", C.c_double), ("max_coldensh", C.c_double),
+                ("tau_photo_limit", C.c_double), ("sigma_HI", C.c_double),
+                ("minlogtau", C.c_double), ("dlogtau", C.c_double), ("weight_floor", C.c_double),
+                ("sqrt2", C.c_double), ("sqrt3", C.c_double), ("pi", C.c_double),
+                ("abu_c", C.c_double), ("bh00", C.c_double), ("albpow", C.c_double),
+                ("colh0", C.c_double), ("temph0", C.c_double), ("S_star", C.c_double),
+                ("scratch_bytes", C.c_size_t)]
+
+
+class Report(C.Structure):
+    _fields_ = [("niter", C.c_int32), ("converged", C.c_int32), ("conv_flag", C.c_int64),
+                ("conv_criterion", C.c_int64), ("sum_nbox_all", C.c_int64), ("visited", C.c_int64),
+                ("photon_loss_all", C.c_double), ("seconds_sweep", C.c_double),
+                ("seconds_chem", C.c_double), ("chem_not_converged", C.c_int32),
+                ("reserved0", C.c_int32),
+                ("it_conv_flag", C.c_int64 * MAX_ITER_LOG), ("it_sum_nbox", C.c_int64 * MAX_ITER_LOG),
+                ("it_rel_change_xh1", C.c_double * MAX_ITER_LOG),
+                ("it_rel_change_xh0", C.c_double * MAX_ITER_LOG),
+                ("it_sum_xh1", C.c_double * MAX_ITER_LOG)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+# every symbol include/c2ray_hip.h declares: (name, restype, argtypes)
+_P, _I32, _I64, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+SYMBOLS = [
+    ("c2r_default_params", C.c_int, [C.POINTER(Params)]),
+    ("c2r_create", C.c_int, [C.POINTER(_P), C.POINTER(Params)]),
+    ("c2r_destroy", None, [_P]),
+    ("c2r_last_error", C.c_char_p, [_P]),
+    ("c2r_set_stream", C.c_int, [_P, _P]),
+    ("c2r_set_tables", C.c_int, [_P, _P, _P, _I32]),
+    ("c2r_set_step", C.c_int, [_P, C.POINTER(_D * 3), _D, _D, C.c_float, _D]),
+    ("c2r_set_sources", C.c_int, [_P, _P, _P, _I32]),
+    ("c2r_set_rank", C.c_int, [_P, _I32, _I32, ALLREDUCE_FN, _P]),
+    ("c2r_bind_device_buffers", C.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("c2r_device_ptr", C.c_int, [_P, _I32, C.POINTER(_P)]),
+    ("c2r_upload", C.c_int, [_P, _I32, _P]),
+    ("c2r_download", C.c_int, [_P, _I32, _P]),
+    ("c2r_zero_rates", C.c_int, [_P]),
+    ("c2r_pass_sources", C.c_int, [_P, C.POINTER(_D), C.POINTER(_I64), C.POINTER(_I64)]),
+    ("c2r_allreduce_rates", C.c_int, [_P]),
+    ("c2r_do_source", C.c_int, [_P, _I32, _P, C.POINTER(_D), C.POINTER(_I32), C.POINTER(_I64)]),
+    ("c2r_global_pass", C.c_int, [_P, _D, C.POINTER(_I64), C.POINTER(_D)]),
+    ("c2r_sum", C.c_int, [_P, _I32, C.POINTER(_D)]),
+    ("c2r_evolve3d_dev", C.c_int, [_P, _D, C.POINTER(Report)]),
+    ("c2r_evolve3d", C.c_int, [_P, _D, _P, _P, _P, _P, _P, C.POINTER(Report)]),
+    ("c2r_profile", C.c_int, [_P, _I32]),
+    ("c2r_profile_read", C.c_int, [_P, C.POINTER(_D), C.POINTER(_I64), C.POINTER(_D), C.POINTER(_I64)]),
+]
+
+_lib = None
+
+
+class C2RayHipError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen libc2ray_hip.so and type every entry point.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise C2RayHipError(
+            "%s not found: build it with `make -C c2-ray3dm_amd/csrc` (or __graft_entry__.build()); "
+            "this package has no CPU fallback" % path)
+    lib = C.CDLL(path)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError = a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def default_params(mesh, device=0):
+    lib = load_library()
+    p = Params()
+    rc = lib.c2r_default_params(C.byref(p))
+    if rc:
+        raise C2RayHipError("c2r_default_params -> %d" % rc)
+    mesh = (mesh,) * 3 if isinstance(mesh, int) else tuple(mesh)
+    p.mesh[:] = mesh
+    p.device = device
+    return p

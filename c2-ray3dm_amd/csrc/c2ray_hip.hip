@@ -1,0 +1,697 @@
+// Host side of the C ABI declared in include/c2ray_hip.h: context, device buffers, the
+// per-shell launch schedule of the source sweep, the global pass and the evolve3D outer loop.
+#include "../../include/c2ray_hip.h"
+#include "../../include/c2ray_constants.h"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace c2r;
+
+namespace {
+
+constexpr int kSumBlocks = 1024;      // fixed grid of every deterministic reduction
+
+struct Ctx {
+    c2r_params prm{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    size_t ncell = 0;
+    // grids: 0 ndens(f32) 1 xh 2 xh_av 3 xh_intermed 4 phih_grid
+    void *grid[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool  own[5] = {false, false, false, false, false};
+    double *d_thick = nullptr, *d_thin = nullptr;
+    bool have_tables = false, have_step = false;
+    double dr[3] = {0, 0, 0}, vol = 0, lls = 0, temper = 0;
+    float clumping = 1.0f;
+    std::vector<int32_t> srcpos;   // 3 x nsrc
+    std::vector<double>  nflux;
+    int nsrc = 0, rank = 0, nranks = 1;
+    c2r_allreduce_fn ar = nullptr;
+    void *ar_user = nullptr;
+    // sweep geometry
+    int hl[3], hr[3], nbox_max = 0, Qmax = 0, R = 0, P = 1;
+    size_t PP = 1;
+    int bps_max = 0;
+    // sweep scratch (one batch of sources)
+    int batch_cap = 0;
+    double *d_planes = nullptr;
+    int *d_srcpos_b = nullptr; double *d_nflux_b = nullptr;
+    int *d_active[2] = {nullptr, nullptr};
+    int *d_nactive = nullptr; int *h_nactive = nullptr;     // pinned
+    double *d_loss_partial = nullptr, *d_loss_acc = nullptr, *d_final_loss = nullptr;
+    int *d_final_nbox = nullptr;
+    double *d_photon_loss = nullptr; long long *d_sum_nbox = nullptr;
+    // reductions
+    double *d_sum_partial = nullptr, *d_sum_out = nullptr;
+    unsigned long long *d_conv = nullptr; unsigned int *d_chemfail = nullptr;
+    struct HostScalars { double sum; double photon_loss; long long sum_nbox; unsigned long long conv; unsigned int chemfail; double pair[2]; } *h_sc = nullptr;  // pinned
+    double *d_dbg = nullptr, *d_pair = nullptr;
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_sweep, ev_chem;
+    size_t ev_sweep_used = 0, ev_chem_used = 0;
+    double prof_sweep_ms = 0, prof_chem_ms = 0; long long prof_sweep_n = 0, prof_chem_n = 0;
+    std::string err;
+};
+
+inline Ctx *C(c2r_ctx *c) { return reinterpret_cast<Ctx *>(c); }
+inline const Ctx *C(const c2r_ctx *c) { return reinterpret_cast<const Ctx *>(c); }
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            char buf_[512];                                                                  \
+            snprintf(buf_, sizeof buf_, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,        \
+                     hipGetErrorString(e_));                                                 \
+            ctx->err = buf_;                                                                 \
+            return (int)e_;                                                                  \
+        }                                                                                    \
+    } while (0)
+
+#define FAIL(code, msg) do { ctx->err = (msg); return (code); } while (0)
+
+size_t grid_bytes(const Ctx *ctx, int which) { return ctx->ncell * (which == 0 ? sizeof(float) : sizeof(double)); }
+
+void free_sweep_scratch(Ctx *ctx)
+{
+    hipFree(ctx->d_planes); hipFree(ctx->d_srcpos_b); hipFree(ctx->d_nflux_b);
+    hipFree(ctx->d_active[0]); hipFree(ctx->d_active[1]);
+    hipFree(ctx->d_loss_partial); hipFree(ctx->d_loss_acc); hipFree(ctx->d_final_loss);
+    hipFree(ctx->d_final_nbox);
+    ctx->d_planes = nullptr; ctx->d_srcpos_b = nullptr; ctx->d_nflux_b = nullptr;
+    ctx->d_active[0] = ctx->d_active[1] = nullptr;
+    ctx->d_loss_partial = ctx->d_loss_acc = ctx->d_final_loss = nullptr; ctx->d_final_nbox = nullptr;
+    ctx->batch_cap = 0;
+}
+
+int n_local_sources(const Ctx *ctx)
+{
+    return ctx->nsrc > ctx->rank ? (ctx->nsrc - ctx->rank + ctx->nranks - 1) / ctx->nranks : 0;
+}
+
+// Per-source scratch: two shells x six face planes of (2R+1)^2 f64.  Size the batch so that it
+// fits the budget; 288 GB of HBM normally holds every source of a rank at once.
+int ensure_sweep_scratch(Ctx *ctx, int want)
+{
+    if (want <= ctx->batch_cap) return C2R_OK;
+    free_sweep_scratch(ctx);
+    const size_t per_src = 2 * 6 * ctx->PP * sizeof(double) + (size_t)ctx->bps_max * sizeof(double) + 64;
+    size_t budget = ctx->prm.scratch_bytes;
+    if (budget == 0) {
+        size_t fr = 0, tot = 0;
+        HIP_TRY(hipMemGetInfo(&fr, &tot));
+        budget = fr / 4;
+    }
+    int cap = (int)std::min<size_t>((size_t)want, std::max<size_t>(1, budget / per_src));
+    HIP_TRY(hipMalloc(&ctx->d_planes, (size_t)cap * 2 * 6 * ctx->PP * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_srcpos_b, (size_t)cap * 3 * sizeof(int)));
+    HIP_TRY(hipMalloc(&ctx->d_nflux_b, (size_t)cap * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_active[0], (size_t)cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&ctx->d_active[1], (size_t)cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&ctx->d_loss_partial, (size_t)cap * ctx->bps_max * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_loss_acc, (size_t)cap * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_final_loss, (size_t)cap * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_final_nbox, (size_t)cap * sizeof(int)));
+    ctx->batch_cap = cap;
+    return C2R_OK;
+}
+
+KParams make_kparams(const Ctx *ctx)
+{
+    KParams k{};
+    const c2r_params &p = ctx->prm;
+    for (int d = 0; d < 3; ++d) { k.n[d] = p.mesh[d]; k.hl[d] = ctx->hl[d]; k.hr[d] = ctx->hr[d]; k.dr[d] = ctx->dr[d]; }
+    k.vol = ctx->vol; k.coldensh_LLS = ctx->lls;
+    k.sigma = p.sigma_HI; k.wfloor = p.weight_floor; k.sqrt2 = p.sqrt2; k.sqrt3 = p.sqrt3;
+    k.fourpi = 4.0 * p.pi;                      // evolve_point.F90:177: 4.0*pi*dist2*path, left to right
+    k.max_coldensh = p.max_coldensh; k.tau_limit = p.tau_photo_limit;
+    k.minlogtau = p.minlogtau; k.dlogtau = p.dlogtau; k.numtau = p.numtau; k.numtau_d = (double)p.numtau;
+    k.eps = p.epsilon;
+    k.R = ctx->R; k.P = ctx->P; k.PP = ctx->PP;
+    k.ndens = (const float *)ctx->grid[0]; k.xh_av = (const double *)ctx->grid[2]; k.phih = (double *)ctx->grid[4];
+    k.thick = ctx->d_thick; k.thin = ctx->d_thin;
+    k.srcpos = ctx->d_srcpos_b; k.normflux = ctx->d_nflux_b; k.planes = ctx->d_planes;
+    return k;
+}
+
+void prof_begin(Ctx *ctx, std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool, size_t &used)
+{
+    if (!ctx->prof) return;
+    if (used == pool.size()) { hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); pool.emplace_back(a, b); }
+    hipEventRecord(pool[used].first, ctx->stream);
+}
+void prof_end(Ctx *ctx, std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool, size_t &used)
+{
+    if (!ctx->prof) return;
+    hipEventRecord(pool[used].second, ctx->stream);
+    ++used;
+}
+void prof_collect(Ctx *ctx)
+{
+    if (!ctx->prof) return;
+    for (size_t i = 0; i < ctx->ev_sweep_used; ++i) { float ms = 0; hipEventElapsedTime(&ms, ctx->ev_sweep[i].first, ctx->ev_sweep[i].second); ctx->prof_sweep_ms += ms; }
+    for (size_t i = 0; i < ctx->ev_chem_used; ++i) { float ms = 0; hipEventElapsedTime(&ms, ctx->ev_chem[i].first, ctx->ev_chem[i].second); ctx->prof_chem_ms += ms; }
+    ctx->prof_sweep_n += (long long)ctx->ev_sweep_used; ctx->prof_chem_n += (long long)ctx->ev_chem_used;
+    ctx->ev_sweep_used = ctx->ev_chem_used = 0;
+}
+
+// Sweep one batch: local sources [first, first+count) of this rank's list.
+// dbg: optional device N^3 array receiving coldensh_out (single-source test path).
+int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *nbox_out,
+                std::vector<double> *loss_out)
+{
+    const c2r_params &p = ctx->prm;
+    std::vector<int> h_pos(3 * (size_t)count), h_act, h_fn(count, 0);
+    std::vector<double> h_nf(count), h_fl(count, 0.0);
+    const bool can_trace = ctx->hr[2] > 0 && ctx->hl[2] > 0;       // while condition, evolve_source.F90:130-131
+    for (int i = 0; i < count; ++i) {
+        const int g = ctx->rank + (first + i) * ctx->nranks;       // master_slave.F90:85
+        for (int d = 0; d < 3; ++d) h_pos[3 * i + d] = ctx->srcpos[3 * (size_t)g + d];
+        h_nf[i] = ctx->nflux[g];
+        const double flux = h_nf[i] * p.S_star;
+        if (flux > p.loss_fraction * flux && can_trace) h_act.push_back(i);
+        else h_fl[i] = flux;                                       // loop never entered: loss = initial value
+    }
+    int n_active = (int)h_act.size();
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->d_srcpos_b, h_pos.data(), h_pos.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->d_nflux_b, h_nf.data(), h_nf.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->d_final_loss, h_fl.data(), h_fl.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->d_final_nbox, h_fn.data(), h_fn.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(ctx->d_loss_acc, 0, (size_t)count * sizeof(double), st));
+    if (n_active) HIP_TRY(hipMemcpyAsync(ctx->d_active[0], h_act.data(), (size_t)n_active * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));      // host vectors go out of scope below
+
+    KParams k = make_kparams(ctx);
+    int cur = 0;
+    for (int nbox = 1; nbox <= ctx->nbox_max && n_active > 0; ++nbox) {
+        int boxR[3], boxL[3];
+        for (int d = 0; d < 3; ++d) {
+            boxR[d] = std::min(p.subboxsize * nbox, ctx->hr[d]);
+            boxL[d] = std::min(p.subboxsize * nbox, ctx->hl[d]);
+        }
+        if (nbox == 1) {
+            hipLaunchKernelGGL(k_source_cells, dim3((n_active + 63) / 64), dim3(64), 0, st, k, n_active,
+                               ctx->d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
+                               ctx->d_loss_acc, dbg);
+        }
+        const int q0 = p.subboxsize * (nbox - 1) + 1, q1 = std::min(p.subboxsize * nbox, ctx->Qmax);
+        for (int q = q0; q <= q1; ++q) {
+            ShellArgs sa{};
+            sa.q = q;
+            const int w = 2 * q + 1;
+            sa.tiles_a = (w + kTileA - 1) / kTileA; sa.tiles_b = (w + kTileB - 1) / kTileB;
+            sa.bps = 6 * sa.tiles_a * sa.tiles_b;
+            sa.has_boundary = 0;
+            for (int d = 0; d < 3; ++d) {
+                sa.boxR[d] = boxR[d]; sa.boxL[d] = boxL[d];
+                if (boxR[d] <= q || boxL[d] <= q) sa.has_boundary = 1;
+            }
+            sa.alam = (double)((float)(q - 1) + 0.5f) / (double)(float)q;
+            sa.active = ctx->d_active[cur]; sa.loss_partial = ctx->d_loss_partial; sa.dbg_cdout = dbg;
+            const size_t nblk = (size_t)n_active * sa.bps;
+            if (nblk > 0x7fffffffULL) FAIL(C2R_EINVAL, "sweep grid too large: lower scratch_bytes to shrink the batch");
+            prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
+            hipLaunchKernelGGL(k_sweep_shell, dim3((unsigned)nblk), dim3(kTileA, kTileB), 0, st, k, sa);
+            prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
+            if (sa.has_boundary)
+                hipLaunchKernelGGL(k_loss_reduce, dim3(n_active), dim3(256), 0, st, ctx->d_active[cur],
+                                   ctx->d_loss_partial, sa.bps, ctx->d_loss_acc);
+        }
+        const int can_grow = (p.subboxsize * nbox < ctx->hr[2]) && (p.subboxsize * nbox < ctx->hl[2]);
+        hipLaunchKernelGGL(k_box_decide, dim3(1), dim3(1024), 0, st, ctx->d_active[cur], n_active,
+                           ctx->d_active[1 - cur], ctx->d_nactive, ctx->d_nflux_b, p.S_star, p.loss_fraction,
+                           can_grow, nbox, ctx->d_loss_acc, ctx->d_final_loss, ctx->d_final_nbox);
+        HIP_TRY(hipMemcpyAsync(ctx->h_nactive, ctx->d_nactive, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n_active = *ctx->h_nactive;
+        cur = 1 - cur;
+    }
+    hipLaunchKernelGGL(k_batch_totals, dim3(1), dim3(64), 0, st, count, ctx->d_final_loss, ctx->d_final_nbox,
+                       ctx->d_photon_loss, ctx->d_sum_nbox);
+    HIP_TRY(hipGetLastError());
+    if (nbox_out) {
+        nbox_out->resize(count);
+        HIP_TRY(hipMemcpyAsync(nbox_out->data(), ctx->d_final_nbox, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, st));
+    }
+    if (loss_out) {
+        loss_out->resize(count);
+        HIP_TRY(hipMemcpyAsync(loss_out->data(), ctx->d_final_loss, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return C2R_OK;
+}
+
+long long visited_for_nbox(const Ctx *ctx, int nbox)
+{
+    if (nbox <= 0) return 0;
+    long long v = 1;
+    for (int d = 0; d < 3; ++d) {
+        const int r = std::min(ctx->prm.subboxsize * nbox, ctx->hr[d]), l = std::min(ctx->prm.subboxsize * nbox, ctx->hl[d]);
+        v *= (long long)(r + l + 1);
+    }
+    return v;
+}
+
+int check_ready(Ctx *ctx)
+{
+    if (!ctx->have_tables) FAIL(C2R_ESTATE, "c2r_set_tables has not been called");
+    if (!ctx->have_step) FAIL(C2R_ESTATE, "c2r_set_step has not been called");
+    return C2R_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int c2r_default_params(c2r_params *p)
+{
+    if (!p) return C2R_EINVAL;
+    memset(p, 0, sizeof *p);
+    p->mesh[0] = p->mesh[1] = p->mesh[2] = 0;
+    p->device = 0;
+    p->subboxsize = C2R_SUBBOXSIZE; p->max_subbox = C2R_MAX_SUBBOX; p->numtau = C2R_NUMTAU;
+    p->max_outer_iter = C2R_MAX_OUTER_ITER; p->max_chem_iter = C2R_MAX_CHEM_ITER;
+    p->epsilon = C2R_EPSILON; p->convergence_fraction = C2R_CONVERGENCE_FRACTION;
+    p->minimum_fractional_change = C2R_MIN_FRACTIONAL_CHANGE;
+    p->minimum_fraction_of_atoms = C2R_MIN_FRACTION_OF_ATOMS;
+    p->loss_fraction = C2R_LOSS_FRACTION; p->max_coldensh = C2R_MAX_COLDENSH;
+    p->tau_photo_limit = C2R_TAU_PHOTO_LIMIT; p->sigma_HI = C2R_SIGMA_HI;
+    p->minlogtau = C2R_MINLOGTAU; p->dlogtau = C2R_DLOGTAU; p->weight_floor = C2R_WEIGHT_FLOOR;
+    p->sqrt2 = C2R_SQRT2; p->sqrt3 = C2R_SQRT3; p->pi = C2R_PI; p->abu_c = C2R_ABU_C;
+    p->bh00 = C2R_BH00; p->albpow = C2R_ALBPOW; p->colh0 = C2R_COLH0; p->temph0 = C2R_TEMPH0;
+    p->S_star = C2R_S_STAR;
+    p->scratch_bytes = 0;
+    return C2R_OK;
+}
+
+int c2r_create(c2r_ctx **out, const c2r_params *p)
+{
+    if (!out || !p) return C2R_EINVAL;
+    *out = nullptr;
+    if (p->mesh[0] < 1 || p->mesh[1] < 1 || p->mesh[2] < 1 || p->numtau < 1 || p->subboxsize < 1) return C2R_EINVAL;
+    Ctx *ctx = new Ctx();
+    ctx->prm = *p;
+    *out = reinterpret_cast<c2r_ctx *>(ctx);     // returned even on failure so c2r_last_error works
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev < 1) FAIL(C2R_ESTATE, "no HIP device: the c2ray_hip path needs a GPU (there is no CPU fallback)");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamCreate(&ctx->stream));
+    ctx->own_stream = true;
+    ctx->ncell = (size_t)p->mesh[0] * p->mesh[1] * p->mesh[2];
+    for (int w = 0; w < 5; ++w) { HIP_TRY(hipMalloc(&ctx->grid[w], grid_bytes(ctx, w))); ctx->own[w] = true; }
+    HIP_TRY(hipMemset(ctx->grid[4], 0, grid_bytes(ctx, 4)));      // evolve_data.F90:76 phih_grid=0.0
+    HIP_TRY(hipMalloc(&ctx->d_thick, (size_t)(p->numtau + 1) * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_thin, (size_t)(p->numtau + 1) * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_nactive, sizeof(int)));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_nactive, sizeof(int)));
+    HIP_TRY(hipMalloc(&ctx->d_photon_loss, sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_sum_nbox, sizeof(long long)));
+    HIP_TRY(hipMalloc(&ctx->d_sum_partial, kSumBlocks * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_sum_out, sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_conv, sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&ctx->d_chemfail, sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(&ctx->d_pair, 2 * sizeof(double)));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_sc, sizeof(*ctx->h_sc)));
+    // trace limits (evolve_source.F90:100-102), identical for every source
+    int zlim = 0;
+    for (int d = 0; d < 3; ++d) {
+        ctx->hr[d] = std::min(p->max_subbox, p->mesh[d] / 2 - 1 + p->mesh[d] % 2);
+        ctx->hl[d] = std::min(p->max_subbox, p->mesh[d] / 2);
+    }
+    zlim = std::min(ctx->hr[2], ctx->hl[2]);
+    ctx->nbox_max = zlim > 0 ? (zlim + p->subboxsize - 1) / p->subboxsize : 0;
+    int reach = 0;
+    for (int d = 0; d < 3; ++d) reach = std::max(reach, std::max(ctx->hl[d], ctx->hr[d]));
+    ctx->Qmax = std::min(ctx->nbox_max * p->subboxsize, reach);
+    ctx->R = ctx->Qmax; ctx->P = 2 * ctx->R + 1; ctx->PP = (size_t)ctx->P * ctx->P;
+    ctx->bps_max = 6 * ((ctx->P + kTileA - 1) / kTileA) * ((ctx->P + kTileB - 1) / kTileB);
+    return C2R_OK;
+}
+
+void c2r_destroy(c2r_ctx *c)
+{
+    if (!c) return;
+    Ctx *ctx = C(c);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    free_sweep_scratch(ctx);
+    for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
+    hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_nactive);
+    if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
+    hipFree(ctx->d_photon_loss); hipFree(ctx->d_sum_nbox); hipFree(ctx->d_sum_partial); hipFree(ctx->d_sum_out);
+    hipFree(ctx->d_conv); hipFree(ctx->d_chemfail); hipFree(ctx->d_dbg); hipFree(ctx->d_pair);
+    if (ctx->h_sc) hipHostFree(ctx->h_sc);
+    for (auto &e : ctx->ev_sweep) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto &e : ctx->ev_chem) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *c2r_last_error(const c2r_ctx *c) { return c ? C(c)->err.c_str() : "null context"; }
+
+int c2r_set_stream(c2r_ctx *c, void *s)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (s == nullptr) {
+        if (!ctx->own_stream) { HIP_TRY(hipStreamCreate(&ctx->stream)); ctx->own_stream = true; }
+    } else {
+        if (ctx->own_stream) { hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+        ctx->stream = (hipStream_t)s;
+    }
+    return C2R_OK;
+}
+
+int c2r_set_tables(c2r_ctx *c, const double *thick, const double *thin, int32_t n)
+{
+    if (!c || !thick || !thin) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (n != ctx->prm.numtau + 1) FAIL(C2R_EINVAL, "table length must be numtau+1");
+    HIP_TRY(hipMemcpy(ctx->d_thick, thick, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_thin, thin, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    ctx->have_tables = true;
+    return C2R_OK;
+}
+
+int c2r_set_step(c2r_ctx *c, const double dr[3], double vol, double lls, float clumping, double temper)
+{
+    if (!c || !dr) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (!(dr[0] > 0) || !(dr[1] > 0) || !(dr[2] > 0) || !(vol > 0) || !(temper > 0)) FAIL(C2R_EINVAL, "dr, vol and temper must be positive");
+    for (int d = 0; d < 3; ++d) ctx->dr[d] = dr[d];
+    ctx->vol = vol; ctx->lls = lls; ctx->clumping = clumping; ctx->temper = temper;
+    ctx->have_step = true;
+    return C2R_OK;
+}
+
+int c2r_set_sources(c2r_ctx *c, const int32_t *srcpos, const double *normflux, int32_t nsrc)
+{
+    if (!c || nsrc < 0 || (nsrc > 0 && (!srcpos || !normflux))) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    ctx->srcpos.assign(srcpos, srcpos + 3 * (size_t)nsrc);
+    ctx->nflux.assign(normflux, normflux + nsrc);
+    ctx->nsrc = nsrc;
+    return C2R_OK;
+}
+
+int c2r_set_rank(c2r_ctx *c, int32_t rank, int32_t nranks, c2r_allreduce_fn fn, void *user)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (nranks < 1 || rank < 0 || rank >= nranks) FAIL(C2R_EINVAL, "need 0 <= rank < nranks");
+    if (nranks > 1 && !fn) FAIL(C2R_EINVAL, "nranks > 1 needs an all-reduce callback");
+    ctx->rank = rank; ctx->nranks = nranks; ctx->ar = fn; ctx->ar_user = user;
+    return C2R_OK;
+}
+
+int c2r_bind_device_buffers(c2r_ctx *c, void *ndens, void *xh, void *xh_av, void *xh_int, void *phih)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    void *in[5] = {ndens, xh, xh_av, xh_int, phih};
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int w = 0; w < 5; ++w) {
+        if (!in[w]) continue;
+        if (ctx->own[w]) { hipFree(ctx->grid[w]); ctx->own[w] = false; }
+        ctx->grid[w] = in[w];
+    }
+    return C2R_OK;
+}
+
+int c2r_device_ptr(c2r_ctx *c, int32_t which, void **ptr)
+{
+    if (!c || !ptr || which < 0 || which > 4) return C2R_EINVAL;
+    *ptr = C(c)->grid[which];
+    return C2R_OK;
+}
+
+int c2r_upload(c2r_ctx *c, int32_t which, const void *host)
+{
+    if (!c || !host || which < 0 || which > 4) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    HIP_TRY(hipMemcpyAsync(ctx->grid[which], host, grid_bytes(ctx, which), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return C2R_OK;
+}
+
+int c2r_download(c2r_ctx *c, int32_t which, void *host)
+{
+    if (!c || !host || which < 0 || which > 4) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    HIP_TRY(hipMemcpyAsync(host, ctx->grid[which], grid_bytes(ctx, which), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return C2R_OK;
+}
+
+int c2r_zero_rates(c2r_ctx *c)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    HIP_TRY(hipMemsetAsync(ctx->grid[4], 0, grid_bytes(ctx, 4), ctx->stream));
+    return C2R_OK;
+}
+
+int c2r_pass_sources(c2r_ctx *c, double *photon_loss, int64_t *sum_nbox, int64_t *visited)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->d_photon_loss, 0, sizeof(double), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_sum_nbox, 0, sizeof(long long), ctx->stream));
+    const int nloc = n_local_sources(ctx);
+    long long vis = 0;
+    if (nloc > 0) {
+        rc = ensure_sweep_scratch(ctx, nloc);
+        if (rc) return rc;
+        std::vector<int> nb;
+        for (int first = 0; first < nloc; first += ctx->batch_cap) {
+            const int count = std::min(ctx->batch_cap, nloc - first);
+            rc = sweep_batch(ctx, first, count, nullptr, &nb, nullptr);
+            if (rc) return rc;
+            for (int v : nb) vis += visited_for_nbox(ctx, v);
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(&ctx->h_sc->photon_loss, ctx->d_photon_loss, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&ctx->h_sc->sum_nbox, ctx->d_sum_nbox, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    if (photon_loss) *photon_loss = ctx->h_sc->photon_loss;
+    if (sum_nbox) *sum_nbox = ctx->h_sc->sum_nbox;
+    if (visited) *visited = vis;
+    return C2R_OK;
+}
+
+int c2r_allreduce_rates(c2r_ctx *c)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (ctx->nranks <= 1 || !ctx->ar) return C2R_OK;
+    if (ctx->ar(ctx->ar_user, ctx->grid[4], ctx->ncell, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-reduce callback failed");
+    return C2R_OK;
+}
+
+int c2r_do_source(c2r_ctx *c, int32_t ns, double *cd_host, double *loss, int32_t *nbox, int64_t *visited)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    if (ns < 1 || ns > ctx->nsrc) FAIL(C2R_EINVAL, "source number out of range");
+    rc = ensure_sweep_scratch(ctx, 1);
+    if (rc) return rc;
+    double *dbg = nullptr;
+    if (cd_host) {
+        if (!ctx->d_dbg) HIP_TRY(hipMalloc(&ctx->d_dbg, ctx->ncell * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(ctx->d_dbg, 0, ctx->ncell * sizeof(double), ctx->stream));   // evolve_source.F90:91
+        dbg = ctx->d_dbg;
+    }
+    HIP_TRY(hipMemsetAsync(ctx->d_photon_loss, 0, sizeof(double), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_sum_nbox, 0, sizeof(long long), ctx->stream));
+    // address the source directly, whatever the rank layout
+    const int sr = ctx->rank, sn = ctx->nranks;
+    ctx->rank = 0; ctx->nranks = 1;
+    std::vector<int> nb; std::vector<double> fl;
+    rc = sweep_batch(ctx, ns - 1, 1, dbg, &nb, &fl);
+    ctx->rank = sr; ctx->nranks = sn;
+    if (rc) return rc;
+    prof_collect(ctx);
+    if (cd_host) {
+        HIP_TRY(hipMemcpyAsync(cd_host, ctx->d_dbg, ctx->ncell * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (loss) *loss = fl[0];
+    if (nbox) *nbox = nb[0];
+    if (visited) *visited = visited_for_nbox(ctx, nb[0]);
+    return C2R_OK;
+}
+
+int c2r_sum(c2r_ctx *c, int32_t which, double *sum)
+{
+    if (!c || !sum || which < 1 || which > 4) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    hipLaunchKernelGGL(k_sum_partial, dim3(kSumBlocks), dim3(256), 0, ctx->stream, ctx->ncell,
+                       (const double *)ctx->grid[which], ctx->d_sum_partial);
+    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, ctx->d_sum_out);
+    HIP_TRY(hipMemcpyAsync(&ctx->h_sc->sum, ctx->d_sum_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *sum = ctx->h_sc->sum;
+    return C2R_OK;
+}
+
+int c2r_global_pass(c2r_ctx *c, double dt, int64_t *conv_flag, double *sum_xh1)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    const c2r_params &p = ctx->prm;
+    ChemParams cp{};
+    cp.dt = dt; cp.eps = p.epsilon; cp.min_frac_change = p.minimum_fractional_change;
+    cp.min_frac_atoms = p.minimum_fraction_of_atoms; cp.abu_c = p.abu_c; cp.deltht_small = C2R_DELTHT_SMALL;
+    cp.max_iter = p.max_chem_iter;
+    // doric.f90:73,78 -- temperature is uniform (isothermal), so both rate coefficients are
+    // per-call constants; evaluated with the host libm like the reference does at run time
+    cp.brech0 = (double)ctx->clumping * p.bh00 * pow(ctx->temper / 1e4, p.albpow);
+    cp.acolh0 = p.colh0 * sqrt(ctx->temper) * exp(-p.temph0 / ctx->temper);
+    HIP_TRY(hipMemsetAsync(ctx->d_conv, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_chemfail, 0, sizeof(unsigned int), ctx->stream));
+    prof_begin(ctx, ctx->ev_chem, ctx->ev_chem_used);
+    hipLaunchKernelGGL(k_global_pass, dim3(kSumBlocks), dim3(256), 0, ctx->stream, cp, ctx->ncell,
+                       (const float *)ctx->grid[0], (const double *)ctx->grid[1], (double *)ctx->grid[2],
+                       (double *)ctx->grid[3], (const double *)ctx->grid[4], ctx->d_sum_partial, ctx->d_conv,
+                       ctx->d_chemfail);
+    prof_end(ctx, ctx->ev_chem, ctx->ev_chem_used);
+    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, ctx->d_sum_out);
+    HIP_TRY(hipMemcpyAsync(&ctx->h_sc->sum, ctx->d_sum_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&ctx->h_sc->conv, ctx->d_conv, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&ctx->h_sc->chemfail, ctx->d_chemfail, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    if (conv_flag) *conv_flag = (int64_t)ctx->h_sc->conv;
+    if (sum_xh1) *sum_xh1 = ctx->h_sc->sum;
+    return C2R_OK;
+}
+
+int c2r_evolve3d_dev(c2r_ctx *c, double dt, c2r_report *rep)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    const c2r_params &p = ctx->prm;
+    c2r_report local;
+    if (!rep) rep = &local;
+    memset(rep, 0, sizeof *rep);
+    using clk = std::chrono::steady_clock;
+    // evolve.F90:145-146  xh_av = xh ; xh_intermed = xh
+    HIP_TRY(hipMemcpyAsync(ctx->grid[2], ctx->grid[1], grid_bytes(ctx, 1), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->grid[3], ctx->grid[1], grid_bytes(ctx, 1), hipMemcpyDeviceToDevice, ctx->stream));
+    int niter = 0;
+    int64_t conv_flag = (int64_t)ctx->ncell;                                           // :149
+    double prev1 = (double)(((2.0f * (float)p.mesh[0]) * (float)p.mesh[1]) * (float)p.mesh[2]);   // :150-151
+    double prev0 = prev1;
+    const int64_t c1 = (int64_t)(p.convergence_fraction * p.mesh[0] * p.mesh[1] * p.mesh[2]);    // :162
+    const int64_t c2 = (ctx->nsrc - 1) / 3;
+    const int64_t conv_criterion = std::min(c1, c2);
+    rep->conv_criterion = conv_criterion;
+    double sum1 = 0.0;
+    rc = c2r_sum(c, 3, &sum1);                                                         // :183
+    if (rc) return rc;
+    for (;;) {
+        const double sum0 = (double)(float)ctx->ncell - sum1;                          // :184
+        const double rel1 = sum1 > 0.0 ? fabs(sum1 - prev1) / sum1 : 1.0;
+        const double rel0 = sum0 > 0.0 ? fabs(sum0 - prev0) / sum0 : 1.0;
+        if (niter > 0 && niter <= C2R_MAX_ITER_LOG) {
+            rep->it_rel_change_xh1[niter - 1] = rel1; rep->it_rel_change_xh0[niter - 1] = rel0;
+            rep->it_sum_xh1[niter - 1] = sum1;
+        }
+        if (conv_flag < conv_criterion || (rel1 < p.convergence_fraction && rel0 < p.convergence_fraction)) {   // :212
+            HIP_TRY(hipMemcpyAsync(ctx->grid[1], ctx->grid[3], grid_bytes(ctx, 1), hipMemcpyDeviceToDevice, ctx->stream));   // :218
+            rep->converged = 1;
+            break;
+        } else if (niter > p.max_outer_iter) {                                         // :228
+            rep->converged = 0;
+            break;
+        }
+        prev1 = sum1; prev0 = sum0;
+        niter++;
+        rc = c2r_zero_rates(c);                                                        // :243
+        if (rc) return rc;
+        auto t0 = clk::now();
+        double loss = 0; int64_t nb = 0, vis = 0;
+        rc = c2r_pass_sources(c, &loss, &nb, &vis);                                    // :246
+        if (rc) return rc;
+        if (ctx->nranks > 1) {
+            rc = c2r_allreduce_rates(c);                                               // evolve.F90:599
+            if (rc) return rc;
+            // evolve.F90:587,612: photon_loss and sum_nbox ride along as a 2-element f64 vector
+            // (sum_nbox is exact in f64)
+            ctx->h_sc->pair[0] = loss; ctx->h_sc->pair[1] = (double)nb;
+            HIP_TRY(hipMemcpyAsync(ctx->d_pair, ctx->h_sc->pair, 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            if (ctx->ar(ctx->ar_user, ctx->d_pair, 2, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-reduce callback failed");
+            HIP_TRY(hipMemcpyAsync(ctx->h_sc->pair, ctx->d_pair, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            loss = ctx->h_sc->pair[0]; nb = (int64_t)llround(ctx->h_sc->pair[1]);
+        }
+        auto t1 = clk::now();
+        rep->photon_loss_all = loss; rep->sum_nbox_all = nb; rep->visited += vis;
+        rc = c2r_global_pass(c, dt, &conv_flag, &sum1);                                // :269
+        if (rc) return rc;
+        auto t2 = clk::now();
+        rep->seconds_sweep += std::chrono::duration<double>(t1 - t0).count();
+        rep->seconds_chem += std::chrono::duration<double>(t2 - t1).count();
+        rep->chem_not_converged = (int32_t)ctx->h_sc->chemfail;
+        if (niter <= C2R_MAX_ITER_LOG) { rep->it_conv_flag[niter - 1] = conv_flag; rep->it_sum_nbox[niter - 1] = nb; }
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    rep->niter = niter; rep->conv_flag = conv_flag;
+    return C2R_OK;
+}
+
+int c2r_evolve3d(c2r_ctx *c, double dt, const float *ndens, double *xh, double *xh_av, double *xh_int,
+                 double *phih, c2r_report *rep)
+{
+    if (!c || !ndens || !xh) return C2R_EINVAL;
+    int rc;
+    if ((rc = c2r_upload(c, 0, ndens))) return rc;
+    if ((rc = c2r_upload(c, 1, xh))) return rc;
+    if ((rc = c2r_evolve3d_dev(c, dt, rep))) return rc;
+    if ((rc = c2r_download(c, 1, xh))) return rc;
+    if (xh_av && (rc = c2r_download(c, 2, xh_av))) return rc;
+    if (xh_int && (rc = c2r_download(c, 3, xh_int))) return rc;
+    if (phih && (rc = c2r_download(c, 4, phih))) return rc;
+    return C2R_OK;
+}
+
+int c2r_profile(c2r_ctx *c, int32_t enable)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    ctx->prof = enable != 0;
+    ctx->prof_sweep_ms = ctx->prof_chem_ms = 0; ctx->prof_sweep_n = ctx->prof_chem_n = 0;
+    return C2R_OK;
+}
+
+int c2r_profile_read(c2r_ctx *c, double *sweep_ms, int64_t *sweep_launches, double *chem_ms, int64_t *chem_launches)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (sweep_ms) *sweep_ms = ctx->prof_sweep_ms;
+    if (sweep_launches) *sweep_launches = ctx->prof_sweep_n;
+    if (chem_ms) *chem_ms = ctx->prof_chem_ms;
+    if (chem_launches) *chem_launches = ctx->prof_chem_n;
+    return C2R_OK;
+}
+
+}  // extern "C"

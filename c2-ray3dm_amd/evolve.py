@@ -1,0 +1,317 @@
+"""Host-side mirror of the reference's evolve modules, one process per GPU.
+
+Names and argument meaning follow the reference:
+
+    evolve3D(time, dt, restart)         evolve.F90:83
+    set_rates_to_zero()                 evolve.F90:430
+    pass_all_sources(niter, dt)         evolve.F90:444
+    do_grid(dt, niter)                  master_slave.F90:53   (static distribution, :74-96)
+    do_source(dt, ns1, niter)           evolve_source.F90:58
+    global_pass(dt) -> conv_flag        evolve.F90:499
+    mpi_accumulate_grid_quantities()    evolve.F90:577        (RCCL all-reduce via torch.distributed)
+
+State that the reference keeps in module-global arrays (xh, ndens, xh_av, xh_intermed,
+phih_grid, srcpos, NormFlux_stellar, dr, vol, coldensh_LLS, clumping) lives in the backend:
+`HipBackend` keeps it in HBM (torch tensors bound to the C-ABI context; torch is only the
+allocator / stream / collective plumbing).  `Evolve` holds the outer convergence loop, written
+once against the small backend interface so the multi-rank logic can be exercised on CPU with a
+test double (tests/_cpu_backend.py) -- the product always runs it on `HipBackend`.
+"""
+import ctypes as C
+import time as _time
+import numpy as np
+
+from . import _capi
+from ._capi import C2RayHipError
+
+CONVERGENCE_FRACTION = 9.99999974737875164e-05     # c2ray_parameters.f90:25 (f32 literal, widened)
+MAX_OUTER_ITER = 100                               # evolve.F90:228
+
+
+def static_source_share(nsrc, rank, npr):
+    """0-based indices of the sources rank `rank` of `npr` traces: do ns1=1+rank,NumSrc,npr
+    (master_slave.F90:85)."""
+    return list(range(rank, nsrc, npr))
+
+
+class HipBackend:
+    """The HIP path: owns a c2r context on one GPU and the device-resident arrays."""
+
+    def __init__(self, mesh, thick, thin, device=0, scratch_bytes=0, use_torch=True):
+        import torch
+        self.torch = torch
+        self.lib = _capi.load_library()
+        if not torch.cuda.is_available():
+            raise C2RayHipError("no GPU visible: the c2ray_hip path has no CPU fallback")
+        self.mesh = (mesh,) * 3 if isinstance(mesh, int) else tuple(mesh)
+        self.ncell = self.mesh[0] * self.mesh[1] * self.mesh[2]
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        p = _capi.default_params(self.mesh, device)
+        p.scratch_bytes = scratch_bytes
+        self.params = p
+        self.ctx = C.c_void_p()
+        rc = self.lib.c2r_create(C.byref(self.ctx), C.byref(p))
+        self._check(rc, "c2r_create")
+        thick = np.ascontiguousarray(thick, dtype=np.float64)
+        thin = np.ascontiguousarray(thin, dtype=np.float64)
+        self._check(self.lib.c2r_set_tables(self.ctx, thick.ctypes.data, thin.ctypes.data, thick.size),
+                    "c2r_set_tables")
+        # device arrays: torch allocates, the context binds (so torch.distributed can reduce phih)
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.ndens = torch.zeros(self.ncell, dtype=torch.float32, device=self.device)
+        self.xh = torch.zeros(self.ncell, **f64)
+        self.xh_av = torch.zeros(self.ncell, **f64)
+        self.xh_intermed = torch.zeros(self.ncell, **f64)
+        self.phih_grid = torch.zeros(self.ncell, **f64)
+        self._check(self.lib.c2r_bind_device_buffers(self.ctx, self.ndens.data_ptr(), self.xh.data_ptr(),
+                                                     self.xh_av.data_ptr(), self.xh_intermed.data_ptr(),
+                                                     self.phih_grid.data_ptr()), "c2r_bind_device_buffers")
+        self.stream = torch.cuda.current_stream(self.device)
+        self._check(self.lib.c2r_set_stream(self.ctx, C.c_void_p(self.stream.cuda_stream)), "c2r_set_stream")
+        self.nsrc = 0
+        self.rank, self.npr = 0, 1
+        self._cb = None
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.c2r_last_error(self.ctx) if self.ctx else b""
+            raise C2RayHipError("%s failed (%d): %s" % (what, rc, (msg or b"").decode()))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.c2r_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- inputs ---------------------------------------------------------------------------------
+    def set_step(self, dr, vol, coldensh_LLS, clumping=1.0, temper=1e4):
+        dr = (dr,) * 3 if np.isscalar(dr) else tuple(dr)
+        self._check(self.lib.c2r_set_step(self.ctx, (C.c_double * 3)(*dr), vol, coldensh_LLS, clumping, temper),
+                    "c2r_set_step")
+
+    def set_sources(self, srcpos, normflux):
+        srcpos = np.ascontiguousarray(srcpos, dtype=np.int32).reshape(-1, 3)
+        normflux = np.ascontiguousarray(normflux, dtype=np.float64)
+        assert len(srcpos) == len(normflux)
+        self.nsrc = len(normflux)
+        self._check(self.lib.c2r_set_sources(self.ctx, srcpos.ctypes.data, normflux.ctypes.data, self.nsrc),
+                    "c2r_set_sources")
+
+    def set_rank(self, rank, npr, allreduce=None):
+        """allreduce(tensor): in-place SUM over ranks of a 1-D f64 device tensor."""
+        self.rank, self.npr = rank, npr
+        if npr > 1:
+            torch = self.torch
+            known = {self.phih_grid.data_ptr(): self.phih_grid}
+
+            def _cb(user, ptr, count, stream):
+                try:
+                    t = known.get(ptr)
+                    if t is None:
+                        t = torch.as_tensor(_DevView(ptr, count), device=self.device)
+                    allreduce(t)
+                    return 0
+                except Exception as exc:      # never unwind through C
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = _capi.ALLREDUCE_FN(_cb)
+        else:
+            self._cb = _capi.ALLREDUCE_FN(0)
+        self._check(self.lib.c2r_set_rank(self.ctx, rank, npr, self._cb, None), "c2r_set_rank")
+
+    def load(self, ndens=None, xh=None):
+        """Host (numpy, Fortran-order flat or (N,N,N) with i fastest when ravelled 'F') -> HBM."""
+        torch = self.torch
+        if ndens is not None:
+            self.ndens.copy_(torch.from_numpy(_flat(ndens, np.float32)))
+        if xh is not None:
+            self.xh.copy_(torch.from_numpy(_flat(xh, np.float64)))
+
+    def fetch(self, name):
+        return getattr(self, name).cpu().numpy()
+
+    # -- backend interface used by Evolve ---------------------------------------------------------
+    def begin_step(self):
+        self.xh_av.copy_(self.xh)                 # evolve.F90:145
+        self.xh_intermed.copy_(self.xh)           # evolve.F90:146
+
+    def accept(self):
+        self.xh.copy_(self.xh_intermed)           # evolve.F90:218
+
+    def sum_xh_intermed(self):
+        s = C.c_double()
+        self._check(self.lib.c2r_sum(self.ctx, _capi.GRID_XH_INTERMED, C.byref(s)), "c2r_sum")
+        return s.value
+
+    def zero_rates(self):
+        self._check(self.lib.c2r_zero_rates(self.ctx), "c2r_zero_rates")
+
+    def pass_sources(self):
+        loss, nb, vis = C.c_double(), C.c_int64(), C.c_int64()
+        self._check(self.lib.c2r_pass_sources(self.ctx, C.byref(loss), C.byref(nb), C.byref(vis)),
+                    "c2r_pass_sources")
+        return loss.value, nb.value, vis.value
+
+    def do_source(self, ns1, want_coldens=False):
+        cd = np.empty(self.ncell, dtype=np.float64) if want_coldens else None
+        loss, nbox, vis = C.c_double(), C.c_int32(), C.c_int64()
+        self._check(self.lib.c2r_do_source(self.ctx, ns1, cd.ctypes.data if want_coldens else None,
+                                           C.byref(loss), C.byref(nbox), C.byref(vis)), "c2r_do_source")
+        return nbox.value, loss.value, vis.value, cd
+
+    def global_pass(self, dt):
+        conv, s = C.c_int64(), C.c_double()
+        self._check(self.lib.c2r_global_pass(self.ctx, dt, C.byref(conv), C.byref(s)), "c2r_global_pass")
+        return conv.value, s.value
+
+    def rates_tensor(self):
+        return self.phih_grid
+
+    def scalars_tensor(self, values):
+        return self.torch.tensor(values, dtype=self.torch.float64, device=self.device)
+
+    # -- whole-step entry point of the C ABI (the loop runs in C++) ---------------------------------
+    def evolve3d_native(self, dt):
+        rep = _capi.Report()
+        self._check(self.lib.c2r_evolve3d_dev(self.ctx, dt, C.byref(rep)), "c2r_evolve3d_dev")
+        return rep
+
+    def profile(self, enable=True):
+        self._check(self.lib.c2r_profile(self.ctx, 1 if enable else 0), "c2r_profile")
+
+    def profile_read(self):
+        a, b, c, d = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()
+        self._check(self.lib.c2r_profile_read(self.ctx, C.byref(a), C.byref(b), C.byref(c), C.byref(d)),
+                    "c2r_profile_read")
+        return {"sweep_ms": a.value, "sweep_launches": b.value, "chem_ms": c.value, "chem_launches": d.value}
+
+
+class _DevView:
+    """__cuda_array_interface__ view of `count` f64 at a raw device pointer."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+def _flat(a, dtype):
+    a = np.asarray(a)
+    if a.ndim == 3:
+        a = np.asfortranarray(a).ravel(order="F")
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Evolve:
+    """The outer loop of one time step over a backend, with the reference's procedure names."""
+
+    def __init__(self, backend, comm=None):
+        """comm: None (single process) or a torch.distributed-like module/object exposing
+        get_rank(), get_world_size(), all_reduce(tensor) with SUM semantics."""
+        self.b = backend
+        self.comm = comm
+        self.rank = comm.get_rank() if comm is not None else 0
+        self.npr = comm.get_world_size() if comm is not None else 1
+        if hasattr(backend, "set_rank"):
+            backend.set_rank(self.rank, self.npr, (lambda t: comm.all_reduce(t)) if comm is not None else None)
+        self.sum_nbox = 0
+        self.sum_nbox_all = 0
+        self.photon_loss = 0.0
+        self.photon_loss_all = 0.0
+        self.visited = 0
+        self.log = []
+
+    # evolve.F90:430
+    def set_rates_to_zero(self):
+        self.b.zero_rates()
+        self.photon_loss = 0.0
+
+    # master_slave.F90:53 -> :74 do_grid_static; the per-source loop and do_source live in the
+    # backend (c2r_pass_sources), which traces this rank's share 1+rank, 1+rank+npr, ...
+    def do_grid(self, dt, niter):
+        loss, nb, vis = self.b.pass_sources()
+        self.photon_loss += loss
+        self.sum_nbox += nb
+        self.visited += vis
+
+    # evolve_source.F90:58 (one source, mainly for tests)
+    def do_source(self, dt, ns1, niter):
+        nbox, loss, vis, _ = self.b.do_source(ns1)
+        self.photon_loss += loss
+        self.sum_nbox += nbox
+        self.visited += vis
+        return nbox
+
+    # evolve.F90:577
+    def mpi_accumulate_grid_quantities(self):
+        if self.npr > 1:
+            self.comm.all_reduce(self.b.rates_tensor())                        # :599 phih_grid
+            t = self.b.scalars_tensor([self.photon_loss, float(self.sum_nbox)])  # :587, :612
+            self.comm.all_reduce(t)
+            vals = t.tolist()
+            self.photon_loss_all, self.sum_nbox_all = vals[0], int(round(vals[1]))
+        else:
+            self.photon_loss_all, self.sum_nbox_all = self.photon_loss, self.sum_nbox
+
+    # evolve.F90:444
+    def pass_all_sources(self, niter, dt):
+        self.sum_nbox = 0
+        self.do_grid(dt, niter)
+        self.mpi_accumulate_grid_quantities()
+
+    # evolve.F90:499
+    def global_pass(self, dt):
+        return self.b.global_pass(dt)
+
+    # evolve.F90:83
+    def evolve3D(self, time, dt, restart=0):
+        if restart != 0:
+            raise NotImplementedError("restart from iteration dumps (evolve.F90:328) is out of scope")
+        b = self.b
+        n = b.mesh
+        ncell = n[0] * n[1] * n[2]
+        b.begin_step()
+        niter = 0
+        conv_flag = ncell
+        prev1 = float(np.float32(2.0) * np.float32(n[0]) * np.float32(n[1]) * np.float32(n[2]))
+        prev0 = prev1
+        conv_criterion = min(int(CONVERGENCE_FRACTION * n[0] * n[1] * n[2]), (b.nsrc - 1) // 3)
+        self.log = []
+        self.visited = 0
+        t_sweep = t_chem = 0.0
+        sum1 = b.sum_xh_intermed()
+        converged = False
+        while True:
+            sum0 = float(np.float32(ncell)) - sum1
+            rel1 = abs(sum1 - prev1) / sum1 if sum1 > 0.0 else 1.0
+            rel0 = abs(sum0 - prev0) / sum0 if sum0 > 0.0 else 1.0
+            if self.log:
+                self.log[-1].update(rel_change_xh1=rel1, rel_change_xh0=rel0, sum_xh1=sum1)
+            if conv_flag < conv_criterion or (rel1 < CONVERGENCE_FRACTION and rel0 < CONVERGENCE_FRACTION):
+                b.accept()
+                converged = True
+                break
+            if niter > MAX_OUTER_ITER:
+                break
+            prev1, prev0 = sum1, sum0
+            niter += 1
+            t0 = _time.perf_counter()
+            self.set_rates_to_zero()
+            self.pass_all_sources(niter, dt)
+            t1 = _time.perf_counter()
+            conv_flag, sum1 = self.global_pass(dt)
+            t2 = _time.perf_counter()
+            t_sweep += t1 - t0
+            t_chem += t2 - t1
+            self.log.append(dict(conv_flag=conv_flag, sum_nbox=self.sum_nbox_all,
+                                 photon_loss=self.photon_loss_all))
+        return dict(niter=niter, converged=converged, conv_flag=conv_flag, conv_criterion=conv_criterion,
+                    sum_nbox_all=self.sum_nbox_all, photon_loss_all=self.photon_loss_all,
+                    visited=self.visited, seconds_sweep=t_sweep, seconds_chem=t_chem, log=self.log)

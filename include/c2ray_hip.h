@@ -1,0 +1,168 @@
+/* c2ray_hip.h -- C ABI of the MI355X-native C2-Ray evolve hot path.
+ *
+ * This is the drop-in boundary.  The reference (garrelt/C2-Ray3Dm) exposes the path as Fortran
+ * module procedures over module-global arrays; a Fortran shim (c2-ray3dm_amd/fortran/
+ * evolve_hip.F90) keeps those names and forwards to the entry points below through
+ * ISO_C_BINDING.  Every entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *  - plain C types only; all grids are column-major (Fortran order) N1 x N2 x N3, 1-based mesh
+ *    positions, exactly the storage of the reference's allocatable module arrays;
+ *  - "host" entry points take host pointers owned by the caller (the Fortran driver) and never
+ *    retain them past the call; "dev" entry points work on device buffers that are either owned
+ *    by the context or bound from outside (c2r_bind_device_buffers: e.g. torch tensors);
+ *  - every function returns 0 on success, a negative C2R_E* code or a positive hipError_t on
+ *    failure (the reference has no status returns: it warns and continues, evolve.F90:230,
+ *    evolve_point.F90:541; non-convergence is therefore reported in c2r_report, not as an error);
+ *  - one context per process and GPU; calls on one context are serialised by the caller, as
+ *    evolve3D is in the reference (called from the main thread of each MPI rank).
+ */
+#ifndef C2RAY_HIP_H
+#define C2RAY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C2R_OK            0
+#define C2R_EINVAL      (-1)   /* bad argument */
+#define C2R_ESTATE      (-2)   /* call order: tables / step scalars / sources / buffers missing */
+#define C2R_ENOMEM      (-3)
+#define C2R_ECALLBACK   (-4)   /* the all-reduce callback failed */
+
+#define C2R_MAX_ITER_LOG 128
+
+typedef struct c2r_ctx c2r_ctx;
+
+/* Numerical parameters of the path: compile-time `parameter`s in the reference, run-time here
+ * so nothing is baked in.  c2r_default_params() fills the shipped values (include/
+ * c2ray_constants.h cites each defining line). */
+typedef struct c2r_params {
+    int32_t mesh[3];                 /* sizes.f90:33  mesh(1:3) */
+    int32_t device;                  /* HIP device ordinal */
+    int32_t subboxsize;              /* c2ray_parameters.f90:54 */
+    int32_t max_subbox;              /* c2ray_parameters.f90:61 */
+    int32_t numtau;                  /* radiation_sizes.f90:14 (tables hold numtau+1 entries) */
+    int32_t max_outer_iter;          /* evolve.F90:228 (100) */
+    int32_t max_chem_iter;           /* evolve_point.F90:541 (400) */
+    int32_t reserved0;
+    double  epsilon;                 /* c2ray_parameters.f90:31 */
+    double  convergence_fraction;    /* :25 */
+    double  minimum_fractional_change; /* :34 */
+    double  minimum_fraction_of_atoms; /* :40 */
+    double  loss_fraction;           /* :67 */
+    double  max_coldensh;            /* evolve_point.F90:95 */
+    double  tau_photo_limit;         /* radiation_photoionrates.F90:244 */
+    double  sigma_HI;                /* cgsphotoconstants.f90:24 */
+    double  minlogtau, dlogtau;      /* radiation_tables.F90:45-47 */
+    double  weight_floor;            /* column_density.f90:289 */
+    double  sqrt2, sqrt3, pi;        /* column_density.f90:52-53, mathconstants.f90:21 */
+    double  abu_c;                   /* abundances.f90:26 */
+    double  bh00, albpow, colh0, temph0; /* cgsconstants.f90:64-86 */
+    double  S_star;                  /* radiation_sed_parameters: table normalisation */
+    size_t  scratch_bytes;           /* cap on per-source sweep scratch (0 = 1/4 of free HBM) */
+} c2r_params;
+
+/* What evolve3D reports through its log (evolve.F90:205-210,249-251,559-566), per call. */
+typedef struct c2r_report {
+    int32_t niter;                   /* outer iterations executed */
+    int32_t converged;               /* 1: xh updated (evolve.F90:218); 0: gave up, xh unchanged (:228) */
+    int64_t conv_flag;               /* non-converged cells of the last global pass */
+    int64_t conv_criterion;          /* evolve.F90:162 */
+    int64_t sum_nbox_all;            /* evolve_source.F90:46 */
+    int64_t visited;                 /* (cell,source) pairs executed over all iterations (this rank) */
+    double  photon_loss_all;         /* evolve_data.F90 photon_loss_all(1) */
+    double  seconds_sweep;           /* wall time inside pass_all_sources, all iterations */
+    double  seconds_chem;            /* wall time inside global_pass, all iterations */
+    int32_t chem_not_converged;      /* cells that hit max_chem_iter in the last global pass */
+    int32_t reserved0;
+    int64_t it_conv_flag[C2R_MAX_ITER_LOG];
+    int64_t it_sum_nbox[C2R_MAX_ITER_LOG];
+    double  it_rel_change_xh1[C2R_MAX_ITER_LOG];   /* Test-2 values seen before iteration k+2 */
+    double  it_rel_change_xh0[C2R_MAX_ITER_LOG];
+    double  it_sum_xh1[C2R_MAX_ITER_LOG];          /* sum(xh_intermed) after global pass k+1 */
+} c2r_report;
+
+/* Sum `count` doubles at device pointer `buf` over all ranks, in place, on `stream`
+ * (replaces MPI_ALLREDUCE of phih_grid, evolve.F90:599-602).  Return 0 on success. */
+typedef int (*c2r_allreduce_fn)(void *user, void *dev_buf, size_t count, void *hip_stream);
+
+/* ---- life cycle ------------------------------------------------------------------------ */
+int  c2r_default_params(c2r_params *p);
+/* evolve_ini (evolve_data.F90:73): allocates the device mirrors of the hot-path arrays. */
+int  c2r_create(c2r_ctx **ctx, const c2r_params *p);
+void c2r_destroy(c2r_ctx *ctx);
+const char *c2r_last_error(const c2r_ctx *ctx);
+/* Run on a caller-provided hipStream_t (NULL = the context's own stream). */
+int  c2r_set_stream(c2r_ctx *ctx, void *hip_stream);
+
+/* ---- inputs the driver owns ------------------------------------------------------------ */
+/* stellar_photo_thick_table / _thin_table (0:NumTau,1), built once by rad_ini
+ * (radiation_tables.F90:95-126). n = numtau+1. */
+int  c2r_set_tables(c2r_ctx *ctx, const double *thick, const double *thin, int32_t n);
+/* Per-time-step scalars the driver recomputes before every evolve3D call (C2Ray.F90:367-376):
+ * dr(1:3), vol (grid.F90, cosmology.F90:161-193), coldensh_LLS (LLS.F90:178-182),
+ * clumping (clumping_module.F90:74), temper_val (temperature_module.F90:34). */
+int  c2r_set_step(c2r_ctx *ctx, const double dr[3], double vol, double coldensh_LLS,
+                  float clumping, double temper);
+/* srcpos(3,NumSrc) (1-based, may lie outside the mesh: wrapped at use) and
+ * NormFlux_stellar(1:NumSrc) (sourceprops.F90:121-123,167-168). */
+int  c2r_set_sources(c2r_ctx *ctx, const int32_t *srcpos, const double *normflux, int32_t nsrc);
+/* MPI rank / size of the static source distribution (master_slave.F90:85:
+ * do ns1=1+rank,NumSrc,npr) and the collective that replaces MPI_ALLREDUCE. */
+int  c2r_set_rank(c2r_ctx *ctx, int32_t rank, int32_t nranks, c2r_allreduce_fn fn, void *user);
+
+/* ---- device buffers -------------------------------------------------------------------- */
+/* Use caller-owned device arrays (N^3 each; ndens f32, the rest f64) instead of the
+ * context's own.  Any pointer may be NULL to keep the context's buffer. */
+int  c2r_bind_device_buffers(c2r_ctx *ctx, void *ndens, void *xh, void *xh_av,
+                             void *xh_intermed, void *phih_grid);
+/* which: 0 ndens, 1 xh, 2 xh_av, 3 xh_intermed, 4 phih_grid */
+int  c2r_device_ptr(c2r_ctx *ctx, int32_t which, void **ptr);
+int  c2r_upload(c2r_ctx *ctx, int32_t which, const void *host);
+int  c2r_download(c2r_ctx *ctx, int32_t which, void *host);
+
+/* ---- the path, piecewise (device-resident data) ------------------------------------------ */
+/* set_rates_to_zero (evolve.F90:430-440) */
+int  c2r_zero_rates(c2r_ctx *ctx);
+/* pass_all_sources (evolve.F90:444-495) for this rank's sources: do_grid_static
+ * (master_slave.F90:74-96) -> do_source (evolve_source.F90:58) -> evolve0D
+ * (evolve_point.F90:83) -> cinterp (column_density.f90:29) + photoion_rates
+ * (radiation_photoionrates.F90:71).  Reads ndens, xh_av; accumulates into phih_grid.
+ * Does NOT reduce across ranks (c2r_allreduce_rates does). */
+int  c2r_pass_sources(c2r_ctx *ctx, double *photon_loss, int64_t *sum_nbox, int64_t *visited);
+/* mpi_accumulate_grid_quantities (evolve.F90:577-616) through the callback; no-op for 1 rank. */
+int  c2r_allreduce_rates(c2r_ctx *ctx);
+/* do_source (evolve_source.F90:58) for ONE source ns (1-based), for tests: optionally returns
+ * the source's full coldensh_out grid (evolve_data.F90 coldensh_out) to a host array. */
+int  c2r_do_source(c2r_ctx *ctx, int32_t ns, double *coldensh_out_host, double *photon_loss_src,
+                   int32_t *nbox, int64_t *visited);
+/* global_pass (evolve.F90:499-573): evolve0D_global + do_chemistry + doric over the mesh.
+ * sum_xh1 (optional) receives sum(xh_intermed) after the pass. */
+int  c2r_global_pass(c2r_ctx *ctx, double dt, int64_t *conv_flag, double *sum_xh1);
+/* sum() of one of the device arrays (evolve.F90:183) */
+int  c2r_sum(c2r_ctx *ctx, int32_t which, double *sum);
+
+/* ---- the path, whole ------------------------------------------------------------------- */
+/* evolve3D(time,dt,restart=0) (evolve.F90:83-281) on the device-resident arrays. */
+int  c2r_evolve3d_dev(c2r_ctx *ctx, double dt, c2r_report *rep);
+/* evolve3D on the driver's host arrays: uploads ndens and xh, runs the loop, downloads xh,
+ * xh_av, xh_intermed, phih_grid (any output pointer may be NULL).  This is what the Fortran
+ * shim calls. */
+int  c2r_evolve3d(c2r_ctx *ctx, double dt, const float *ndens, double *xh, double *xh_av,
+                  double *xh_intermed, double *phih_grid, c2r_report *rep);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* HIP-event timing of the two hot kernels on the context's stream (bench.py's roofline leg).
+ * enable!=0 resets the counters.  Times are sums of per-launch event intervals. */
+int  c2r_profile(c2r_ctx *ctx, int32_t enable);
+int  c2r_profile_read(c2r_ctx *ctx, double *sweep_ms, int64_t *sweep_launches,
+                      double *chem_ms, int64_t *chem_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C2RAY_HIP_H */

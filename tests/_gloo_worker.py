@@ -1,0 +1,36 @@
+"""Worker of tests/test_host.py::test_two_ranks_gloo_equals_one_rank (one process per rank)."""
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch.distributed as dist   # noqa: E402
+import __graft_entry__ as g        # noqa: E402
+from tests._util import F, load_case, oracle_for, load_tables   # noqa: E402
+from tests._cpu_backend import OracleBackend                   # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    pkg = g.load_package()
+    tables = load_tables()
+    m, a = load_case("evolve32_std_bubbles")
+    s = m["steps"]["step001"]
+    b = OracleBackend(oracle_for(s, tables, m["n"]), F(a["step001_ndens"]), F(a["step001_xh_before"]),
+                      s["srcpos"], s["normflux"])
+    r = pkg.Evolve(b, comm=dist).evolve3D(0.0, s["dt"], 0)
+    import torch
+    mine = torch.from_numpy(b.xh.copy())
+    gathered = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(gathered, mine)
+    if dist.get_rank() == 0:
+        np.savez(sys.argv[1], niter=r["niter"], sum_nbox_all=r["sum_nbox_all"],
+                 photon_loss_all=r["photon_loss_all"], xh=b.xh, phih=b.phih_grid,
+                 xh_rank1=gathered[1].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,213 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+  (a) the golden fixtures recorded from the compiled reference, and
+  (b) the oracle on the same seeded inputs.
+Tolerances: integer results (nbox, visited, conv_flag, niter) exact; f64 results differ from the
+reference only through the device's log10/exp (not correctly rounded on either side):
+  coldensh_out  rel 1e-11,  Gamma  rel 1e-9,  photon loss  rel 1e-10,  xh  abs 1e-9
+-- far inside the 1e-5 on xh that BASELINE.json's north_star asks for."""
+import numpy as np
+import pytest
+from tests._util import F, load_case, oracle_for, expand, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL_CD, TOL_GAMMA, TOL_LOSS, TOL_X = 1e-11, 1e-9, 1e-10, 1e-9
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+def make_backend(pkg, tables, m, n, nd, xh, **kw):
+    b = pkg.HipBackend(n, *tables, device=0, **kw)
+    b.set_step((m["dr1"], m["dr2"], m["dr3"]), m["vol"], m["coldensh_LLS"], m["clumping"])
+    b.set_sources(m["srcpos"], m["normflux"])
+    b.set_rank(0, 1)
+    b.load(ndens=nd, xh=xh)
+    return b
+
+
+def gamma_err(got, ref):
+    """relative error of Gamma where it matters, absolute floor far below any physical rate"""
+    return relerr(got, ref, floor=1e-60)
+
+
+@pytest.mark.parametrize("name", ["sweep32_std_x999", "sweep33_std_x999", "sweep32_bubbles"])
+def test_sweep_vs_reference_fixture(pkg, tables, name):
+    m, a = load_case(name)
+    n = m["n"]
+    nd, xh = F(expand(a["ndens"], n)), F(expand(a["xh"], n))
+    b = make_backend(pkg, tables, m, n, nd, xh)
+    b.begin_step(); b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    assert nbox == m["sum_nbox"]
+    assert abs(loss - m["photon_loss"]) <= TOL_LOSS * abs(m["photon_loss"])
+    phih = b.fetch("phih_grid")
+    ref = F(a["phih"])
+    assert np.count_nonzero(phih) == m["phih_nonzero"]
+    assert np.array_equal(phih == 0, ref == 0)
+    assert gamma_err(phih, ref) < TOL_GAMMA
+    # one source alone: its full coldensh_out grid
+    ns = m["ns_dump"]
+    b.zero_rates()
+    nb1, l1, v1, cd = b.do_source(ns, want_coldens=True)
+    cref = F(a["coldensh_out"])
+    assert np.array_equal(cd == 0, cref == 0)
+    assert relerr(cd, cref) < TOL_CD
+    b.close()
+
+
+def test_sweep64_planes_vs_reference_fixture(pkg, tables):
+    m, a = load_case("sweep64_bubbles")
+    n = m["n"]
+    nd, xh = F(expand(a["ndens"], n)), F(expand(a["xh"], n))
+    b = make_backend(pkg, tables, m, n, nd, xh)
+    b.begin_step(); b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    assert nbox == m["sum_nbox"]
+    assert abs(loss - m["photon_loss"]) <= TOL_LOSS * abs(m["photon_loss"])
+    p3 = b.fetch("phih_grid").reshape((n, n, n), order="F")
+    s = [(p - 1) % n for p in m["srcpos"][m["ns_dump"] - 1]]
+    assert gamma_err(p3[s[0]], a["phih_px"]) < TOL_GAMMA
+    assert gamma_err(p3[:, s[1]], a["phih_py"]) < TOL_GAMMA
+    assert gamma_err(p3[:, :, s[2]], a["phih_pz"]) < TOL_GAMMA
+    assert np.count_nonzero(p3) == m["phih_nonzero"]
+    assert abs(float(np.sum(p3, dtype=np.longdouble)) / m["phih_sum"] - 1) < 1e-10
+    b.close()
+
+
+@pytest.mark.parametrize("name,native", [("evolve32_onesrc", True), ("evolve32_onesrc", False),
+                                         ("evolve32_std_bubbles", True), ("evolve32_std_bubbles", False),
+                                         ("evolve64_std_bubbles", True)])
+def test_evolve3d_vs_reference_fixture(pkg, tables, name, native):
+    """Whole time steps: same outer-iteration count, same non-converged-cell sequence, xh within
+    TOL_X of the Fortran.  native=True runs the loop inside the C ABI (c2r_evolve3d_dev, what the
+    Fortran shim calls), native=False the Python host mirror (Evolve.evolve3D)."""
+    m, a = load_case(name)
+    n = m["n"]
+    for tag, s in m["steps"].items():
+        xh0 = F(a[tag + "_xh_before"]); nd = F(a[tag + "_ndens"])
+        b = make_backend(pkg, tables, s, n, nd, xh0)
+        if native:
+            rep = b.evolve3d_native(s["dt"])
+            niter, conv_seq = rep.niter, list(rep.it_conv_flag[:rep.niter])
+            nbox_all, loss_all, converged = rep.sum_nbox_all, rep.photon_loss_all, rep.converged
+            rel = np.array([rep.it_rel_change_xh1[:niter], rep.it_rel_change_xh0[:niter]]).T
+        else:
+            ev = pkg.Evolve(b)
+            r = ev.evolve3D(0.0, s["dt"], 0)
+            niter, conv_seq = r["niter"], [e["conv_flag"] for e in r["log"]]
+            nbox_all, loss_all, converged = r["sum_nbox_all"], r["photon_loss_all"], r["converged"]
+            rel = np.array([[e["rel_change_xh1"], e["rel_change_xh0"]] for e in r["log"]])
+        assert converged
+        assert niter == s["niter"], (tag, niter, s["niter"])
+        assert conv_seq == s["log"]["nonconv"]
+        assert nbox_all == s["sum_nbox_all"]
+        assert abs(loss_all - s["photon_loss_all"]) <= TOL_LOSS * abs(s["photon_loss_all"]) + 1e-300
+        assert relerr(rel, np.array(s["log"]["test2"][1:])) < 1e-7
+        xh = b.fetch("xh")
+        assert np.max(np.abs(xh - F(a[tag + "_xh_after"]))) < TOL_X
+        if tag + "_phih_grid" in a:
+            assert gamma_err(b.fetch("phih_grid"), F(a[tag + "_phih_grid"])) < TOL_GAMMA
+            assert np.max(np.abs(b.fetch("xh_av") - F(a[tag + "_xh_av"]))) < TOL_X
+        b.close()
+
+
+def _random_case(n, nsrc, seed, pkg):
+    rng = np.random.default_rng(seed)
+    tp = pkg.TestProblem(n)
+    s = tp.step(1)
+    nd = (s["ndens"] * np.exp(0.5 * rng.standard_normal(n ** 3))).astype(np.float32)
+    xh = np.clip(10.0 ** rng.uniform(-4, 0, n ** 3) * 0.9999, 1e-6, 0.9999)
+    # smooth the ionized field a little: blocks of 4^3 share a value, like bubbles
+    x3 = xh.reshape((n, n, n), order="F")
+    c = max(1, n // 8)
+    x3[:] = np.repeat(np.repeat(np.repeat(x3[::c, ::c, ::c], c, 0), c, 1), c, 2)[:n, :n, :n]
+    pos, nf = pkg.seeded_sources(n, nsrc, seed=seed)
+    return s, nd, F(x3), pos, nf
+
+
+@pytest.mark.parametrize("n,nsrc,seed", [(24, 7, 1), (40, 20, 2), (48, 33, 3), (21, 5, 4)])
+def test_pass_and_global_vs_oracle_seeded(pkg, tables, n, nsrc, seed):
+    """Seeded random density / ionization / sources at meshes the fixtures do not cover
+    (odd and even, sources anywhere incl. next to the periodic seam)."""
+    s, nd, xh, pos, nf = _random_case(n, nsrc, seed, pkg)
+    o = oracle_for(s, tables, n)
+    phih_o = np.zeros(o.ncell)
+    oloss, onb, ovis = o.pass_sources(nd, xh, phih_o, pos, nf)
+    b = make_backend(pkg, tables, dict(s, srcpos=pos, normflux=nf), n, nd, xh)
+    b.begin_step(); b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    assert (nbox, vis) == (onb, ovis)
+    assert abs(loss - oloss) <= TOL_LOSS * abs(oloss) + 1e-300
+    phih = b.fetch("phih_grid")
+    assert np.array_equal(phih == 0, phih_o == 0)
+    assert gamma_err(phih, phih_o) < TOL_GAMMA
+    xav, xint = xh.copy(), xh.copy()
+    oconv = o.global_pass(s["dt"], nd, xh, xav, xint, phih_o)
+    conv, sum1 = b.global_pass(s["dt"])
+    assert conv == oconv
+    assert np.max(np.abs(b.fetch("xh_intermed") - xint)) < TOL_X
+    assert np.max(np.abs(b.fetch("xh_av") - xav)) < TOL_X
+    assert abs(sum1 - o.sum(xint)) < 1e-9 * n ** 3
+    b.close()
+
+
+def test_small_scratch_batches_equal_one_batch(pkg, tables):
+    """Sources processed in several batches (scratch cap) give the same rates as one batch."""
+    n, nsrc = 32, 12
+    s, nd, xh, pos, nf = _random_case(n, nsrc, 9, pkg)
+    res = []
+    for cap in (0, 1):      # 0 = everything at once; 1 byte = one source per batch
+        b = make_backend(pkg, tables, dict(s, srcpos=pos, normflux=nf), n, nd, xh, scratch_bytes=cap)
+        b.begin_step(); b.zero_rates()
+        out = b.pass_sources()
+        res.append((out, b.fetch("phih_grid")))
+        b.close()
+    assert res[0][0][1:] == res[1][0][1:]
+    assert abs(res[0][0][0] - res[1][0][0]) <= 1e-13 * abs(res[0][0][0])
+    assert relerr(res[0][1], res[1][1], floor=1e-60) < 1e-12
+
+
+def test_edge_cases(pkg, tables):
+    """No sources; a zero-flux source; a source outside [1,N] (wrapped); error codes."""
+    n = 16
+    s, nd, xh, pos, nf = _random_case(n, 3, 5, pkg)
+    o = oracle_for(s, tables, n)
+    # zero-flux + out-of-range position
+    pos2 = np.array([[5, 5, 5], [n + 3, -2, 2 * n + 1], [7, 9, 11]], dtype=np.int32)
+    nf2 = np.array([1e8, 1e9, 0.0])
+    phih_o = np.zeros(o.ncell)
+    oloss, onb, ovis = o.pass_sources(nd, xh, phih_o, pos2, nf2)
+    b = make_backend(pkg, tables, dict(s, srcpos=pos2, normflux=nf2), n, nd, xh)
+    b.begin_step(); b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    assert (nbox, vis) == (onb, ovis)
+    assert abs(loss - oloss) <= TOL_LOSS * abs(oloss)
+    assert gamma_err(b.fetch("phih_grid"), phih_o) < TOL_GAMMA
+    # no sources at all: nothing traced, rates stay zero, the global pass still runs
+    b.set_sources(np.zeros((0, 3), dtype=np.int32), np.zeros(0))
+    b.zero_rates()
+    assert b.pass_sources() == (0.0, 0, 0)
+    assert not b.fetch("phih_grid").any()
+    with pytest.raises(pkg.C2RayHipError):
+        b.do_source(1)
+    b.close()
+
+
+def test_runs_are_reproducible_to_rounding(pkg, tables):
+    """Gamma is accumulated with f64 atomics: the order of equal-distance sources may differ
+    between runs, everything else is deterministic (loss, nbox, coldens are bit-identical)."""
+    n, nsrc = 32, 16
+    s, nd, xh, pos, nf = _random_case(n, nsrc, 11, pkg)
+    b = make_backend(pkg, tables, dict(s, srcpos=pos, normflux=nf), n, nd, xh)
+    outs = []
+    for _ in range(2):
+        b.begin_step(); b.zero_rates()
+        r = b.pass_sources()
+        outs.append((r, b.fetch("phih_grid")))
+    assert outs[0][0] == outs[1][0]
+    assert relerr(outs[0][1], outs[1][1], floor=1e-60) < 1e-14
+    b.close()
