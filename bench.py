@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the C2-Ray evolve hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2]/[3], SURVEY.md s8d state B): 256^3 mesh of the reference's test
+problem (uniform mean IGM at z=9, pre-ionised to x=0.999 so every source traces out to its
+photon-loss limit), S=1000 seeded sources (positions uniform, rates log-uniform 1e54..1e57 /s).
+A "step" is ONE outer iteration of evolve3D (evolve.F90:170-272): zero the rates, sweep every
+source (sharded over the GPUs, static 1+rank,NumSrc,npr), all-reduce Gamma over RCCL, global
+chemistry pass.  The total source count is fixed, so --gpus N is STRONG scaling.
+
+metric = cells-traced/s = N^3 x S x K / wall  (BASELINE.json).  Inputs are resident in HBM before the
+timed region.  One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+SWEEP_BYTES_PER_VISIT = 28       # ndens 4 + xh_av 8 + phih_grid 16 (RMW)
+CHEM_BYTES_PER_CELL = 44
+
+
+def cpu_baseline(mesh, x_init, srcpos, normflux, budget_s=20.0):
+    """The CPU path timed on this box's host cores, on a bounded sample (the first few sources
+    of the same list, same mesh and state).  Prefers the compiled reference (oracle/_ref, OpenMP
+    build -- TIMING only), else the serial C oracle ("port")."""
+    from c2ray3dm_amd.testproblem import write_source_file
+    ncores = os.cpu_count() or 1
+    exe = os.path.join(ROOT, "oracle", "_ref", "N%d" % mesh, "omp", "ref_driver")
+    per_src_guess = (mesh ** 3) * 2.1e-7 * 0.65           # ~209 ns per visited cell
+    if os.path.exists(exe):
+        threads = min(8, ncores)                          # the reference's scheme is at most 8-way
+        nsamp = int(max(1, min(len(normflux), budget_s / (per_src_guess / min(threads, 3.0)))))
+        d = tempfile.mkdtemp(prefix="c2r_cpu_")
+        try:
+            os.makedirs(d + "/results"); os.makedirs(d + "/dump")
+            open(d + "/answers", "w").write("n\nn\n1\n7\n10\n1\n")
+            write_source_file(d + "/test_sources.dat", srcpos[:nsamp], normflux[:nsamp])
+            open(d + "/driver.nml", "w").write("&ctl mode='sweep', x_init=%.17g, ns_dump=0, nrep=1 /\n" % x_init)
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+            subprocess.check_call([exe, "answers"], cwd=d, env=env, stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.DEVNULL, timeout=600)
+            kv = dict(l.split() for l in open(d + "/dump/step001_sweep.txt"))
+            sec = float(kv["seconds_per_pass"])
+            return {"value": mesh ** 3 * nsamp / sec, "unit": "cells-traced/s", "cores": threads,
+                    "kind": "reference", "seconds": sec,
+                    "sample": "compiled Fortran reference (OpenMP build, %d threads), do_source over the first "
+                              "%d of the bench's sources on the same %d^3 mesh and x=%.3f state, sum_nbox=%s"
+                              % (threads, nsamp, mesh, x_init, kv["sum_nbox"])}
+        except Exception as exc:          # fall through to the port
+            sys.stderr.write("cpu_baseline: reference run failed (%r), using the C port\n" % (exc,))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    from oracle.oracle import Oracle
+    from tests._util import load_tables
+    from c2ray3dm_amd.testproblem import TestProblem
+    tp = TestProblem(mesh); s = tp.step(1)
+    nd, xh = tp.fields(1, x_init)
+    o = Oracle(mesh, s["dr1"], s["vol"], s["coldensh_LLS"], *load_tables())
+    nsamp = int(max(1, min(len(normflux), budget_s / per_src_guess)))
+    phih = np.zeros(o.ncell)
+    t0 = time.perf_counter()
+    loss, nb, vis = o.pass_sources(nd, xh, phih, srcpos[:nsamp], normflux[:nsamp])
+    sec = time.perf_counter() - t0
+    return {"value": mesh ** 3 * nsamp / sec, "unit": "cells-traced/s", "cores": 1, "kind": "port",
+            "seconds": sec,
+            "sample": "serial C oracle, pass over the first %d of the bench's sources on the same %d^3 mesh and "
+                      "x=%.3f state, sum_nbox=%d, visited=%d" % (nsamp, mesh, x_init, nb, vis)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mesh", type=int, default=256)
+    ap.add_argument("--sources", type=int, default=1000)
+    ap.add_argument("--x-init", type=float, default=0.999)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--native-loop", action="store_true",
+                    help="time whole evolve3D calls through c2r_evolve3d_dev instead of single iterations")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    from tests._util import load_tables
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n, S = args.mesh, args.sources
+    tp = pkg.TestProblem(n)
+    s = tp.step(1)
+    nd, xh = tp.fields(1, args.x_init)
+    srcpos, normflux = pkg.seeded_sources(n, S)
+    b = pkg.HipBackend(n, *load_tables(), device=local_rank)
+    b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], s["clumping"], s["temper"])
+    b.set_sources(srcpos, normflux)
+    b.load(ndens=nd, xh=xh)
+    ev = pkg.Evolve(b, comm=dist if world > 1 else None)
+    b.begin_step()
+
+    def one_step(k):
+        ev.set_rates_to_zero()
+        ev.pass_all_sources(k, s["dt"])
+        return ev.global_pass(s["dt"])
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        one_step(k)
+    sync()
+    b.profile(True)
+    ev.visited = 0
+    nbox_hist = []
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(k)
+        nbox_hist.append(ev.sum_nbox_all)
+    sync()
+    dt_wall = time.perf_counter() - t0
+    prof = b.profile_read()
+    # max over ranks of the wall time; sum over ranks of the visited pairs
+    stats = torch.tensor([dt_wall, float(ev.visited), prof["sweep_ms"], float(prof["sweep_launches"])],
+                         dtype=torch.float64, device=b.device)
+    if world > 1:
+        tmax = stats.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_wall = float(tmax[0]); visited_all = float(tsum[1])
+    else:
+        visited_all = float(stats[1])
+
+    if rank == 0:
+        value = float(n) ** 3 * S * args.steps / dt_wall
+        vis_rank = float(ev.visited)
+        launches = max(1, prof["sweep_launches"])
+        sweep_s = prof["sweep_ms"] * 1e-3
+        achieved = SWEEP_BYTES_PER_VISIT * vis_rank / sweep_s / 1e9 if sweep_s > 0 else 0.0
+        out = {
+            "metric": "cells-traced/sec (grid^3 x sources / wallclock) on 256^3",
+            "value": value, "unit": "cells-traced/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt_wall / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d^3 mesh, %d sources (seeded), reference test problem at z=9 pre-ionised to "
+                                   "x=%.3f, one evolve3D outer iteration per step (sweep all sources + all-reduce + "
+                                   "global chemistry pass)" % (n, S, args.x_init),
+                       "mesh": n, "sources": S, "sources_per_gpu": len(pkg.static_source_share(S, 0, world)),
+                       "parallelism": "sources sharded over %d GPU(s), RCCL all-reduce of Gamma" % world,
+                       "visited_cell_sources_per_step": visited_all / args.steps,
+                       "visited_per_s": visited_all / dt_wall,
+                       "mean_subboxes_per_source": [x / S for x in nbox_hist]},
+            "roofline": {"bound": "hbm", "kernel": "k_sweep_shell", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "algorithmic_bytes_per_launch": SWEEP_BYTES_PER_VISIT * vis_rank / launches,
+                         "avg_launch_ms": prof["sweep_ms"] / launches, "launches": prof["sweep_launches"],
+                         "chem_kernel_ms_per_launch": prof["chem_ms"] / max(1, prof["chem_launches"]),
+                         "chem_achieved_GBs": (CHEM_BYTES_PER_CELL * float(n) ** 3 * prof["chem_launches"] /
+                                               (prof["chem_ms"] * 1e-3) / 1e9) if prof["chem_ms"] > 0 else 0.0,
+                         "note": "f64 VALU (divide/log10/sqrt) binds this kernel before HBM does; see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, args.x_init, srcpos, normflux)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    b.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,13 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    # One HIP runtime per process: torch bundles its own libamdhip64; importing it first makes
+    # this library bind to the same copy (loading the system copy first leaves torch unable to
+    # see the GPU).  A Fortran/C host without torch simply uses the system runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise C2RayHipError(
             "%s not found: build it with `make -C c2-ray3dm_amd/csrc` (or __graft_entry__.build()); "
