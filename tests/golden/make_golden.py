@@ -230,6 +230,41 @@ def case_sweep(name, n, sources, x_init=None, dens_seed=None, xfield=None, ns_du
     print(name, "sum_nbox", kv["sum_nbox"], "loss", kv["photon_loss"], "phih_nonzero", kv["phih_nonzero"])
 
 
+def read_sm3d(path, dtype):
+    """Fortran sequential records: int32 12 | 3 x int32 | int32 12 | int32 nbytes | data | int32 nbytes"""
+    raw = open(path, "rb").read()
+    n = np.frombuffer(raw, dtype=np.int32, count=3, offset=4)
+    nb = int(np.frombuffer(raw, dtype=np.int32, count=1, offset=20)[0])
+    data = np.frombuffer(raw, dtype=dtype, count=nb // np.dtype(dtype).itemsize, offset=24)
+    return data.reshape(tuple(int(v) for v in n), order="F")
+
+
+def case_refrun(name, n, sources):
+    """The reference's OWN program (C2Ray.F90, all 14 slices x 10 steps) on its test problem:
+    the outputs a user of the reference sees.  Used by the drop-in integration test."""
+    d = "/tmp/c2ray_golden_refrun"
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d + "/results")
+    open(d + "/answers", "w").write(ANSWERS)
+    with open(d + "/test_sources.dat", "w") as f:
+        f.write("%d\n" % len(sources))
+        for (i, j, k, flux) in sources:
+            f.write("%d %d %d %.17e 0.0\n" % (i, j, k, flux))
+    exe = os.path.join(REF, "N%d" % n, "serial", "c2ray_test")
+    subprocess.check_call([exe, "answers"], cwd=d, stdout=subprocess.DEVNULL)
+    outs = sorted(f for f in os.listdir(d + "/results") if f.startswith("xfrac3D_"))
+    nonconv = [int(l.split(":")[1]) for l in open(d + "/results/C2Ray.log") if "Number of non-converged points:" in l]
+    keep = [outs[0], outs[len(outs) // 2], outs[-1]]
+    arrays = {"xfrac_" + f[len("xfrac3D_"):-4]: read_sm3d(d + "/results/" + f, np.float64) for f in keep}
+    arrays.update({"ionrates_" + f[len("xfrac3D_"):-4]:
+                   read_sm3d(d + "/results/IonRates3D_" + f[len("xfrac3D_"):], np.float32) for f in keep[-1:]})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    json.dump({"n": n, "outputs": outs, "kept": keep, "nonconv": nonconv, "total_outer_iterations": len(nonconv),
+               "sources": [list(s) for s in sources], "answers": ANSWERS},
+              open(os.path.join(HERE, name + ".json"), "w"), indent=1)
+    print(name, "outputs", len(outs), "outer iterations", len(nonconv))
+
+
 def main():
     which = set(sys.argv[1:])
     def want(k): return not which or k in which
@@ -238,6 +273,7 @@ def main():
     # config[0] of BASELINE.json: the reference's own test problem, 32^3, one source, cold start
     if want("evolve32"): case_evolve("evolve32_onesrc", 32, SRC_ONE, 12, [1, 2, 3, 12])
     # pre-ionised gas, the 10-source list (positions wrap periodically): sub-box growth to the limit
+    if want("refrun32"): case_refrun("refrun32_onesrc", 32, SRC_ONE)
     if want("sweep32"): case_sweep("sweep32_std_x999", 32, SRC_STD, x_init=0.999)
     if want("sweep33"): case_sweep("sweep33_std_x999", 33, SRC_STD, x_init=0.999, dens_seed=33)
     # perturbed density + ionized bubbles: exercises max_coldensh stop, thin/thick cells, clipping
