@@ -66,6 +66,7 @@ SYMBOLS = [
     ("c2r_sum", C.c_int, [_P, _I32, C.POINTER(_D)]),
     ("c2r_evolve3d_dev", C.c_int, [_P, _D, C.POINTER(Report)]),
     ("c2r_evolve3d", C.c_int, [_P, _D, _P, _P, _P, _P, _P, C.POINTER(Report)]),
+    ("c2r_selftest", C.c_int, [_P, C.POINTER(_I64)]),
     ("c2r_profile", C.c_int, [_P, _I32]),
     ("c2r_profile_read", C.c_int, [_P, C.POINTER(_D), C.POINTER(_I64), C.POINTER(_D), C.POINTER(_I64)]),
 ]

@@ -25,6 +25,8 @@ struct Ctx {
     size_t ncell = 0;
     // grids: 0 ndens(f32) 1 xh 2 xh_av 3 xh_intermed 4 phih_grid
     void *grid[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // (x,y)-transposed replicas for the +-x faces of the sweep (owned): ndens_T, xh_av_T, phih_T
+    float *d_ndens_T = nullptr; double *d_xhav_T = nullptr, *d_phih_T = nullptr;
     bool  own[5] = {false, false, false, false, false};
     double *d_thick = nullptr, *d_thin = nullptr;
     bool have_tables = false, have_step = false;
@@ -38,11 +40,11 @@ struct Ctx {
     // sweep geometry
     int hl[3], hr[3], nbox_max = 0, Qmax = 0, R = 0, P = 1;
     size_t PP = 1;
-    int bps_max = 0;
+    int tiles_cap = 0;          // ceil(P*P/256): most tiles any face plane needs
     // sweep scratch (one batch of sources)
     int batch_cap = 0;
     double *d_planes = nullptr;
-    int *d_srcpos_b = nullptr; double *d_nflux_b = nullptr;
+    int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr;
     int *d_active[2] = {nullptr, nullptr};
     int *d_nactive = nullptr; int *h_nactive = nullptr;     // pinned
     double *d_loss_partial = nullptr, *d_loss_acc = nullptr, *d_final_loss = nullptr;
@@ -82,11 +84,11 @@ size_t grid_bytes(const Ctx *ctx, int which) { return ctx->ncell * (which == 0 ?
 
 void free_sweep_scratch(Ctx *ctx)
 {
-    hipFree(ctx->d_planes); hipFree(ctx->d_srcpos_b); hipFree(ctx->d_nflux_b);
+    hipFree(ctx->d_planes); hipFree(ctx->d_srcpos_b); hipFree(ctx->d_srcw_b); hipFree(ctx->d_nflux_b);
     hipFree(ctx->d_active[0]); hipFree(ctx->d_active[1]);
     hipFree(ctx->d_loss_partial); hipFree(ctx->d_loss_acc); hipFree(ctx->d_final_loss);
     hipFree(ctx->d_final_nbox);
-    ctx->d_planes = nullptr; ctx->d_srcpos_b = nullptr; ctx->d_nflux_b = nullptr;
+    ctx->d_planes = nullptr; ctx->d_srcpos_b = nullptr; ctx->d_srcw_b = nullptr; ctx->d_nflux_b = nullptr;
     ctx->d_active[0] = ctx->d_active[1] = nullptr;
     ctx->d_loss_partial = ctx->d_loss_acc = ctx->d_final_loss = nullptr; ctx->d_final_nbox = nullptr;
     ctx->batch_cap = 0;
@@ -103,7 +105,7 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
 {
     if (want <= ctx->batch_cap) return C2R_OK;
     free_sweep_scratch(ctx);
-    const size_t per_src = 2 * 6 * ctx->PP * sizeof(double) + (size_t)ctx->bps_max * sizeof(double) + 64;
+    const size_t per_src = 2 * 6 * ctx->PP * sizeof(double) + (size_t)6 * ctx->tiles_cap * sizeof(double) + 64;
     size_t budget = ctx->prm.scratch_bytes;
     if (budget == 0) {
         size_t fr = 0, tot = 0;
@@ -111,17 +113,44 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
         budget = fr / 4;
     }
     int cap = (int)std::min<size_t>((size_t)want, std::max<size_t>(1, budget / per_src));
+    cap = std::min(cap, 65535);                 // grid.z of k_sweep_shell
     HIP_TRY(hipMalloc(&ctx->d_planes, (size_t)cap * 2 * 6 * ctx->PP * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_srcpos_b, (size_t)cap * 3 * sizeof(int)));
+    HIP_TRY(hipMalloc(&ctx->d_srcw_b, (size_t)cap * 3 * sizeof(int)));
     HIP_TRY(hipMalloc(&ctx->d_nflux_b, (size_t)cap * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_active[0], (size_t)cap * sizeof(int)));
     HIP_TRY(hipMalloc(&ctx->d_active[1], (size_t)cap * sizeof(int)));
-    HIP_TRY(hipMalloc(&ctx->d_loss_partial, (size_t)cap * ctx->bps_max * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_loss_partial, (size_t)cap * 6 * ctx->tiles_cap * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_loss_acc, (size_t)cap * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_final_loss, (size_t)cap * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_final_nbox, (size_t)cap * sizeof(int)));
     ctx->batch_cap = cap;
     return C2R_OK;
+}
+
+// udiv() precondition: the divisor's significand must not be all ones (Markstein's exception)
+bool udiv_ok(double d)
+{
+    uint64_t u; memcpy(&u, &d, sizeof u);
+    return std::isnormal(d) && (u & 0xFFFFFFFFFFFFFULL) != 0xFFFFFFFFFFFFFULL;
+}
+
+// The cells face f owns in shell q, clipped to the trace limits (see FaceRect)
+FaceRect face_rect(const Ctx *ctx, int f, int q)
+{
+    FaceRect r{};
+    const int axis = 2 - (f >> 1), pd = (f & 1) ? -q : q;
+    if (pd < -ctx->hl[axis] || pd > ctx->hr[axis]) return r;
+    const int ua = (axis == 0) ? 1 : 0, va = (axis == 2) ? 1 : 2;
+    const int qa = (axis == 0) ? q - 1 : q;          // x faces own |a| < q
+    const int qb = (axis == 2) ? q : q - 1;          // y and x faces own |b| < q
+    const int a_lo = std::max(-qa, -ctx->hl[ua]), a_hi = std::min(qa, ctx->hr[ua]);
+    const int b_lo = std::max(-qb, -ctx->hl[va]), b_hi = std::min(qb, ctx->hr[va]);
+    if (a_hi < a_lo || b_hi < b_lo) return r;
+    r.a_lo = a_lo; r.wa = a_hi - a_lo + 1; r.b_lo = b_lo; r.wb = b_hi - b_lo + 1;
+    r.magic = r.wa > 1 ? (unsigned)((1ULL << 32) / (unsigned)r.wa + 1ULL) : 0u;
+    r.ntiles = (int)(((long long)r.wa * r.wb + kBlock - 1) / kBlock);
+    return r;
 }
 
 KParams make_kparams(const Ctx *ctx)
@@ -135,10 +164,13 @@ KParams make_kparams(const Ctx *ctx)
     k.max_coldensh = p.max_coldensh; k.tau_limit = p.tau_photo_limit;
     k.minlogtau = p.minlogtau; k.dlogtau = p.dlogtau; k.numtau = p.numtau; k.numtau_d = (double)p.numtau;
     k.eps = p.epsilon;
+    k.inv_dlogtau = 1.0 / p.dlogtau; k.inv_dr0 = 1.0 / ctx->dr[0];
+    k.exact_udiv = udiv_ok(p.dlogtau) && udiv_ok(ctx->dr[0]);
     k.R = ctx->R; k.P = ctx->P; k.PP = ctx->PP;
     k.ndens = (const float *)ctx->grid[0]; k.xh_av = (const double *)ctx->grid[2]; k.phih = (double *)ctx->grid[4];
+    k.ndens_T = ctx->d_ndens_T; k.xh_av_T = ctx->d_xhav_T; k.phih_T = ctx->d_phih_T;
     k.thick = ctx->d_thick; k.thin = ctx->d_thin;
-    k.srcpos = ctx->d_srcpos_b; k.normflux = ctx->d_nflux_b; k.planes = ctx->d_planes;
+    k.srcpos = ctx->d_srcpos_b; k.srcw = ctx->d_srcw_b; k.normflux = ctx->d_nflux_b; k.planes = ctx->d_planes;
     return k;
 }
 
@@ -169,12 +201,16 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
                 std::vector<double> *loss_out)
 {
     const c2r_params &p = ctx->prm;
-    std::vector<int> h_pos(3 * (size_t)count), h_act, h_fn(count, 0);
+    std::vector<int> h_pos(3 * (size_t)count), h_posw(3 * (size_t)count), h_act, h_fn(count, 0);
     std::vector<double> h_nf(count), h_fl(count, 0.0);
     const bool can_trace = ctx->hr[2] > 0 && ctx->hl[2] > 0;       // while condition, evolve_source.F90:130-131
     for (int i = 0; i < count; ++i) {
         const int g = ctx->rank + (first + i) * ctx->nranks;       // master_slave.F90:85
-        for (int d = 0; d < 3; ++d) h_pos[3 * i + d] = ctx->srcpos[3 * (size_t)g + d];
+        for (int d = 0; d < 3; ++d) {
+            h_pos[3 * i + d] = ctx->srcpos[3 * (size_t)g + d];
+            const int m = (h_pos[3 * i + d] - 1) % p.mesh[d];
+            h_posw[3 * i + d] = m < 0 ? m + p.mesh[d] : m;         // evolve_point.F90:122 for the source cell
+        }
         h_nf[i] = ctx->nflux[g];
         const double flux = h_nf[i] * p.S_star;
         if (flux > p.loss_fraction * flux && can_trace) h_act.push_back(i);
@@ -183,6 +219,7 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
     int n_active = (int)h_act.size();
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemcpyAsync(ctx->d_srcpos_b, h_pos.data(), h_pos.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->d_srcw_b, h_posw.data(), h_posw.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ctx->d_nflux_b, h_nf.data(), h_nf.size() * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ctx->d_final_loss, h_fl.data(), h_fl.size() * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ctx->d_final_nbox, h_fn.data(), h_fn.size() * sizeof(int), hipMemcpyHostToDevice, st));
@@ -207,24 +244,23 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
         for (int q = q0; q <= q1; ++q) {
             ShellArgs sa{};
             sa.q = q;
-            const int w = 2 * q + 1;
-            sa.tiles_a = (w + kTileA - 1) / kTileA; sa.tiles_b = (w + kTileB - 1) / kTileB;
-            sa.bps = 6 * sa.tiles_a * sa.tiles_b;
+            sa.tiles_max = 0;
+            for (int f = 0; f < 6; ++f) { sa.face[f] = face_rect(ctx, f, q); sa.tiles_max = std::max(sa.tiles_max, sa.face[f].ntiles); }
+            if (sa.tiles_max == 0) continue;
             sa.has_boundary = 0;
             for (int d = 0; d < 3; ++d) {
                 sa.boxR[d] = boxR[d]; sa.boxL[d] = boxL[d];
                 if (boxR[d] <= q || boxL[d] <= q) sa.has_boundary = 1;
             }
             sa.alam = (double)((float)(q - 1) + 0.5f) / (double)(float)q;
+            sa.dp2 = (double)q * (double)q; sa.inv_dp2 = 1.0 / sa.dp2;
             sa.active = ctx->d_active[cur]; sa.loss_partial = ctx->d_loss_partial; sa.dbg_cdout = dbg;
-            const size_t nblk = (size_t)n_active * sa.bps;
-            if (nblk > 0x7fffffffULL) FAIL(C2R_EINVAL, "sweep grid too large: lower scratch_bytes to shrink the batch");
             prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
-            hipLaunchKernelGGL(k_sweep_shell, dim3((unsigned)nblk), dim3(kTileA, kTileB), 0, st, k, sa);
+            hipLaunchKernelGGL(k_sweep_shell, dim3(sa.tiles_max, 6, n_active), dim3(kBlock), 0, st, k, sa);
             prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
             if (sa.has_boundary)
                 hipLaunchKernelGGL(k_loss_reduce, dim3(n_active), dim3(256), 0, st, ctx->d_active[cur],
-                                   ctx->d_loss_partial, sa.bps, ctx->d_loss_acc);
+                                   ctx->d_loss_partial, 6 * sa.tiles_max, ctx->d_loss_acc);
         }
         const int can_grow = (p.subboxsize * nbox < ctx->hr[2]) && (p.subboxsize * nbox < ctx->hl[2]);
         hipLaunchKernelGGL(k_box_decide, dim3(1), dim3(1024), 0, st, ctx->d_active[cur], n_active,
@@ -247,6 +283,31 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
         HIP_TRY(hipMemcpyAsync(loss_out->data(), ctx->d_final_loss, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
+    return C2R_OK;
+}
+
+// +-x faces read (x,y)-transposed replicas so that their waves, which run along y, touch unit
+// stride: refresh the replicas before a pass, fold their Gamma back after it.
+int sweep_prepare(Ctx *ctx)
+{
+    const c2r_params &p = ctx->prm;
+    const dim3 g((p.mesh[0] + 31) / 32, (p.mesh[1] + 31) / 32, p.mesh[2]);
+    hipLaunchKernelGGL((k_transpose_xy<float, false>), g, dim3(256), 0, ctx->stream, p.mesh[0], p.mesh[1], p.mesh[2],
+                       (const float *)ctx->grid[0], ctx->d_ndens_T);
+    hipLaunchKernelGGL((k_transpose_xy<double, false>), g, dim3(256), 0, ctx->stream, p.mesh[0], p.mesh[1], p.mesh[2],
+                       (const double *)ctx->grid[2], ctx->d_xhav_T);
+    HIP_TRY(hipMemsetAsync(ctx->d_phih_T, 0, grid_bytes(ctx, 4), ctx->stream));
+    return C2R_OK;
+}
+
+int sweep_finish(Ctx *ctx)
+{
+    const c2r_params &p = ctx->prm;
+    // phih_T is [k][i][j]: transposing it back swaps the roles of the two mesh extents
+    const dim3 g((p.mesh[1] + 31) / 32, (p.mesh[0] + 31) / 32, p.mesh[2]);
+    hipLaunchKernelGGL((k_transpose_xy<double, true>), g, dim3(256), 0, ctx->stream, p.mesh[1], p.mesh[0], p.mesh[2],
+                       (const double *)ctx->d_phih_T, (double *)ctx->grid[4]);
+    HIP_TRY(hipGetLastError());
     return C2R_OK;
 }
 
@@ -310,6 +371,10 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     ctx->ncell = (size_t)p->mesh[0] * p->mesh[1] * p->mesh[2];
     for (int w = 0; w < 5; ++w) { HIP_TRY(hipMalloc(&ctx->grid[w], grid_bytes(ctx, w))); ctx->own[w] = true; }
     HIP_TRY(hipMemset(ctx->grid[4], 0, grid_bytes(ctx, 4)));      // evolve_data.F90:76 phih_grid=0.0
+    if (ctx->ncell >= (1ULL << 31)) FAIL(C2R_EINVAL, "mesh too large for 32-bit cell indices");
+    HIP_TRY(hipMalloc(&ctx->d_ndens_T, grid_bytes(ctx, 0)));
+    HIP_TRY(hipMalloc(&ctx->d_xhav_T, grid_bytes(ctx, 2)));
+    HIP_TRY(hipMalloc(&ctx->d_phih_T, grid_bytes(ctx, 4)));
     HIP_TRY(hipMalloc(&ctx->d_thick, (size_t)(p->numtau + 1) * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_thin, (size_t)(p->numtau + 1) * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_nactive, sizeof(int)));
@@ -334,7 +399,7 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     for (int d = 0; d < 3; ++d) reach = std::max(reach, std::max(ctx->hl[d], ctx->hr[d]));
     ctx->Qmax = std::min(ctx->nbox_max * p->subboxsize, reach);
     ctx->R = ctx->Qmax; ctx->P = 2 * ctx->R + 1; ctx->PP = (size_t)ctx->P * ctx->P;
-    ctx->bps_max = 6 * ((ctx->P + kTileA - 1) / kTileA) * ((ctx->P + kTileB - 1) / kTileB);
+    ctx->tiles_cap = (int)((ctx->PP + kBlock - 1) / kBlock);
     return C2R_OK;
 }
 
@@ -346,6 +411,7 @@ void c2r_destroy(c2r_ctx *c)
     free_sweep_scratch(ctx);
     for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
     hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_nactive);
+    hipFree(ctx->d_ndens_T); hipFree(ctx->d_xhav_T); hipFree(ctx->d_phih_T);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
     hipFree(ctx->d_photon_loss); hipFree(ctx->d_sum_nbox); hipFree(ctx->d_sum_partial); hipFree(ctx->d_sum_out);
     hipFree(ctx->d_conv); hipFree(ctx->d_chemfail); hipFree(ctx->d_dbg); hipFree(ctx->d_pair);
@@ -474,6 +540,7 @@ int c2r_pass_sources(c2r_ctx *c, double *photon_loss, int64_t *sum_nbox, int64_t
     if (nloc > 0) {
         rc = ensure_sweep_scratch(ctx, nloc);
         if (rc) return rc;
+        if ((rc = sweep_prepare(ctx))) return rc;
         std::vector<int> nb;
         for (int first = 0; first < nloc; first += ctx->batch_cap) {
             const int count = std::min(ctx->batch_cap, nloc - first);
@@ -481,6 +548,7 @@ int c2r_pass_sources(c2r_ctx *c, double *photon_loss, int64_t *sum_nbox, int64_t
             if (rc) return rc;
             for (int v : nb) vis += visited_for_nbox(ctx, v);
         }
+        if ((rc = sweep_finish(ctx))) return rc;
     }
     HIP_TRY(hipMemcpyAsync(&ctx->h_sc->photon_loss, ctx->d_photon_loss, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&ctx->h_sc->sum_nbox, ctx->d_sum_nbox, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -522,7 +590,9 @@ int c2r_do_source(c2r_ctx *c, int32_t ns, double *cd_host, double *loss, int32_t
     const int sr = ctx->rank, sn = ctx->nranks;
     ctx->rank = 0; ctx->nranks = 1;
     std::vector<int> nb; std::vector<double> fl;
-    rc = sweep_batch(ctx, ns - 1, 1, dbg, &nb, &fl);
+    rc = sweep_prepare(ctx);
+    if (!rc) rc = sweep_batch(ctx, ns - 1, 1, dbg, &nb, &fl);
+    if (!rc) rc = sweep_finish(ctx);
     ctx->rank = sr; ctx->nranks = sn;
     if (rc) return rc;
     prof_collect(ctx);
@@ -671,6 +741,26 @@ int c2r_evolve3d(c2r_ctx *c, double dt, const float *ndens, double *xh, double *
     if (xh_av && (rc = c2r_download(c, 2, xh_av))) return rc;
     if (xh_int && (rc = c2r_download(c, 3, xh_int))) return rc;
     if (phih && (rc = c2r_download(c, 4, phih))) return rc;
+    return C2R_OK;
+}
+
+int c2r_selftest(c2r_ctx *c, int64_t *mismatches)
+{
+    if (!c || !mismatches) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    unsigned int *d_bad = nullptr;
+    HIP_TRY(hipMalloc(&d_bad, sizeof(unsigned int)));
+    HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(unsigned int), ctx->stream));
+    const int n = 1 << 22;
+    const double divisors[4] = {ctx->prm.dlogtau, ctx->have_step ? ctx->dr[0] : 1.37848875056274974e+24, 49.0, 16129.0};
+    for (int i = 0; i < 4; ++i)
+        hipLaunchKernelGGL(k_selftest_div, dim3(n / 256), dim3(256), 0, ctx->stream, n, divisors[i], 1.0 / divisors[i],
+                           0x1234567ULL * (i + 1), d_bad);
+    unsigned int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    hipFree(d_bad);
+    *mismatches = bad;
     return C2R_OK;
 }
 

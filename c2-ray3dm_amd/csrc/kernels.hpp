@@ -15,9 +15,7 @@
 
 namespace c2r {
 
-constexpr int kTileA = 64;   // lanes of a wave run along the fast plane axis
-constexpr int kTileB = 4;    // one wave per plane row, 4 rows per 256-thread block
-constexpr int kBlock = kTileA * kTileB;
+constexpr int kBlock = 256;   // threads per block; a face's owned rectangle is flattened into tiles of 256
 
 struct KParams {
     int n[3];
@@ -27,37 +25,91 @@ struct KParams {
     double coldensh_LLS;
     double sigma, wfloor, sqrt2, sqrt3, fourpi;
     double max_coldensh, tau_limit, minlogtau, dlogtau, numtau_d, eps;
+    // correctly rounded reciprocals of launch-invariant divisors (exact division in 3 FMAs, see udiv)
+    double inv_dlogtau, inv_dr0;
+    int exact_udiv;            // 0: a divisor fails the precondition of udiv -> plain IEEE division
     int numtau;
     int R, P;                  // plane centre offset and pitch (P = 2R+1)
     size_t PP;                 // P*P
-    const float  *ndens;
+    const float  *ndens;       // [k][j][i]  (i fastest)        evolve_point.F90:146
     const double *xh_av;
     double *phih;
+    const float  *ndens_T;     // [k][i][j]  (j fastest): replicas read by the +-x faces, whose
+    const double *xh_av_T;     //            waves run along y
+    double *phih_T;            // Gamma of the +-x faces, added back after the pass
     const double *thick, *thin;
-    const int    *srcpos;      // 3 x S_batch (unwrapped, 1-based)
+    const int    *srcpos;      // 3 x S_batch (unwrapped, 1-based: cinterp's real(i0) needs it)
+    const int    *srcw;        // 3 x S_batch wrapped to 0..N-1
     const double *normflux;    // S_batch
     double *planes;            // [S_batch][2][6][P][P]
 };
 
+// Cells of one cube face that this face OWNS in shell q, as a rectangle in plane coordinates
+// (a,b), already clipped to the trace limits; flattened row-major into tiles of 256 threads.
+struct FaceRect {
+    int a_lo, wa, b_lo, wb;
+    unsigned magic;            // t / wa == umulhi(t, magic) for t < wa*wb (0: wa == 1)
+    int ntiles;                // 0: face absent from this shell
+};
+
 struct ShellArgs {
     int q;
-    int tiles_a, tiles_b, bps;   // tiles per face plane, blocks per source
-    int boxR[3], boxL[3];        // limits of the current sub-box (last_r/last_l - srcpos)
     int has_boundary;
+    int tiles_max;               // grid.x; loss_partial is [n_active][6][tiles_max]
+    int boxR[3], boxL[3];        // limits of the current sub-box (last_r/last_l - srcpos)
     double alam;                 // (q-0.5)/q, column_density.f90:112 (sign cancels)
+    double dp2, inv_dp2;         // q*q and its correctly rounded reciprocal
+    FaceRect face[6];
     const int *active;           // compacted list of local source indices
-    double *loss_partial;        // [n_active][bps]
+    double *loss_partial;
     double *dbg_cdout;           // optional N^3 coldensh_out of the (single) source, else null
 };
 
 __device__ __forceinline__ int pmod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
+
+// ---- IEEE-exact f64 division without the generic expansion ---------------------------------------
+// hipcc expands a/b into div_scale x2, rcp, 4 fma, mul, fma, div_fmas, div_fixup.  The scaling and
+// fix-up only matter for operands near the exponent limits; every quotient of this kernel is far
+// inside the normal range, so the bare Newton-Raphson core gives the same correctly rounded
+// result in 8 instructions.  c2r_selftest compares both forms bit for bit on the device.
+__device__ __forceinline__ double rcp_nr(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double fdiv(double n, double d)
+{
+    const double r = rcp_nr(d);
+    const double q = n * r;
+    const double rem = __builtin_fma(-d, q, n);
+    return __builtin_fma(rem, r, q);
+}
+__device__ __forceinline__ double frcp(double d)        // 1.0/d
+{
+    const double r = rcp_nr(d);
+    const double rem = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(rem, r, r);
+}
+// n/d for a launch-invariant d with rd = RN(1/d) from the host (Markstein: q' = RN(q + r*rd) with
+// r = n - q*d exact is the correctly rounded quotient unless d's significand is all ones; the
+// host checks that and clears exact_udiv otherwise).
+__device__ __forceinline__ double udiv(double n, double d, double rd, int exact)
+{
+    if (!exact) return n / d;
+    const double q = n * rd;
+    const double r = __builtin_fma(-q, d, n);
+    return __builtin_fma(r, rd, q);
+}
 
 // radiation_photoionrates.F90:184-228  set_tau_table_positions + read_table
 __device__ __forceinline__ double table_lookup(const double *__restrict__ tab, double tau,
                                                const KParams &p)
 {
     const double lt = log10(fmax(1.0e-20, tau));
-    const double od = fmin(p.numtau_d, fmax(0.0, 1.0 + (lt - p.minlogtau) / p.dlogtau));
+    const double od = fmin(p.numtau_d, fmax(0.0, 1.0 + udiv(lt - p.minlogtau, p.dlogtau, p.inv_dlogtau, p.exact_udiv)));
     const int ip = (int)od;
     const double res = od - (double)ip;
     const int ip1 = min(p.numtau, ip + 1);
@@ -80,7 +132,7 @@ __device__ __forceinline__ double photoion(const KParams &p, double cd_in, doubl
         p_cell = nflux * (tau_out - tau_in) * table_lookup(p.thin, tau_in, p);
         p_out = p_in - p_cell;
     }
-    return p_cell / vol_ph;
+    return fdiv(p_cell, vol_ph);
 }
 
 // Deterministic block sum (fixed order): wave shuffles, then the 4 wave sums in order.
@@ -136,43 +188,44 @@ __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0
 // x-face (y,z).  A cell on an edge/corner of the cube belongs to the face of highest priority
 // (z over y over x: the branch order of cinterp); its owner also stores it into the other
 // faces' planes, which read it in shell q+1.
+// grid = (tiles, 6 faces, active sources); a wave runs along plane axis a, which is the
+// unit-stride axis of the arrays the face reads (x for z/y faces, y in the transposed replicas
+// for x faces).
 __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
 {
     __shared__ double sm[4];
-    const int blk = blockIdx.x;
-    const int sl = blk / sa.bps;
-    int r = blk - sl * sa.bps;
-    const int s = sa.active[sl];
-    const int tiles = sa.tiles_a * sa.tiles_b;
-    const int face = r / tiles;  r -= face * tiles;
-    const int tb = r / sa.tiles_a, ta = r - tb * sa.tiles_a;
-    const int q = sa.q;
-    const int axis = 2 - (face >> 1);            // 2:z 1:y 0:x
-    const int sg = (face & 1) ? -1 : 1;
-    const int pd = sg * q;
-    const int a = -q + ta * kTileA + (int)threadIdx.x;
-    const int b = -q + tb * kTileB + (int)threadIdx.y;
-
-    // mesh-axis deltas of this cell (selects, not a runtime-indexed array: that would spill)
-    const int d0 = (axis == 0) ? pd : a;
-    const int d1 = (axis == 2) ? b : ((axis == 1) ? pd : a);
-    const int d2 = (axis == 2) ? pd : b;
-    bool valid = (abs(a) <= q) && (abs(b) <= q);
-    valid = valid && d0 >= -p.hl[0] && d0 <= p.hr[0] && d1 >= -p.hl[1] && d1 <= p.hr[1] &&
-            d2 >= -p.hl[2] && d2 <= p.hr[2];
-    const bool owner = (axis == 2) || (axis == 1 && abs(b) < q) || (axis == 0 && abs(a) < q && abs(b) < q);
-
+    const int face = blockIdx.y;
+    const int sl = blockIdx.z;
+    const int tile = blockIdx.x;
+    const FaceRect fr = sa.face[face];
     double loss = 0.0;
-    if (valid && owner) {
+    const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
+    const unsigned bi = fr.magic ? __umulhi(t, fr.magic) : t;
+    if (tile < fr.ntiles && bi < (unsigned)fr.wb) {
+        const int s = sa.active[sl];
+        const int q = sa.q;
+        const int axis = 2 - (face >> 1);            // 2:z 1:y 0:x
+        const int pd = (face & 1) ? -q : q;
+        const int a = fr.a_lo + (int)(t - bi * (unsigned)fr.wa);
+        const int b = fr.b_lo + (int)bi;
+        // mesh-axis deltas and the source coordinates seen along (a,b); all block-uniform selects
+        const int d0 = (axis == 0) ? pd : a;
+        const int d1 = (axis == 2) ? b : ((axis == 1) ? pd : a);
+        const int d2 = (axis == 2) ? pd : b;
         const int s0 = p.srcpos[3 * s + 0], s1 = p.srcpos[3 * s + 1], s2 = p.srcpos[3 * s + 2];
-        const int su = (axis == 0) ? s1 : s0;      // source coordinate on plane axis a / b
+        const int su = (axis == 0) ? s1 : s0;
         const int sv = (axis == 2) ? s1 : s2;
-        const int i = pmod(s0 + d0 - 1, p.n[0]);
-        const int j = pmod(s1 + d1 - 1, p.n[1]);
-        const int k = pmod(s2 + d2 - 1, p.n[2]);
-        const size_t id = (size_t)i + (size_t)p.n[0] * ((size_t)j + (size_t)p.n[1] * (size_t)k);
-        const double xav_raw = p.xh_av[id];
-        const double nd = (double)p.ndens[id];
+        // periodic wrap (evolve_point.F90:122): |d| <= N/2, so one conditional step each way
+        int c0 = p.srcw[3 * s + 0] + d0, c1 = p.srcw[3 * s + 1] + d1, c2 = p.srcw[3 * s + 2] + d2;
+        c0 += (c0 < 0) ? p.n[0] : 0;  c0 -= (c0 >= p.n[0]) ? p.n[0] : 0;
+        c1 += (c1 < 0) ? p.n[1] : 0;  c1 -= (c1 >= p.n[1]) ? p.n[1] : 0;
+        c2 += (c2 < 0) ? p.n[2] : 0;  c2 -= (c2 >= p.n[2]) ? p.n[2] : 0;
+        const unsigned id_n = (unsigned)c0 + (unsigned)p.n[0] * ((unsigned)c1 + (unsigned)p.n[1] * (unsigned)c2);
+        const unsigned id_t = (unsigned)c1 + (unsigned)p.n[1] * ((unsigned)c0 + (unsigned)p.n[0] * (unsigned)c2);
+        const bool xf = (axis == 0);
+        const unsigned id = xf ? id_t : id_n;
+        const double xav_raw = (xf ? p.xh_av_T : p.xh_av)[id];
+        const double nd = (double)(xf ? p.ndens_T : p.ndens)[id];
 
         // upstream corners in plane q-1 of this face (zero weight outside |.| <= q-1)
         const int sga = a < 0 ? -1 : 1, sgb = b < 0 ? -1 : 1;
@@ -180,68 +233,116 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         const double *prev = p.planes + ((size_t)s * 2 + ((q - 1) & 1)) * 6 * p.PP + (size_t)face * p.PP;
         const int qm = q - 1;
         const bool ina = abs(a) <= qm, inam = abs(am) <= qm, inb = abs(b) <= qm, inbm = abs(bm) <= qm;
-        const double c1 = (inam && inbm) ? prev[(size_t)(bm + p.R) * p.P + (am + p.R)] : 0.0;
-        const double c2 = (ina && inbm) ? prev[(size_t)(bm + p.R) * p.P + (a + p.R)] : 0.0;
-        const double c3 = (inam && inb) ? prev[(size_t)(b + p.R) * p.P + (am + p.R)] : 0.0;
-        const double c4 = (ina && inb) ? prev[(size_t)(b + p.R) * p.P + (a + p.R)] : 0.0;
+        const int o = (b + p.R) * p.P + (a + p.R);
+        const double c1v = (inam && inbm) ? prev[o - sgb * p.P - sga] : 0.0;
+        const double c2v = (ina && inbm) ? prev[o - sgb * p.P] : 0.0;
+        const double c3v = (inam && inb) ? prev[o - sga] : 0.0;
+        const double c4v = (ina && inb) ? prev[o] : 0.0;
 
-        // cinterp, generic in (a,b,pd): the three branches differ only by which axes play (u,v)
-        const double du = (double)(float)a, dv = (double)(float)b, dp = (double)(float)pd;
-        const double uc = sa.alam * du + (double)(float)su;
-        const double vc = sa.alam * dv + (double)(float)sv;
-        const double ddu = 2.0 * fabs(uc - (double)((float)(su + am) + 0.5f * (float)sga));
-        const double ddv = 2.0 * fabs(vc - (double)((float)(sv + bm) + 0.5f * (float)sgb));
-        const double w1 = ((1. - ddu) * (1. - ddv)) * (1.0 / fmax(p.wfloor, c1 * p.sigma));
-        const double w2 = ((1. - ddv) * ddu) * (1.0 / fmax(p.wfloor, c2 * p.sigma));
-        const double w3 = ((1. - ddu) * ddv) * (1.0 / fmax(p.wfloor, c3 * p.sigma));
-        const double w4 = (ddu * ddv) * (1.0 / fmax(p.wfloor, c4 * p.sigma));
-        double cdi = (c1 * w1 + c2 * w2 + c3 * w3 + c4 * w4) / (w1 + w2 + w3 + w4);
+        // cinterp, generic in (a,b,pd): the three branches differ only by which axes play (u,v).
+        // real(int) conversions of the reference are f32 but exact (|.| < 2^24): cvt i32->f64.
+        const double du = (double)a, dv = (double)b;
+        const double uc = sa.alam * du + (double)su;
+        const double vc = sa.alam * dv + (double)sv;
+        const double ddu = 2.0 * fabs(uc - ((double)(su + am) + 0.5 * (double)sga));
+        const double ddv = 2.0 * fabs(vc - ((double)(sv + bm) + 0.5 * (double)sgb));
+        const double w1 = ((1. - ddu) * (1. - ddv)) * frcp(fmax(p.wfloor, c1v * p.sigma));
+        const double w2 = ((1. - ddv) * ddu) * frcp(fmax(p.wfloor, c2v * p.sigma));
+        const double w3 = ((1. - ddu) * ddv) * frcp(fmax(p.wfloor, c3v * p.sigma));
+        const double w4 = (ddu * ddv) * frcp(fmax(p.wfloor, c4v * p.sigma));
+        double cdi = fdiv(c1v * w1 + c2v * w2 + c3v * w3 + c4v * w4, w1 + w2 + w3 + w4);
         if (q == 1 && (abs(a) == 1 || abs(b) == 1))
             cdi = (abs(a) == 1 && abs(b) == 1) ? p.sqrt3 * cdi : p.sqrt2 * cdi;
-        double path = sqrt((du * du + dv * dv) / (dp * dp) + 1.0);
+        double path = sqrt(udiv(du * du + dv * dv, sa.dp2, sa.inv_dp2, p.exact_udiv) + 1.0);
 
         // evolve0D
         path = path * p.dr[0];
-        const double xs = p.dr[0] * (double)(float)d0;
-        const double ys = p.dr[1] * (double)(float)d1;
-        const double zs = p.dr[2] * (double)(float)d2;
+        const double xs = p.dr[0] * (double)d0;
+        const double ys = p.dr[1] * (double)d1;
+        const double zs = p.dr[2] * (double)d2;
         const double dist2 = xs * xs + ys * ys + zs * zs;
         const double vol_ph = p.fourpi * dist2 * path;
-        const double cd_in = cdi + p.coldensh_LLS * path / p.dr[0];
+        const double cd_in = cdi + udiv(p.coldensh_LLS * path, p.dr[0], p.inv_dr0, p.exact_udiv);
         const double xav1 = fmax(xav_raw, p.eps);
         const double xav0 = fmax(1.0 - xav1, p.eps);
         const double cd_out = cd_in + xav0 * nd * path;
 
         // store into this face's plane and into the planes of the faces sharing the cell
         double *cur = p.planes + ((size_t)s * 2 + (q & 1)) * 6 * p.PP;
-        cur[(size_t)face * p.PP + (size_t)(b + p.R) * p.P + (a + p.R)] = cd_out;
+        cur[(size_t)face * p.PP + o] = cd_out;
         if (axis == 2) {
             if (abs(a) == q)   // x-face (u=y=b, v=z=pd)
-                cur[(size_t)(a > 0 ? 4 : 5) * p.PP + (size_t)(pd + p.R) * p.P + (b + p.R)] = cd_out;
+                cur[(size_t)(a > 0 ? 4 : 5) * p.PP + (pd + p.R) * p.P + (b + p.R)] = cd_out;
             if (abs(b) == q)   // y-face (u=x=a, v=z=pd)
-                cur[(size_t)(b > 0 ? 2 : 3) * p.PP + (size_t)(pd + p.R) * p.P + (a + p.R)] = cd_out;
+                cur[(size_t)(b > 0 ? 2 : 3) * p.PP + (pd + p.R) * p.P + (a + p.R)] = cd_out;
         } else if (axis == 1) {
             if (abs(a) == q)   // x-face (u=y=pd, v=z=b)
-                cur[(size_t)(a > 0 ? 4 : 5) * p.PP + (size_t)(b + p.R) * p.P + (pd + p.R)] = cd_out;
+                cur[(size_t)(a > 0 ? 4 : 5) * p.PP + (b + p.R) * p.P + (pd + p.R)] = cd_out;
         }
-        if (sa.dbg_cdout) sa.dbg_cdout[id] = cd_out;
+        if (sa.dbg_cdout) sa.dbg_cdout[id_n] = cd_out;
 
         const double nflux = p.normflux[s];
         if (!(cd_in > p.max_coldensh) && nflux > 0.0) {
             double p_out;
-            const double gamma = photoion(p, cd_in, cd_out, vol_ph, nflux, p_out) / (xav0 * nd);
-            if (gamma != 0.0) atomicAdd(&p.phih[id], gamma);
+            const double gamma = fdiv(photoion(p, cd_in, cd_out, vol_ph, nflux, p_out), xav0 * nd);
+            if (gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id], gamma);
             if (sa.has_boundary) {
                 const bool bnd = d0 == sa.boxR[0] || d1 == sa.boxR[1] || d2 == sa.boxR[2] ||
                                  d0 == -sa.boxL[0] || d1 == -sa.boxL[1] || d2 == -sa.boxL[2];
-                if (bnd) loss = p_out * p.vol / vol_ph;
+                if (bnd) loss = fdiv(p_out * p.vol, vol_ph);
             }
         }
     }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
-        if (threadIdx.x == 0 && threadIdx.y == 0) sa.loss_partial[(size_t)sl * sa.bps + (blk - sl * sa.bps)] = tot;
+        if (threadIdx.x == 0)
+            sa.loss_partial[((size_t)sl * 6 + face) * sa.tiles_max + tile] = tot;
     }
+}
+
+// out[j + N1*(i + N0*k)] = in[i + N0*(j + N1*k)]: (x,y) transpose of every z-plane through LDS.
+template <typename T, bool ACCUM>
+__global__ __launch_bounds__(256) void k_transpose_xy(int n0, int n1, int n2, const T *__restrict__ in, T *__restrict__ out)
+{
+    __shared__ T tile[32][33];
+    const int k = blockIdx.z;
+    const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + tx, j = j0 + r;
+        if (i < n0 && j < n1) tile[r][tx] = in[(size_t)i + (size_t)n0 * ((size_t)j + (size_t)n1 * k)];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + tx, i = i0 + r;
+        if (i < n0 && j < n1) {
+            const size_t o = (size_t)j + (size_t)n1 * ((size_t)i + (size_t)n0 * k);
+            if (ACCUM) out[o] += tile[tx][r]; else out[o] = tile[tx][r];
+        }
+    }
+}
+
+// Device self-test of the division helpers against the compiler's IEEE division (c2r_selftest).
+__global__ void k_selftest_div(int n, double d_uniform, double rd_uniform, unsigned long long seed,
+                               unsigned int *mismatch)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long x = seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)(i + 1);
+    auto next = [&x]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    // operands spread over the magnitudes the kernels meet: 1e-40 .. 1e130
+    auto rnd = [&](double lo10, double hi10) {
+        const double u = (double)(next() >> 11) * (1.0 / 9007199254740992.0);
+        const double m = 1.0 + (double)(next() >> 11) * (1.0 / 9007199254740992.0);
+        return m * exp10(lo10 + (hi10 - lo10) * u);
+    };
+    const double num = rnd(-40, 130), den = rnd(-10, 80), w = rnd(-0.3, 7);
+    unsigned int bad = 0;
+    if (fdiv(num, den) != num / den) bad |= 1;
+    if (frcp(w) != 1.0 / w) bad |= 2;
+    const double nu = rnd(-30, 30);
+    if (udiv(nu, d_uniform, rd_uniform, 1) != nu / d_uniform) bad |= 4;
+    if (bad) atomicAdd(mismatch, 1u);
 }
 
 // Adds the block partials of one shell launch to loss_acc[source], in a fixed order.
@@ -251,7 +352,7 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const int *active, const do
     __shared__ double sm[4];
     const int sl = blockIdx.x;
     double v = 0.0;
-    for (int i = threadIdx.x; i < bps; i += 256) v += loss_partial[(size_t)sl * bps + i];
+    for (int i = threadIdx.x; i < bps; i += 256) v += loss_partial[(size_t)sl * bps + i];   // bps = 6*tiles_max
     const double tot = block_sum_256(v, sm);
     if (threadIdx.x == 0) loss_acc[active[sl]] += tot;
 }

@@ -184,6 +184,11 @@ class HipBackend:
         self._check(self.lib.c2r_evolve3d_dev(self.ctx, dt, C.byref(rep)), "c2r_evolve3d_dev")
         return rep
 
+    def selftest(self):
+        bad = C.c_int64()
+        self._check(self.lib.c2r_selftest(self.ctx, C.byref(bad)), "c2r_selftest")
+        return bad.value
+
     def profile(self, enable=True):
         self._check(self.lib.c2r_profile(self.ctx, 1 if enable else 0), "c2r_profile")
 

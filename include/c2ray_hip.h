@@ -155,6 +155,11 @@ int  c2r_evolve3d_dev(c2r_ctx *ctx, double dt, c2r_report *rep);
 int  c2r_evolve3d(c2r_ctx *ctx, double dt, const float *ndens, double *xh, double *xh_av,
                   double *xh_intermed, double *phih_grid, c2r_report *rep);
 
+/* Device self-test: the kernels' division helpers (bare Newton-Raphson core, reciprocal-multiply
+ * for launch-invariant divisors) against the compiler's IEEE division on 4x2^22 pseudo-random
+ * operand sets; *mismatches must come back 0. */
+int  c2r_selftest(c2r_ctx *ctx, int64_t *mismatches);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* HIP-event timing of the two hot kernels on the context's stream (bench.py's roofline leg).
  * enable!=0 resets the counters.  Times are sums of per-launch event intervals. */

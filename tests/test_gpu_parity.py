@@ -197,6 +197,15 @@ def test_edge_cases(pkg, tables):
     b.close()
 
 
+def test_division_helpers_are_ieee_exact(pkg, tables):
+    """The kernels replace hipcc's generic f64 division expansion by its bare Newton-Raphson core and,
+    for launch-invariant divisors, by a reciprocal multiply with an exact remainder step; both must
+    return the same bits as `/` (4 x 2^22 operand sets on the device)."""
+    b = pkg.HipBackend(8, *tables, device=0)
+    assert b.selftest() == 0
+    b.close()
+
+
 def test_runs_are_reproducible_to_rounding(pkg, tables):
     """Gamma is accumulated with f64 atomics: the order of equal-distance sources may differ
     between runs, everything else is deterministic (loss, nbox, coldens are bit-identical)."""
