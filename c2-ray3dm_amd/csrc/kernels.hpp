@@ -104,17 +104,58 @@ __device__ __forceinline__ double udiv(double n, double d, double rd, int exact)
     return __builtin_fma(r, rd, q);
 }
 
-// radiation_photoionrates.F90:184-228  set_tau_table_positions + read_table
-__device__ __forceinline__ double table_lookup(const double *__restrict__ tab, double tau,
-                                               const KParams &p)
+// log10 for the table position (radiation_photoionrates.F90:195).  The device library's log10
+// spends 105 VALU instructions on double-double arithmetic to stay under 1 ulp RELATIVE error;
+// the table position needs ABSOLUTE accuracy in log10(tau) (od = 1 + (lt+20)/0.012), which the
+// classic argument reduction x = 2^e * m, m in [sqrt(1/2), sqrt(2)), log(m) = 2 atanh(s) with
+// s = f/(2+f) and a degree-7 minimax polynomial in s^2 (the published fdlibm e_log.c / e_log10.c
+// scheme and coefficients) delivers in ~32 instructions: error <= ~1 ulp of the result, the same
+// class as glibc's log10 that the reference calls.  -DC2R_LOG10_OCML selects the library version.
+__device__ __forceinline__ double log10_pos(double x)      // x > 0, normal
 {
-    const double lt = log10(fmax(1.0e-20, tau));
+#ifdef C2R_LOG10_OCML
+    return log10(x);
+#else
+    double m = __builtin_amdgcn_frexp_mant(x);              // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;                                      // [sqrt(1/2), sqrt(2))
+    e = lo ? e - 1 : e;
+    const double dk = (double)e;
+    const double f = m - 1.0;
+    const double s = f * rcp_nr(2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
+                                        3.999999999940941908e-01);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01,
+                                        1.818357216161805012e-01), 2.857142874366239149e-01),
+                                        6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double lm = f - (hfsq - s * (hfsq + R));           // log(m)
+    // dk*log10_2hi is exact (low 32 bits of the constant are zero)
+    const double hi = __builtin_fma(lm, 4.34294481903251816668e-01, dk * 3.01029995663611771306e-01);
+    return __builtin_fma(dk, 3.69423907715893078616e-13, hi);
+#endif
+}
+
+// radiation_photoionrates.F90:184-208  set_tau_table_positions
+struct TauPos { int ip, ip1; double res; };
+__device__ __forceinline__ TauPos tau_pos(double tau, const KParams &p)
+{
+    const double lt = log10_pos(fmax(1.0e-20, tau));
     const double od = fmin(p.numtau_d, fmax(0.0, 1.0 + udiv(lt - p.minlogtau, p.dlogtau, p.inv_dlogtau, p.exact_udiv)));
-    const int ip = (int)od;
-    const double res = od - (double)ip;
-    const int ip1 = min(p.numtau, ip + 1);
-    const double t0 = tab[ip], t1 = tab[ip1];
-    return t0 + (t1 - t0) * res;
+    TauPos t;
+    t.ip = (int)od;
+    t.res = od - (double)t.ip;
+    t.ip1 = min(p.numtau, t.ip + 1);
+    return t;
+}
+// radiation_photoionrates.F90:212-228  read_table
+__device__ __forceinline__ double read_table(const double *__restrict__ tab, const TauPos &t)
+{
+    const double t0 = tab[t.ip], t1 = tab[t.ip1];
+    return t0 + (t1 - t0) * t.res;
 }
 
 // radiation_photoionrates.F90:71-179, :233-317 for NumFreqBnd=1, stellar table.
@@ -123,13 +164,14 @@ __device__ __forceinline__ double photoion(const KParams &p, double cd_in, doubl
                                            double vol_ph, double nflux, double &p_out)
 {
     const double tau_in = cd_in * p.sigma, tau_out = cd_out * p.sigma;
-    const double p_in = nflux * table_lookup(p.thick, tau_in, p);
+    const TauPos pin = tau_pos(tau_in, p);
+    const double p_in = nflux * read_table(p.thick, pin);
     double p_cell;
     if (fabs(tau_out - tau_in) > p.tau_limit) {
-        p_out = nflux * table_lookup(p.thick, tau_out, p);
+        p_out = nflux * read_table(p.thick, tau_pos(tau_out, p));
         p_cell = p_in - p_out;
     } else {
-        p_cell = nflux * (tau_out - tau_in) * table_lookup(p.thin, tau_in, p);
+        p_cell = nflux * (tau_out - tau_in) * read_table(p.thin, pin);
         p_out = p_in - p_cell;
     }
     return fdiv(p_cell, vol_ph);
