@@ -164,6 +164,12 @@ def main():
         launches = max(1, prof["sweep_launches"])
         sweep_s = prof["sweep_ms"] * 1e-3
         achieved = SWEEP_BYTES_PER_VISIT * vis_rank / sweep_s / 1e9 if sweep_s > 0 else 0.0
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "TRAFFIC.json")
+        if os.path.exists(tpath):      # PMC counters of the same command, from the latest committed profile
+            tj = json.load(open(tpath))
+            traffic = (tj["fetch_corrected_bytes_per_visit"] + tj["write_bytes_per_visit"]) * vis_rank / launches
+            traffic_note = tj["source"]
         out = {
             "metric": "cells-traced/sec (grid^3 x sources / wallclock) on 256^3",
             "value": value, "unit": "cells-traced/s", "n_gpus": world, "steps": args.steps,
@@ -179,7 +185,7 @@ def main():
                        "mean_subboxes_per_source": [x / S for x in nbox_hist]},
             "roofline": {"bound": "hbm", "kernel": "k_sweep_shell", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": SWEEP_BYTES_PER_VISIT * vis_rank / launches,
                          "avg_launch_ms": prof["sweep_ms"] / launches, "launches": prof["sweep_launches"],
                          "chem_kernel_ms_per_launch": prof["chem_ms"] / max(1, prof["chem_launches"]),
