@@ -1,0 +1,45 @@
+"""Worker of tests/test_gpu_two_ranks.py: two ranks, both on cuda:0 (the GPU box has one GPU), gloo
+for the collective (RCCL refuses two ranks on one device; the data path is otherwise the product's:
+HipBackend + Evolve with comm=torch.distributed, and the C++ loop with the all-reduce callback)."""
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch                        # noqa: E402
+import torch.distributed as dist   # noqa: E402
+import __graft_entry__ as g        # noqa: E402
+from tests._util import F, load_case, load_tables   # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    pkg = g.load_package()
+    tables = load_tables()
+    m, a = load_case("evolve32_std_bubbles")
+    s = m["steps"]["step001"]
+    out = {}
+    for mode in ("python", "native"):
+        b = pkg.HipBackend(m["n"], *tables, device=0)
+        b.set_step((s["dr1"], s["dr2"], s["dr3"]), s["vol"], s["coldensh_LLS"], s["clumping"])
+        b.set_sources(s["srcpos"], s["normflux"])
+        b.load(ndens=F(a["step001_ndens"]), xh=F(a["step001_xh_before"]))
+        ev = pkg.Evolve(b, comm=dist)          # sets rank/size and the callback in the context
+        if mode == "python":
+            r = ev.evolve3D(0.0, s["dt"], 0)
+            niter, nbox, loss, conv = r["niter"], r["sum_nbox_all"], r["photon_loss_all"], [e["conv_flag"] for e in r["log"]]
+        else:
+            rep = b.evolve3d_native(s["dt"])
+            niter, nbox, loss, conv = rep.niter, rep.sum_nbox_all, rep.photon_loss_all, list(rep.it_conv_flag[:rep.niter])
+        out[mode] = dict(niter=niter, nbox=nbox, loss=loss, conv=np.array(conv), xh=b.fetch("xh"), phih=b.fetch("phih_grid"))
+        b.close()
+    if dist.get_rank() == 0:
+        flat = {"%s_%s" % (k, kk): v for k, d in out.items() for kk, v in d.items()}
+        np.savez(sys.argv[1], **flat)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+"""GPU tests at BASELINE.json's grid sizes: direct comparison with the oracle for a handful of
+sources (the serial oracle needs ~0.2 us per visited cell, so a few sources at 128^3/256^3 take
+seconds), and size-independent properties with many sources: additivity of Gamma / photon loss /
+sub-box counts over disjoint source sets (which is also what sharding over ranks relies on) and
+periodic translation of the whole problem."""
+import numpy as np
+import pytest
+from tests._util import F, oracle_for, relerr
+
+pytestmark = pytest.mark.gpu
+TOL_GAMMA, TOL_LOSS, TOL_X = 1e-9, 1e-10, 1e-9
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+def field_case(pkg, n, seed, x_mode):
+    rng = np.random.default_rng(seed)
+    tp = pkg.TestProblem(n)
+    s = tp.step(1)
+    c = n // 16
+    coarse = rng.standard_normal((16, 16, 16))
+    g = np.repeat(np.repeat(np.repeat(coarse, c, 0), c, 1), c, 2)
+    nd = (s["ndens"] * np.exp(0.7 * g - 0.245)).astype(np.float32)
+    if x_mode == "ionized":
+        xh = np.full((n, n, n), 0.999) * (1.0 - 1e-4 * rng.random((n, n, n)))
+    else:       # ionized bubbles in neutral gas
+        xc = 10.0 ** rng.uniform(-3.7, 0.0, (16, 16, 16))
+        xh = np.clip(np.repeat(np.repeat(np.repeat(xc, c, 0), c, 1), c, 2), 1e-6, 0.9995)
+    return s, F(nd), F(xh)
+
+
+def backend(pkg, tables, s, n, nd, xh, pos, nf):
+    b = pkg.HipBackend(n, *tables, device=0)
+    b.set_step((s["dr1"], s["dr2"], s["dr3"]), s["vol"], s["coldensh_LLS"], s["clumping"])
+    b.set_sources(pos, nf)
+    b.set_rank(0, 1)
+    b.load(ndens=nd, xh=xh)
+    b.begin_step()
+    return b
+
+
+@pytest.mark.parametrize("n,nsrc,x_mode,seed", [(128, 6, "bubbles", 21), (128, 4, "ionized", 22), (256, 2, "ionized", 23)])
+def test_pass_vs_oracle_at_full_size(pkg, tables, n, nsrc, x_mode, seed):
+    s, nd, xh = field_case(pkg, n, seed, x_mode)
+    pos, nf = pkg.seeded_sources(n, nsrc, seed=seed)
+    o = oracle_for(s, tables, n)
+    phih_o = np.zeros(o.ncell)
+    oloss, onb, ovis = o.pass_sources(nd, xh, phih_o, pos, nf)
+    b = backend(pkg, tables, s, n, nd, xh, pos, nf)
+    b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    assert (nbox, vis) == (onb, ovis)
+    assert abs(loss - oloss) <= TOL_LOSS * abs(oloss) + 1e-300
+    phih = b.fetch("phih_grid")
+    assert np.array_equal(phih == 0, phih_o == 0)
+    assert relerr(phih, phih_o, floor=1e-60) < TOL_GAMMA
+    xav, xint = xh.copy(), xh.copy()
+    oconv = o.global_pass(s["dt"], nd, xh, xav, xint, phih_o)
+    conv, _ = b.global_pass(s["dt"])
+    assert conv == oconv
+    assert np.max(np.abs(b.fetch("xh_intermed") - xint)) < TOL_X
+    b.close()
+
+
+def test_additivity_over_source_sets_256(pkg, tables):
+    """Gamma, photon loss and sub-box counts of a pass are sums over sources: any split of the
+    source list (here: the two rank shares 1+rank,NumSrc,2 of master_slave.F90:85) adds up to the
+    pass over the whole list."""
+    n, nsrc = 256, 48
+    s, nd, xh = field_case(pkg, n, 31, "bubbles")
+    pos, nf = pkg.seeded_sources(n, nsrc, seed=31)
+    b = backend(pkg, tables, s, n, nd, xh, pos, nf)
+    b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    whole = b.fetch("phih_grid")
+    parts, lsum, nsum, vsum = np.zeros_like(whole), 0.0, 0, 0
+    for r in range(2):
+        idx = pkg.static_source_share(nsrc, r, 2)
+        b.set_sources(pos[idx], nf[idx])
+        b.zero_rates()
+        l, nb, v = b.pass_sources()
+        parts += b.fetch("phih_grid"); lsum += l; nsum += nb; vsum += v
+    assert (nsum, vsum) == (nbox, vis)
+    assert abs(lsum - loss) <= 1e-13 * abs(loss)
+    assert relerr(parts, whole, floor=1e-60) < 1e-13
+    b.close()
+
+
+def test_periodic_translation_128(pkg, tables):
+    """Shifting sources and fields together by a lattice vector shifts Gamma with them (the mesh is
+    periodic, evolve_point.F90:122).  Not bitwise: cinterp adds real(i0) to the crossing point, so
+    the rounding depends on the absolute source coordinate."""
+    n, nsrc = 128, 8
+    s, nd, xh = field_case(pkg, n, 41, "bubbles")
+    pos, nf = pkg.seeded_sources(n, nsrc, seed=41)
+    b = backend(pkg, tables, s, n, nd, xh, pos, nf)
+    b.zero_rates()
+    r0 = b.pass_sources()
+    g0 = b.fetch("phih_grid").reshape((n, n, n), order="F")
+    sh = (37, 101, 64)
+    roll = lambda a: np.roll(a.reshape((n, n, n), order="F"), sh, axis=(0, 1, 2))
+    b.load(ndens=F(roll(nd)), xh=F(roll(xh)))
+    b.begin_step()
+    b.set_sources(pos + np.array(sh, dtype=np.int32), nf)       # positions beyond N wrap at use
+    b.zero_rates()
+    r1 = b.pass_sources()
+    g1 = b.fetch("phih_grid").reshape((n, n, n), order="F")
+    assert r0[1:] == r1[1:]
+    assert abs(r0[0] - r1[0]) <= 1e-10 * abs(r0[0])
+    assert relerr(g1, np.roll(g0, sh, axis=(0, 1, 2)), floor=1e-60) < 1e-9
+    b.close()
+
+
+def test_evolve3d_native_equals_python_loop_128(pkg, tables):
+    """One whole time step at 128^3, 12 sources, cold start: the C++ loop behind the C ABI and the
+    Python host mirror agree on every iteration and on xh."""
+    n, nsrc = 128, 12
+    tp = pkg.TestProblem(n); s = tp.step(1)
+    nd, xh = tp.fields(1)
+    pos, nf = pkg.seeded_sources(n, nsrc, seed=5)
+    out = []
+    for native in (True, False):
+        b = backend(pkg, tables, s, n, nd, xh, pos, nf)
+        if native:
+            rep = b.evolve3d_native(s["dt"])
+            hist = (rep.niter, list(rep.it_conv_flag[:rep.niter]), rep.sum_nbox_all)
+        else:
+            r = pkg.Evolve(b).evolve3D(0.0, s["dt"], 0)
+            hist = (r["niter"], [e["conv_flag"] for e in r["log"]], r["sum_nbox_all"])
+        out.append((hist, b.fetch("xh")))
+        b.close()
+    assert out[0][0] == out[1][0]
+    assert np.max(np.abs(out[0][1] - out[1][1])) < 1e-12

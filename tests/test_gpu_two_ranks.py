@@ -1,0 +1,32 @@
+"""GPU test of the multi-rank path with two processes on the one GPU of the test box (gloo as the
+collective, see tests/_gpu2_worker.py): sources sharded 1+rank,NumSrc,npr, Gamma + {photon loss, nbox}
+all-reduced, global pass replicated -- against the reference fixture."""
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+from tests._util import F, load_case
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_match_reference(tmp_path):
+    out = tmp_path / "out.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29741",
+                           os.path.join(ROOT, "tests", "_gpu2_worker.py"), str(out)], env=env, cwd=ROOT, timeout=580)
+    got = np.load(out)
+    m, a = load_case("evolve32_std_bubbles")
+    s = m["steps"]["step001"]
+    for mode in ("python", "native"):
+        assert int(got[mode + "_niter"]) == s["niter"]
+        assert list(got[mode + "_conv"]) == s["log"]["nonconv"]
+        assert int(got[mode + "_nbox"]) == s["sum_nbox_all"]
+        assert abs(float(got[mode + "_loss"]) - s["photon_loss_all"]) <= 1e-10 * abs(s["photon_loss_all"])
+        assert np.max(np.abs(got[mode + "_xh"] - F(a["step001_xh_after"]))) < 1e-9
+        ref = F(a["step001_phih_grid"])
+        assert np.max(np.abs(got[mode + "_phih"] - ref) / np.maximum(ref, 1e-60)) < 1e-8
