@@ -117,7 +117,8 @@ def main():
     s = tp.step(1)
     nd, xh = tp.fields(1, args.x_init)
     srcpos, normflux = pkg.seeded_sources(n, S)
-    b = pkg.HipBackend(n, *load_tables(), device=local_rank)
+    thick, thin, _ = pkg.build_tables()          # rad_ini on the host (c2r_build_tables)
+    b = pkg.HipBackend(n, thick, thin, device=local_rank)
     b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], s["clumping"], s["temper"])
     b.set_sources(srcpos, normflux)
     b.load(ndens=nd, xh=xh)

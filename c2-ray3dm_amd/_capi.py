@@ -40,6 +40,14 @@ class Report(C.Structure):
                 ("it_sum_xh1", C.c_double * MAX_ITER_LOG)]
 
 
+class SedParams(C.Structure):
+    _fields_ = [("T_eff", C.c_double), ("S_star", C.c_double), ("min_freq", C.c_double),
+                ("max_freq", C.c_double), ("pl_index_cross_section", C.c_double), ("hplanck", C.c_double),
+                ("k_B", C.c_double), ("two_pi_over_c_square", C.c_double), ("R_solar", C.c_double),
+                ("pi", C.c_double), ("minlogtau", C.c_double), ("maxlogtau", C.c_double),
+                ("numtau", C.c_int32), ("reserved0", C.c_int32)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 # every symbol include/c2ray_hip.h declares: (name, restype, argtypes)
@@ -66,6 +74,8 @@ SYMBOLS = [
     ("c2r_sum", C.c_int, [_P, _I32, C.POINTER(_D)]),
     ("c2r_evolve3d_dev", C.c_int, [_P, _D, C.POINTER(Report)]),
     ("c2r_evolve3d", C.c_int, [_P, _D, _P, _P, _P, _P, _P, C.POINTER(Report)]),
+    ("c2r_default_sed", C.c_int, [C.POINTER(SedParams)]),
+    ("c2r_build_tables", C.c_int, [C.POINTER(SedParams), _P, _P, _I32, C.POINTER(_D)]),
     ("c2r_selftest", C.c_int, [_P, C.POINTER(_I64)]),
     ("c2r_profile", C.c_int, [_P, _I32]),
     ("c2r_profile_read", C.c_int, [_P, C.POINTER(_D), C.POINTER(_I64), C.POINTER(_D), C.POINTER(_I64)]),
@@ -83,7 +93,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("C2RAY_HIP_LIB") or LIB_PATH     # env override: A/B builds of the library
     # One HIP runtime per process: torch bundles its own libamdhip64; importing it first makes
     # this library bind to the same copy (loading the system copy first leaves torch unable to
     # see the GPU).  A Fortran/C host without torch simply uses the system runtime.
@@ -114,3 +124,18 @@ def default_params(mesh, device=0):
     p.mesh[:] = mesh
     p.device = device
     return p
+
+
+def build_tables(sed=None):
+    """rad_ini on the host (c2r_build_tables): returns (thick, thin, R_star)."""
+    import numpy as np
+    lib = load_library()
+    if sed is None:
+        sed = SedParams()
+        lib.c2r_default_sed(C.byref(sed))
+    n = sed.numtau + 1
+    thick, thin, r = np.empty(n), np.empty(n), C.c_double()
+    rc = lib.c2r_build_tables(C.byref(sed), thick.ctypes.data, thin.ctypes.data, n, C.byref(r))
+    if rc:
+        raise C2RayHipError("c2r_build_tables -> %d" % rc)
+    return thick, thin, r.value

@@ -327,7 +327,11 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         if (!(cd_in > p.max_coldensh) && nflux > 0.0) {
             double p_out;
             const double gamma = fdiv(photoion(p, cd_in, cd_out, vol_ph, nflux, p_out), xav0 * nd);
+#ifdef C2R_AB_PLAIN_STORE      // timing experiment only: wrong results
+            if (gamma != 0.0) (xf ? p.phih_T : p.phih)[id] = gamma;
+#else
             if (gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id], gamma);
+#endif
             if (sa.has_boundary) {
                 const bool bnd = d0 == sa.boxR[0] || d1 == sa.boxR[1] || d2 == sa.boxR[2] ||
                                  d0 == -sa.boxL[0] || d1 == -sa.boxL[1] || d2 == -sa.boxL[2];

@@ -155,6 +155,23 @@ int  c2r_evolve3d_dev(c2r_ctx *ctx, double dt, c2r_report *rep);
 int  c2r_evolve3d(c2r_ctx *ctx, double dt, const float *ndens, double *xh, double *xh_av,
                   double *xh_intermed, double *phih_grid, c2r_report *rep);
 
+/* ---- rate tables (one-time set-up; host code, needs no GPU and no context) ------------------ */
+/* SED and table parameters: compile-time `parameter`s of sed_parameters.f90, radiation_sizes.f90,
+ * radiation_tables.F90:45-47 and the cgs constant modules. */
+typedef struct c2r_sed_params {
+    double T_eff, S_star, min_freq, max_freq;   /* black body, sed_parameters.f90 */
+    double pl_index_cross_section;              /* radiation_sizes.f90:85 */
+    double hplanck, k_B, two_pi_over_c_square, R_solar, pi;
+    double minlogtau, maxlogtau;
+    int32_t numtau, reserved0;
+} c2r_sed_params;
+int  c2r_default_sed(c2r_sed_params *p);
+/* rad_ini (radiation_tables.F90:95-126): spectrum_parms, setup_scalingfactors,
+ * romberg_initialisation, spec_diag, spec_integration for the black-body source with
+ * NumFreqBnd=1.  Fills stellar_photo_thick_table / _thin_table(0:numtau); n = numtau+1.
+ * R_star (optional) returns the rescaled black-body radius the reference logs. */
+int  c2r_build_tables(const c2r_sed_params *sed, double *thick, double *thin, int32_t n, double *R_star);
+
 /* Device self-test: the kernels' division helpers (bare Newton-Raphson core, reciprocal-multiply
  * for launch-invariant divisors) against the compiler's IEEE division on 4x2^22 pseudo-random
  * operand sets; *mismatches must come back 0. */

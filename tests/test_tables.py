@@ -1,0 +1,49 @@
+"""CPU tests of the rate-table builder (c2r_build_tables: the reference's rad_ini chain,
+radiation_tables.F90 / radiation_sed_parameters.F90 / romberg.f90) against the tables dumped from
+the compiled reference.  Host code: no GPU needed."""
+import ctypes as C
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+def test_tables_equal_reference_bit_for_bit(pkg, tables):
+    thick, thin, r_star = pkg.build_tables()
+    assert np.array_equal(thick, tables[0])
+    assert np.array_equal(thin, tables[1])
+    # known answers the reference logs (radiation_tables.F90:212-215)
+    assert abs(thick[0] / 9.999999999999995e47 - 1) < 1e-15
+    assert abs(thin[0] / 4.567323859246105e47 - 1) < 1e-15
+    assert 1e11 < r_star < 1.2e11          # rescaled black-body radius (1.62 R_solar)
+
+
+def test_table_properties(pkg):
+    thick, thin, _ = pkg.build_tables()
+    # tau=0 entry integrates the bare SED to S_star; thick decreases monotonically with tau
+    assert np.all(np.diff(thick[1:]) <= 0)
+    assert thick[1] <= thick[0] and thick[-1] >= 0
+    # d(thick)/d(tau) = -thin (definition of the two integrands): check by finite differences
+    tau = np.concatenate([[0.0], 10.0 ** (-20.0 + 0.012 * np.arange(2000))])
+    k = np.arange(1200, 1700)      # tau ~ 1e-5.6 .. 2.5
+    num = -(thick[k + 1] - thick[k - 1]) / (tau[k + 1] - tau[k - 1])
+    assert np.max(np.abs(num / thin[k] - 1)) < 2e-3
+
+
+def test_other_sed_parameters(pkg):
+    """A hotter black body and a different optical-depth grid: sizes and normalisation follow."""
+    sed = pkg.SedParams()
+    pkg.load_library().c2r_default_sed(C.byref(sed))
+    sed.T_eff = 1.0e5
+    thick, thin, _ = pkg.build_tables(sed)
+    assert abs(thick[0] / sed.S_star - 1) < 1e-12
+    ref = pkg.build_tables()[0]
+    # harder spectrum: more photons survive a large optical depth
+    assert thick[1700] > ref[1700]
+    bad = pkg.SedParams()
+    pkg.load_library().c2r_default_sed(C.byref(bad))
+    assert pkg.load_library().c2r_build_tables(C.byref(bad), thick.ctypes.data, thin.ctypes.data, 17, None) != 0
