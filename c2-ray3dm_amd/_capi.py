@@ -37,7 +37,11 @@ class Report(C.Structure):
                 ("it_conv_flag", C.c_int64 * MAX_ITER_LOG), ("it_sum_nbox", C.c_int64 * MAX_ITER_LOG),
                 ("it_rel_change_xh1", C.c_double * MAX_ITER_LOG),
                 ("it_rel_change_xh0", C.c_double * MAX_ITER_LOG),
-                ("it_sum_xh1", C.c_double * MAX_ITER_LOG)]
+                ("it_sum_xh1", C.c_double * MAX_ITER_LOG),
+                ("h0_before", C.c_double), ("h1_before", C.c_double), ("h0_after", C.c_double),
+                ("h1_after", C.c_double), ("totrec", C.c_double), ("totcollisions", C.c_double),
+                ("dh0", C.c_double), ("total_ion", C.c_double), ("totalsrc", C.c_double),
+                ("photcons", C.c_double), ("it_photcons", C.c_double * MAX_ITER_LOG)]
 
 
 class SedParams(C.Structure):
@@ -71,6 +75,7 @@ SYMBOLS = [
     ("c2r_allreduce_rates", C.c_int, [_P]),
     ("c2r_do_source", C.c_int, [_P, _I32, _P, C.POINTER(_D), C.POINTER(_I32), C.POINTER(_I64)]),
     ("c2r_global_pass", C.c_int, [_P, _D, C.POINTER(_I64), C.POINTER(_D)]),
+    ("c2r_photon_sums", C.c_int, [_P, _I32, _I32, C.POINTER(_D * 4)]),
     ("c2r_sum", C.c_int, [_P, _I32, C.POINTER(_D)]),
     ("c2r_evolve3d_dev", C.c_int, [_P, _D, C.POINTER(Report)]),
     ("c2r_evolve3d", C.c_int, [_P, _D, _P, _P, _P, _P, _P, C.POINTER(Report)]),

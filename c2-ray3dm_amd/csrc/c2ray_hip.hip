@@ -53,7 +53,7 @@ struct Ctx {
     // reductions
     double *d_sum_partial = nullptr, *d_sum_out = nullptr;
     unsigned long long *d_conv = nullptr; unsigned int *d_chemfail = nullptr;
-    struct HostScalars { double sum; double photon_loss; long long sum_nbox; unsigned long long conv; unsigned int chemfail; double pair[2]; } *h_sc = nullptr;  // pinned
+    struct HostScalars { double sum; double photon_loss; long long sum_nbox; unsigned long long conv; unsigned int chemfail; double pair[2]; double four[4]; } *h_sc = nullptr;  // pinned
     double *d_dbg = nullptr, *d_pair = nullptr;
     // profiling
     bool prof = false;
@@ -381,8 +381,8 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipHostMalloc((void **)&ctx->h_nactive, sizeof(int)));
     HIP_TRY(hipMalloc(&ctx->d_photon_loss, sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_sum_nbox, sizeof(long long)));
-    HIP_TRY(hipMalloc(&ctx->d_sum_partial, kSumBlocks * sizeof(double)));
-    HIP_TRY(hipMalloc(&ctx->d_sum_out, sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_sum_partial, 4 * kSumBlocks * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_sum_out, 4 * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_conv, sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&ctx->d_chemfail, sizeof(unsigned int)));
     HIP_TRY(hipMalloc(&ctx->d_pair, 2 * sizeof(double)));
@@ -619,6 +619,28 @@ int c2r_sum(c2r_ctx *c, int32_t which, double *sum)
     return C2R_OK;
 }
 
+int c2r_photon_sums(c2r_ctx *c, int32_t which_l, int32_t which_r, double out[4])
+{
+    if (!c || !out || which_l < 1 || which_l > 3 || which_r < 1 || which_r > 3) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    const c2r_params &p = ctx->prm;
+    // photonstatistics.F90:166-172: same rate coefficients as doric, host libm
+    const double rec = (double)ctx->clumping * p.bh00 * pow(ctx->temper / 1e4, p.albpow);
+    const double col = p.colh0 * sqrt(ctx->temper) * exp(-p.temph0 / ctx->temper);
+    hipLaunchKernelGGL(k_photon_sums, dim3(kSumBlocks), dim3(256), 0, ctx->stream, ctx->ncell,
+                       (const float *)ctx->grid[0], (const double *)ctx->grid[which_l],
+                       (const double *)ctx->grid[which_r], p.abu_c, rec, col, ctx->d_sum_partial);
+    for (int m = 0; m < 4; ++m)
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks,
+                           ctx->d_sum_partial + (size_t)m * kSumBlocks, ctx->d_sum_out + m);
+    HIP_TRY(hipMemcpyAsync(ctx->h_sc->four, ctx->d_sum_out, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int m = 0; m < 4; ++m) out[m] = ctx->h_sc->four[m];
+    return C2R_OK;
+}
+
 int c2r_global_pass(c2r_ctx *c, double dt, int64_t *conv_flag, double *sum_xh1)
 {
     if (!c) return C2R_EINVAL;
@@ -675,6 +697,10 @@ int c2r_evolve3d_dev(c2r_ctx *c, double dt, c2r_report *rep)
     const int64_t c2 = (ctx->nsrc - 1) / 3;
     const int64_t conv_criterion = std::min(c1, c2);
     rep->conv_criterion = conv_criterion;
+    double before[4], after[4], totalsrc = 0.0;
+    if ((rc = c2r_photon_sums(c, 1, 1, before))) return rc;                            // :136 state_before(xh)
+    for (int i = 0; i < ctx->nsrc; ++i) totalsrc += ctx->nflux[i];                      // photonstatistics.F90:266
+    totalsrc = totalsrc * p.S_star * dt;
     double sum1 = 0.0;
     rc = c2r_sum(c, 3, &sum1);                                                         // :183
     if (rc) return rc;
@@ -722,10 +748,26 @@ int c2r_evolve3d_dev(c2r_ctx *c, double dt, c2r_report *rep)
         rep->seconds_sweep += std::chrono::duration<double>(t1 - t0).count();
         rep->seconds_chem += std::chrono::duration<double>(t2 - t1).count();
         rep->chem_not_converged = (int32_t)ctx->h_sc->chemfail;
-        if (niter <= C2R_MAX_ITER_LOG) { rep->it_conv_flag[niter - 1] = conv_flag; rep->it_sum_nbox[niter - 1] = nb; }
+        if (niter <= C2R_MAX_ITER_LOG) {
+            rep->it_conv_flag[niter - 1] = conv_flag; rep->it_sum_nbox[niter - 1] = nb;
+            // evolve.F90:570 calculate_photon_statistics(dt,xh_intermed,xh_av) + report: conservation line
+            if ((rc = c2r_photon_sums(c, 3, 2, after))) return rc;
+            const double trec = after[2] * ctx->vol * dt, tcol = after[3] * ctx->vol * dt;
+            const double tion = trec + (before[0] * ctx->vol - after[0] * ctx->vol);
+            rep->it_photcons[niter - 1] = totalsrc > 0.0 ? (tion - tcol) / totalsrc : 0.0;
+        }
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     rep->niter = niter; rep->conv_flag = conv_flag;
+    // evolve.F90:277-279 calculate_photon_statistics(dt,xh,xh_av)
+    if ((rc = c2r_photon_sums(c, 1, 2, after))) return rc;
+    rep->h0_before = before[0] * ctx->vol; rep->h1_before = before[1] * ctx->vol;
+    rep->h0_after = after[0] * ctx->vol;   rep->h1_after = after[1] * ctx->vol;
+    rep->totrec = after[2] * ctx->vol * dt; rep->totcollisions = after[3] * ctx->vol * dt;
+    rep->dh0 = rep->h0_before - rep->h0_after;                                        // photonstatistics.F90:225
+    rep->total_ion = rep->totrec + rep->dh0;
+    rep->totalsrc = totalsrc;
+    rep->photcons = totalsrc > 0.0 ? (rep->total_ion - rep->totcollisions) / totalsrc : 0.0;   // :268 (LLS_loss = 0)
     return C2R_OK;
 }
 

@@ -519,6 +519,33 @@ __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell,
     }
 }
 
+// photonstatistics.F90:104-217: the four mesh sums of state_before/state_after/total_rates in one
+// pass (h0, h1 from xh_l; recombination and collisional-ionization sums from xh_r).
+// partial is [4][gridDim.x].
+__global__ __launch_bounds__(256) void k_photon_sums(size_t ncell, const float *__restrict__ ndens,
+                                                     const double *__restrict__ xl, const double *__restrict__ xr,
+                                                     double abu_c, double rec_coef, double col_coef, double *partial)
+{
+    __shared__ double sm[4];
+    double h0 = 0.0, h1 = 0.0, tr = 0.0, tc = 0.0;
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < ncell; id += (size_t)gridDim.x * 256) {
+        const double nd = (double)ndens[id];
+        const double x = xl[id];
+        h0 += nd * (1.0 - x);
+        h1 += nd * x;
+        const double y1 = xr[id], y0 = 1.0 - y1;
+        const double de = nd * (y1 + abu_c);
+        tr += nd * y1 * de * rec_coef;
+        tc += nd * y0 * de * col_coef;
+    }
+    double v[4] = {h0, h1, tr, tc};
+    for (int m = 0; m < 4; ++m) {
+        const double tot = block_sum_256(v[m], sm);
+        if (threadIdx.x == 0) partial[(size_t)m * gridDim.x + blockIdx.x] = tot;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_sum_partial(size_t n, const double *__restrict__ a, double *partial)
 {
     __shared__ double sm[4];

@@ -93,6 +93,7 @@ class HipBackend:
     # -- inputs ---------------------------------------------------------------------------------
     def set_step(self, dr, vol, coldensh_LLS, clumping=1.0, temper=1e4):
         dr = (dr,) * 3 if np.isscalar(dr) else tuple(dr)
+        self.vol = vol
         self._check(self.lib.c2r_set_step(self.ctx, (C.c_double * 3)(*dr), vol, coldensh_LLS, clumping, temper),
                     "c2r_set_step")
 
@@ -101,6 +102,7 @@ class HipBackend:
         normflux = np.ascontiguousarray(normflux, dtype=np.float64)
         assert len(srcpos) == len(normflux)
         self.nsrc = len(normflux)
+        self.normflux_sum = float(np.sum(normflux))
         self._check(self.lib.c2r_set_sources(self.ctx, srcpos.ctypes.data, normflux.ctypes.data, self.nsrc),
                     "c2r_set_sources")
 
@@ -166,6 +168,13 @@ class HipBackend:
         self._check(self.lib.c2r_do_source(self.ctx, ns1, cd.ctypes.data if want_coldens else None,
                                            C.byref(loss), C.byref(nbox), C.byref(vis)), "c2r_do_source")
         return nbox.value, loss.value, vis.value, cd
+
+    def photon_sums(self, which_l, which_r):
+        """photonstatistics.F90 mesh sums: arrays by name ('xh', 'xh_av', 'xh_intermed')."""
+        ids = {"xh": _capi.GRID_XH, "xh_av": _capi.GRID_XH_AV, "xh_intermed": _capi.GRID_XH_INTERMED}
+        out = (C.c_double * 4)()
+        self._check(self.lib.c2r_photon_sums(self.ctx, ids[which_l], ids[which_r], C.byref(out)), "c2r_photon_sums")
+        return tuple(out)
 
     def global_pass(self, dt):
         conv, s = C.c_int64(), C.c_double()
@@ -291,6 +300,8 @@ class Evolve:
         self.log = []
         self.visited = 0
         t_sweep = t_chem = 0.0
+        stats = hasattr(b, "photon_sums")
+        before = b.photon_sums("xh", "xh") if stats else None          # evolve.F90:136 state_before
         sum1 = b.sum_xh_intermed()
         converged = False
         while True:
@@ -317,6 +328,17 @@ class Evolve:
             t_chem += t2 - t1
             self.log.append(dict(conv_flag=conv_flag, sum_nbox=self.sum_nbox_all,
                                  photon_loss=self.photon_loss_all))
-        return dict(niter=niter, converged=converged, conv_flag=conv_flag, conv_criterion=conv_criterion,
+        phot = {}
+        if stats:                                                        # evolve.F90:277-279
+            after = b.photon_sums("xh", "xh_av")
+            vol = b.vol
+            totrec, totcol = after[2] * vol * dt, after[3] * vol * dt
+            dh0 = before[0] * vol - after[0] * vol
+            totalsrc = b.normflux_sum * b.params.S_star * dt
+            phot = dict(totrec=totrec, totcollisions=totcol, dh0=dh0, total_ion=totrec + dh0, totalsrc=totalsrc,
+                        photcons=(totrec + dh0 - totcol) / totalsrc if totalsrc > 0 else 0.0,
+                        h1_before=before[1] * vol, h1_after=after[1] * vol)
+        return dict(photon_statistics=phot,
+                    niter=niter, converged=converged, conv_flag=conv_flag, conv_criterion=conv_criterion,
                     sum_nbox_all=self.sum_nbox_all, photon_loss_all=self.photon_loss_all,
                     visited=self.visited, seconds_sweep=t_sweep, seconds_chem=t_chem, log=self.log)

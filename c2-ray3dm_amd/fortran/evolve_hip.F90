@@ -66,6 +66,8 @@ module evolve
      integer(c_int64_t) :: it_conv_flag(C2R_MAX_ITER_LOG), it_sum_nbox(C2R_MAX_ITER_LOG)
      real(c_double) :: it_rel_change_xh1(C2R_MAX_ITER_LOG), it_rel_change_xh0(C2R_MAX_ITER_LOG), &
           it_sum_xh1(C2R_MAX_ITER_LOG)
+     real(c_double) :: h0_before, h1_before, h0_after, h1_after, totrec, totcollisions, dh0, &
+          total_ion, totalsrc, photcons, it_photcons(C2R_MAX_ITER_LOG)
   end type c2r_report
 
   interface

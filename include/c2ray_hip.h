@@ -84,6 +84,12 @@ typedef struct c2r_report {
     double  it_rel_change_xh1[C2R_MAX_ITER_LOG];   /* Test-2 values seen before iteration k+2 */
     double  it_rel_change_xh0[C2R_MAX_ITER_LOG];
     double  it_sum_xh1[C2R_MAX_ITER_LOG];          /* sum(xh_intermed) after global pass k+1 */
+    /* photon statistics of the step, as photonstatistics.F90 leaves them after evolve3D
+     * (state_before :104, state_after :190, total_rates :137, total_ionizations :222,
+     * report_photonstatistics :254) */
+    double  h0_before, h1_before, h0_after, h1_after;
+    double  totrec, totcollisions, dh0, total_ion, totalsrc, photcons;
+    double  it_photcons[C2R_MAX_ITER_LOG];         /* conservation ratio logged after each global pass */
 } c2r_report;
 
 /* Sum `count` doubles at device pointer `buf` over all ranks, in place, on `stream`
@@ -143,6 +149,10 @@ int  c2r_do_source(c2r_ctx *ctx, int32_t ns, double *coldensh_out_host, double *
 /* global_pass (evolve.F90:499-573): evolve0D_global + do_chemistry + doric over the mesh.
  * sum_xh1 (optional) receives sum(xh_intermed) after the pass. */
 int  c2r_global_pass(c2r_ctx *ctx, double dt, int64_t *conv_flag, double *sum_xh1);
+/* The four mesh sums of photonstatistics.F90 in one pass over device arrays `which_l`/`which_r`
+ * (1 xh, 2 xh_av, 3 xh_intermed): out = { sum n(1-x_l), sum n x_l, recombination sum, collisional
+ * ionization sum } (state_before/_after :104-217, total_rates :137-185), unscaled by vol and dt. */
+int  c2r_photon_sums(c2r_ctx *ctx, int32_t which_l, int32_t which_r, double out[4]);
 /* sum() of one of the device arrays (evolve.F90:183) */
 int  c2r_sum(c2r_ctx *ctx, int32_t which, double *sum);
 

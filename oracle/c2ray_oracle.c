@@ -342,6 +342,27 @@ double oracle_sum(const double *a, size_t n)
     return s;
 }
 
+/* photonstatistics.F90:104-217  state_before / state_after / total_rates: the four mesh sums
+ * (sequential, k-j-i order) before scaling.  out = { h0, h1, totrec, totcollisions } where
+ * h0,h1 use xh_l and the rate sums use xh_r. */
+void oracle_photon_sums(const oracle_cfg *c, const float *ndens, const double *xh_l, const double *xh_r,
+                        double out[4])
+{
+    const size_t ncell = (size_t)c->n[0] * c->n[1] * c->n[2];
+    double h0 = 0.0, h1 = 0.0, totrec = 0.0, totcoll = 0.0;
+    const double rec = pow(c->temper / 1e4, C2R_ALBPOW), sq = sqrt(c->temper), ex = exp(-C2R_TEMPH0 / c->temper);
+    for (size_t id = 0; id < ncell; ++id) {
+        const double nd = (double)ndens[id];
+        h0 = h0 + nd * (1.0 - xh_l[id]);
+        h1 = h1 + nd * xh_l[id];
+        const double y1 = xh_r[id], y0 = 1.0 - xh_r[id];
+        const double de = nd * (y1 + C2R_ABU_C);
+        totrec = totrec + nd * y1 * de * c->clumping * C2R_BH00 * rec;         /* :166-168 */
+        totcoll = totcoll + nd * y0 * de * C2R_COLH0 * sq * ex;                /* :169-172 */
+    }
+    out[0] = h0; out[1] = h1; out[2] = totrec; out[3] = totcoll;
+}
+
 typedef struct {
     int    niter;                   /* outer iterations done                       */
     int    converged;               /* 1 = xh updated (evolve.F90:218), 0 = gave up (:228) */
@@ -354,6 +375,8 @@ typedef struct {
     double it_rel1[128], it_rel0[128]; /* Test-2 values seen at the TOP of iteration k+1 */
     long   it_sum_nbox[128];
     double it_sum_xh1[128];         /* sum(xh_intermed) after global pass k        */
+    /* photon statistics of the step (photonstatistics.F90, evolve.F90:136,277) */
+    double totrec, totcollisions, dh0, total_ion;
 } oracle_report;
 
 /* evolve.F90:83-281  evolve3D (restart=0), single rank. */
@@ -373,6 +396,8 @@ void oracle_evolve3d(const oracle_cfg *c, double dt, const float *ndens, double 
     long c2 = (nsrc - 1) / 3;
     const long conv_criterion = c1 < c2 ? c1 : c2;
     memset(rep, 0, sizeof(*rep));
+    double before[4], after[4];
+    oracle_photon_sums(c, ndens, xh, xh, before);                              /* state_before, evolve.F90:136 */
     for (;;) {
         const double sum1 = oracle_sum(xh_intermed, ncell);                    /* :183 */
         const double sum0 = (double)(float)ncell - sum1;                       /* :184 */
@@ -399,4 +424,9 @@ void oracle_evolve3d(const oracle_cfg *c, double dt, const float *ndens, double 
         if (niter <= 128) { rep->it_conv_flag[niter - 1] = conv_flag; rep->it_sum_nbox[niter - 1] = nb; }
     }
     rep->niter = niter; rep->conv_flag = conv_flag;
+    oracle_photon_sums(c, ndens, xh, xh_av, after);                            /* evolve.F90:277 */
+    rep->totrec = after[2] * c->vol * dt;
+    rep->totcollisions = after[3] * c->vol * dt;
+    rep->dh0 = before[0] * c->vol - after[0] * c->vol;
+    rep->total_ion = rep->totrec + rep->dh0;
 }

@@ -29,7 +29,9 @@ class Report(C.Structure):
                 ("photon_loss_all", C.c_double), ("sum_nbox_all", C.c_long), ("visited", C.c_long),
                 ("it_conv_flag", C.c_long * 128), ("it_rel1", C.c_double * 128),
                 ("it_rel0", C.c_double * 128), ("it_sum_nbox", C.c_long * 128),
-                ("it_sum_xh1", C.c_double * 128)]
+                ("it_sum_xh1", C.c_double * 128),
+                ("totrec", C.c_double), ("totcollisions", C.c_double), ("dh0", C.c_double),
+                ("total_ion", C.c_double)]
 
 
 def lib():
@@ -119,6 +121,11 @@ class Oracle:
                               _p(xh_int), _p(phih), _p(srcpos), _p(normflux),
                               C.c_int(len(normflux)), C.byref(rep))
         return rep, xh_av, xh_int, phih
+
+    def photon_sums(self, ndens, xh_l, xh_r):
+        out = (C.c_double * 4)()
+        lib().oracle_photon_sums(C.byref(self.cfg), _p(ndens), _p(xh_l), _p(xh_r), out)
+        return tuple(out)
 
     @staticmethod
     def sum(a):

@@ -39,7 +39,7 @@ program ref_driver
   use times, only: time_ini, set_timesteps
   use sourceprops, only: source_properties_ini, source_properties, NumSrc, srcpos, &
        NormFlux_stellar
-  use photonstatistics, only: photon_loss
+  use photonstatistics, only: photon_loss, totrec, totcollisions, dh0, total_ion
   use evolve_data, only: evolve_ini, phih_grid, xh_av, xh_intermed, coldensh_out, &
        photon_loss_all
   use evolve_source, only: do_source, sum_nbox, sum_nbox_all
@@ -175,6 +175,11 @@ program ref_driver
            open(newunit=u, file=trim(out_dir)//trim(tag)//'_out.txt', status='replace')
            write(u,'(A,1X,ES26.17E3)') 'photon_loss_all', photon_loss_all(1)
            write(u,'(A,1X,I12)') 'sum_nbox_all', sum_nbox_all
+           ! photon statistics of the step (photonstatistics.F90:82-228, called at evolve.F90:277)
+           write(u,'(A,1X,ES26.17E3)') 'totrec', totrec
+           write(u,'(A,1X,ES26.17E3)') 'totcollisions', totcollisions
+           write(u,'(A,1X,ES26.17E3)') 'dh0', dh0
+           write(u,'(A,1X,ES26.17E3)') 'total_ion', total_ion
            close(u)
         endif
         sim_time = sim_time + actual_dt

@@ -95,18 +95,25 @@ def test_evolve3d_vs_reference_fixture(pkg, tables, name, native):
             niter, conv_seq = rep.niter, list(rep.it_conv_flag[:rep.niter])
             nbox_all, loss_all, converged = rep.sum_nbox_all, rep.photon_loss_all, rep.converged
             rel = np.array([rep.it_rel_change_xh1[:niter], rep.it_rel_change_xh0[:niter]]).T
+            phot = {k: getattr(rep, k) for k in ("totrec", "totcollisions", "dh0", "total_ion")}
         else:
             ev = pkg.Evolve(b)
             r = ev.evolve3D(0.0, s["dt"], 0)
             niter, conv_seq = r["niter"], [e["conv_flag"] for e in r["log"]]
             nbox_all, loss_all, converged = r["sum_nbox_all"], r["photon_loss_all"], r["converged"]
             rel = np.array([[e["rel_change_xh1"], e["rel_change_xh0"]] for e in r["log"]])
+            phot = r["photon_statistics"]
         assert converged
         assert niter == s["niter"], (tag, niter, s["niter"])
         assert conv_seq == s["log"]["nonconv"]
         assert nbox_all == s["sum_nbox_all"]
         assert abs(loss_all - s["photon_loss_all"]) <= TOL_LOSS * abs(s["photon_loss_all"]) + 1e-300
         assert relerr(rel, np.array(s["log"]["test2"][1:])) < 1e-7
+        # photon statistics of the step (photonstatistics.F90 module variables after evolve3D);
+        # dh0 is a difference of two ~1e70 sums, so its error is absolute at the 1e-13 * h0 level
+        for k in ("totrec", "totcollisions", "total_ion"):
+            assert abs(phot[k] / s[k] - 1) < 1e-9, (k, phot[k], s[k])
+        assert abs(phot["dh0"] - s["dh0"]) < 1e-9 * abs(s["total_ion"])
         xh = b.fetch("xh")
         assert np.max(np.abs(xh - F(a[tag + "_xh_after"]))) < TOL_X
         if tag + "_phih_grid" in a:

@@ -133,6 +133,9 @@ def test_evolve3d_steps(tables, name):
             assert np.array_equal(xav, F(a[tag + "_xh_av"]))
         assert rep.sum_nbox_all == s["sum_nbox_all"]
         assert rep.photon_loss_all == s["photon_loss_all"]
+        # photon statistics module variables after the step (photonstatistics.F90)
+        for k in ("totrec", "totcollisions", "dh0", "total_ion"):
+            assert getattr(rep, k) == s[k], k
         # logged Test-2 values and mean x (printed with 16-17 digits by the reference)
         t2 = np.array(s["log"]["test2"][1:])
         mine = np.array([rep.it_rel1[:rep.niter], rep.it_rel0[:rep.niter]]).T
