@@ -1,0 +1,140 @@
+"""On-disk formats around the hot path, so the harness can consume the inputs
+the reference consumes and post-processing tools can read what we write:
+
+  * density input      `read_density_file`  density_module.F90:203-243  (nbody_*: densityformat/
+                       densityaccess/densityheader): 3 x int32 header + N^3 float32, either a plain
+                       stream or Fortran sequential records
+  * source lists       `count_or_read_in_sources` sourceprops.F90:259-391: N, then one line per source
+                       `i j k col4 [col5 ...]`; Test UV model: NormFlux = col4/S_star (:627-631),
+                       sources with sum(col4:) <= 0 are dropped (:363)
+  * 3-D outputs        `write_sm3d_dp/si_file_routine` read_sm3d.f90:63-103, used for xfrac3D_z.bin
+                       (f64, output.F90:285-317) and IonRates3D_z.bin (f32, output.F90:342-360):
+                       Fortran sequential records  [12][n1 n2 n3][12] [nbytes][data][nbytes]
+All arrays are (n1,n2,n3) with the first index fastest on disk (Fortran order).
+"""
+import os
+import numpy as np
+
+S_STAR = 1.00000000000000004e+48
+
+
+def _rec(f, payload):
+    n = np.int32(len(payload)).tobytes()
+    f.write(n); f.write(payload); f.write(n)
+
+
+def _read_rec(raw, off):
+    n = int(np.frombuffer(raw, dtype=np.int32, count=1, offset=off)[0])
+    body = raw[off + 4: off + 4 + n]
+    if int(np.frombuffer(raw, dtype=np.int32, count=1, offset=off + 4 + n)[0]) != n:
+        raise ValueError("corrupt Fortran record")
+    return body, off + 8 + n
+
+
+def write_sm3d(path, a):
+    """read_sm3d.f90:63-103: header record shape(1:3), data record."""
+    a = np.asarray(a)
+    if a.ndim != 3 or a.dtype not in (np.float32, np.float64):
+        raise ValueError("sm3d files hold 3-D float32/float64 arrays")
+    with open(path, "wb") as f:
+        _rec(f, np.asarray(a.shape, dtype=np.int32).tobytes())
+        _rec(f, np.asfortranarray(a).tobytes(order="F"))
+
+
+def read_sm3d(path, dtype=None):
+    raw = open(path, "rb").read()
+    hdr, off = _read_rec(raw, 0)
+    shape = tuple(int(v) for v in np.frombuffer(hdr, dtype=np.int32))
+    body, off = _read_rec(raw, off)
+    ncell = shape[0] * shape[1] * shape[2]
+    if dtype is None:
+        dtype = {4: np.float32, 8: np.float64}[len(body) // ncell]
+    return np.frombuffer(body, dtype=dtype).reshape(shape, order="F").copy()
+
+
+def zred_str(zred):
+    return "%.3f" % zred                      # output.F90:188  write(zred_str,"(f6.3)") zred_now
+
+
+def write_xfrac3D(results_dir, zred, xh, mesh=None):
+    """output.F90:285-317 stream 2: xh (f64)."""
+    path = os.path.join(results_dir, "xfrac3D_%s.bin" % zred_str(zred))
+    write_sm3d(path, _as3d(xh, mesh, np.float64))
+    return path
+
+
+def write_IonRates3D(results_dir, zred, phih_grid, mesh=None):
+    """output.F90:342-360 stream 3: real(phih_grid, kind=si)."""
+    path = os.path.join(results_dir, "IonRates3D_%s.bin" % zred_str(zred))
+    write_sm3d(path, _as3d(phih_grid, mesh, np.float64).astype(np.float32))
+    return path
+
+
+def _as3d(a, mesh, dtype):
+    a = np.asarray(a, dtype=dtype)
+    if a.ndim == 1:
+        mesh = (mesh,) * 3 if np.isscalar(mesh) else tuple(mesh)
+        a = a.reshape(mesh, order="F")
+    return a
+
+
+def read_density(path, mesh=None, access="stream", header=True):
+    """density_module.F90:203-243.  Returns float32 (n1,n2,n3)."""
+    raw = open(path, "rb").read()
+    if access == "stream":
+        off = 0
+        if header:
+            shape = tuple(int(v) for v in np.frombuffer(raw, dtype=np.int32, count=3))
+            off = 12
+        else:
+            shape = (mesh,) * 3 if np.isscalar(mesh) else tuple(mesh)
+        data = np.frombuffer(raw, dtype=np.float32, count=shape[0] * shape[1] * shape[2], offset=off)
+    else:                                      # "sequential": record markers around header and data
+        off = 0
+        if header:
+            hdr, off = _read_rec(raw, 0)
+            shape = tuple(int(v) for v in np.frombuffer(hdr, dtype=np.int32))
+        else:
+            shape = (mesh,) * 3 if np.isscalar(mesh) else tuple(mesh)
+        body, off = _read_rec(raw, off)
+        data = np.frombuffer(body, dtype=np.float32)
+    if mesh is not None:
+        want = (mesh,) * 3 if np.isscalar(mesh) else tuple(mesh)
+        if shape != want:                      # density_module.F90:218-222
+            raise ValueError("file with densities unusable: mesh found in file %r, expected %r" % (shape, want))
+    return data.reshape(shape, order="F").copy()
+
+
+def write_density(path, ndens, access="stream", header=True):
+    a = np.asarray(ndens, dtype=np.float32)
+    with open(path, "wb") as f:
+        hdr = np.asarray(a.shape, dtype=np.int32).tobytes()
+        body = np.asfortranarray(a).tobytes(order="F")
+        if access == "stream":
+            if header:
+                f.write(hdr)
+            f.write(body)
+        else:
+            if header:
+                _rec(f, hdr)
+            _rec(f, body)
+
+
+def read_sources(path, S_star=S_STAR):
+    """Test UV model (sourceprops.F90:293-391, 627-631): (srcpos (S,3) int32, NormFlux_stellar (S,))."""
+    with open(path) as f:
+        n = int(f.readline().split()[0])
+        pos, flux = [], []
+        for _ in range(n):
+            cols = [float(t.replace("d", "e").replace("D", "e")) for t in f.readline().split()]
+            if sum(cols[3:]) > 0.0:                                    # :363 summed_weighted_mass > 0
+                pos.append([int(cols[0]), int(cols[1]), int(cols[2])])  # :304 int(srclist(1:3))
+                flux.append(cols[3] / S_star)                          # :380, :630
+    return np.asarray(pos, dtype=np.int32).reshape(-1, 3), np.asarray(flux, dtype=np.float64)
+
+
+def write_sources(path, srcpos, normflux, S_star=S_STAR):
+    with open(path, "w") as f:
+        f.write("%d\n" % len(normflux))
+        for (i, j, k), nf in zip(srcpos, normflux):
+            f.write("%d %d %d %.17e 0.0\n" % (i, j, k, nf * S_star))

@@ -1,0 +1,56 @@
+"""Stand-alone driver of the reference's test problem on the HIP path: the loop of C2Ray.F90:267-427
+(redshift slices -> time steps -> evolve3D -> outputs) with the set-up of nbody_test.F90,
+cosmology.F90, LLS.F90 and sourceprops.F90 restated in testproblem.py, reading the reference's
+source-list format and writing its xfrac3D / IonRates3D files (fileio.py).
+
+    python -m ...  is not needed: call run_test_problem() (tests/test_gpu_harness.py does).
+"""
+import os
+import numpy as np
+
+from .evolve import Evolve, HipBackend
+from .testproblem import TestProblem, STEPS_PER_SLICE, XH_INITIAL
+from . import fileio
+from ._capi import build_tables
+
+
+def run_test_problem(mesh, source_file, results_dir, nslices=14, device=0, comm=None, native_loop=True,
+                     log=None):
+    """Runs nslices x 10 time steps from z=9 (inputs/input_example_test: no restart, UV model 7,
+    10 steps and 1 output per slice).  Returns the per-step evolve3D reports."""
+    os.makedirs(results_dir, exist_ok=True)
+    tp = TestProblem(mesh)
+    thick, thin, _ = build_tables()                        # rad_ini
+    srcpos, normflux = fileio.read_sources(source_file)    # source_properties, Test model
+    b = HipBackend(mesh, thick, thin, device=device)
+    b.set_sources(srcpos, normflux)
+    ev = Evolve(b, comm=comm)
+    rank = comm.get_rank() if comm is not None else 0
+    ncell = mesh ** 3
+    b.load(xh=np.full(ncell, XH_INITIAL))                  # ionfractions_module.F90:49
+    reports = []
+    if rank == 0:                                          # C2Ray.F90:343: output at sim_time = 0
+        fileio.write_xfrac3D(results_dir, tp.zred_at(0.0), b.fetch("xh"), mesh)
+        fileio.write_IonRates3D(results_dir, tp.zred_at(0.0), b.fetch("phih_grid"), mesh)
+    step = 0
+    for nz in range(nslices):
+        for _ in range(STEPS_PER_SLICE):
+            step += 1
+            s = tp.step(step)
+            b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], s["clumping"], s["temper"])
+            b.load(ndens=np.full(ncell, s["ndens"], dtype=np.float32))      # cosmo_evol rescales ndens
+            if native_loop and comm is None:
+                rep = b.evolve3d_native(s["dt"])
+                reports.append(dict(niter=rep.niter, converged=bool(rep.converged), photcons=rep.photcons))
+            else:
+                r = ev.evolve3D((step - 1) * tp.dt, s["dt"], 0)
+                reports.append(dict(niter=r["niter"], converged=r["converged"],
+                                    photcons=r["photon_statistics"].get("photcons")))
+            if log:
+                log("step %d niter %d" % (step, reports[-1]["niter"]))
+        z_out = tp.zred_at(step * tp.dt)                   # C2Ray.F90:393-398: output at the end of the slice
+        if rank == 0:
+            fileio.write_xfrac3D(results_dir, z_out, b.fetch("xh"), mesh)
+            fileio.write_IonRates3D(results_dir, z_out, b.fetch("phih_grid"), mesh)
+    b.close()
+    return reports

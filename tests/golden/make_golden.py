@@ -257,9 +257,13 @@ def case_refrun(name, n, sources):
     keep = [outs[0], outs[len(outs) // 2], outs[-1]]
     arrays = {"xfrac_" + f[len("xfrac3D_"):-4]: read_sm3d(d + "/results/" + f, np.float64) for f in keep}
     arrays.update({"ionrates_" + f[len("xfrac3D_"):-4]:
-                   read_sm3d(d + "/results/IonRates3D_" + f[len("xfrac3D_"):], np.float32) for f in keep[-1:]})
+                   read_sm3d(d + "/results/IonRates3D_" + f[len("xfrac3D_"):], np.float32) for f in keep[:1]})
+    import hashlib
+    sha = {f: hashlib.sha256(open(d + "/results/" + f, "rb").read()).hexdigest()
+           for f in keep + ["IonRates3D_" + keep[0][len("xfrac3D_"):]]}
+    zs = [float(l.split()[2]) for l in open(d + "/results/C2Ray.log") if l.strip().startswith("Doing redshift:")]
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
-    json.dump({"n": n, "outputs": outs, "kept": keep, "nonconv": nonconv, "total_outer_iterations": len(nonconv),
+    json.dump({"n": n, "outputs": outs, "kept": keep, "nonconv": nonconv, "sha256": sha, "slice_redshifts": zs, "total_outer_iterations": len(nonconv),
                "sources": [list(s) for s in sources], "answers": ANSWERS},
               open(os.path.join(HERE, name + ".json"), "w"), indent=1)
     print(name, "outputs", len(outs), "outer iterations", len(nonconv))

@@ -1,0 +1,83 @@
+"""CPU tests of the on-disk formats (c2-ray3dm_amd/fileio.py) against files the reference wrote
+(sha256 of its xfrac3D / IonRates3D outputs, tests/golden/refrun32_onesrc.json) and its two
+shipped source lists."""
+import hashlib
+import json
+import os
+import numpy as np
+import pytest
+from tests._util import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def fio():
+    import __graft_entry__ as g
+    return g.load_package().fileio
+
+
+@pytest.fixture(scope="module")
+def refrun():
+    return (json.load(open(os.path.join(GOLDEN, "refrun32_onesrc.json"))),
+            np.load(os.path.join(GOLDEN, "refrun32_onesrc.npz")))
+
+
+def sha(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def test_xfrac_and_ionrates_files_are_byte_identical_to_the_reference(fio, refrun, tmp_path):
+    m, a = refrun
+    for f in m["kept"]:
+        z = float(f[len("xfrac3D_"):-4])
+        p = fio.write_xfrac3D(str(tmp_path), z, a["xfrac_" + f[len("xfrac3D_"):-4]])
+        assert os.path.basename(p) == f
+        assert sha(p) == m["sha256"][f]
+    zf = m["kept"][0][len("xfrac3D_"):-4]
+    # the reference writes real(phih_grid, kind=si); the fixture holds those f32 values
+    p = fio.write_IonRates3D(str(tmp_path), float(zf), a["ionrates_" + zf].astype(np.float64))
+    assert sha(p) == m["sha256"]["IonRates3D_%s.bin" % zf]
+    back = fio.read_sm3d(p)
+    assert back.dtype == np.float32 and np.array_equal(back, a["ionrates_" + zf])
+    x = fio.read_sm3d(str(tmp_path / m["kept"][0]))
+    assert x.dtype == np.float64 and x.shape == (32, 32, 32)
+
+
+def test_output_file_names_follow_the_slice_redshifts(fio, refrun):
+    m, _ = refrun
+    # output.F90:188: f6.3 of the redshift; the reference's run produced these names
+    names = {"xfrac3D_%s.bin" % fio.zred_str(z) for z in m["slice_redshifts"]}
+    assert names <= set(m["outputs"])
+
+
+def test_source_list_round_trip_and_test_model(fio, tmp_path):
+    pos = np.array([[50, 50, 50], [20, 10, 90], [3, 300, -2]], dtype=np.int32)
+    nf = np.array([1e9, 1e6, 2.5e7])
+    p = str(tmp_path / "test_sources.dat")
+    fio.write_sources(p, pos, nf)
+    pos2, nf2 = fio.read_sources(p)
+    assert np.array_equal(pos, pos2) and np.allclose(nf, nf2, rtol=1e-15)
+    # the reference's shipped lists (inputs/test_sources_*.dat), restated as text
+    open(p, "w").write("1\n50 50 50 1e57 0.0\n")
+    pos3, nf3 = fio.read_sources(p)
+    assert pos3.tolist() == [[50, 50, 50]] and nf3[0] == 1e57 / 1.00000000000000004e+48
+    # zero-luminosity lines are dropped (sourceprops.F90:363), Fortran d-exponents accepted
+    open(p, "w").write("3\n1 2 3 0.0 0.0\n4 5 6 1d55 0.0\n7 8 9 0.0 1e50\n")
+    pos4, nf4 = fio.read_sources(p)
+    assert pos4.tolist() == [[4, 5, 6], [7, 8, 9]] and nf4[1] == 0.0
+
+
+@pytest.mark.parametrize("access", ["stream", "sequential"])
+def test_density_file_round_trip(fio, tmp_path, access):
+    rng = np.random.default_rng(3)
+    nd = rng.random((6, 5, 4)).astype(np.float32)
+    p = str(tmp_path / "dens.bin")
+    fio.write_density(p, nd, access=access)
+    raw = open(p, "rb").read()
+    if access == "stream":          # density_module.F90:213-243 with densityaccess="stream"
+        assert len(raw) == 12 + nd.size * 4
+        assert np.frombuffer(raw, dtype=np.int32, count=3).tolist() == [6, 5, 4]
+        assert np.frombuffer(raw, dtype=np.float32, offset=12)[1] == nd[1, 0, 0]     # first index fastest
+    back = fio.read_density(p, mesh=(6, 5, 4), access=access)
+    assert np.array_equal(back, nd)
+    with pytest.raises(ValueError):
+        fio.read_density(p, mesh=(6, 5, 5), access=access)

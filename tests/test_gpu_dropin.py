@@ -49,7 +49,7 @@ def test_reference_driver_with_hip_evolve_matches_pure_reference_run():
             z = f[len("xfrac3D_"):-4]
             x = read_sm3d(d + "/results/" + f, np.float64)
             assert np.max(np.abs(x - a["xfrac_" + z])) < 1e-8, f
-        z = m["kept"][-1][len("xfrac3D_"):-4]
+        z = m["kept"][0][len("xfrac3D_"):-4]          # the final output: rates of the last step
         g = read_sm3d(d + "/results/IonRates3D_" + z + ".bin", np.float32)
         ref = a["ionrates_" + z]
         assert np.max(np.abs(g - ref) / np.maximum(np.abs(ref), 1e-30)) < 1e-5     # f32 output file
