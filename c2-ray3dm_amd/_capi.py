@@ -78,6 +78,7 @@ SYMBOLS = [
     ("c2r_photon_sums", C.c_int, [_P, _I32, _I32, C.POINTER(_D * 4)]),
     ("c2r_sum", C.c_int, [_P, _I32, C.POINTER(_D)]),
     ("c2r_evolve3d_dev", C.c_int, [_P, _D, C.POINTER(Report)]),
+    ("c2r_evolve3d_restart_dev", C.c_int, [_P, _D, _I32, _D, C.POINTER(Report)]),
     ("c2r_evolve3d", C.c_int, [_P, _D, _P, _P, _P, _P, _P, C.POINTER(Report)]),
     ("c2r_default_sed", C.c_int, [C.POINTER(SedParams)]),
     ("c2r_build_tables", C.c_int, [C.POINTER(SedParams), _P, _P, _I32, C.POINTER(_D)]),

@@ -675,7 +675,7 @@ int c2r_global_pass(c2r_ctx *c, double dt, int64_t *conv_flag, double *sum_xh1)
     return C2R_OK;
 }
 
-int c2r_evolve3d_dev(c2r_ctx *c, double dt, c2r_report *rep)
+static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double restart_loss, c2r_report *rep)
 {
     if (!c) return C2R_EINVAL;
     Ctx *ctx = C(c);
@@ -686,13 +686,15 @@ int c2r_evolve3d_dev(c2r_ctx *c, double dt, c2r_report *rep)
     if (!rep) rep = &local;
     memset(rep, 0, sizeof *rep);
     using clk = std::chrono::steady_clock;
-    // evolve.F90:145-146  xh_av = xh ; xh_intermed = xh
-    HIP_TRY(hipMemcpyAsync(ctx->grid[2], ctx->grid[1], grid_bytes(ctx, 1), hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->grid[3], ctx->grid[1], grid_bytes(ctx, 1), hipMemcpyDeviceToDevice, ctx->stream));
     int niter = 0;
     int64_t conv_flag = (int64_t)ctx->ncell;                                           // :149
     double prev1 = (double)(((2.0f * (float)p.mesh[0]) * (float)p.mesh[1]) * (float)p.mesh[2]);   // :150-151
     double prev0 = prev1;
+    if (restart_niter < 0) {
+        // evolve.F90:145-146  xh_av = xh ; xh_intermed = xh
+        HIP_TRY(hipMemcpyAsync(ctx->grid[2], ctx->grid[1], grid_bytes(ctx, 1), hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->grid[3], ctx->grid[1], grid_bytes(ctx, 1), hipMemcpyDeviceToDevice, ctx->stream));
+    }
     const int64_t c1 = (int64_t)(p.convergence_fraction * p.mesh[0] * p.mesh[1] * p.mesh[2]);    // :162
     const int64_t c2 = (ctx->nsrc - 1) / 3;
     const int64_t conv_criterion = std::min(c1, c2);
@@ -702,7 +704,17 @@ int c2r_evolve3d_dev(c2r_ctx *c, double dt, c2r_report *rep)
     for (int i = 0; i < ctx->nsrc; ++i) totalsrc += ctx->nflux[i];                      // photonstatistics.F90:266
     totalsrc = totalsrc * p.S_star * dt;
     double sum1 = 0.0;
-    rc = c2r_sum(c, 3, &sum1);                                                         // :183
+    if (restart_niter >= 0) {
+        // evolve.F90:153-157: start_from_dump loaded niter, photon_loss_all, phih_grid, xh_av and
+        // xh_intermed (the caller put them in the device arrays); one global pass; the saved
+        // previous-sum variables (evolve.F90:67-74) are zero in a freshly started process
+        niter = restart_niter;
+        prev1 = prev0 = 0.0;
+        rep->photon_loss_all = restart_loss;
+        rc = c2r_global_pass(c, dt, &conv_flag, &sum1);
+    } else {
+        rc = c2r_sum(c, 3, &sum1);                                                     // :183
+    }
     if (rc) return rc;
     for (;;) {
         const double sum0 = (double)(float)ctx->ncell - sum1;                          // :184
@@ -769,6 +781,17 @@ int c2r_evolve3d_dev(c2r_ctx *c, double dt, c2r_report *rep)
     rep->totalsrc = totalsrc;
     rep->photcons = totalsrc > 0.0 ? (rep->total_ion - rep->totcollisions) / totalsrc : 0.0;   // :268 (LLS_loss = 0)
     return C2R_OK;
+}
+
+int c2r_evolve3d_dev(c2r_ctx *c, double dt, c2r_report *rep)
+{
+    return evolve3d_worker(c, dt, -1, 0.0, rep);
+}
+
+int c2r_evolve3d_restart_dev(c2r_ctx *c, double dt, int32_t niter, double photon_loss_all, c2r_report *rep)
+{
+    if (niter < 0) return C2R_EINVAL;
+    return evolve3d_worker(c, dt, niter, photon_loss_all, rep);
 }
 
 int c2r_evolve3d(c2r_ctx *c, double dt, const float *ndens, double *xh, double *xh_av, double *xh_int,

@@ -18,6 +18,7 @@ once against the small backend interface so the multi-rank logic can be exercise
 test double (tests/_cpu_backend.py) -- the product always runs it on `HipBackend`.
 """
 import ctypes as C
+import os
 import time as _time
 import numpy as np
 
@@ -129,13 +130,14 @@ class HipBackend:
             self._cb = _capi.ALLREDUCE_FN(0)
         self._check(self.lib.c2r_set_rank(self.ctx, rank, npr, self._cb, None), "c2r_set_rank")
 
-    def load(self, ndens=None, xh=None):
+    def load(self, ndens=None, xh=None, xh_av=None, xh_intermed=None, phih_grid=None):
         """Host (numpy, Fortran-order flat or (N,N,N) with i fastest when ravelled 'F') -> HBM."""
         torch = self.torch
         if ndens is not None:
             self.ndens.copy_(torch.from_numpy(_flat(ndens, np.float32)))
-        if xh is not None:
-            self.xh.copy_(torch.from_numpy(_flat(xh, np.float64)))
+        for name, a in (("xh", xh), ("xh_av", xh_av), ("xh_intermed", xh_intermed), ("phih_grid", phih_grid)):
+            if a is not None:
+                getattr(self, name).copy_(torch.from_numpy(_flat(a, np.float64)))
 
     def fetch(self, name):
         return getattr(self, name).cpu().numpy()
@@ -188,9 +190,13 @@ class HipBackend:
         return self.torch.tensor(values, dtype=self.torch.float64, device=self.device)
 
     # -- whole-step entry point of the C ABI (the loop runs in C++) ---------------------------------
-    def evolve3d_native(self, dt):
+    def evolve3d_native(self, dt, restart_niter=None, restart_photon_loss=0.0):
         rep = _capi.Report()
-        self._check(self.lib.c2r_evolve3d_dev(self.ctx, dt, C.byref(rep)), "c2r_evolve3d_dev")
+        if restart_niter is None:
+            self._check(self.lib.c2r_evolve3d_dev(self.ctx, dt, C.byref(rep)), "c2r_evolve3d_dev")
+        else:
+            self._check(self.lib.c2r_evolve3d_restart_dev(self.ctx, dt, restart_niter, restart_photon_loss,
+                                                          C.byref(rep)), "c2r_evolve3d_restart_dev")
         return rep
 
     def selftest(self):
@@ -241,6 +247,9 @@ class Evolve:
         self.photon_loss_all = 0.0
         self.visited = 0
         self.log = []
+        self.dump_dir = "./"               # file_admin.f90:23
+        self.dump_interval_s = 15.0 * 60   # evolve.F90:260 (None: never)
+        self._ndump = 0
 
     # evolve.F90:430
     def set_rates_to_zero(self):
@@ -284,26 +293,51 @@ class Evolve:
     def global_pass(self, dt):
         return self.b.global_pass(dt)
 
+    # evolve.F90:285-324
+    def write_iteration_dump(self, niter):
+        from . import fileio
+        self._ndump += 1
+        name = "iterdump2.bin" if self._ndump % 2 == 0 else "iterdump1.bin"
+        b = self.b
+        fileio.write_iteration_dump(os.path.join(self.dump_dir, name), niter, self.photon_loss_all,
+                                    b.fetch("phih_grid"), b.fetch("xh_av"), b.fetch("xh_intermed"), mesh=b.mesh)
+
+    # evolve.F90:328-426
+    def start_from_dump(self, restart):
+        from . import fileio
+        name = {1: "iterdump1.bin", 2: "iterdump2.bin", 3: "iterdump.bin"}[restart]
+        niter, loss, phih, xav, xint = fileio.read_iteration_dump(os.path.join(self.dump_dir, name), self.b.mesh)
+        self.b.load(xh_av=xav, xh_intermed=xint, phih_grid=phih)      # every rank reads the same file (:393-416)
+        self.photon_loss_all = loss
+        return niter
+
     # evolve.F90:83
     def evolve3D(self, time, dt, restart=0):
-        if restart != 0:
-            raise NotImplementedError("restart from iteration dumps (evolve.F90:328) is out of scope")
         b = self.b
         n = b.mesh
         ncell = n[0] * n[1] * n[2]
-        b.begin_step()
         niter = 0
         conv_flag = ncell
         prev1 = float(np.float32(2.0) * np.float32(n[0]) * np.float32(n[1]) * np.float32(n[2]))
         prev0 = prev1
+        if restart == 0:
+            b.begin_step()
+        else:
+            niter = self.start_from_dump(restart)                        # :156
+            prev1 = prev0 = 0.0                                          # saved module variables, zero in a new run
         conv_criterion = min(int(CONVERGENCE_FRACTION * n[0] * n[1] * n[2]), (b.nsrc - 1) // 3)
         self.log = []
         self.visited = 0
         t_sweep = t_chem = 0.0
         stats = hasattr(b, "photon_sums")
         before = b.photon_sums("xh", "xh") if stats else None          # evolve.F90:136 state_before
-        sum1 = b.sum_xh_intermed()
+        if restart == 0:
+            sum1 = b.sum_xh_intermed()
+        else:
+            conv_flag, sum1 = self.global_pass(dt)                       # :157
+            self.log.append(dict(conv_flag=conv_flag, sum_nbox=0, photon_loss=self.photon_loss_all))
         converged = False
+        t_last_dump = _time.perf_counter()
         while True:
             sum0 = float(np.float32(ncell)) - sum1
             rel1 = abs(sum1 - prev1) / sum1 if sum1 > 0.0 else 1.0
@@ -322,6 +356,11 @@ class Evolve:
             self.set_rates_to_zero()
             self.pass_all_sources(niter, dt)
             t1 = _time.perf_counter()
+            # evolve.F90:253-266: rank 0 writes iterdump1/2.bin alternately when the interval has passed
+            if self.rank == 0 and self.dump_interval_s is not None and \
+                    _time.perf_counter() - t_last_dump > self.dump_interval_s:
+                self.write_iteration_dump(niter)
+                t_last_dump = _time.perf_counter()
             conv_flag, sum1 = self.global_pass(dt)
             t2 = _time.perf_counter()
             t_sweep += t1 - t0

@@ -138,3 +138,32 @@ def write_sources(path, srcpos, normflux, S_star=S_STAR):
         f.write("%d\n" % len(normflux))
         for (i, j, k), nf in zip(srcpos, normflux):
             f.write("%d %d %d %.17e 0.0\n" % (i, j, k, nf * S_star))
+
+
+def write_iteration_dump(path, niter, photon_loss_all, phih_grid, xh_av, xh_intermed, mesh=None):
+    """write_iteration_dump (evolve.F90:285-324): Fortran sequential records
+    niter (int32) | photon_loss_all(NumFreqBnd=1) f64 | phih_grid | xh_av | xh_intermed (N^3 f64 each)."""
+    with open(path, "wb") as f:
+        _rec(f, np.int32(niter).tobytes())
+        _rec(f, np.asarray([photon_loss_all], dtype=np.float64).tobytes())
+        for a in (phih_grid, xh_av, xh_intermed):
+            _rec(f, np.asfortranarray(_as3d(a, mesh, np.float64)).tobytes(order="F"))
+
+
+def read_iteration_dump(path, mesh):
+    """start_from_dump (evolve.F90:328-426).  Returns (niter, photon_loss_all, phih, xh_av, xh_intermed)
+    with the arrays flat in Fortran order."""
+    raw = open(path, "rb").read()
+    body, off = _read_rec(raw, 0)
+    niter = int(np.frombuffer(body, dtype=np.int32)[0])
+    body, off = _read_rec(raw, off)
+    loss = float(np.frombuffer(body, dtype=np.float64)[0])
+    mesh = (mesh,) * 3 if np.isscalar(mesh) else tuple(mesh)
+    arrs = []
+    for _ in range(3):
+        body, off = _read_rec(raw, off)
+        a = np.frombuffer(body, dtype=np.float64)
+        if a.size != mesh[0] * mesh[1] * mesh[2]:
+            raise ValueError("iteration dump does not match the mesh")
+        arrs.append(a.copy())
+    return (niter, loss) + tuple(arrs)

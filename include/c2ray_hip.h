@@ -159,6 +159,11 @@ int  c2r_sum(c2r_ctx *ctx, int32_t which, double *sum);
 /* ---- the path, whole ------------------------------------------------------------------- */
 /* evolve3D(time,dt,restart=0) (evolve.F90:83-281) on the device-resident arrays. */
 int  c2r_evolve3d_dev(c2r_ctx *ctx, double dt, c2r_report *rep);
+/* evolve3D(time,dt,restart/=0) (evolve.F90:153-157): the caller has loaded an iteration dump
+ * (start_from_dump, evolve.F90:328-426: niter, photon_loss_all, phih_grid, xh_av, xh_intermed)
+ * into the device arrays; runs the global pass and continues the convergence loop from `niter`. */
+int  c2r_evolve3d_restart_dev(c2r_ctx *ctx, double dt, int32_t niter, double photon_loss_all,
+                              c2r_report *rep);
 /* evolve3D on the driver's host arrays: uploads ndens and xh, runs the loop, downloads xh,
  * xh_av, xh_intermed, phih_grid (any output pointer may be NULL).  This is what the Fortran
  * shim calls. */

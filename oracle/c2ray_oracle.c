@@ -379,19 +379,29 @@ typedef struct {
     double totrec, totcollisions, dh0, total_ion;
 } oracle_report;
 
-/* evolve.F90:83-281  evolve3D (restart=0), single rank. */
-void oracle_evolve3d(const oracle_cfg *c, double dt, const float *ndens, double *xh,
-                     double *xh_av, double *xh_intermed, double *phih,
-                     const int *srcpos, const double *normflux, int nsrc, oracle_report *rep)
+/* evolve.F90:83-281  evolve3D, single rank.  restart_niter < 0: fresh start (restart=0).
+ * restart_niter >= 0: the state (phih, xh_av, xh_intermed, niter) was loaded by start_from_dump
+ * (evolve.F90:155-157): a global pass is run first, and the previous-sum variables are whatever the
+ * module holds -- zero in a fresh process (they are saved module variables, evolve.F90:67-74). */
+void oracle_evolve3d_x(const oracle_cfg *c, double dt, const float *ndens, double *xh,
+                       double *xh_av, double *xh_intermed, double *phih,
+                       const int *srcpos, const double *normflux, int nsrc, int restart_niter,
+                       oracle_report *rep)
 {
     const size_t ncell = (size_t)c->n[0] * c->n[1] * c->n[2];
-    memcpy(xh_av, xh, ncell * sizeof(double));                                 /* :145-146 */
-    memcpy(xh_intermed, xh, ncell * sizeof(double));
     int niter = 0;
     long conv_flag = (long)ncell;
     double prev1 = (double)(((2.0f * (float)c->n[0]) * (float)c->n[1]) * (float)c->n[2]);   /* :150-151 */
     double prev0 = prev1;
     double rel1 = 1.0, rel0 = 1.0;
+    if (restart_niter < 0) {
+        memcpy(xh_av, xh, ncell * sizeof(double));                             /* :145-146 */
+        memcpy(xh_intermed, xh, ncell * sizeof(double));
+    } else {
+        niter = restart_niter;
+        prev1 = prev0 = 0.0;
+        conv_flag = oracle_global_pass(c, dt, ndens, xh, xh_av, xh_intermed, phih);      /* :157 */
+    }
     long c1 = (long)(C2R_CONVERGENCE_FRACTION * c->n[0] * c->n[1] * c->n[2]);  /* :162 */
     long c2 = (nsrc - 1) / 3;
     const long conv_criterion = c1 < c2 ? c1 : c2;
@@ -429,4 +439,11 @@ void oracle_evolve3d(const oracle_cfg *c, double dt, const float *ndens, double 
     rep->totcollisions = after[3] * c->vol * dt;
     rep->dh0 = before[0] * c->vol - after[0] * c->vol;
     rep->total_ion = rep->totrec + rep->dh0;
+}
+
+void oracle_evolve3d(const oracle_cfg *c, double dt, const float *ndens, double *xh,
+                     double *xh_av, double *xh_intermed, double *phih,
+                     const int *srcpos, const double *normflux, int nsrc, oracle_report *rep)
+{
+    oracle_evolve3d_x(c, dt, ndens, xh, xh_av, xh_intermed, phih, srcpos, normflux, nsrc, -1, rep);
 }

@@ -122,6 +122,16 @@ class Oracle:
                               C.c_int(len(normflux)), C.byref(rep))
         return rep, xh_av, xh_int, phih
 
+    def evolve3d_restart(self, dt, ndens, xh, xh_av, xh_intermed, phih, srcpos, normflux, niter0):
+        """evolve3D(restart/=0) after start_from_dump loaded (niter0, phih, xh_av, xh_intermed)."""
+        srcpos = np.ascontiguousarray(srcpos, dtype=np.int32)
+        normflux = np.ascontiguousarray(normflux, dtype=np.float64)
+        rep = Report()
+        lib().oracle_evolve3d_x(C.byref(self.cfg), C.c_double(dt), _p(ndens), _p(xh), _p(xh_av),
+                                _p(xh_intermed), _p(phih), _p(srcpos), _p(normflux),
+                                C.c_int(len(normflux)), C.c_int(niter0), C.byref(rep))
+        return rep
+
     def photon_sums(self, ndens, xh_l, xh_r):
         out = (C.c_double * 4)()
         lib().oracle_photon_sums(C.byref(self.cfg), _p(ndens), _p(xh_l), _p(xh_r), out)

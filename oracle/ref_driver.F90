@@ -163,10 +163,15 @@ program ref_driver
            stop
         endif
 
-        ! mode 'evolve'
+        ! mode 'evolve' (restart_flag=0) or 'restart' (restart_flag=3: the reference reads
+        ! ./iterdump.bin through start_from_dump, evolve.F90:328, on the first step)
         if (istep >= dump_first .and. istep <= dump_last) call dump_inputs(tag)
         write(logf,*) 'REFDRIVER step ', istep
-        call evolve3D(sim_time, actual_dt, 0)
+        if (trim(mode) == 'restart' .and. istep == 1) then
+           call evolve3D(sim_time, actual_dt, 3)
+        else
+           call evolve3D(sim_time, actual_dt, 0)
+        endif
         if (istep >= dump_first .and. istep <= dump_last) then
            call dump_r8(trim(tag)//'_xh_after', xh)
            call dump_r8(trim(tag)//'_xh_av', xh_av)

@@ -21,6 +21,15 @@ class OracleBackend:
         self.nsrc = len(self.normflux)
         self.rank, self.npr = 0, 1
 
+    def load(self, ndens=None, xh=None, xh_av=None, xh_intermed=None, phih_grid=None):
+        for name, a in (("ndens", ndens), ("xh", xh), ("xh_av", xh_av), ("xh_intermed", xh_intermed),
+                        ("phih_grid", phih_grid)):
+            if a is not None:
+                getattr(self, name)[:] = np.asarray(a).ravel(order="F") if np.asarray(a).ndim == 3 else a
+
+    def fetch(self, name):
+        return getattr(self, name).copy()
+
     def set_rank(self, rank, npr, allreduce=None):
         self.rank, self.npr = rank, npr
 

@@ -269,6 +269,45 @@ def case_refrun(name, n, sources):
     print(name, "outputs", len(outs), "outer iterations", len(nonconv))
 
 
+def case_restart(name, n, sources, dens_seed, xfield, k_iter=2):
+    """evolve3D(restart=3): the reference resumes a time step from an iteration dump
+    (start_from_dump, evolve.F90:328).  The dump is a genuine mid-iteration state -- k_iter outer
+    iterations of the (pinned) oracle on the same inputs -- written by OUR writer
+    (fileio.write_iteration_dump) and read by the REFERENCE's reader."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    from oracle.oracle import Oracle
+    fio = g.load_package().fileio
+    dens = density_factor(n, dens_seed)
+    # a plain run first, only to learn the step's scalars and arrays
+    d = run_driver(n, sources, {"mode": "'evolve'", "nsteps": 1, "dump_first": 1, "dump_last": 1}, dens=dens, xfield=xfield)
+    kv = read_kv(d + "/dump/step001_in.txt")
+    nd = rd(d, "step001_ndens.f32", n, np.float32); xh0 = rd(d, "step001_xh_before.f64", n)
+    t = np.load(os.path.join(HERE, "tables.npz"))
+    o = Oracle(n, (kv["dr1"], kv["dr2"], kv["dr3"]), kv["vol"], kv["coldensh_LLS"], t["thick"], t["thin"], kv["clumping"])
+    F = lambda a: np.asfortranarray(a).ravel(order="F").copy()
+    ndf, xh = F(nd), F(xh0)
+    xav, xint, phih, loss = xh.copy(), xh.copy(), np.zeros(n ** 3), 0.0
+    for _ in range(k_iter):
+        phih[:] = 0.0
+        loss, nb, vis = o.pass_sources(ndf, xav, phih, kv["srcpos"], kv["normflux"])
+        o.global_pass(kv["dt"], ndf, xh, xav, xint, phih)
+    def w_dump(p): fio.write_iteration_dump(p, k_iter, loss, phih, xav, xint, mesh=n)
+    d = run_driver(n, sources, {"mode": "'restart'", "nsteps": 1, "dump_first": 1, "dump_last": 1}, dens=dens,
+                   xfield=xfield, extra_files={"iterdump.bin": w_dump})
+    log = parse_log(d + "/results/C2Ray.log")
+    kv = read_kv(d + "/dump/step001_in.txt"); kv.update(read_kv(d + "/dump/step001_out.txt"))
+    kv["log"] = log[0]; kv["niter_after_restart"] = len(log[0]["nonconv"]); kv["dump_niter"] = k_iter
+    kv["dump_photon_loss_all"] = loss
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), ndens=nd, xh_before=xh0,
+                        dump_phih=phih.reshape((n, n, n), order="F"), dump_xh_av=xav.reshape((n, n, n), order="F"),
+                        dump_xh_intermed=xint.reshape((n, n, n), order="F"),
+                        xh_after=rd(d, "step001_xh_after.f64", n), phih_grid=rd(d, "step001_phih_grid.f64", n),
+                        xh_av=rd(d, "step001_xh_av.f64", n))
+    json.dump({"n": n, **kv}, open(os.path.join(HERE, name + ".json"), "w"), indent=1)
+    print(name, "global passes after restart:", kv["niter_after_restart"], "nonconv", log[0]["nonconv"])
+
+
 def main():
     which = set(sys.argv[1:])
     def want(k): return not which or k in which
@@ -287,6 +326,11 @@ def main():
     if want("evolve32b"):
         x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 6.0)
         case_evolve("evolve32_std_bubbles", 32, SRC_STD, 3, [1, 3], dens_seed=11, xfield=x)
+    if want("restart32"):
+        x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 6.0)
+        case_restart("restart32_std_bubbles", 32, SRC_STD, 11, x)
+        # one source: conv_criterion = 0, so only Test 2 can end the step and real iterations follow
+        case_restart("restart32_onesrc", 32, SRC_ONE, 12, None, k_iter=3)
     if want("sweep64"):
         x = bubble_xfield(64, [(50, 50, 50), (20, 10, 10), (6, 8, 50), (20, 10, 26)], 14.0)
         srcs = SRC_STD[:8] + [(72, 72, 50, 1e58), (20, 10, 90, 1e54)]

@@ -227,3 +227,26 @@ def test_runs_are_reproducible_to_rounding(pkg, tables):
     assert outs[0][0] == outs[1][0]
     assert relerr(outs[0][1], outs[1][1], floor=1e-60) < 1e-14
     b.close()
+
+
+@pytest.mark.parametrize("name", ["restart32_std_bubbles", "restart32_onesrc"])
+@pytest.mark.parametrize("native", [True, False])
+def test_restart_from_iteration_dump(pkg, tables, tmp_path, name, native):
+    """evolve3D(restart=3) on the GPU against what the reference did from the same dump file."""
+    m, a = load_case(name)
+    n = m["n"]
+    b = make_backend(pkg, tables, m, n, F(a["ndens"]), F(a["xh_before"]))
+    if native:
+        b.load(xh_av=a["dump_xh_av"], xh_intermed=a["dump_xh_intermed"], phih_grid=a["dump_phih"])
+        rep = b.evolve3d_native(m["dt"], restart_niter=m["dump_niter"], restart_photon_loss=m["dump_photon_loss_all"])
+        conv = list(rep.it_conv_flag[m["dump_niter"]:rep.niter])
+        assert rep.converged and conv == m["log"]["nonconv"][1:]
+    else:
+        pkg.fileio.write_iteration_dump(str(tmp_path / "iterdump.bin"), m["dump_niter"], m["dump_photon_loss_all"],
+                                        a["dump_phih"], a["dump_xh_av"], a["dump_xh_intermed"])
+        ev = pkg.Evolve(b); ev.dump_dir = str(tmp_path)
+        r = ev.evolve3D(0.0, m["dt"], 3)
+        assert r["converged"] and [e["conv_flag"] for e in r["log"]] == m["log"]["nonconv"]
+    assert np.max(np.abs(b.fetch("xh") - F(a["xh_after"]))) < TOL_X
+    assert gamma_err(b.fetch("phih_grid"), F(a["phih_grid"])) < 1e-8
+    b.close()

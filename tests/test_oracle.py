@@ -145,3 +145,24 @@ def test_evolve3d_steps(tables, name):
         # average sub-boxes per source line (evolve.F90:249)
         avg = np.array(rep.it_sum_nbox[:rep.niter]) / np.float32(len(s["normflux"]))
         assert relerr(avg, s["log"]["avg_nbox"]) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["restart32_std_bubbles", "restart32_onesrc"])
+def test_evolve3d_restart_from_iteration_dump(tables, name):
+    """evolve3D(restart=3): state loaded from an iteration dump, one global pass, then the loop
+    (evolve.F90:153-157).  The fixture's dump was written by fileio.write_iteration_dump and read by
+    the reference's own start_from_dump."""
+    m, a = load_case(name)
+    n = m["n"]
+    o = oracle_for(m, tables, n)
+    xh = F(a["xh_before"]); nd = F(a["ndens"])
+    xav, xint, phih = F(a["dump_xh_av"]), F(a["dump_xh_intermed"]), F(a["dump_phih"])
+    rep = o.evolve3d_restart(m["dt"], nd, xh, xav, xint, phih, m["srcpos"], m["normflux"], m["dump_niter"])
+    assert rep.converged == 1
+    k0 = m["dump_niter"]
+    # the log holds the restart's own global pass first, then one entry per further iteration
+    assert rep.niter - k0 == m["niter_after_restart"] - 1
+    assert list(rep.it_conv_flag[k0:rep.niter]) == m["log"]["nonconv"][1:]
+    assert np.array_equal(xh, F(a["xh_after"]))
+    assert np.array_equal(phih, F(a["phih_grid"]))
+    assert np.array_equal(xav, F(a["xh_av"]))
