@@ -113,6 +113,7 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
         budget = fr / 4;
     }
     int cap = (int)std::min<size_t>((size_t)want, std::max<size_t>(1, budget / per_src));
+    if (const char *e = getenv("C2R_BATCH_CAP")) cap = std::max(1, std::min(cap, atoi(e)));      // experiments
     cap = std::min(cap, 65535);                 // grid.z of k_sweep_shell
     HIP_TRY(hipMalloc(&ctx->d_planes, (size_t)cap * 2 * 6 * ctx->PP * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_srcpos_b, (size_t)cap * 3 * sizeof(int)));

@@ -15,7 +15,10 @@
 
 namespace c2r {
 
-constexpr int kBlock = 256;   // threads per block; a face's owned rectangle is flattened into tiles of 256
+#ifndef C2R_BLOCK
+#define C2R_BLOCK 256
+#endif
+constexpr int kBlock = C2R_BLOCK;   // threads per block of the sweep; a face's owned rectangle is flattened into tiles of kBlock
 
 struct KParams {
     int n[3];
@@ -224,6 +227,29 @@ __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0
         loss_acc[s] += p_out * p.vol / vol_ph;
 }
 
+// ---- buffer addressing (SRSRC descriptor + 32-bit byte offset) ---------------------------------------
+// A descriptor built from block-uniform values lets every access use a 32-bit VGPR offset (no 64-bit
+// address arithmetic per lane) and gives a free range check: an offset beyond the buffer reads 0,
+// which is exactly the value of a zero-weight upstream corner.
+typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+constexpr unsigned kOOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, v), r, (int)byte_off, 0, 0);
+}
+
 // ---- one Chebyshev shell of every active source ------------------------------------------------
 // evolve0D (evolve_point.F90:83-299) + cinterp (column_density.f90:29-271) + photoion_rates.
 // faces: 0:+z 1:-z 2:+y 3:-y 4:+x 5:-x.  Plane coordinates (a,b): z-face (x,y); y-face (x,z);
@@ -235,7 +261,7 @@ __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0
 // for x faces).
 __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
 {
-    __shared__ double sm[4];
+    __shared__ double sm[16];
     const int face = blockIdx.y;
     const int sl = blockIdx.z;
     const int tile = blockIdx.x;
@@ -266,20 +292,26 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         const unsigned id_t = (unsigned)c1 + (unsigned)p.n[1] * ((unsigned)c0 + (unsigned)p.n[0] * (unsigned)c2);
         const bool xf = (axis == 0);
         const unsigned id = xf ? id_t : id_n;
-        const double xav_raw = (xf ? p.xh_av_T : p.xh_av)[id];
-        const double nd = (double)(xf ? p.ndens_T : p.ndens)[id];
+        const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
+        const __amdgpu_buffer_rsrc_t r_x = make_rsrc(xf ? (const void *)p.xh_av_T : (const void *)p.xh_av, ncell * 8u);
+        const __amdgpu_buffer_rsrc_t r_n = make_rsrc(xf ? (const void *)p.ndens_T : (const void *)p.ndens, ncell * 4u);
+        const double xav_raw = buf_load_f64(r_x, id * 8u);
+        const double nd = (double)buf_load_f32(r_n, id * 4u);
 
         // upstream corners in plane q-1 of this face (zero weight outside |.| <= q-1)
         const int sga = a < 0 ? -1 : 1, sgb = b < 0 ? -1 : 1;
         const int am = a - sga, bm = b - sgb;
-        const double *prev = p.planes + ((size_t)s * 2 + ((q - 1) & 1)) * 6 * p.PP + (size_t)face * p.PP;
+        const unsigned plane_bytes = (unsigned)p.PP * 8u;
+        const __amdgpu_buffer_rsrc_t r_prev =
+            make_rsrc(p.planes + ((size_t)s * 2 + ((q - 1) & 1)) * 6 * p.PP + (size_t)face * p.PP, plane_bytes);
         const int qm = q - 1;
         const bool ina = abs(a) <= qm, inam = abs(am) <= qm, inb = abs(b) <= qm, inbm = abs(bm) <= qm;
         const int o = (b + p.R) * p.P + (a + p.R);
-        const double c1v = (inam && inbm) ? prev[o - sgb * p.P - sga] : 0.0;
-        const double c2v = (ina && inbm) ? prev[o - sgb * p.P] : 0.0;
-        const double c3v = (inam && inb) ? prev[o - sga] : 0.0;
-        const double c4v = (ina && inb) ? prev[o] : 0.0;
+        const unsigned o8 = (unsigned)o * 8u, da8 = (unsigned)(sga * 8), db8 = (unsigned)(sgb * p.P * 8);
+        const double c1v = buf_load_f64(r_prev, (inam && inbm) ? o8 - db8 - da8 : kOOB);
+        const double c2v = buf_load_f64(r_prev, (ina && inbm) ? o8 - db8 : kOOB);
+        const double c3v = buf_load_f64(r_prev, (inam && inb) ? o8 - da8 : kOOB);
+        const double c4v = buf_load_f64(r_prev, (ina && inb) ? o8 : kOOB);
 
         // cinterp, generic in (a,b,pd): the three branches differ only by which axes play (u,v).
         // real(int) conversions of the reference are f32 but exact (|.| < 2^24): cvt i32->f64.
@@ -310,16 +342,16 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         const double cd_out = cd_in + xav0 * nd * path;
 
         // store into this face's plane and into the planes of the faces sharing the cell
-        double *cur = p.planes + ((size_t)s * 2 + (q & 1)) * 6 * p.PP;
-        cur[(size_t)face * p.PP + o] = cd_out;
+        const __amdgpu_buffer_rsrc_t r_cur = make_rsrc(p.planes + ((size_t)s * 2 + (q & 1)) * 6 * p.PP, 6u * plane_bytes);
+        buf_store_f64(r_cur, (unsigned)face * plane_bytes + o8, cd_out);
         if (axis == 2) {
             if (abs(a) == q)   // x-face (u=y=b, v=z=pd)
-                cur[(size_t)(a > 0 ? 4 : 5) * p.PP + (pd + p.R) * p.P + (b + p.R)] = cd_out;
+                buf_store_f64(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((pd + p.R) * p.P + (b + p.R)) * 8u, cd_out);
             if (abs(b) == q)   // y-face (u=x=a, v=z=pd)
-                cur[(size_t)(b > 0 ? 2 : 3) * p.PP + (pd + p.R) * p.P + (a + p.R)] = cd_out;
+                buf_store_f64(r_cur, (b > 0 ? 2u : 3u) * plane_bytes + (unsigned)((pd + p.R) * p.P + (a + p.R)) * 8u, cd_out);
         } else if (axis == 1) {
             if (abs(a) == q)   // x-face (u=y=pd, v=z=b)
-                cur[(size_t)(a > 0 ? 4 : 5) * p.PP + (b + p.R) * p.P + (pd + p.R)] = cd_out;
+                buf_store_f64(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((b + p.R) * p.P + (pd + p.R)) * 8u, cd_out);
         }
         if (sa.dbg_cdout) sa.dbg_cdout[id_n] = cd_out;
 
@@ -327,11 +359,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         if (!(cd_in > p.max_coldensh) && nflux > 0.0) {
             double p_out;
             const double gamma = fdiv(photoion(p, cd_in, cd_out, vol_ph, nflux, p_out), xav0 * nd);
-#ifdef C2R_AB_PLAIN_STORE      // timing experiment only: wrong results
-            if (gamma != 0.0) (xf ? p.phih_T : p.phih)[id] = gamma;
-#else
             if (gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id], gamma);
-#endif
             if (sa.has_boundary) {
                 const bool bnd = d0 == sa.boxR[0] || d1 == sa.boxR[1] || d2 == sa.boxR[2] ||
                                  d0 == -sa.boxL[0] || d1 == -sa.boxL[1] || d2 == -sa.boxL[2];
