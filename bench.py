@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--sources", type=int, default=1000)
     ap.add_argument("--x-init", type=float, default=0.999)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="per-source Gamma grids reduced in source order instead of f64 atomics")
     ap.add_argument("--native-loop", action="store_true",
                     help="time whole evolve3D calls through c2r_evolve3d_dev instead of single iterations")
     args = ap.parse_args()
@@ -118,7 +120,7 @@ def main():
     nd, xh = tp.fields(1, args.x_init)
     srcpos, normflux = pkg.seeded_sources(n, S)
     thick, thin, _ = pkg.build_tables()          # rad_ini on the host (c2r_build_tables)
-    b = pkg.HipBackend(n, thick, thin, device=local_rank)
+    b = pkg.HipBackend(n, thick, thin, device=local_rank, deterministic=args.deterministic)
     b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], s["clumping"], s["temper"])
     b.set_sources(srcpos, normflux)
     b.load(ndens=nd, xh=xh)
@@ -179,7 +181,7 @@ def main():
             "config": {"workload": "%d^3 mesh, %d sources (seeded), reference test problem at z=9 pre-ionised to "
                                    "x=%.3f, one evolve3D outer iteration per step (sweep all sources + all-reduce + "
                                    "global chemistry pass)" % (n, S, args.x_init),
-                       "mesh": n, "sources": S, "sources_per_gpu": len(pkg.static_source_share(S, 0, world)),
+                       "mesh": n, "sources": S, "gamma_accumulation": "ordered" if args.deterministic else "atomic", "sources_per_gpu": len(pkg.static_source_share(S, 0, world)),
                        "parallelism": "sources sharded over %d GPU(s), RCCL all-reduce of Gamma" % world,
                        "visited_cell_sources_per_step": visited_all / args.steps,
                        "visited_per_s": visited_all / dt_wall,

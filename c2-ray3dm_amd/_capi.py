@@ -16,7 +16,7 @@ GRID_NDENS, GRID_XH, GRID_XH_AV, GRID_XH_INTERMED, GRID_PHIH = range(5)
 class Params(C.Structure):
     _fields_ = [("mesh", C.c_int32 * 3), ("device", C.c_int32), ("subboxsize", C.c_int32),
                 ("max_subbox", C.c_int32), ("numtau", C.c_int32), ("max_outer_iter", C.c_int32),
-                ("max_chem_iter", C.c_int32), ("reserved0", C.c_int32),
+                ("max_chem_iter", C.c_int32), ("deterministic_rates", C.c_int32),
                 ("epsilon", C.c_double), ("convergence_fraction", C.c_double),
                 ("minimum_fractional_change", C.c_double), ("minimum_fraction_of_atoms", C.c_double),
                 ("loss_fraction", C.c_double), ("max_coldensh", C.c_double),

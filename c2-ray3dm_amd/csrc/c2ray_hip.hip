@@ -45,6 +45,7 @@ struct Ctx {
     int batch_cap = 0;
     double *d_planes = nullptr;
     int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr;
+    double *d_gbox = nullptr;   // deterministic mode: [batch_cap][2][ncell]
     int *d_active[2] = {nullptr, nullptr};
     int *d_nactive = nullptr; int *h_nactive = nullptr;     // pinned
     double *d_loss_partial = nullptr, *d_loss_acc = nullptr, *d_final_loss = nullptr;
@@ -84,11 +85,11 @@ size_t grid_bytes(const Ctx *ctx, int which) { return ctx->ncell * (which == 0 ?
 
 void free_sweep_scratch(Ctx *ctx)
 {
-    hipFree(ctx->d_planes); hipFree(ctx->d_srcpos_b); hipFree(ctx->d_srcw_b); hipFree(ctx->d_nflux_b);
+    hipFree(ctx->d_planes); hipFree(ctx->d_gbox); hipFree(ctx->d_srcpos_b); hipFree(ctx->d_srcw_b); hipFree(ctx->d_nflux_b);
     hipFree(ctx->d_active[0]); hipFree(ctx->d_active[1]);
     hipFree(ctx->d_loss_partial); hipFree(ctx->d_loss_acc); hipFree(ctx->d_final_loss);
     hipFree(ctx->d_final_nbox);
-    ctx->d_planes = nullptr; ctx->d_srcpos_b = nullptr; ctx->d_srcw_b = nullptr; ctx->d_nflux_b = nullptr;
+    ctx->d_planes = nullptr; ctx->d_gbox = nullptr; ctx->d_srcpos_b = nullptr; ctx->d_srcw_b = nullptr; ctx->d_nflux_b = nullptr;
     ctx->d_active[0] = ctx->d_active[1] = nullptr;
     ctx->d_loss_partial = ctx->d_loss_acc = ctx->d_final_loss = nullptr; ctx->d_final_nbox = nullptr;
     ctx->batch_cap = 0;
@@ -105,7 +106,8 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
 {
     if (want <= ctx->batch_cap) return C2R_OK;
     free_sweep_scratch(ctx);
-    const size_t per_src = 2 * 6 * ctx->PP * sizeof(double) + (size_t)6 * ctx->tiles_cap * sizeof(double) + 64;
+    const size_t per_src = 2 * 6 * ctx->PP * sizeof(double) + (size_t)6 * ctx->tiles_cap * sizeof(double) + 64 +
+                           (ctx->prm.deterministic_rates ? 2 * ctx->ncell * sizeof(double) : 0);
     size_t budget = ctx->prm.scratch_bytes;
     if (budget == 0) {
         size_t fr = 0, tot = 0;
@@ -116,6 +118,7 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
     if (const char *e = getenv("C2R_BATCH_CAP")) cap = std::max(1, std::min(cap, atoi(e)));      // experiments
     cap = std::min(cap, 65535);                 // grid.z of k_sweep_shell
     HIP_TRY(hipMalloc(&ctx->d_planes, (size_t)cap * 2 * 6 * ctx->PP * sizeof(double)));
+    if (ctx->prm.deterministic_rates) HIP_TRY(hipMalloc(&ctx->d_gbox, (size_t)cap * 2 * ctx->ncell * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_srcpos_b, (size_t)cap * 3 * sizeof(int)));
     HIP_TRY(hipMalloc(&ctx->d_srcw_b, (size_t)cap * 3 * sizeof(int)));
     HIP_TRY(hipMalloc(&ctx->d_nflux_b, (size_t)cap * sizeof(double)));
@@ -170,6 +173,7 @@ KParams make_kparams(const Ctx *ctx)
     k.R = ctx->R; k.P = ctx->P; k.PP = ctx->PP;
     k.ndens = (const float *)ctx->grid[0]; k.xh_av = (const double *)ctx->grid[2]; k.phih = (double *)ctx->grid[4];
     k.ndens_T = ctx->d_ndens_T; k.xh_av_T = ctx->d_xhav_T; k.phih_T = ctx->d_phih_T;
+    k.gbox = ctx->d_gbox;
     k.thick = ctx->d_thick; k.thin = ctx->d_thin;
     k.srcpos = ctx->d_srcpos_b; k.srcw = ctx->d_srcw_b; k.normflux = ctx->d_nflux_b; k.planes = ctx->d_planes;
     return k;
@@ -272,6 +276,9 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
         n_active = *ctx->h_nactive;
         cur = 1 - cur;
     }
+    if (ctx->d_gbox)
+        hipLaunchKernelGGL(k_gamma_reduce, dim3((unsigned)((ctx->ncell + 255) / 256)), dim3(256), 0, st, k, count,
+                           ctx->d_final_nbox, p.subboxsize, (double *)ctx->grid[4]);
     hipLaunchKernelGGL(k_batch_totals, dim3(1), dim3(64), 0, st, count, ctx->d_final_loss, ctx->d_final_nbox,
                        ctx->d_photon_loss, ctx->d_sum_nbox);
     HIP_TRY(hipGetLastError());

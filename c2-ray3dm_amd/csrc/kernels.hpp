@@ -40,6 +40,8 @@ struct KParams {
     const float  *ndens_T;     // [k][i][j]  (j fastest): replicas read by the +-x faces, whose
     const double *xh_av_T;     //            waves run along y
     double *phih_T;            // Gamma of the +-x faces, added back after the pass
+    double *gbox;              // deterministic mode: [S_batch][2][ncell] per-source Gamma ([0] x-fastest cells of
+                               // z/y faces, [1] y-fastest cells of x faces); null: atomics into phih/phih_T
     const double *thick, *thin;
     const int    *srcpos;      // 3 x S_batch (unwrapped, 1-based: cinterp's real(i0) needs it)
     const int    *srcw;        // 3 x S_batch wrapped to 0..N-1
@@ -220,8 +222,9 @@ __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0
     double p_out = 0.0, gamma = 0.0;
     if (nflux > 0.0) {      // cd_in = 0 is never above max_coldensh
         gamma = photoion(p, cd_in, cd_out, vol_ph, nflux, p_out) / (xav0 * nd);
-        atomicAdd(&p.phih[id], gamma);
+        if (!p.gbox) atomicAdd(&p.phih[id], gamma);
     }
+    if (p.gbox) p.gbox[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = gamma;
     // degenerate meshes only: the source cell itself sits on the sub-box surface
     if (boxR0 == 0 || boxR1 == 0 || boxR2 == 0 || boxL0 == 0 || boxL1 == 0 || boxL2 == 0)
         loss_acc[s] += p_out * p.vol / vol_ph;
@@ -356,22 +359,59 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         if (sa.dbg_cdout) sa.dbg_cdout[id_n] = cd_out;
 
         const double nflux = p.normflux[s];
+        double gamma = 0.0;
         if (!(cd_in > p.max_coldensh) && nflux > 0.0) {
             double p_out;
-            const double gamma = fdiv(photoion(p, cd_in, cd_out, vol_ph, nflux, p_out), xav0 * nd);
-            if (gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id], gamma);
+            gamma = fdiv(photoion(p, cd_in, cd_out, vol_ph, nflux, p_out), xav0 * nd);
+            if (!p.gbox && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id], gamma);
             if (sa.has_boundary) {
                 const bool bnd = d0 == sa.boxR[0] || d1 == sa.boxR[1] || d2 == sa.boxR[2] ||
                                  d0 == -sa.boxL[0] || d1 == -sa.boxL[1] || d2 == -sa.boxL[2];
                 if (bnd) loss = fdiv(p_out * p.vol, vol_ph);
             }
         }
+        // deterministic mode: every visited cell records its rate (zero included) for k_gamma_reduce
+        if (p.gbox) p.gbox[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + id] = gamma;
     }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
         if (threadIdx.x == 0)
             sa.loss_partial[((size_t)sl * 6 + face) * sa.tiles_max + tile] = tot;
     }
+}
+
+// Deterministic mode: phih(cell) += Gamma_s(cell) for the sources of a batch IN SOURCE ORDER (the order
+// of the serial reference, evolve_point.F90:283 inside master_slave.F90:85's loop).  One thread per
+// cell; a source contributes where the cell lies inside its final sub-box (evolve_source.F90:135-136).
+__global__ __launch_bounds__(256) void k_gamma_reduce(KParams p, int nsrc, const int *final_nbox, int subbox,
+                                                      double *phih)
+{
+    const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
+    const unsigned id = blockIdx.x * 256u + threadIdx.x;
+    if (id >= ncell) return;
+    const int c0 = (int)(id % (unsigned)p.n[0]);
+    const unsigned r = id / (unsigned)p.n[0];
+    const int c1 = (int)(r % (unsigned)p.n[1]), c2 = (int)(r / (unsigned)p.n[1]);
+    const unsigned id_t = (unsigned)c1 + (unsigned)p.n[1] * ((unsigned)c0 + (unsigned)p.n[0] * (unsigned)c2);
+    double acc = phih[id];
+    for (int s = 0; s < nsrc; ++s) {
+        const int nb = final_nbox[s];                 // uniform
+        if (nb <= 0) continue;
+        const int ext = subbox * nb;
+        int d0 = c0 - p.srcw[3 * s + 0], d1 = c1 - p.srcw[3 * s + 1], d2 = c2 - p.srcw[3 * s + 2];
+        d0 -= (d0 > p.hr[0]) ? p.n[0] : 0;  d0 += (d0 < -p.hl[0]) ? p.n[0] : 0;
+        d1 -= (d1 > p.hr[1]) ? p.n[1] : 0;  d1 += (d1 < -p.hl[1]) ? p.n[1] : 0;
+        d2 -= (d2 > p.hr[2]) ? p.n[2] : 0;  d2 += (d2 < -p.hl[2]) ? p.n[2] : 0;
+        const bool in = d0 >= -min(ext, p.hl[0]) && d0 <= min(ext, p.hr[0]) &&
+                        d1 >= -min(ext, p.hl[1]) && d1 <= min(ext, p.hr[1]) &&
+                        d2 >= -min(ext, p.hl[2]) && d2 <= min(ext, p.hr[2]);
+        if (in) {
+            const bool xf = abs(d0) > abs(d1) && abs(d0) > abs(d2);      // cinterp branch priority z > y > x
+            const double *g = p.gbox + ((size_t)s * 2 + (xf ? 1 : 0)) * ncell;
+            acc = acc + g[xf ? id_t : id];
+        }
+    }
+    phih[id] = acc;
 }
 
 // out[j + N1*(i + N0*k)] = in[i + N0*(j + N1*k)]: (x,y) transpose of every z-plane through LDS.

@@ -38,7 +38,7 @@ def static_source_share(nsrc, rank, npr):
 class HipBackend:
     """The HIP path: owns a c2r context on one GPU and the device-resident arrays."""
 
-    def __init__(self, mesh, thick, thin, device=0, scratch_bytes=0, use_torch=True):
+    def __init__(self, mesh, thick, thin, device=0, scratch_bytes=0, deterministic=False):
         import torch
         self.torch = torch
         self.lib = _capi.load_library()
@@ -50,6 +50,7 @@ class HipBackend:
         torch.cuda.set_device(self.device)
         p = _capi.default_params(self.mesh, device)
         p.scratch_bytes = scratch_bytes
+        p.deterministic_rates = 1 if deterministic else 0
         self.params = p
         self.ctx = C.c_void_p()
         rc = self.lib.c2r_create(C.byref(self.ctx), C.byref(p))

@@ -50,7 +50,7 @@ module evolve
   !> mirror of struct c2r_params (include/c2ray_hip.h)
   type, bind(C) :: c2r_params
      integer(c_int32_t) :: mesh(3), device, subboxsize, max_subbox, numtau, max_outer_iter, &
-          max_chem_iter, reserved0
+          max_chem_iter, deterministic_rates
      real(c_double) :: epsilon, convergence_fraction, minimum_fractional_change, &
           minimum_fraction_of_atoms, loss_fraction, max_coldensh, tau_photo_limit, sigma_HI, &
           minlogtau, dlogtau, weight_floor, sqrt2, sqrt3, pi, abu_c, bh00, albpow, colh0, temph0, S_star

@@ -48,7 +48,10 @@ typedef struct c2r_params {
     int32_t numtau;                  /* radiation_sizes.f90:14 (tables hold numtau+1 entries) */
     int32_t max_outer_iter;          /* evolve.F90:228 (100) */
     int32_t max_chem_iter;           /* evolve_point.F90:541 (400) */
-    int32_t reserved0;
+    int32_t deterministic_rates;     /* 0: Gamma accumulated with f64 atomics (reproducible to rounding);
+                                      * 1: per-source Gamma grids reduced in source order: bit-reproducible, and
+                                      *    the summation order of the serial reference (evolve_point.F90:283);
+                                      *    costs 16 B x N^3 of scratch per source in flight */
     double  epsilon;                 /* c2ray_parameters.f90:31 */
     double  convergence_fraction;    /* :25 */
     double  minimum_fractional_change; /* :34 */

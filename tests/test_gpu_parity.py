@@ -250,3 +250,43 @@ def test_restart_from_iteration_dump(pkg, tables, tmp_path, name, native):
     assert np.max(np.abs(b.fetch("xh") - F(a["xh_after"]))) < TOL_X
     assert gamma_err(b.fetch("phih_grid"), F(a["phih_grid"])) < 1e-8
     b.close()
+
+
+def test_deterministic_rates_mode(pkg, tables):
+    """deterministic_rates=1: per-source Gamma grids summed in source order (the serial reference's
+    order) instead of atomics: bit-identical from run to run, equal to the atomic mode to rounding,
+    same parity with the reference fixture."""
+    m, a = load_case("sweep32_bubbles")
+    n = m["n"]
+    nd, xh = F(expand(a["ndens"], n)), F(expand(a["xh"], n))
+    runs = []
+    for det in (True, True, False):
+        b = make_backend(pkg, tables, m, n, nd, xh, deterministic=det)
+        b.begin_step(); b.zero_rates()
+        r = b.pass_sources()
+        runs.append((r, b.fetch("phih_grid")))
+        b.close()
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])        # bitwise
+    assert runs[0][0] == runs[2][0]
+    assert relerr(runs[0][1], runs[2][1], floor=1e-60) < 1e-13
+    ref = F(a["phih"])
+    assert np.array_equal(runs[0][1] == 0, ref == 0)
+    assert gamma_err(runs[0][1], ref) < TOL_GAMMA
+
+
+def test_deterministic_mode_whole_step_and_batches(pkg, tables):
+    """A whole evolve3D step in deterministic mode (iteration history of the reference), and
+    several source batches (scratch cap) giving bit-identical rates to one batch."""
+    m, a = load_case("evolve32_std_bubbles")
+    s = m["steps"]["step001"]
+    n = m["n"]
+    out = []
+    for cap in (0, 600000):          # 600 kB: one source per batch at 32^3 (2 x 262 kB of Gamma grids each)
+        b = make_backend(pkg, tables, s, n, F(a["step001_ndens"]), F(a["step001_xh_before"]),
+                         deterministic=True, scratch_bytes=cap)
+        rep = b.evolve3d_native(s["dt"])
+        assert rep.niter == s["niter"] and list(rep.it_conv_flag[:rep.niter]) == s["log"]["nonconv"]
+        assert np.max(np.abs(b.fetch("xh") - F(a["step001_xh_after"]))) < TOL_X
+        out.append(b.fetch("phih_grid"))
+        b.close()
+    assert np.array_equal(out[0], out[1])
