@@ -64,6 +64,8 @@ SYMBOLS = [
     ("c2r_set_stream", C.c_int, [_P, _P]),
     ("c2r_set_tables", C.c_int, [_P, _P, _P, _I32]),
     ("c2r_set_step", C.c_int, [_P, C.POINTER(_D * 3), _D, _D, C.c_float, _D]),
+    ("c2r_set_lls", C.c_int, [_P, _I32, _P, _D]),
+    ("c2r_set_clumping_grid", C.c_int, [_P, _P]),
     ("c2r_set_sources", C.c_int, [_P, _P, _P, _I32]),
     ("c2r_set_rank", C.c_int, [_P, _I32, _I32, ALLREDUCE_FN, _P]),
     ("c2r_bind_device_buffers", C.c_int, [_P, _P, _P, _P, _P, _P]),

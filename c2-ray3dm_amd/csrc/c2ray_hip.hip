@@ -27,6 +27,9 @@ struct Ctx {
     void *grid[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // (x,y)-transposed replicas for the +-x faces of the sweep (owned): ndens_T, xh_av_T, phih_T
     float *d_ndens_T = nullptr; double *d_xhav_T = nullptr, *d_phih_T = nullptr;
+    // optional per-cell inputs of the non-default physics switches
+    int lls_type = 1; double R_max_LLS = 0.0;
+    float *d_lls = nullptr, *d_lls_T = nullptr, *d_clump = nullptr;
     bool  own[5] = {false, false, false, false, false};
     double *d_thick = nullptr, *d_thin = nullptr;
     bool have_tables = false, have_step = false;
@@ -174,6 +177,7 @@ KParams make_kparams(const Ctx *ctx)
     k.ndens = (const float *)ctx->grid[0]; k.xh_av = (const double *)ctx->grid[2]; k.phih = (double *)ctx->grid[4];
     k.ndens_T = ctx->d_ndens_T; k.xh_av_T = ctx->d_xhav_T; k.phih_T = ctx->d_phih_T;
     k.gbox = ctx->d_gbox;
+    k.lls_type = ctx->lls_type; k.R_max2 = ctx->R_max_LLS * ctx->R_max_LLS; k.lls = ctx->d_lls; k.lls_T = ctx->d_lls_T;
     k.thick = ctx->d_thick; k.thin = ctx->d_thin;
     k.srcpos = ctx->d_srcpos_b; k.srcw = ctx->d_srcw_b; k.normflux = ctx->d_nflux_b; k.planes = ctx->d_planes;
     return k;
@@ -420,6 +424,7 @@ void c2r_destroy(c2r_ctx *c)
     for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
     hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_nactive);
     hipFree(ctx->d_ndens_T); hipFree(ctx->d_xhav_T); hipFree(ctx->d_phih_T);
+    hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
     hipFree(ctx->d_photon_loss); hipFree(ctx->d_sum_nbox); hipFree(ctx->d_sum_partial); hipFree(ctx->d_sum_out);
     hipFree(ctx->d_conv); hipFree(ctx->d_chemfail); hipFree(ctx->d_dbg); hipFree(ctx->d_pair);
@@ -465,6 +470,38 @@ int c2r_set_step(c2r_ctx *c, const double dr[3], double vol, double lls, float c
     for (int d = 0; d < 3; ++d) ctx->dr[d] = dr[d];
     ctx->vol = vol; ctx->lls = lls; ctx->clumping = clumping; ctx->temper = temper;
     ctx->have_step = true;
+    return C2R_OK;
+}
+
+int c2r_set_lls(c2r_ctx *c, int32_t type, const float *lls_grid, double R_max_LLS)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (type < 1 || type > 3) FAIL(C2R_EINVAL, "type_of_LLS must be 1, 2 or 3");
+    if (type == 2 && !lls_grid) FAIL(C2R_EINVAL, "type_of_LLS=2 needs the LLS grid");
+    if (type == 3 && !(R_max_LLS > 0.0)) FAIL(C2R_EINVAL, "type_of_LLS=3 needs R_max_LLS > 0");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (type == 2) {
+        const c2r_params &p = ctx->prm;
+        if (!ctx->d_lls) { HIP_TRY(hipMalloc(&ctx->d_lls, grid_bytes(ctx, 0))); HIP_TRY(hipMalloc(&ctx->d_lls_T, grid_bytes(ctx, 0))); }
+        HIP_TRY(hipMemcpyAsync(ctx->d_lls, lls_grid, grid_bytes(ctx, 0), hipMemcpyHostToDevice, ctx->stream));
+        const dim3 g((p.mesh[0] + 31) / 32, (p.mesh[1] + 31) / 32, p.mesh[2]);
+        hipLaunchKernelGGL((k_transpose_xy<float, false>), g, dim3(256), 0, ctx->stream, p.mesh[0], p.mesh[1], p.mesh[2],
+                           (const float *)ctx->d_lls, ctx->d_lls_T);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->lls_type = type; ctx->R_max_LLS = R_max_LLS;
+    return C2R_OK;
+}
+
+int c2r_set_clumping_grid(c2r_ctx *c, const float *clump_grid)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (!clump_grid) { hipFree(ctx->d_clump); ctx->d_clump = nullptr; return C2R_OK; }
+    if (!ctx->d_clump) HIP_TRY(hipMalloc(&ctx->d_clump, grid_bytes(ctx, 0)));
+    HIP_TRY(hipMemcpy(ctx->d_clump, clump_grid, grid_bytes(ctx, 0), hipMemcpyHostToDevice));
     return C2R_OK;
 }
 
@@ -635,11 +672,11 @@ int c2r_photon_sums(c2r_ctx *c, int32_t which_l, int32_t which_r, double out[4])
     if (rc) return rc;
     const c2r_params &p = ctx->prm;
     // photonstatistics.F90:166-172: same rate coefficients as doric, host libm
-    const double rec = (double)ctx->clumping * p.bh00 * pow(ctx->temper / 1e4, p.albpow);
-    const double col = p.colh0 * sqrt(ctx->temper) * exp(-p.temph0 / ctx->temper);
     hipLaunchKernelGGL(k_photon_sums, dim3(kSumBlocks), dim3(256), 0, ctx->stream, ctx->ncell,
                        (const float *)ctx->grid[0], (const double *)ctx->grid[which_l],
-                       (const double *)ctx->grid[which_r], p.abu_c, rec, col, ctx->d_sum_partial);
+                       (const double *)ctx->grid[which_r], p.abu_c, (double)ctx->clumping, (const float *)ctx->d_clump,
+                       p.bh00, pow(ctx->temper / 1e4, p.albpow), p.colh0, sqrt(ctx->temper),
+                       exp(-p.temph0 / ctx->temper), ctx->d_sum_partial);
     for (int m = 0; m < 4; ++m)
         hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks,
                            ctx->d_sum_partial + (size_t)m * kSumBlocks, ctx->d_sum_out + m);
@@ -663,6 +700,7 @@ int c2r_global_pass(c2r_ctx *c, double dt, int64_t *conv_flag, double *sum_xh1)
     // doric.f90:73,78 -- temperature is uniform (isothermal), so both rate coefficients are
     // per-call constants; evaluated with the host libm like the reference does at run time
     cp.brech0 = (double)ctx->clumping * p.bh00 * pow(ctx->temper / 1e4, p.albpow);
+    cp.bh00 = p.bh00; cp.recpow = pow(ctx->temper / 1e4, p.albpow); cp.clump = ctx->d_clump;
     cp.acolh0 = p.colh0 * sqrt(ctx->temper) * exp(-p.temph0 / ctx->temper);
     HIP_TRY(hipMemsetAsync(ctx->d_conv, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_chemfail, 0, sizeof(unsigned int), ctx->stream));

@@ -40,6 +40,10 @@ struct KParams {
     const float  *ndens_T;     // [k][i][j]  (j fastest): replicas read by the +-x faces, whose
     const double *xh_av_T;     //            waves run along y
     double *phih_T;            // Gamma of the +-x faces, added back after the pass
+    // non-default physics switches (c2ray_parameters.f90:80-99)
+    int lls_type;              // 1 homogeneous, 2 per-cell grid, 3 hard barrier
+    double R_max2;             // R_max_LLS^2 (type 3)
+    const float *lls, *lls_T;  // LLS_grid and its (x,y)-transposed replica (type 2)
     double *gbox;              // deterministic mode: [S_batch][2][ncell] per-source Gamma ([0] x-fastest cells of
                                // z/y faces, [1] y-fastest cells of x faces); null: atomics into phih/phih_T
     const double *thick, *thin;
@@ -339,7 +343,16 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         const double zs = p.dr[2] * (double)d2;
         const double dist2 = xs * xs + ys * ys + zs * zs;
         const double vol_ph = p.fourpi * dist2 * path;
-        const double cd_in = cdi + udiv(p.coldensh_LLS * path, p.dr[0], p.inv_dr0, p.exact_udiv);
+        // LLS opacity (evolve_point.F90:186-196): homogeneous column, per-cell column (LLS_point), or a
+        // hard barrier at R_max that only stops the transfer
+        double cd_in = cdi;
+        bool stop_far = false;
+        if (p.lls_type == 3) {
+            stop_far = dist2 > p.R_max2;
+        } else {
+            const double lls = (p.lls_type == 2) ? (double)(xf ? p.lls_T : p.lls)[id] : p.coldensh_LLS;
+            cd_in = cdi + udiv(lls * path, p.dr[0], p.inv_dr0, p.exact_udiv);
+        }
         const double xav1 = fmax(xav_raw, p.eps);
         const double xav0 = fmax(1.0 - xav1, p.eps);
         const double cd_out = cd_in + xav0 * nd * path;
@@ -360,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
 
         const double nflux = p.normflux[s];
         double gamma = 0.0;
-        if (!(cd_in > p.max_coldensh) && nflux > 0.0) {
+        if (!stop_far && !(cd_in > p.max_coldensh) && nflux > 0.0) {
             double p_out;
             gamma = fdiv(photoion(p, cd_in, cd_out, vol_ph, nflux, p_out), xav0 * nd);
             if (!p.gbox && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id], gamma);
@@ -526,6 +539,8 @@ __global__ void k_batch_totals(int nsrc, const double *final_loss, const int *fi
 struct ChemParams {
     double dt, eps, min_frac_change, min_frac_atoms, abu_c, deltht_small;
     double brech0, acolh0;        // doric.f90:73,78 evaluated on the host for the step's temperature
+    double bh00, recpow;          // brech0 = clumping*bh00*recpow when clumping comes from a grid
+    const float *clump;           // clumping_grid (clumping_module.F90:116) or null
     int max_iter;
 };
 
@@ -548,6 +563,7 @@ __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell,
         double hav0 = 1.0 - hav1;
         const double nd = (double)ndens[id];
         const double gamma = phih[id];
+        const double brech0 = c.clump ? (double)c.clump[id] * c.bh00 * c.recpow : c.brech0;   // evolve_point.F90:443-445
         double h1 = h_old1, h0 = h_old0;
         int nit = 0;
         for (;;) {
@@ -555,9 +571,9 @@ __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell,
             const double yh0_av_old = hav0;
             const double de = nd * (hav1 + c.abu_c);                 // tped.f90:81
             const double aih0 = gamma + de * c.acolh0;
-            const double delth = aih0 + de * c.brech0;
+            const double delth = aih0 + de * brech0;
             const double eq1 = aih0 / delth;
-            const double eq0 = de * c.brech0 / delth;
+            const double eq0 = de * brech0 / delth;
             const double deltht = delth * c.dt;
             const double ee = exp(-deltht);
             h1 = (h_old1 - eq1) * ee + eq1;
@@ -592,7 +608,9 @@ __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell,
 // partial is [4][gridDim.x].
 __global__ __launch_bounds__(256) void k_photon_sums(size_t ncell, const float *__restrict__ ndens,
                                                      const double *__restrict__ xl, const double *__restrict__ xr,
-                                                     double abu_c, double rec_coef, double col_coef, double *partial)
+                                                     double abu_c, double clumping, const float *__restrict__ clump,
+                                                     double bh00, double recpow, double colh0, double sqrtt, double expt,
+                                                     double *partial)
 {
     __shared__ double sm[4];
     double h0 = 0.0, h1 = 0.0, tr = 0.0, tc = 0.0;
@@ -603,8 +621,9 @@ __global__ __launch_bounds__(256) void k_photon_sums(size_t ncell, const float *
         h1 += nd * x;
         const double y1 = xr[id], y0 = 1.0 - y1;
         const double de = nd * (y1 + abu_c);
-        tr += nd * y1 * de * rec_coef;
-        tc += nd * y0 * de * col_coef;
+        const double cl = clump ? (double)clump[id] : clumping;
+        tr += nd * y1 * de * cl * bh00 * recpow;              // photonstatistics.F90:166-168, left to right
+        tc += nd * y0 * de * colh0 * sqrtt * expt;            // :169-172
     }
     double v[4] = {h0, h1, tr, tc};
     for (int m = 0; m < 4; ++m) {

@@ -99,6 +99,16 @@ class HipBackend:
         self._check(self.lib.c2r_set_step(self.ctx, (C.c_double * 3)(*dr), vol, coldensh_LLS, clumping, temper),
                     "c2r_set_step")
 
+    def set_lls(self, type_of_LLS=1, lls_grid=None, R_max_LLS=0.0):
+        g = None if lls_grid is None else _flat(lls_grid, np.float32)
+        self._check(self.lib.c2r_set_lls(self.ctx, type_of_LLS, None if g is None else g.ctypes.data, R_max_LLS),
+                    "c2r_set_lls")
+
+    def set_clumping_grid(self, clump_grid=None):
+        g = None if clump_grid is None else _flat(clump_grid, np.float32)
+        self._check(self.lib.c2r_set_clumping_grid(self.ctx, None if g is None else g.ctypes.data),
+                    "c2r_set_clumping_grid")
+
     def set_sources(self, srcpos, normflux):
         srcpos = np.ascontiguousarray(srcpos, dtype=np.int32).reshape(-1, 3)
         normflux = np.ascontiguousarray(normflux, dtype=np.float64)

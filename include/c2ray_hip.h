@@ -117,6 +117,15 @@ int  c2r_set_tables(c2r_ctx *ctx, const double *thick, const double *thin, int32
  * clumping (clumping_module.F90:74), temper_val (temperature_module.F90:34). */
 int  c2r_set_step(c2r_ctx *ctx, const double dr[3], double vol, double coldensh_LLS,
                   float clumping, double temper);
+/* Non-default LLS treatment (c2ray_parameters.f90:80-99 type_of_LLS, evolve_point.F90:186-196):
+ * 1 homogeneous column per cell (coldensh_LLS of c2r_set_step; the default), 2 position-dependent
+ * column LLS_grid(i,j,k) (LLS.F90:199-212; host f32 N^3, copied), 3 hard barrier: no transfer beyond
+ * R_max_LLS (proper cm, LLS.F90:191). */
+int  c2r_set_lls(c2r_ctx *ctx, int32_t type_of_LLS, const float *lls_grid, double R_max_LLS);
+/* Position-dependent clumping factor clumping_grid(i,j,k) (type_of_clumping 3-5; clumping_point,
+ * clumping_module.F90:106-118) used by doric and the photon statistics; NULL returns to the scalar
+ * clumping of c2r_set_step. */
+int  c2r_set_clumping_grid(c2r_ctx *ctx, const float *clump_grid);
 /* srcpos(3,NumSrc) (1-based, may lie outside the mesh: wrapped at use) and
  * NormFlux_stellar(1:NumSrc) (sourceprops.F90:121-123,167-168). */
 int  c2r_set_sources(c2r_ctx *ctx, const int32_t *srcpos, const double *normflux, int32_t nsrc);

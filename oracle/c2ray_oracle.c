@@ -31,6 +31,11 @@ typedef struct {
     double S_star;            /* table normalisation             radiation_sed_parameters */
     const double *thick;      /* stellar_photo_thick_table(0:NumTau,1) */
     const double *thin;       /* stellar_photo_thin_table(0:NumTau,1)  */
+    /* non-default physics switches of c2ray_parameters.f90:75-99 (0/NULL = shipped behaviour) */
+    int    lls_type;          /* type_of_LLS: 1 homogeneous, 2 LLS_grid per cell, 3 hard barrier at R_max_LLS */
+    double R_max_LLS;         /* LLS.F90:191  R_max/(1+z), proper cm (type 3)                  */
+    const float *lls_grid;    /* LLS.F90:208  LLS_grid (f32), type 2                           */
+    const float *clump_grid;  /* clumping_module.F90:116 clumping_grid (f32), type_of_clumping 3-5 */
 } oracle_cfg;
 
 static inline int pmod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
@@ -192,6 +197,7 @@ static void evolve0d(sweep_t *s, const int rt[3])
     const double xav0 = dmax(1.0 - xav1, C2R_EPSILON);                         /* :140 */
     const double nd = (double)s->ndens[id];
     double cd_in, path, vol_ph;
+    int stop_far = 0;
     if (rt[0] == s->src[0] && rt[1] == s->src[1] && rt[2] == s->src[2]) {      /* :151 */
         cd_in = 0.0;
         path = 0.5 * c->dr[0];
@@ -204,9 +210,14 @@ static void evolve0d(sweep_t *s, const int rt[3])
         const double zs = c->dr[2] * (double)(float)(rt[2] - s->src[2]);
         const double dist2 = xs * xs + ys * ys + zs * zs;
         vol_ph = 4.0 * C2R_PI * dist2 * path;                                  /* :177 */
-        cd_in = cd_in + c->coldensh_LLS * path / c->dr[0];                     /* :194 */
+        if (c->lls_type == 3) {                                                /* :187-191 */
+            if (dist2 > c->R_max_LLS * c->R_max_LLS) stop_far = 1;
+        } else {
+            const double lls = c->lls_type == 2 ? (double)c->lls_grid[id] : c->coldensh_LLS;   /* :193 LLS_point */
+            cd_in = cd_in + lls * path / c->dr[0];                             /* :194 */
+        }
     }
-    const int stop = cd_in > C2R_MAX_COLDENSH;                                 /* :201 */
+    const int stop = stop_far || cd_in > C2R_MAX_COLDENSH;                     /* :201 */
     const double cd_out = cd_in + xav0 * nd * path;                            /* :247, doric.f90:153 */
     s->cdout[id] = cd_out;
     double phi[3] = {0.0, 0.0, 0.0};
@@ -315,7 +326,7 @@ long oracle_global_pass(const oracle_cfg *c, double dt, const float *ndens, cons
             const double yh0_av_old = h_av[0];
             h[0] = h_old[0]; h[1] = h_old[1];                                  /* :463 */
             const double de = nd * (h_av[1] + C2R_ABU_C);                      /* tped.f90:81 */
-            oracle_doric(dt, c->temper, de, c->clumping, h, h_av, gamma);
+            oracle_doric(dt, c->temper, de, c->clump_grid ? (double)c->clump_grid[id] : c->clumping, h, h_av, gamma);   /* :443-445 clumping_point */
             if (fabs((h_av[0] - yh0_av_old) / h_av[0]) < C2R_MIN_FRACTIONAL_CHANGE ||
                 h_av[0] < C2R_MIN_FRACTION_OF_ATOMS) break;                    /* :531-538 */
             if (nit > C2R_MAX_CHEM_ITER) break;                                /* :541 */
@@ -357,7 +368,7 @@ void oracle_photon_sums(const oracle_cfg *c, const float *ndens, const double *x
         h1 = h1 + nd * xh_l[id];
         const double y1 = xh_r[id], y0 = 1.0 - xh_r[id];
         const double de = nd * (y1 + C2R_ABU_C);
-        totrec = totrec + nd * y1 * de * c->clumping * C2R_BH00 * rec;         /* :166-168 */
+        totrec = totrec + nd * y1 * de * (c->clump_grid ? (double)c->clump_grid[id] : c->clumping) * C2R_BH00 * rec;   /* :163-168 */
         totcoll = totcoll + nd * y0 * de * C2R_COLH0 * sq * ex;                /* :169-172 */
     }
     out[0] = h0; out[1] = h1; out[2] = totrec; out[3] = totcoll;

@@ -21,7 +21,9 @@ def build():
 class Cfg(C.Structure):
     _fields_ = [("n", C.c_int * 3), ("dr", C.c_double * 3), ("vol", C.c_double),
                 ("coldensh_LLS", C.c_double), ("clumping", C.c_double), ("temper", C.c_double),
-                ("S_star", C.c_double), ("thick", C.c_void_p), ("thin", C.c_void_p)]
+                ("S_star", C.c_double), ("thick", C.c_void_p), ("thin", C.c_void_p),
+                ("lls_type", C.c_int), ("R_max_LLS", C.c_double), ("lls_grid", C.c_void_p),
+                ("clump_grid", C.c_void_p)]
 
 
 class Report(C.Structure):
@@ -55,14 +57,18 @@ class Oracle:
     """Holds the per-step scalars and the tables; arrays are passed per call (Fortran order)."""
 
     def __init__(self, n, dr, vol, coldensh_LLS, thick, thin, clumping=1.0, temper=1e4,
-                 S_star=1.00000000000000004e+48):
+                 S_star=1.00000000000000004e+48, lls_type=1, R_max_LLS=0.0, lls_grid=None, clump_grid=None):
         n = (n, n, n) if np.isscalar(n) else tuple(n)
         dr = (dr, dr, dr) if np.isscalar(dr) else tuple(dr)
         self.thick = np.ascontiguousarray(thick, dtype=np.float64)
         self.thin = np.ascontiguousarray(thin, dtype=np.float64)
         assert self.thick.size == 2001 and self.thin.size == 2001
+        self.lls_grid = None if lls_grid is None else np.ascontiguousarray(lls_grid, dtype=np.float32)
+        self.clump_grid = None if clump_grid is None else np.ascontiguousarray(clump_grid, dtype=np.float32)
         self.cfg = Cfg((C.c_int * 3)(*n), (C.c_double * 3)(*dr), vol, coldensh_LLS, clumping,
-                       temper, S_star, _p(self.thick), _p(self.thin))
+                       temper, S_star, _p(self.thick), _p(self.thin), lls_type, R_max_LLS,
+                       None if self.lls_grid is None else _p(self.lls_grid),
+                       None if self.clump_grid is None else _p(self.clump_grid))
         self.n = n
         self.ncell = n[0] * n[1] * n[2]
 

@@ -32,16 +32,34 @@ SRCS="precision.f90 mathconstants.f90 cgsconstants.f90 cgsastroconstants.f90 c2r
  evolve_data.F90 column_density.f90 evolve_point.F90 evolve_source.F90 master_slave.F90
  evolve.F90 output.F90"
 
-build_variant () {   # $1 = mesh, $2 = subdir, $3 = extra flags
-  local N=$1 B=$HERE/_ref/N$1/$2 FLAGS="-DGFORT -O2 $3"
+# Physics variants: like the mesh, the LLS and clumping models are compile-time parameters of
+# c2ray_parameters.f90 that the reference's CheckList tells the user to edit ("LLS model", "clumping").
+#   lls2   type_of_LLS=2       position-dependent LLS column (LLS_grid)
+#   lls3   type_of_LLS=3       hard barrier at R_max_cMpc
+#   clump5 type_of_clumping=5  pre-computed clumping grid (clumping_grid)
+params_for_variant () {   # $1 = variant, $2 = output file
+  case "$1" in
+    lls2)   sed 's|^\( *integer,parameter :: type_of_LLS=\)1|\12|' "$REF/c2ray_parameters.f90" > "$2"; grep -q "type_of_LLS=2" "$2" ;;
+    lls3)   sed 's|^\( *integer,parameter :: type_of_LLS=\)1|\13|' "$REF/c2ray_parameters.f90" > "$2"; grep -q "type_of_LLS=3" "$2" ;;
+    clump5) sed 's|^\( *integer,parameter :: type_of_clumping=\)1|\15|' "$REF/c2ray_parameters.f90" > "$2"; grep -q "type_of_clumping=5" "$2" ;;
+    *) echo "unknown variant $1" >&2; exit 1 ;;
+  esac
+}
+
+build_variant () {   # $1 = mesh[:variant], $2 = subdir, $3 = extra flags
+  local N=${1%%:*} V="" FLAGS="-DGFORT -O2 $3"
+  [ "$1" != "$N" ] && V=${1#*:}
+  local B=$HERE/_ref/N$N${V:+_$V}/$2
   mkdir -p "$B"
   sed "s|^\( *integer,dimension(Ndim),parameter,public :: mesh=\)(/ 300, 300, 300 /)|\1(/ $N, $N, $N /)|" \
       "$REF/sizes.f90" > "$B/sizes.f90"
   grep -q "mesh=(/ $N, $N, $N /)" "$B/sizes.f90"
+  [ -n "$V" ] && params_for_variant "$V" "$B/c2ray_parameters.f90"
   local objs=""
   for s in $SRCS; do
     local src o
     if [ "${s#@}" != "$s" ]; then src="$B/${s#@}"; else src="$REF/$s"; fi
+    [ -n "$V" ] && [ "$s" = "c2ray_parameters.f90" ] && src="$B/c2ray_parameters.f90"
     o="$B/$(basename "${s#@}" | sed 's/\.[fF]90$/.o/')"
     if [ ! -f "$o" ] || [ "$src" -nt "$o" ]; then
       ( cd "$B" && $FC $FLAGS -c "$src" -o "$o" 2>>"$B/build.log" )
@@ -76,7 +94,9 @@ build_hip_dropin () {   # $1 = mesh
 
 for N in "$@"; do
   build_variant "$N" serial ""
-  build_hip_dropin "$N"
-  build_variant "$N" omp "-fopenmp -DMY_OPENMP"
-  echo "built oracle/_ref/N$N/{serial,omp}/{c2ray_test,ref_driver}"
+  if [ "${N%%:*}" = "$N" ]; then       # timing build and drop-in program only for the shipped parameters
+    build_hip_dropin "$N"
+    build_variant "$N" omp "-fopenmp -DMY_OPENMP"
+  fi
+  echo "built oracle/_ref/N${N/:/_}"
 done

@@ -34,8 +34,8 @@ program ref_driver
   use material, only: material_ini
   use density_module, only: density_init, ndens
   use ionfractions_module, only: xh
-  use clumping_module, only: set_clumping, load_clumping_model, clumping
-  use lls_module, only: set_LLS, coldensh_LLS
+  use clumping_module, only: set_clumping, load_clumping_model, clumping, clumping_grid
+  use lls_module, only: set_LLS, coldensh_LLS, LLS_grid, R_max_LLS
   use times, only: time_ini, set_timesteps
   use sourceprops, only: source_properties_ini, source_properties, NumSrc, srcpos, &
        NormFlux_stellar
@@ -53,8 +53,9 @@ program ref_driver
   integer            :: nsteps = 1, dump_first = 1, dump_last = 1, ns_dump = 1, nrep = 1
   real(kind=dp)      :: x_init = -1.0_dp
   character(len=512) :: dens_file = 'none', x_file = 'none', out_dir = './dump/'
+  character(len=512) :: lls_file = 'none', clump_file = 'none'
   namelist /ctl/ mode, nsteps, x_init, dens_file, x_file, dump_first, dump_last, &
-       ns_dump, nrep, out_dir
+       ns_dump, nrep, out_dir, lls_file, clump_file
 
   character(len=512) :: answers
   integer :: restart = 0, nz0 = 1, ierror = 0, nz, u, istep, ns, irep
@@ -122,6 +123,21 @@ program ref_driver
         endif
         if (type_of_clumping /= 5) call set_clumping(zred)
         if (use_LLS .and. type_of_LLS /= 2) call set_LLS(zred)
+
+        ! builds with type_of_LLS=2 / type_of_clumping=5: the reference would read its grids from
+        ! N-body products; here they come from files written by make_golden.py
+        if (istep == 1 .and. trim(lls_file) /= 'none') then
+           if (.not. allocated(LLS_grid)) allocate(LLS_grid(mesh(1),mesh(2),mesh(3)))
+           open(newunit=u, file=trim(lls_file), access='stream', form='unformatted', status='old')
+           read(u) LLS_grid
+           close(u)
+        endif
+        if (istep == 1 .and. trim(clump_file) /= 'none') then
+           if (.not. allocated(clumping_grid)) allocate(clumping_grid(mesh(1),mesh(2),mesh(3)))
+           open(newunit=u, file=trim(clump_file), access='stream', form='unformatted', status='old')
+           read(u) clumping_grid
+           close(u)
+        endif
 
         if (istep == 1) then
            if (x_init >= 0.0_dp) xh = x_init
@@ -240,6 +256,9 @@ contains
     write(uu,'(A,1X,ES26.17E3)') 'clumping', real(clumping,dp)
     write(uu,'(A,1X,ES26.17E3)') 'S_star', S_star
     write(uu,'(A,1X,ES26.17E3)') 'zred', zred
+    write(uu,'(A,1X,I12)') 'type_of_LLS', type_of_LLS
+    write(uu,'(A,1X,I12)') 'type_of_clumping', type_of_clumping
+    write(uu,'(A,1X,ES26.17E3)') 'R_max_LLS', R_max_LLS
     write(uu,'(A,1X,I12)') 'NumSrc', NumSrc
     do is = 1, NumSrc
        write(uu,'(A,1X,3(I8,1X),ES26.17E3)') 'src', srcpos(1,is), srcpos(2,is), srcpos(3,is), &

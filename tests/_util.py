@@ -22,12 +22,15 @@ def load_case(name):
     return meta, arrays
 
 
-def oracle_for(meta, tables, n=None):
+def oracle_for(meta, tables, n=None, lls_grid=None, clump_grid=None):
     """Oracle configured with the per-step scalars recorded from the reference."""
     from oracle.oracle import Oracle
     thick, thin = tables
     return Oracle(n or meta["mesh"], (meta["dr1"], meta["dr2"], meta["dr3"]), meta["vol"],
-                  meta["coldensh_LLS"], thick, thin, clumping=meta["clumping"], S_star=meta["S_star"])
+                  meta["coldensh_LLS"], thick, thin, clumping=meta["clumping"], S_star=meta["S_star"],
+                  lls_type=meta.get("type_of_LLS", 1), R_max_LLS=meta.get("R_max_LLS", 0.0),
+                  lls_grid=None if lls_grid is None else F(lls_grid),
+                  clump_grid=None if clump_grid is None else F(clump_grid))
 
 
 def expand(a, n):

@@ -52,7 +52,7 @@ def bubble_xfield(n, centres, radius, x_in=0.9995, x_out=2e-4, seed=7):
     return np.clip(x, 1e-6, 1.0 - 1e-6)
 
 
-def run_driver(n, sources, nml, dens=None, xfield=None, extra_files=None, omp=False, threads=1):
+def run_driver(n, sources, nml, dens=None, xfield=None, extra_files=None, omp=False, threads=1, variant=None):
     d = "/tmp/c2ray_golden_run"
     shutil.rmtree(d, ignore_errors=True)
     os.makedirs(d + "/results")
@@ -74,7 +74,7 @@ def run_driver(n, sources, nml, dens=None, xfield=None, extra_files=None, omp=Fa
         writer(os.path.join(d, name))
     with open(d + "/driver.nml", "w") as f:
         f.write("&ctl " + ", ".join("%s=%s" % kv for kv in nml.items()) + " /\n")
-    exe = os.path.join(REF, "N%d" % n, "omp" if omp else "serial", "ref_driver")
+    exe = os.path.join(REF, "N%d%s" % (n, "_" + variant if variant else ""), "omp" if omp else "serial", "ref_driver")
     env = dict(os.environ, OMP_NUM_THREADS=str(threads))
     subprocess.check_call([exe, "answers"], cwd=d, env=env, stdout=subprocess.DEVNULL)
     return d
@@ -174,10 +174,16 @@ def case_point():
           (len(out["cinterp_out_a"]), len(out["cinterp_out_b"]), len(photo), len(dor)))
 
 
-def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, keep=("xh_after", "phih_grid", "xh_av")):
+def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, keep=("xh_after", "phih_grid", "xh_av"),
+                variant=None, lls_grid=None, clump_grid=None):
     dens = density_factor(n, dens_seed) if dens_seed is not None else None
-    d = run_driver(n, sources, {"mode": "'evolve'", "nsteps": nsteps, "dump_first": dump[0],
-                                "dump_last": dump[-1]}, dens=dens, xfield=xfield)
+    nml = {"mode": "'evolve'", "nsteps": nsteps, "dump_first": dump[0], "dump_last": dump[-1]}
+    extra = {}
+    if lls_grid is not None:
+        extra["lls.f32"] = lambda p: lls_grid.astype(np.float32).T.tofile(p); nml["lls_file"] = "'lls.f32'"
+    if clump_grid is not None:
+        extra["clump.f32"] = lambda p: clump_grid.astype(np.float32).T.tofile(p); nml["clump_file"] = "'clump.f32'"
+    d = run_driver(n, sources, nml, dens=dens, xfield=xfield, variant=variant, extra_files=extra)
     log = parse_log(d + "/results/C2Ray.log")
     arrays, meta = {}, {"n": n, "steps": {}}
     for s in dump:
@@ -191,6 +197,8 @@ def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, kee
         arrays[tag + "_ndens"] = rd(d, tag + "_ndens.f32", n, np.float32)
         for k in keep:
             arrays[tag + "_" + k] = rd(d, "%s_%s.f64" % (tag, k), n)
+    if lls_grid is not None: arrays["lls_grid"] = lls_grid.astype(np.float32)
+    if clump_grid is not None: arrays["clump_grid"] = clump_grid.astype(np.float32)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
     json.dump(meta, open(os.path.join(HERE, name + ".json"), "w"), indent=1)
     print(name, {t: m["niter"] for t, m in meta["steps"].items()})
@@ -331,6 +339,15 @@ def main():
         case_restart("restart32_std_bubbles", 32, SRC_STD, 11, x)
         # one source: conv_criterion = 0, so only Test 2 can end the step and real iterations follow
         case_restart("restart32_onesrc", 32, SRC_ONE, 12, None, k_iter=3)
+    # non-default physics switches (reference rebuilt with the one parameter changed, ref_build.sh N:variant)
+    if want("variants"):
+        x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 7.0)
+        rng = np.random.default_rng(77)
+        lls = (7.0e16 * 10.0 ** rng.uniform(-1.0, 1.0, (32, 32, 32)))
+        case_evolve("evolve32_lls2", 32, SRC_STD, 1, [1], dens_seed=11, xfield=x, variant="lls2", lls_grid=lls)
+        case_evolve("evolve32_lls3", 32, SRC_STD, 1, [1], dens_seed=11, xfield=x, variant="lls3")
+        clump = 1.0 + 9.0 * rng.random((32, 32, 32)) ** 3
+        case_evolve("evolve32_clump5", 32, SRC_STD, 1, [1], dens_seed=11, xfield=x, variant="clump5", clump_grid=clump)
     if want("sweep64"):
         x = bubble_xfield(64, [(50, 50, 50), (20, 10, 10), (6, 8, 50), (20, 10, 26)], 14.0)
         srcs = SRC_STD[:8] + [(72, 72, 50, 1e58), (20, 10, 90, 1e54)]

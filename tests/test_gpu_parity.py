@@ -290,3 +290,27 @@ def test_deterministic_mode_whole_step_and_batches(pkg, tables):
         out.append(b.fetch("phih_grid"))
         b.close()
     assert np.array_equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("name", ["evolve32_lls2", "evolve32_lls3", "evolve32_clump5"])
+def test_physics_variants_vs_reference(pkg, tables, name):
+    """type_of_LLS=2 / 3 and a clumping grid (c2r_set_lls, c2r_set_clumping_grid) against the reference
+    rebuilt with that one parameter changed."""
+    m, a = load_case(name)
+    n = m["n"]
+    s = m["steps"]["step001"]
+    b = make_backend(pkg, tables, s, n, F(a["step001_ndens"]), F(a["step001_xh_before"]))
+    if s["type_of_LLS"] != 1:
+        b.set_lls(s["type_of_LLS"], a["lls_grid"] if "lls_grid" in a else None, s["R_max_LLS"])
+    if "clump_grid" in a:
+        b.set_clumping_grid(a["clump_grid"])
+    rep = b.evolve3d_native(s["dt"])
+    assert rep.converged and rep.niter == s["niter"]
+    assert list(rep.it_conv_flag[:rep.niter]) == s["log"]["nonconv"]
+    assert rep.sum_nbox_all == s["sum_nbox_all"]
+    assert abs(rep.photon_loss_all - s["photon_loss_all"]) <= TOL_LOSS * abs(s["photon_loss_all"]) + 1e-300
+    assert np.max(np.abs(b.fetch("xh") - F(a["step001_xh_after"]))) < TOL_X
+    assert gamma_err(b.fetch("phih_grid"), F(a["step001_phih_grid"])) < TOL_GAMMA
+    for k in ("totrec", "totcollisions", "total_ion"):
+        assert abs(getattr(rep, k) / s[k] - 1) < 1e-9, k
+    b.close()

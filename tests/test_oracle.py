@@ -166,3 +166,23 @@ def test_evolve3d_restart_from_iteration_dump(tables, name):
     assert np.array_equal(xh, F(a["xh_after"]))
     assert np.array_equal(phih, F(a["phih_grid"]))
     assert np.array_equal(xav, F(a["xh_av"]))
+
+
+@pytest.mark.parametrize("name", ["evolve32_lls2", "evolve32_lls3", "evolve32_clump5"])
+def test_evolve3d_physics_variants(tables, name):
+    """Non-default switches of c2ray_parameters.f90 (reference rebuilt with type_of_LLS=2 / 3 or
+    type_of_clumping=5): position-dependent LLS column (evolve_point.F90:193), hard barrier at R_max
+    (:187-191), clumping grid in doric and the photon statistics (evolve_point.F90:443-445)."""
+    m, a = load_case(name)
+    n = m["n"]
+    s = m["steps"]["step001"]
+    o = oracle_for(s, tables, n, lls_grid=a["lls_grid"] if "lls_grid" in a else None,
+                   clump_grid=a["clump_grid"] if "clump_grid" in a else None)
+    xh = F(a["step001_xh_before"]); nd = F(a["step001_ndens"])
+    rep, xav, xint, phih = o.evolve3d(s["dt"], nd, xh, s["srcpos"], s["normflux"])
+    assert rep.niter == s["niter"] and list(rep.it_conv_flag[:rep.niter]) == s["log"]["nonconv"]
+    assert np.array_equal(xh, F(a["step001_xh_after"]))
+    assert np.array_equal(phih, F(a["step001_phih_grid"]))
+    assert rep.sum_nbox_all == s["sum_nbox_all"] and rep.photon_loss_all == s["photon_loss_all"]
+    for k in ("totrec", "totcollisions", "dh0", "total_ion"):
+        assert getattr(rep, k) == s[k], k
