@@ -45,7 +45,7 @@ struct Ctx {
     size_t PP = 1;
     int tiles_cap = 0;          // ceil(P*P/256): most tiles any face plane needs
     // sweep scratch (one batch of sources)
-    int batch_cap = 0;
+    int batch_cap = 0, batch_want = 0;
     double *d_planes = nullptr;
     int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr;
     double *d_gbox = nullptr;   // deterministic mode: [batch_cap][2][ncell]
@@ -95,7 +95,7 @@ void free_sweep_scratch(Ctx *ctx)
     ctx->d_planes = nullptr; ctx->d_gbox = nullptr; ctx->d_srcpos_b = nullptr; ctx->d_srcw_b = nullptr; ctx->d_nflux_b = nullptr;
     ctx->d_active[0] = ctx->d_active[1] = nullptr;
     ctx->d_loss_partial = ctx->d_loss_acc = ctx->d_final_loss = nullptr; ctx->d_final_nbox = nullptr;
-    ctx->batch_cap = 0;
+    ctx->batch_cap = 0; ctx->batch_want = 0;
 }
 
 int n_local_sources(const Ctx *ctx)
@@ -107,7 +107,8 @@ int n_local_sources(const Ctx *ctx)
 // fits the budget; 288 GB of HBM normally holds every source of a rank at once.
 int ensure_sweep_scratch(Ctx *ctx, int want)
 {
-    if (want <= ctx->batch_cap) return C2R_OK;
+    // batch_want: the request the current allocation was sized for (it may have been capped by the budget)
+    if (want <= ctx->batch_cap || want <= ctx->batch_want) return C2R_OK;
     free_sweep_scratch(ctx);
     const size_t per_src = 2 * 6 * ctx->PP * sizeof(double) + (size_t)6 * ctx->tiles_cap * sizeof(double) + 64 +
                            (ctx->prm.deterministic_rates ? 2 * ctx->ncell * sizeof(double) : 0);
@@ -132,6 +133,7 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
     HIP_TRY(hipMalloc(&ctx->d_final_loss, (size_t)cap * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_final_nbox, (size_t)cap * sizeof(int)));
     ctx->batch_cap = cap;
+    ctx->batch_want = want;
     return C2R_OK;
 }
 
@@ -265,7 +267,20 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
             sa.dp2 = (double)q * (double)q; sa.inv_dp2 = 1.0 / sa.dp2;
             sa.active = ctx->d_active[cur]; sa.loss_partial = ctx->d_loss_partial; sa.dbg_cdout = dbg;
             prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
-            hipLaunchKernelGGL(k_sweep_shell, dim3(sa.tiles_max, 6, n_active), dim3(kBlock), 0, st, k, sa);
+            {
+                const dim3 grid(sa.tiles_max, 6, n_active), blk(kBlock);
+                const bool det = ctx->d_gbox != nullptr;
+#define C2R_LAUNCH_SWEEP(D, L) hipLaunchKernelGGL((k_sweep_shell<D, L>), grid, blk, 0, st, k, sa)
+                switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
+                    case 2: C2R_LAUNCH_SWEEP(false, 1); break;
+                    case 3: C2R_LAUNCH_SWEEP(true, 1); break;
+                    case 4: C2R_LAUNCH_SWEEP(false, 2); break;
+                    case 5: C2R_LAUNCH_SWEEP(true, 2); break;
+                    case 6: C2R_LAUNCH_SWEEP(false, 3); break;
+                    default: C2R_LAUNCH_SWEEP(true, 3); break;
+                }
+#undef C2R_LAUNCH_SWEEP
+            }
             prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
             if (sa.has_boundary)
                 hipLaunchKernelGGL(k_loss_reduce, dim3(n_active), dim3(256), 0, st, ctx->d_active[cur],

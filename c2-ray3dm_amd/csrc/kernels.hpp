@@ -266,6 +266,8 @@ __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned
 // grid = (tiles, 6 faces, active sources); a wave runs along plane axis a, which is the
 // unit-stride axis of the arrays the face reads (x for z/y faces, y in the transposed replicas
 // for x faces).
+// DET: deterministic_rates mode (per-source Gamma grids instead of atomics); LLS: type_of_LLS (1,2,3)
+template <bool DET, int LLS>
 __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
 {
     __shared__ double sm[16];
@@ -347,10 +349,10 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         // hard barrier at R_max that only stops the transfer
         double cd_in = cdi;
         bool stop_far = false;
-        if (p.lls_type == 3) {
+        if (LLS == 3) {
             stop_far = dist2 > p.R_max2;
         } else {
-            const double lls = (p.lls_type == 2) ? (double)(xf ? p.lls_T : p.lls)[id] : p.coldensh_LLS;
+            const double lls = (LLS == 2) ? (double)(xf ? p.lls_T : p.lls)[id] : p.coldensh_LLS;
             cd_in = cdi + udiv(lls * path, p.dr[0], p.inv_dr0, p.exact_udiv);
         }
         const double xav1 = fmax(xav_raw, p.eps);
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         if (!stop_far && !(cd_in > p.max_coldensh) && nflux > 0.0) {
             double p_out;
             gamma = fdiv(photoion(p, cd_in, cd_out, vol_ph, nflux, p_out), xav0 * nd);
-            if (!p.gbox && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id], gamma);
+            if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id], gamma);
             if (sa.has_boundary) {
                 const bool bnd = d0 == sa.boxR[0] || d1 == sa.boxR[1] || d2 == sa.boxR[2] ||
                                  d0 == -sa.boxL[0] || d1 == -sa.boxL[1] || d2 == -sa.boxL[2];
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
             }
         }
         // deterministic mode: every visited cell records its rate (zero included) for k_gamma_reduce
-        if (p.gbox) p.gbox[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + id] = gamma;
+        if (DET) p.gbox[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + id] = gamma;
     }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
