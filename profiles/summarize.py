@@ -17,10 +17,16 @@ import os
 import sys
 
 
+def kname(full):
+    """'void c2r::k_sweep_shell<false, 1>(c2r::KParams, ...)' -> 'c2r::k_sweep_shell'"""
+    k = full.split("(")[0].split("<")[0].strip()
+    return k[5:] if k.startswith("void ") else k
+
+
 def per_kernel(path):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = kname(r["Kernel_Name"])
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
     return agg
@@ -31,7 +37,7 @@ def main():
     visited = float(sys.argv[2]) if len(sys.argv) > 2 else None
     out = {"kernels": {}}
     for r in csv.DictReader(open(os.path.join(d, "kernel_stats.csv"))):
-        k = r["Name"].split("(")[0]
+        k = kname(r["Name"])
         if k.startswith("c2r::"):
             out["kernels"][k] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                  "total_ns": float(r["TotalDurationNs"]), "pct": float(r["Percentage"])}
