@@ -92,8 +92,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--deterministic", action="store_true",
                     help="per-source Gamma grids reduced in source order instead of f64 atomics")
-    ap.add_argument("--native-loop", action="store_true",
-                    help="time whole evolve3D calls through c2r_evolve3d_dev instead of single iterations")
     args = ap.parse_args()
 
     import torch

@@ -314,3 +314,38 @@ def test_physics_variants_vs_reference(pkg, tables, name):
     for k in ("totrec", "totcollisions", "total_ion"):
         assert abs(getattr(rep, k) / s[k] - 1) < 1e-9, k
     b.close()
+
+
+@pytest.mark.parametrize("mesh,seed", [((24, 20, 16), 61), ((17, 32, 23), 62)])
+def test_non_cubic_mesh_vs_oracle(pkg, tables, mesh, seed):
+    """mesh(1:3) need not be equal (sizes.f90:33) nor dr(1:3): trace limits, clipping and the sub-box
+    surface are per axis; the loop condition looks at z only (evolve_source.F90:130-131)."""
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(seed)
+    ncell = mesh[0] * mesh[1] * mesh[2]
+    s = pkg.TestProblem(32).step(1)
+    dr = (s["dr1"], 1.3 * s["dr1"], 0.8 * s["dr1"])
+    vol = dr[0] * dr[1] * dr[2]
+    nd = (s["ndens"] * np.exp(0.5 * rng.standard_normal(ncell))).astype(np.float32)
+    xh = np.clip(10.0 ** rng.uniform(-4, 0, ncell) * 0.9999, 1e-6, 0.9999)
+    nsrc = 9
+    pos = np.stack([rng.integers(1, mesh[d] + 1, nsrc) for d in range(3)], axis=1).astype(np.int32)
+    nf = 10.0 ** rng.uniform(6, 9, nsrc)
+    o = Oracle(mesh, dr, vol, s["coldensh_LLS"], *tables)
+    phih_o = np.zeros(ncell)
+    oloss, onb, ovis = o.pass_sources(nd, xh, phih_o, pos, nf)
+    b = pkg.HipBackend(mesh, *tables, device=0)
+    b.set_step(dr, vol, s["coldensh_LLS"], 1.0)
+    b.set_sources(pos, nf); b.set_rank(0, 1); b.load(ndens=nd, xh=xh)
+    b.begin_step(); b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    assert (nbox, vis) == (onb, ovis)
+    assert abs(loss - oloss) <= TOL_LOSS * abs(oloss) + 1e-300
+    phih = b.fetch("phih_grid")
+    assert np.array_equal(phih == 0, phih_o == 0)
+    assert gamma_err(phih, phih_o) < TOL_GAMMA
+    xav, xint = xh.copy(), xh.copy()
+    oconv = o.global_pass(s["dt"], nd, xh, xav, xint, phih_o)
+    conv, _ = b.global_pass(s["dt"])
+    assert conv == oconv and np.max(np.abs(b.fetch("xh_intermed") - xint)) < TOL_X
+    b.close()
