@@ -398,7 +398,9 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     ctx->ncell = (size_t)p->mesh[0] * p->mesh[1] * p->mesh[2];
     for (int w = 0; w < 5; ++w) { HIP_TRY(hipMalloc(&ctx->grid[w], grid_bytes(ctx, w))); ctx->own[w] = true; }
     HIP_TRY(hipMemset(ctx->grid[4], 0, grid_bytes(ctx, 4)));      // evolve_data.F90:76 phih_grid=0.0
-    if (ctx->ncell >= (1ULL << 31)) FAIL(C2R_EINVAL, "mesh too large for 32-bit cell indices");
+    if (ctx->ncell >= (1ULL << 31) || p->mesh[0] >= (1 << 23) || p->mesh[1] >= (1 << 23) || p->mesh[2] >= (1 << 23) ||
+        (uint64_t)p->mesh[1] * p->mesh[2] >= (1ULL << 24) || (uint64_t)p->mesh[0] * p->mesh[2] >= (1ULL << 24))
+        FAIL(C2R_EINVAL, "mesh too large for the 32-bit / 24-bit index arithmetic of the sweep");
     HIP_TRY(hipMalloc(&ctx->d_ndens_T, grid_bytes(ctx, 0)));
     HIP_TRY(hipMalloc(&ctx->d_xhav_T, grid_bytes(ctx, 2)));
     HIP_TRY(hipMalloc(&ctx->d_phih_T, grid_bytes(ctx, 4)));

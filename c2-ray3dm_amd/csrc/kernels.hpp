@@ -292,15 +292,20 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         const int s0 = p.srcpos[3 * s + 0], s1 = p.srcpos[3 * s + 1], s2 = p.srcpos[3 * s + 2];
         const int su = (axis == 0) ? s1 : s0;
         const int sv = (axis == 2) ? s1 : s2;
-        // periodic wrap (evolve_point.F90:122): |d| <= N/2, so one conditional step each way
-        int c0 = p.srcw[3 * s + 0] + d0, c1 = p.srcw[3 * s + 1] + d1, c2 = p.srcw[3 * s + 2] + d2;
-        c0 += (c0 < 0) ? p.n[0] : 0;  c0 -= (c0 >= p.n[0]) ? p.n[0] : 0;
-        c1 += (c1 < 0) ? p.n[1] : 0;  c1 -= (c1 >= p.n[1]) ? p.n[1] : 0;
-        c2 += (c2 < 0) ? p.n[2] : 0;  c2 -= (c2 >= p.n[2]) ? p.n[2] : 0;
-        const unsigned id_n = (unsigned)c0 + (unsigned)p.n[0] * ((unsigned)c1 + (unsigned)p.n[1] * (unsigned)c2);
-        const unsigned id_t = (unsigned)c1 + (unsigned)p.n[1] * ((unsigned)c0 + (unsigned)p.n[0] * (unsigned)c2);
+        // periodic wrap (evolve_point.F90:122): srcw + d + n lies in [n/2, 5n/2); min(c, c-n) as
+        // unsigned folds [n, 2n) onto [0, n), twice
+        unsigned c0 = (unsigned)(p.srcw[3 * s + 0] + p.n[0] + d0);
+        unsigned c1 = (unsigned)(p.srcw[3 * s + 1] + p.n[1] + d1);
+        unsigned c2 = (unsigned)(p.srcw[3 * s + 2] + p.n[2] + d2);
+        c0 = min(c0, c0 - (unsigned)p.n[0]);  c0 = min(c0, c0 - (unsigned)p.n[0]);
+        c1 = min(c1, c1 - (unsigned)p.n[1]);  c1 = min(c1, c1 - (unsigned)p.n[1]);
+        c2 = min(c2, c2 - (unsigned)p.n[2]);  c2 = min(c2, c2 - (unsigned)p.n[2]);
+        // cell index in the array this face reads: x-fastest, or y-fastest in the transposed replicas
+        // (block-uniform choice; 24-bit multiplies: every factor is below 2^24)
         const bool xf = (axis == 0);
-        const unsigned id = xf ? id_t : id_n;
+        const unsigned ca = xf ? c1 : c0, cb = xf ? c0 : c1;
+        const unsigned na = xf ? (unsigned)p.n[1] : (unsigned)p.n[0], nb = xf ? (unsigned)p.n[0] : (unsigned)p.n[1];
+        const unsigned id = ca + __umul24(na, cb + __umul24(nb, c2));
         const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
         const __amdgpu_buffer_rsrc_t r_x = make_rsrc(xf ? (const void *)p.xh_av_T : (const void *)p.xh_av, ncell * 8u);
         const __amdgpu_buffer_rsrc_t r_n = make_rsrc(xf ? (const void *)p.ndens_T : (const void *)p.ndens, ncell * 4u);
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
             if (abs(a) == q)   // x-face (u=y=pd, v=z=b)
                 buf_store_f64(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((b + p.R) * p.P + (pd + p.R)) * 8u, cd_out);
         }
-        if (sa.dbg_cdout) sa.dbg_cdout[id_n] = cd_out;
+        if (sa.dbg_cdout) sa.dbg_cdout[c0 + (unsigned)p.n[0] * (c1 + (unsigned)p.n[1] * c2)] = cd_out;
 
         const double nflux = p.normflux[s];
         double gamma = 0.0;
