@@ -265,6 +265,7 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
             }
             sa.alam = (double)((float)(q - 1) + 0.5f) / (double)(float)q;
             sa.dp2 = (double)q * (double)q; sa.inv_dp2 = 1.0 / sa.dp2;
+            for (int d = 0; d < 3; ++d) { const double t = ctx->dr[d] * (double)q; sa.d2axis[d] = t * t; }   // sign drops out
             sa.active = ctx->d_active[cur]; sa.loss_partial = ctx->d_loss_partial; sa.dbg_cdout = dbg;
             prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
             {

@@ -68,6 +68,7 @@ struct ShellArgs {
     int boxR[3], boxL[3];        // limits of the current sub-box (last_r/last_l - srcpos)
     double alam;                 // (q-0.5)/q, column_density.f90:112 (sign cancels)
     double dp2, inv_dp2;         // q*q and its correctly rounded reciprocal
+    double d2axis[3];            // (dr_d * q)^2: the own-axis term of dist2 for faces normal to d
     FaceRect face[6];
     const int *active;           // compacted list of local source indices
     double *loss_partial;
@@ -332,8 +333,9 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         const double du = (double)a, dv = (double)b;
         const double uc = sa.alam * du + (double)su;
         const double vc = sa.alam * dv + (double)sv;
-        const double ddu = 2.0 * fabs(uc - ((double)(su + am) + 0.5 * (double)sga));
-        const double ddv = 2.0 * fabs(vc - ((double)(sv + bm) + 0.5 * (double)sgb));
+        // real(im)+0.5*sgni (column_density.f90:117) is a half-integer: one conversion of 2*im+sgni
+        const double ddu = 2.0 * fabs(uc - 0.5 * (double)(2 * (su + am) + sga));
+        const double ddv = 2.0 * fabs(vc - 0.5 * (double)(2 * (sv + bm) + sgb));
         const double w1 = ((1. - ddu) * (1. - ddv)) * frcp(fmax(p.wfloor, c1v * p.sigma));
         const double w2 = ((1. - ddv) * ddu) * frcp(fmax(p.wfloor, c2v * p.sigma));
         const double w3 = ((1. - ddu) * ddv) * frcp(fmax(p.wfloor, c3v * p.sigma));
@@ -345,10 +347,15 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
 
         // evolve0D
         path = path * p.dr[0];
+        // dist2 = xs*xs + ys*ys + zs*zs (evolve_point.F90:171-174); the term of the face's own axis
+        // is the same for the whole launch (sa.d2axis = (dr_axis * q)^2)
         const double xs = p.dr[0] * (double)d0;
         const double ys = p.dr[1] * (double)d1;
         const double zs = p.dr[2] * (double)d2;
-        const double dist2 = xs * xs + ys * ys + zs * zs;
+        const double xx = (axis == 0) ? sa.d2axis[0] : xs * xs;
+        const double yy = (axis == 1) ? sa.d2axis[1] : ys * ys;
+        const double zz = (axis == 2) ? sa.d2axis[2] : zs * zs;
+        const double dist2 = xx + yy + zz;
         const double vol_ph = p.fourpi * dist2 * path;
         // LLS opacity (evolve_point.F90:186-196): homogeneous column, per-cell column (LLS_point), or a
         // hard barrier at R_max that only stops the transfer
