@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--mesh", type=int, default=256)
     ap.add_argument("--sources", type=int, default=1000)
     ap.add_argument("--x-init", type=float, default=0.999)
+    ap.add_argument("--density", choices=["uniform", "lognormal"], default="uniform",
+                    help="lognormal: sigma_ln=1, mean 1 times the same mean density (SURVEY.md s8d, config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--deterministic", action="store_true",
                     help="per-source Gamma grids reduced in source order instead of f64 atomics")
@@ -98,8 +100,6 @@ def main():
     import torch.distributed as dist
     import __graft_entry__ as g
     pkg = g.load_package()
-    from tests._util import load_tables
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -121,6 +121,9 @@ def main():
     tp = pkg.TestProblem(n)
     s = tp.step(1)
     nd, xh = tp.fields(1, args.x_init)
+    if args.density == "lognormal":
+        rng = np.random.default_rng(20261003)
+        nd = (nd * np.exp(rng.standard_normal(nd.size, dtype=np.float32) - 0.5)).astype(np.float32)
     srcpos, normflux = pkg.seeded_sources(n, S)
     thick, thin, _ = pkg.build_tables()          # rad_ini on the host (c2r_build_tables)
     b = pkg.HipBackend(n, thick, thin, device=local_rank, deterministic=args.deterministic)
@@ -182,8 +185,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt_wall / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d^3 mesh, %d sources (seeded), reference test problem at z=9 pre-ionised to "
-                                   "x=%.3f, one evolve3D outer iteration per step (sweep all sources + all-reduce + "
-                                   "global chemistry pass)" % (n, S, args.x_init),
+                                   "x=%.3f, %s density, one evolve3D outer iteration per step (sweep all sources + "
+                                   "all-reduce + global chemistry pass)" % (n, S, args.x_init, args.density),
                        "mesh": n, "sources": S, "gamma_accumulation": "ordered" if args.deterministic else "atomic", "sources_per_gpu": len(pkg.static_source_share(S, 0, world)),
                        "parallelism": "sources sharded over %d GPU(s), RCCL all-reduce of Gamma" % world,
                        "visited_cell_sources_per_step": visited_all / args.steps,
