@@ -9,3 +9,4 @@ from ._capi import (load_library, default_params, build_tables, Params, Report, 
 from .evolve import Evolve, HipBackend, static_source_share  # noqa: F401
 from .testproblem import TestProblem, seeded_sources  # noqa: F401
 from . import fileio  # noqa: F401
+from . import _capi  # noqa: F401

@@ -1,0 +1,78 @@
+"""GPU tests of the C ABI's contract: call-order errors, argument checks, host-pointer entry point
+(c2r_evolve3d, what the Fortran shim calls), context-owned buffers and streams."""
+import ctypes as C
+import numpy as np
+import pytest
+from tests._util import F, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+def test_call_order_and_argument_errors(pkg, tables):
+    lib = pkg.load_library()
+    p = pkg.default_params(16)
+    ctx = C.c_void_p()
+    assert lib.c2r_create(C.byref(ctx), C.byref(p)) == 0
+    loss, nb, vis = C.c_double(), C.c_int64(), C.c_int64()
+    # no tables / step scalars yet: C2R_ESTATE (-2), with a message
+    assert lib.c2r_pass_sources(ctx, C.byref(loss), C.byref(nb), C.byref(vis)) == -2
+    assert b"c2r_set_tables" in lib.c2r_last_error(ctx)
+    thick, thin = tables
+    assert lib.c2r_set_tables(ctx, thick.ctypes.data, thin.ctypes.data, 17) == -1          # wrong length
+    assert lib.c2r_set_tables(ctx, thick.ctypes.data, thin.ctypes.data, 2001) == 0
+    assert lib.c2r_pass_sources(ctx, C.byref(loss), C.byref(nb), C.byref(vis)) == -2
+    assert b"c2r_set_step" in lib.c2r_last_error(ctx)
+    dr = (C.c_double * 3)(1e24, 1e24, 1e24)
+    assert lib.c2r_set_step(ctx, C.byref(dr), -1.0, 1e16, 1.0, 1e4) == -1                  # vol <= 0
+    assert lib.c2r_set_step(ctx, C.byref(dr), 1e72, 1e16, 1.0, 1e4) == 0
+    assert lib.c2r_set_rank(ctx, 2, 2, pkg._capi.ALLREDUCE_FN(0), None) == -1            # rank >= nranks
+    assert lib.c2r_set_rank(ctx, 0, 2, pkg._capi.ALLREDUCE_FN(0), None) == -1            # nranks > 1 without a callback
+    assert lib.c2r_set_lls(ctx, 2, None, 0.0) == -1 and lib.c2r_set_lls(ctx, 3, None, 0.0) == -1
+    assert lib.c2r_do_source(ctx, 1, None, None, None, None) == -1                          # no sources set
+    # no sources: a pass is legal and does nothing
+    assert lib.c2r_pass_sources(ctx, C.byref(loss), C.byref(nb), C.byref(vis)) == 0
+    assert (loss.value, nb.value, vis.value) == (0.0, 0, 0)
+    lib.c2r_destroy(ctx)
+    bad = pkg.default_params(0)
+    assert lib.c2r_create(C.byref(ctx), C.byref(bad)) == -1
+
+
+def test_host_pointer_evolve3d_is_what_the_shim_calls(pkg, tables):
+    """c2r_evolve3d with the driver's host arrays (context-owned device buffers, own stream):
+    same results as the device-resident path, inputs other than xh untouched."""
+    lib = pkg.load_library()
+    m, a = load_case("evolve32_std_bubbles")
+    s = m["steps"]["step001"]
+    n = m["n"]
+    p = pkg.default_params(n)
+    ctx = C.c_void_p()
+    assert lib.c2r_create(C.byref(ctx), C.byref(p)) == 0
+    thick, thin = tables
+    assert lib.c2r_set_tables(ctx, thick.ctypes.data, thin.ctypes.data, 2001) == 0
+    dr = (C.c_double * 3)(s["dr1"], s["dr2"], s["dr3"])
+    assert lib.c2r_set_step(ctx, C.byref(dr), s["vol"], s["coldensh_LLS"], s["clumping"], 1e4) == 0
+    pos = np.ascontiguousarray(s["srcpos"], dtype=np.int32); nf = np.ascontiguousarray(s["normflux"], dtype=np.float64)
+    assert lib.c2r_set_sources(ctx, pos.ctypes.data, nf.ctypes.data, len(nf)) == 0
+    nd = F(a["step001_ndens"]); xh = F(a["step001_xh_before"]); nd0 = nd.copy()
+    xav, xint, phih = np.empty(n ** 3), np.empty(n ** 3), np.empty(n ** 3)
+    rep = pkg.Report()
+    assert lib.c2r_evolve3d(ctx, s["dt"], nd.ctypes.data, xh.ctypes.data, xav.ctypes.data, xint.ctypes.data,
+                            phih.ctypes.data, C.byref(rep)) == 0
+    assert rep.niter == s["niter"] and rep.converged == 1
+    assert np.array_equal(nd, nd0)
+    assert np.max(np.abs(xh - F(a["step001_xh_after"]))) < 1e-9
+    assert np.max(np.abs(xav - F(a["step001_xh_av"]))) < 1e-9
+    assert np.array_equal(xint, xh)                 # evolve.F90:218 xh = xh_intermed on convergence
+    ref = F(a["step001_phih_grid"])
+    assert np.max(np.abs(phih - ref) / np.maximum(ref, 1e-60)) < 1e-8
+    # optional outputs may be NULL
+    xh2 = F(a["step001_xh_before"])
+    assert lib.c2r_evolve3d(ctx, s["dt"], nd.ctypes.data, xh2.ctypes.data, None, None, None, None) == 0
+    assert np.max(np.abs(xh2 - xh)) < 1e-13
+    lib.c2r_destroy(ctx)
