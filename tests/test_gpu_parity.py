@@ -316,7 +316,8 @@ def test_physics_variants_vs_reference(pkg, tables, name):
     b.close()
 
 
-@pytest.mark.parametrize("mesh,seed", [((24, 20, 16), 61), ((17, 32, 23), 62)])
+@pytest.mark.parametrize("mesh,seed", [((24, 20, 16), 61), ((17, 32, 23), 62), ((1, 16, 12), 63), ((12, 1, 9), 64),
+                                       ((16, 16, 2), 65), ((3, 3, 3), 66), ((2, 9, 8), 67)])
 def test_non_cubic_mesh_vs_oracle(pkg, tables, mesh, seed):
     """mesh(1:3) need not be equal (sizes.f90:33) nor dr(1:3): trace limits, clipping and the sub-box
     surface are per axis; the loop condition looks at z only (evolve_source.F90:130-131)."""
