@@ -25,8 +25,9 @@ struct Ctx {
     size_t ncell = 0;
     // grids: 0 ndens(f32) 1 xh 2 xh_av 3 xh_intermed 4 phih_grid
     void *grid[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    // (x,y)-transposed replicas for the +-x faces of the sweep (owned): ndens_T, xh_av_T, phih_T
-    float *d_ndens_T = nullptr; double *d_xhav_T = nullptr, *d_phih_T = nullptr;
+    // per-pass inputs of the sweep (owned): n_HI per cell and its (x,y)-transposed replica for the +-x
+    // faces, and the transposed Gamma accumulator of those faces
+    double *d_nhi = nullptr, *d_nhi_T = nullptr, *d_phih_T = nullptr;
     // optional per-cell inputs of the non-default physics switches
     int lls_type = 1; double R_max_LLS = 0.0;
     float *d_lls = nullptr, *d_lls_T = nullptr, *d_clump = nullptr;
@@ -176,8 +177,7 @@ KParams make_kparams(const Ctx *ctx)
     k.inv_dlogtau = 1.0 / p.dlogtau; k.inv_dr0 = 1.0 / ctx->dr[0];
     k.exact_udiv = udiv_ok(p.dlogtau) && udiv_ok(ctx->dr[0]);
     k.R = ctx->R; k.P = ctx->P; k.PP = ctx->PP;
-    k.ndens = (const float *)ctx->grid[0]; k.xh_av = (const double *)ctx->grid[2]; k.phih = (double *)ctx->grid[4];
-    k.ndens_T = ctx->d_ndens_T; k.xh_av_T = ctx->d_xhav_T; k.phih_T = ctx->d_phih_T;
+    k.nhi = ctx->d_nhi; k.nhi_T = ctx->d_nhi_T; k.phih = (double *)ctx->grid[4]; k.phih_T = ctx->d_phih_T;
     k.gbox = ctx->d_gbox;
     k.lls_type = ctx->lls_type; k.R_max2 = ctx->R_max_LLS * ctx->R_max_LLS; k.lls = ctx->d_lls; k.lls_T = ctx->d_lls_T;
     k.thick = ctx->d_thick; k.thin = ctx->d_thin;
@@ -320,10 +320,8 @@ int sweep_prepare(Ctx *ctx)
 {
     const c2r_params &p = ctx->prm;
     const dim3 g((p.mesh[0] + 31) / 32, (p.mesh[1] + 31) / 32, p.mesh[2]);
-    hipLaunchKernelGGL((k_transpose_xy<float, false>), g, dim3(256), 0, ctx->stream, p.mesh[0], p.mesh[1], p.mesh[2],
-                       (const float *)ctx->grid[0], ctx->d_ndens_T);
-    hipLaunchKernelGGL((k_transpose_xy<double, false>), g, dim3(256), 0, ctx->stream, p.mesh[0], p.mesh[1], p.mesh[2],
-                       (const double *)ctx->grid[2], ctx->d_xhav_T);
+    hipLaunchKernelGGL(k_prepare_nhi, g, dim3(256), 0, ctx->stream, p.mesh[0], p.mesh[1], p.mesh[2], p.epsilon,
+                       (const float *)ctx->grid[0], (const double *)ctx->grid[2], ctx->d_nhi, ctx->d_nhi_T);
     HIP_TRY(hipMemsetAsync(ctx->d_phih_T, 0, grid_bytes(ctx, 4), ctx->stream));
     return C2R_OK;
 }
@@ -402,8 +400,8 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     if (ctx->ncell >= (1ULL << 31) || p->mesh[0] >= (1 << 23) || p->mesh[1] >= (1 << 23) || p->mesh[2] >= (1 << 23) ||
         (uint64_t)p->mesh[1] * p->mesh[2] >= (1ULL << 24) || (uint64_t)p->mesh[0] * p->mesh[2] >= (1ULL << 24))
         FAIL(C2R_EINVAL, "mesh too large for the 32-bit / 24-bit index arithmetic of the sweep");
-    HIP_TRY(hipMalloc(&ctx->d_ndens_T, grid_bytes(ctx, 0)));
-    HIP_TRY(hipMalloc(&ctx->d_xhav_T, grid_bytes(ctx, 2)));
+    HIP_TRY(hipMalloc(&ctx->d_nhi, grid_bytes(ctx, 2)));
+    HIP_TRY(hipMalloc(&ctx->d_nhi_T, grid_bytes(ctx, 2)));
     HIP_TRY(hipMalloc(&ctx->d_phih_T, grid_bytes(ctx, 4)));
     HIP_TRY(hipMalloc(&ctx->d_thick, (size_t)(p->numtau + 1) * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_thin, (size_t)(p->numtau + 1) * sizeof(double)));
@@ -441,7 +439,7 @@ void c2r_destroy(c2r_ctx *c)
     free_sweep_scratch(ctx);
     for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
     hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_nactive);
-    hipFree(ctx->d_ndens_T); hipFree(ctx->d_xhav_T); hipFree(ctx->d_phih_T);
+    hipFree(ctx->d_nhi); hipFree(ctx->d_nhi_T); hipFree(ctx->d_phih_T);
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
     hipFree(ctx->d_photon_loss); hipFree(ctx->d_sum_nbox); hipFree(ctx->d_sum_partial); hipFree(ctx->d_sum_out);

@@ -34,11 +34,12 @@ struct KParams {
     int numtau;
     int R, P;                  // plane centre offset and pitch (P = 2R+1)
     size_t PP;                 // P*P
-    const float  *ndens;       // [k][j][i]  (i fastest)        evolve_point.F90:146
-    const double *xh_av;
+    // n_HI = max(1-max(xh_av,eps),eps)*ndens per cell (evolve_point.F90:137-146, doric.f90:153), the only
+    // way the sweep uses xh_av and ndens: evaluated once per cell and pass by k_prepare_nhi instead of
+    // once per (cell, source); nhi is [k][j][i] (i fastest), nhi_T [k][i][j] (j fastest) for the +-x
+    // faces, whose waves run along y
+    const double *nhi, *nhi_T;
     double *phih;
-    const float  *ndens_T;     // [k][i][j]  (j fastest): replicas read by the +-x faces, whose
-    const double *xh_av_T;     //            waves run along y
     double *phih_T;            // Gamma of the +-x faces, added back after the pass
     // non-default physics switches (c2ray_parameters.f90:80-99)
     int lls_type;              // 1 homogeneous, 2 per-cell grid, 3 hard barrier
@@ -212,13 +213,11 @@ __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0
     const int j = pmod(p.srcpos[3 * s + 1] - 1, p.n[1]);
     const int k = pmod(p.srcpos[3 * s + 2] - 1, p.n[2]);
     const size_t id = (size_t)i + (size_t)p.n[0] * ((size_t)j + (size_t)p.n[1] * (size_t)k);
-    const double xav1 = fmax(p.xh_av[id], p.eps);
-    const double xav0 = fmax(1.0 - xav1, p.eps);
-    const double nd = (double)p.ndens[id];
+    const double nhi = p.nhi[id];
     const double cd_in = 0.0;
     const double path = 0.5 * p.dr[0];
     const double vol_ph = p.dr[0] * p.dr[1] * p.dr[2];
-    const double cd_out = cd_in + xav0 * nd * path;
+    const double cd_out = cd_in + nhi * path;
     // plane q=0 of every face is the single cell (0,0)
     for (int f = 0; f < 6; ++f)
         p.planes[((size_t)s * 2 + 0) * 6 * p.PP + (size_t)f * p.PP + (size_t)p.R * p.P + p.R] = cd_out;
@@ -226,7 +225,7 @@ __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0
     const double nflux = p.normflux[s];
     double p_out = 0.0, gamma = 0.0;
     if (nflux > 0.0) {      // cd_in = 0 is never above max_coldensh
-        gamma = photoion(p, cd_in, cd_out, vol_ph, nflux, p_out) / (xav0 * nd);
+        gamma = photoion(p, cd_in, cd_out, vol_ph, nflux, p_out) / nhi;
         if (!p.gbox) atomicAdd(&p.phih[id], gamma);
     }
     if (p.gbox) p.gbox[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = gamma;
@@ -308,10 +307,8 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         const unsigned na = xf ? (unsigned)p.n[1] : (unsigned)p.n[0], nb = xf ? (unsigned)p.n[0] : (unsigned)p.n[1];
         const unsigned id = ca + __umul24(na, cb + __umul24(nb, c2));
         const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
-        const __amdgpu_buffer_rsrc_t r_x = make_rsrc(xf ? (const void *)p.xh_av_T : (const void *)p.xh_av, ncell * 8u);
-        const __amdgpu_buffer_rsrc_t r_n = make_rsrc(xf ? (const void *)p.ndens_T : (const void *)p.ndens, ncell * 4u);
-        const double xav_raw = buf_load_f64(r_x, id * 8u);
-        const double nd = (double)buf_load_f32(r_n, id * 4u);
+        const __amdgpu_buffer_rsrc_t r_x = make_rsrc(xf ? p.nhi_T : p.nhi, ncell * 8u);
+        const double nhi = buf_load_f64(r_x, id * 8u);
 
         // upstream corners in plane q-1 of this face (zero weight outside |.| <= q-1)
         const int sga = a < 0 ? -1 : 1, sgb = b < 0 ? -1 : 1;
@@ -367,9 +364,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
             const double lls = (LLS == 2) ? (double)(xf ? p.lls_T : p.lls)[id] : p.coldensh_LLS;
             cd_in = cdi + udiv(lls * path, p.dr[0], p.inv_dr0, p.exact_udiv);
         }
-        const double xav1 = fmax(xav_raw, p.eps);
-        const double xav0 = fmax(1.0 - xav1, p.eps);
-        const double cd_out = cd_in + xav0 * nd * path;
+        const double cd_out = cd_in + nhi * path;
 
         // store into this face's plane and into the planes of the faces sharing the cell
         const __amdgpu_buffer_rsrc_t r_cur = make_rsrc(p.planes + ((size_t)s * 2 + (q & 1)) * 6 * p.PP, 6u * plane_bytes);
@@ -389,7 +384,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         double gamma = 0.0;
         if (!stop_far && !(cd_in > p.max_coldensh) && nflux > 0.0) {
             double p_out;
-            gamma = fdiv(photoion(p, cd_in, cd_out, vol_ph, nflux, p_out), xav0 * nd);
+            gamma = fdiv(photoion(p, cd_in, cd_out, vol_ph, nflux, p_out), nhi);
             if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id], gamma);
             if (sa.has_boundary) {
                 const bool bnd = d0 == sa.boxR[0] || d1 == sa.boxR[1] || d2 == sa.boxR[2] ||
@@ -439,6 +434,34 @@ __global__ __launch_bounds__(256) void k_gamma_reduce(KParams p, int nsrc, const
         }
     }
     phih[id] = acc;
+}
+
+// nhi[i,j,k] = max(1-max(xh_av,eps),eps) * ndens (ion%h_av(0)*ndens_p of evolve0D) and its (x,y)-transposed
+// replica, one z-plane tile at a time through LDS.
+__global__ __launch_bounds__(256) void k_prepare_nhi(int n0, int n1, int n2, double eps, const float *__restrict__ ndens,
+                                                     const double *__restrict__ xh_av, double *__restrict__ nhi,
+                                                     double *__restrict__ nhi_T)
+{
+    __shared__ double tile[32][33];
+    const int k = blockIdx.z;
+    const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + tx, j = j0 + r;
+        if (i < n0 && j < n1) {
+            const size_t id = (size_t)i + (size_t)n0 * ((size_t)j + (size_t)n1 * k);
+            const double xav1 = fmax(xh_av[id], eps);
+            const double xav0 = fmax(1.0 - xav1, eps);
+            const double v = xav0 * (double)ndens[id];
+            nhi[id] = v;
+            tile[r][tx] = v;
+        }
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + tx, i = i0 + r;
+        if (i < n0 && j < n1) nhi_T[(size_t)j + (size_t)n1 * ((size_t)i + (size_t)n0 * k)] = tile[tx][r];
+    }
 }
 
 // out[j + N1*(i + N0*k)] = in[i + N0*(j + N1*k)]: (x,y) transpose of every z-plane through LDS.
