@@ -51,7 +51,9 @@ struct Ctx {
     int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr;
     double *d_gbox = nullptr;   // deterministic mode: [batch_cap][2][ncell]
     int *d_active[2] = {nullptr, nullptr};
-    int *d_nactive = nullptr; int *h_nactive = nullptr;     // pinned
+    int *d_nactive = nullptr;                                // [2]: length of d_active[0/1]
+    int *h_nactive = nullptr;                                // pinned, one slot per sub-box
+    std::vector<hipEvent_t> ev_box;                          // 'slot written' events
     double *d_loss_partial = nullptr, *d_loss_acc = nullptr, *d_final_loss = nullptr;
     int *d_final_nbox = nullptr;
     double *d_photon_loss = nullptr; long long *d_sum_nbox = nullptr;
@@ -236,18 +238,25 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
     HIP_TRY(hipMemcpyAsync(ctx->d_final_nbox, h_fn.data(), h_fn.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(ctx->d_loss_acc, 0, (size_t)count * sizeof(double), st));
     if (n_active) HIP_TRY(hipMemcpyAsync(ctx->d_active[0], h_act.data(), (size_t)n_active * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->d_nactive, &n_active, sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));      // host vectors go out of scope below
 
     KParams k = make_kparams(ctx);
     int cur = 0;
-    for (int nbox = 1; nbox <= ctx->nbox_max && n_active > 0; ++nbox) {
+    // The active count lives on the device (d_nactive[cur]); the host only needs an upper bound to
+    // size the grids.  It runs ONE sub-box ahead: box n+1 is enqueued (sized by the count known
+    // after box n-1) before the count after box n is read back, so the GPU never drains while the
+    // host waits; blocks of sources that retired in between return at once.
+    int bound = n_active;          // upper bound of the device count for the launches being enqueued
+    int pending = 0;               // sub-box whose count has been requested but not read yet (0: none)
+    for (int nbox = 1; nbox <= ctx->nbox_max && bound > 0; ++nbox) {
         int boxR[3], boxL[3];
         for (int d = 0; d < 3; ++d) {
             boxR[d] = std::min(p.subboxsize * nbox, ctx->hr[d]);
             boxL[d] = std::min(p.subboxsize * nbox, ctx->hl[d]);
         }
         if (nbox == 1) {
-            hipLaunchKernelGGL(k_source_cells, dim3((n_active + 63) / 64), dim3(64), 0, st, k, n_active,
+            hipLaunchKernelGGL(k_source_cells, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
                                ctx->d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
                                ctx->d_loss_acc, dbg);
         }
@@ -266,10 +275,11 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
             sa.alam = (double)((float)(q - 1) + 0.5f) / (double)(float)q;
             sa.dp2 = (double)q * (double)q; sa.inv_dp2 = 1.0 / sa.dp2;
             for (int d = 0; d < 3; ++d) { const double t = ctx->dr[d] * (double)q; sa.d2axis[d] = t * t; }   // sign drops out
-            sa.active = ctx->d_active[cur]; sa.loss_partial = ctx->d_loss_partial; sa.dbg_cdout = dbg;
+            sa.active = ctx->d_active[cur]; sa.n_active = ctx->d_nactive + cur;
+            sa.loss_partial = ctx->d_loss_partial; sa.dbg_cdout = dbg;
             prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
             {
-                const dim3 grid(sa.tiles_max, 6, n_active), blk(kBlock);
+                const dim3 grid(sa.tiles_max, 6, bound), blk(kBlock);
                 const bool det = ctx->d_gbox != nullptr;
 #define C2R_LAUNCH_SWEEP(D, L) hipLaunchKernelGGL((k_sweep_shell<D, L>), grid, blk, 0, st, k, sa)
                 switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
@@ -284,17 +294,22 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
             }
             prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
             if (sa.has_boundary)
-                hipLaunchKernelGGL(k_loss_reduce, dim3(n_active), dim3(256), 0, st, ctx->d_active[cur],
+                hipLaunchKernelGGL(k_loss_reduce, dim3(bound), dim3(256), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
                                    ctx->d_loss_partial, 6 * sa.tiles_max, ctx->d_loss_acc);
         }
         const int can_grow = (p.subboxsize * nbox < ctx->hr[2]) && (p.subboxsize * nbox < ctx->hl[2]);
-        hipLaunchKernelGGL(k_box_decide, dim3(1), dim3(1024), 0, st, ctx->d_active[cur], n_active,
-                           ctx->d_active[1 - cur], ctx->d_nactive, ctx->d_nflux_b, p.S_star, p.loss_fraction,
+        hipLaunchKernelGGL(k_box_decide, dim3(1), dim3(1024), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
+                           ctx->d_active[1 - cur], ctx->d_nactive + (1 - cur), ctx->d_nflux_b, p.S_star, p.loss_fraction,
                            can_grow, nbox, ctx->d_loss_acc, ctx->d_final_loss, ctx->d_final_nbox);
-        HIP_TRY(hipMemcpyAsync(ctx->h_nactive, ctx->d_nactive, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        n_active = *ctx->h_nactive;
+        HIP_TRY(hipMemcpyAsync(ctx->h_nactive + nbox, ctx->d_nactive + (1 - cur), sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(ctx->ev_box[nbox], st));
         cur = 1 - cur;
+        // read the count of the PREVIOUS sub-box (its copy was enqueued a whole box of launches ago)
+        if (pending) {
+            HIP_TRY(hipEventSynchronize(ctx->ev_box[pending]));
+            bound = ctx->h_nactive[pending];
+        }
+        pending = nbox;
     }
     if (ctx->d_gbox)
         hipLaunchKernelGGL(k_gamma_reduce, dim3((unsigned)((ctx->ncell + 255) / 256)), dim3(256), 0, st, k, count,
@@ -405,8 +420,7 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipMalloc(&ctx->d_phih_T, grid_bytes(ctx, 4)));
     HIP_TRY(hipMalloc(&ctx->d_thick, (size_t)(p->numtau + 1) * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_thin, (size_t)(p->numtau + 1) * sizeof(double)));
-    HIP_TRY(hipMalloc(&ctx->d_nactive, sizeof(int)));
-    HIP_TRY(hipHostMalloc((void **)&ctx->h_nactive, sizeof(int)));
+    HIP_TRY(hipMalloc(&ctx->d_nactive, 2 * sizeof(int)));
     HIP_TRY(hipMalloc(&ctx->d_photon_loss, sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_sum_nbox, sizeof(long long)));
     HIP_TRY(hipMalloc(&ctx->d_sum_partial, 4 * kSumBlocks * sizeof(double)));
@@ -428,6 +442,9 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     ctx->Qmax = std::min(ctx->nbox_max * p->subboxsize, reach);
     ctx->R = ctx->Qmax; ctx->P = 2 * ctx->R + 1; ctx->PP = (size_t)ctx->P * ctx->P;
     ctx->tiles_cap = (int)((ctx->PP + kBlock - 1) / kBlock);
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_nactive, (size_t)(ctx->nbox_max + 2) * sizeof(int)));
+    ctx->ev_box.resize(ctx->nbox_max + 2);
+    for (auto &e : ctx->ev_box) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return C2R_OK;
 }
 
@@ -445,6 +462,7 @@ void c2r_destroy(c2r_ctx *c)
     hipFree(ctx->d_photon_loss); hipFree(ctx->d_sum_nbox); hipFree(ctx->d_sum_partial); hipFree(ctx->d_sum_out);
     hipFree(ctx->d_conv); hipFree(ctx->d_chemfail); hipFree(ctx->d_dbg); hipFree(ctx->d_pair);
     if (ctx->h_sc) hipHostFree(ctx->h_sc);
+    for (auto &e : ctx->ev_box) hipEventDestroy(e);
     for (auto &e : ctx->ev_sweep) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : ctx->ev_chem) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);

@@ -72,6 +72,7 @@ struct ShellArgs {
     double d2axis[3];            // (dr_d * q)^2: the own-axis term of dist2 for faces normal to d
     FaceRect face[6];
     const int *active;           // compacted list of local source indices
+    const int *n_active;         // its length on the device: the grid may be sized by an older, larger count
     double *loss_partial;
     double *dbg_cdout;           // optional N^3 coldensh_out of the (single) source, else null
 };
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
     const int face = blockIdx.y;
     const int sl = blockIdx.z;
     const int tile = blockIdx.x;
+    if (sl >= *sa.n_active) return;              // block-uniform: this source retired after the launch was sized
     const FaceRect fr = sa.face[face];
     double loss = 0.0;
     const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
@@ -510,11 +512,12 @@ __global__ void k_selftest_div(int n, double d_uniform, double rd_uniform, unsig
 }
 
 // Adds the block partials of one shell launch to loss_acc[source], in a fixed order.
-__global__ __launch_bounds__(256) void k_loss_reduce(const int *active, const double *loss_partial, int bps,
-                                                     double *loss_acc)
+__global__ __launch_bounds__(256) void k_loss_reduce(const int *active, const int *n_active, const double *loss_partial,
+                                                     int bps, double *loss_acc)
 {
     __shared__ double sm[4];
     const int sl = blockIdx.x;
+    if (sl >= *n_active) return;
     double v = 0.0;
     for (int i = threadIdx.x; i < bps; i += 256) v += loss_partial[(size_t)sl * bps + i];   // bps = 6*tiles_max
     const double tot = block_sum_256(v, sm);
@@ -524,13 +527,14 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const int *active, const do
 // End of sub-box `nbox` (evolve_source.F90:128-131): keep a source active while more than
 // loss_fraction of its photons leave the box and the box can still grow in z.  Compacts the
 // active list (stable), finalises the others.  One block of 1024 threads.
-__global__ __launch_bounds__(1024) void k_box_decide(const int *active_in, int n_in, int *active_out,
+__global__ __launch_bounds__(1024) void k_box_decide(const int *active_in, const int *n_in_dev, int *active_out,
                                                      int *n_out, const double *normflux, double S_star,
                                                      double loss_fraction, int can_grow, int nbox,
                                                      double *loss_acc, double *final_loss, int *final_nbox)
 {
     __shared__ int scan[1024];
     __shared__ int base;
+    const int n_in = *n_in_dev;
     if (threadIdx.x == 0) base = 0;
     __syncthreads();
     for (int start = 0; start < n_in; start += 1024) {
