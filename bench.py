@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--density", choices=["uniform", "lognormal"], default="uniform",
                     help="lognormal: sigma_ln=1, mean 1 times the same mean density (SURVEY.md s8d, config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--balance", action="store_true",
+                    help="cost-balanced source shares (by the previous pass) instead of the static stride")
     ap.add_argument("--deterministic", action="store_true",
                     help="per-source Gamma grids reduced in source order instead of f64 atomics")
     args = ap.parse_args()
@@ -130,7 +132,7 @@ def main():
     b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], s["clumping"], s["temper"])
     b.set_sources(srcpos, normflux)
     b.load(ndens=nd, xh=xh)
-    ev = pkg.Evolve(b, comm=dist if world > 1 else None)
+    ev = pkg.Evolve(b, comm=dist if world > 1 else None, balance=args.balance)
     b.begin_step()
 
     def one_step(k):

@@ -39,6 +39,8 @@ struct Ctx {
     std::vector<int32_t> srcpos;   // 3 x nsrc
     std::vector<double>  nflux;
     int nsrc = 0, rank = 0, nranks = 1;
+    bool explicit_share = false; std::vector<int32_t> share;   // c2r_set_source_share: this rank's sources
+    std::vector<int32_t> last_nbox;                              // final sub-box count per local source, last pass
     c2r_allreduce_fn ar = nullptr;
     void *ar_user = nullptr;
     // sweep geometry
@@ -103,6 +105,7 @@ void free_sweep_scratch(Ctx *ctx)
 
 int n_local_sources(const Ctx *ctx)
 {
+    if (ctx->explicit_share) return (int)ctx->share.size();
     return ctx->nsrc > ctx->rank ? (ctx->nsrc - ctx->rank + ctx->nranks - 1) / ctx->nranks : 0;
 }
 
@@ -218,7 +221,8 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
     std::vector<double> h_nf(count), h_fl(count, 0.0);
     const bool can_trace = ctx->hr[2] > 0 && ctx->hl[2] > 0;       // while condition, evolve_source.F90:130-131
     for (int i = 0; i < count; ++i) {
-        const int g = ctx->rank + (first + i) * ctx->nranks;       // master_slave.F90:85
+        const int g = ctx->explicit_share ? ctx->share[first + i]
+                                          : ctx->rank + (first + i) * ctx->nranks;      // master_slave.F90:85
         for (int d = 0; d < 3; ++d) {
             h_pos[3 * i + d] = ctx->srcpos[3 * (size_t)g + d];
             const int m = (h_pos[3 * i + d] - 1) % p.mesh[d];
@@ -546,6 +550,7 @@ int c2r_set_sources(c2r_ctx *c, const int32_t *srcpos, const double *normflux, i
     ctx->srcpos.assign(srcpos, srcpos + 3 * (size_t)nsrc);
     ctx->nflux.assign(normflux, normflux + nsrc);
     ctx->nsrc = nsrc;
+    ctx->explicit_share = false; ctx->share.clear(); ctx->last_nbox.clear();
     return C2R_OK;
 }
 
@@ -556,6 +561,26 @@ int c2r_set_rank(c2r_ctx *c, int32_t rank, int32_t nranks, c2r_allreduce_fn fn, 
     if (nranks < 1 || rank < 0 || rank >= nranks) FAIL(C2R_EINVAL, "need 0 <= rank < nranks");
     if (nranks > 1 && !fn) FAIL(C2R_EINVAL, "nranks > 1 needs an all-reduce callback");
     ctx->rank = rank; ctx->nranks = nranks; ctx->ar = fn; ctx->ar_user = user;
+    return C2R_OK;
+}
+
+int c2r_set_source_share(c2r_ctx *c, const int32_t *idx, int32_t n)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (!idx || n < 0) { ctx->explicit_share = false; ctx->share.clear(); return C2R_OK; }
+    for (int i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= ctx->nsrc) FAIL(C2R_EINVAL, "source index out of range");
+    ctx->share.assign(idx, idx + n);
+    ctx->explicit_share = true;
+    return C2R_OK;
+}
+
+int c2r_last_nbox(c2r_ctx *c, int32_t *nbox, int32_t n)
+{
+    if (!c || (n > 0 && !nbox)) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (n != (int32_t)ctx->last_nbox.size()) FAIL(C2R_EINVAL, "length must equal the number of sources this rank swept");
+    for (int i = 0; i < n; ++i) nbox[i] = ctx->last_nbox[i];
     return C2R_OK;
 }
 
@@ -621,11 +646,12 @@ int c2r_pass_sources(c2r_ctx *c, double *photon_loss, int64_t *sum_nbox, int64_t
         if (rc) return rc;
         if ((rc = sweep_prepare(ctx))) return rc;
         std::vector<int> nb;
+        ctx->last_nbox.clear();
         for (int first = 0; first < nloc; first += ctx->batch_cap) {
             const int count = std::min(ctx->batch_cap, nloc - first);
             rc = sweep_batch(ctx, first, count, nullptr, &nb, nullptr);
             if (rc) return rc;
-            for (int v : nb) vis += visited_for_nbox(ctx, v);
+            for (int v : nb) { vis += visited_for_nbox(ctx, v); ctx->last_nbox.push_back(v); }
         }
         if ((rc = sweep_finish(ctx))) return rc;
     }
@@ -667,12 +693,13 @@ int c2r_do_source(c2r_ctx *c, int32_t ns, double *cd_host, double *loss, int32_t
     HIP_TRY(hipMemsetAsync(ctx->d_sum_nbox, 0, sizeof(long long), ctx->stream));
     // address the source directly, whatever the rank layout
     const int sr = ctx->rank, sn = ctx->nranks;
-    ctx->rank = 0; ctx->nranks = 1;
+    const bool se = ctx->explicit_share;
+    ctx->rank = 0; ctx->nranks = 1; ctx->explicit_share = false;
     std::vector<int> nb; std::vector<double> fl;
     rc = sweep_prepare(ctx);
     if (!rc) rc = sweep_batch(ctx, ns - 1, 1, dbg, &nb, &fl);
     if (!rc) rc = sweep_finish(ctx);
-    ctx->rank = sr; ctx->nranks = sn;
+    ctx->rank = sr; ctx->nranks = sn; ctx->explicit_share = se;
     if (rc) return rc;
     prof_collect(ctx);
     if (cd_host) {

@@ -35,6 +35,29 @@ def static_source_share(nsrc, rank, npr):
     return list(range(rank, nsrc, npr))
 
 
+def box_cost(nbox, mesh, subbox=5):
+    """Cells a source visits when it ends with `nbox` sub-boxes (evolve_source.F90:100-102,135-136)."""
+    v = np.ones_like(np.asarray(nbox), dtype=np.int64)
+    for n in mesh:
+        hr, hl = n // 2 - 1 + n % 2, n // 2
+        v = v * (np.minimum(subbox * np.asarray(nbox), hr) + np.minimum(subbox * np.asarray(nbox), hl) + 1)
+    return np.where(np.asarray(nbox) > 0, v, 0)
+
+
+def balanced_source_shares(cost, npr):
+    """Longest-processing-time partition of the sources over npr ranks (deterministic: ties by source
+    index, then by rank).  Each share is returned in ascending source order."""
+    cost = np.asarray(cost, dtype=np.int64)
+    order = sorted(range(len(cost)), key=lambda i: (-int(cost[i]), i))
+    load = [0] * npr
+    shares = [[] for _ in range(npr)]
+    for i in order:
+        r = min(range(npr), key=lambda k: (load[k], k))
+        shares[r].append(i)
+        load[r] += int(cost[i]) + 1          # +1: every source costs something, keeps counts even at zero cost
+    return [sorted(sh) for sh in shares]
+
+
 class HipBackend:
     """The HIP path: owns a c2r context on one GPU and the device-resident arrays."""
 
@@ -114,9 +137,30 @@ class HipBackend:
         normflux = np.ascontiguousarray(normflux, dtype=np.float64)
         assert len(srcpos) == len(normflux)
         self.nsrc = len(normflux)
+        self.share = None
         self.normflux_sum = float(np.sum(normflux))
         self._check(self.lib.c2r_set_sources(self.ctx, srcpos.ctypes.data, normflux.ctypes.data, self.nsrc),
                     "c2r_set_sources")
+
+    def set_source_share(self, indices=None):
+        """Explicit list of this rank's sources (0-based) instead of the static stride; None resets."""
+        if indices is None:
+            self._check(self.lib.c2r_set_source_share(self.ctx, None, -1), "c2r_set_source_share")
+            self.share = None
+        else:
+            idx = np.ascontiguousarray(indices, dtype=np.int32)
+            self._check(self.lib.c2r_set_source_share(self.ctx, idx.ctypes.data, len(idx)), "c2r_set_source_share")
+            self.share = idx
+
+    def local_sources(self):
+        sh = getattr(self, "share", None)
+        return np.asarray(sh if sh is not None else static_source_share(self.nsrc, self.rank, self.npr), dtype=np.int64)
+
+    def last_nbox(self):
+        n = len(self.local_sources())
+        out = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.c2r_last_nbox(self.ctx, out.ctypes.data, n), "c2r_last_nbox")
+        return out
 
     def set_rank(self, rank, npr, allreduce=None):
         """allreduce(tensor): in-place SUM over ranks of a 1-D f64 device tensor."""
@@ -243,11 +287,15 @@ def _flat(a, dtype):
 class Evolve:
     """The outer loop of one time step over a backend, with the reference's procedure names."""
 
-    def __init__(self, backend, comm=None):
+    def __init__(self, backend, comm=None, balance=False):
         """comm: None (single process) or a torch.distributed-like module/object exposing
-        get_rank(), get_world_size(), all_reduce(tensor) with SUM semantics."""
+        get_rank(), get_world_size(), all_reduce(tensor) with SUM semantics.
+        balance: re-partition the sources over the ranks before every pass by the cost each had in the
+        previous pass (volume of its final sub-box) instead of the static 1+rank,NumSrc,npr rule."""
         self.b = backend
         self.comm = comm
+        self.balance = balance
+        self.nbox_per_source = None
         self.rank = comm.get_rank() if comm is not None else 0
         self.npr = comm.get_world_size() if comm is not None else 1
         if hasattr(backend, "set_rank"):
@@ -270,7 +318,17 @@ class Evolve:
     # master_slave.F90:53 -> :74 do_grid_static; the per-source loop and do_source live in the
     # backend (c2r_pass_sources), which traces this rank's share 1+rank, 1+rank+npr, ...
     def do_grid(self, dt, niter):
+        if self.balance and self.npr > 1 and self.nbox_per_source is not None:
+            cost = box_cost(self.nbox_per_source, self.b.mesh)
+            self.b.set_source_share(balanced_source_shares(cost, self.npr)[self.rank])
         loss, nb, vis = self.b.pass_sources()
+        if self.balance and self.npr > 1:
+            # every rank learns every source's sub-box count: own entries, zero elsewhere, summed
+            mine = np.zeros(self.b.nsrc, dtype=np.float64)
+            mine[self.b.local_sources()] = self.b.last_nbox()
+            t = self.b.scalars_tensor(mine.tolist())
+            self.comm.all_reduce(t)
+            self.nbox_per_source = np.rint(np.asarray(t.tolist())).astype(np.int64)
         self.photon_loss += loss
         self.sum_nbox += nb
         self.visited += vis

@@ -133,6 +133,14 @@ int  c2r_set_sources(c2r_ctx *ctx, const int32_t *srcpos, const double *normflux
  * do ns1=1+rank,NumSrc,npr) and the collective that replaces MPI_ALLREDUCE. */
 int  c2r_set_rank(c2r_ctx *ctx, int32_t rank, int32_t nranks, c2r_allreduce_fn fn, void *user);
 
+/* Cost-balanced alternative to the static distribution (the reference's answer to
+ * imbalance is its master/worker scheduler, master_slave.F90:124-330): the 0-based global indices
+ * of the sources THIS rank sweeps, in sweep order.  idx=NULL returns to the static rule.
+ * c2r_set_sources resets it.  c2r_last_nbox returns the sub-box count each of this rank's sources
+ * ended with in the last c2r_pass_sources (its cost is the volume of that box). */
+int  c2r_set_source_share(c2r_ctx *ctx, const int32_t *idx, int32_t n);
+int  c2r_last_nbox(c2r_ctx *ctx, int32_t *nbox, int32_t n);
+
 /* ---- device buffers -------------------------------------------------------------------- */
 /* Use caller-owned device arrays (N^3 each; ndens f32, the rest f64) instead of the
  * context's own.  Any pointer may be NULL to keep the context's buffer. */

@@ -46,9 +46,22 @@ class OracleBackend:
     def zero_rates(self):
         self.phih_grid[:] = 0.0
 
+    def set_source_share(self, indices=None):
+        self.share = None if indices is None else np.asarray(indices, dtype=np.int64)
+
+    def local_sources(self):
+        sh = getattr(self, "share", None)
+        return np.asarray(sh if sh is not None else list(range(self.rank, self.nsrc, self.npr)), dtype=np.int64)
+
+    def last_nbox(self):
+        return np.asarray(self._last_nbox, dtype=np.int32)
+
     def pass_sources(self):
-        return self.o.pass_sources(self.ndens, self.xh_av, self.phih_grid, self.srcpos, self.normflux,
-                                   self.rank, self.npr)
+        loss, nb, vis, self._last_nbox = 0.0, 0, 0, []
+        for i in self.local_sources():
+            n1, l1, v1, _ = self.o.do_source(self.ndens, self.xh_av, self.phih_grid, self.srcpos[i], self.normflux[i])
+            loss = loss + l1; nb += n1; vis += v1; self._last_nbox.append(n1)
+        return loss, nb, vis
 
     def global_pass(self, dt):
         conv = self.o.global_pass(dt, self.ndens, self.xh, self.xh_av, self.xh_intermed, self.phih_grid)

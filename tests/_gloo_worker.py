@@ -19,7 +19,8 @@ def main():
     s = m["steps"]["step001"]
     b = OracleBackend(oracle_for(s, tables, m["n"]), F(a["step001_ndens"]), F(a["step001_xh_before"]),
                       s["srcpos"], s["normflux"])
-    r = pkg.Evolve(b, comm=dist).evolve3D(0.0, s["dt"], 0)
+    balance = len(sys.argv) > 2 and sys.argv[2] == "balance"
+    r = pkg.Evolve(b, comm=dist, balance=balance).evolve3D(0.0, s["dt"], 0)
     import torch
     mine = torch.from_numpy(b.xh.copy())
     gathered = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]

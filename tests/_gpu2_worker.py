@@ -20,13 +20,13 @@ def main():
     m, a = load_case("evolve32_std_bubbles")
     s = m["steps"]["step001"]
     out = {}
-    for mode in ("python", "native"):
+    for mode in ("python", "native", "balanced"):
         b = pkg.HipBackend(m["n"], *tables, device=0)
         b.set_step((s["dr1"], s["dr2"], s["dr3"]), s["vol"], s["coldensh_LLS"], s["clumping"])
         b.set_sources(s["srcpos"], s["normflux"])
         b.load(ndens=F(a["step001_ndens"]), xh=F(a["step001_xh_before"]))
-        ev = pkg.Evolve(b, comm=dist)          # sets rank/size and the callback in the context
-        if mode == "python":
+        ev = pkg.Evolve(b, comm=dist, balance=(mode == "balanced"))   # sets rank/size and the callback in the context
+        if mode in ("python", "balanced"):
             r = ev.evolve3D(0.0, s["dt"], 0)
             niter, nbox, loss, conv = r["niter"], r["sum_nbox_all"], r["photon_loss_all"], [e["conv_flag"] for e in r["log"]]
         else:

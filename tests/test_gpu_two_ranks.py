@@ -22,7 +22,7 @@ def test_two_ranks_on_one_gpu_match_reference(tmp_path):
     got = np.load(out)
     m, a = load_case("evolve32_std_bubbles")
     s = m["steps"]["step001"]
-    for mode in ("python", "native"):
+    for mode in ("python", "native", "balanced"):
         assert int(got[mode + "_niter"]) == s["niter"]
         assert list(got[mode + "_conv"]) == s["log"]["nonconv"]
         assert int(got[mode + "_nbox"]) == s["sum_nbox_all"]

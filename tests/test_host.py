@@ -149,8 +149,25 @@ def test_iteration_dump_then_restart_reproduces_the_rest_of_the_step(pkg, tmp_pa
     assert np.max(np.abs(b2.xh - b.xh)) < 1e-2
 
 
+def test_balanced_source_shares(pkg):
+    """LPT partition by the previous pass's sub-box volume: a partition, deterministic, and far more
+    even than the static stride when a few sources dominate."""
+    rng = np.random.default_rng(0)
+    nbox = rng.integers(1, 27, 200)
+    nbox[::8] = 26                                    # the static stride gives rank 0 all the expensive ones
+    cost = pkg.box_cost(nbox, (256, 256, 256))
+    assert cost[nbox == 26][0] == 256 ** 3 and pkg.box_cost(np.array([0, 1]), (32, 32, 32)).tolist() == [0, 11 ** 3]
+    sh = pkg.balanced_source_shares(cost, 8)
+    assert sorted(sum(sh, [])) == list(range(200))
+    assert sh == pkg.balanced_source_shares(cost, 8)
+    load = np.array([cost[s].sum() for s in sh], dtype=np.float64)
+    static = np.array([cost[pkg.static_source_share(200, r, 8)].sum() for r in range(8)], dtype=np.float64)
+    assert load.max() / load.mean() < 1.02 < static.max() / static.mean()
+
+
 @pytest.mark.timeout(300)
-def test_two_ranks_gloo_equals_one_rank(pkg, tmp_path):
+@pytest.mark.parametrize("mode", ["static", "balance"])
+def test_two_ranks_gloo_equals_one_rank(pkg, tmp_path, mode):
     """world_size=2 over gloo: sources sharded 1+rank,NumSrc,npr, Gamma/photon-loss/nbox summed with
     all_reduce, every rank runs the global pass.  Result must equal the single-rank run up to the
     re-association of the Gamma sum (the reference's MPI path has the same property)."""
@@ -158,7 +175,7 @@ def test_two_ranks_gloo_equals_one_rank(pkg, tmp_path):
     out = tmp_path / "out.npz"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29731", script, str(out)],
+                           "--master-addr", "127.0.0.1", "--master-port", "29731", script, str(out), mode],
                           env=env, cwd=ROOT, timeout=280)
     got = np.load(out)
     from tests._cpu_backend import OracleBackend
