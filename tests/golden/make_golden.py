@@ -325,6 +325,8 @@ def main():
     if want("evolve32"): case_evolve("evolve32_onesrc", 32, SRC_ONE, 12, [1, 2, 3, 12])
     # pre-ionised gas, the 10-source list (positions wrap periodically): sub-box growth to the limit
     if want("refrun32"): case_refrun("refrun32_onesrc", 32, SRC_ONE)
+    # ten sources (positions wrap at 32^3): overlapping regions, conv_criterion = 3, sub-boxes to the limit
+    if want("refrun32std"): case_refrun("refrun32_std", 32, SRC_STD)
     if want("sweep32"): case_sweep("sweep32_std_x999", 32, SRC_STD, x_init=0.999)
     if want("sweep33"): case_sweep("sweep33_std_x999", 33, SRC_STD, x_init=0.999, dens_seed=33)
     # perturbed density + ionized bubbles: exercises max_coldensh stop, thin/thick cells, clipping

@@ -27,9 +27,10 @@ def read_sm3d(path, dtype):
 
 
 @pytest.mark.skipif(not os.path.exists(EXE), reason="drop-in program not built (needs the reference: oracle/ref_build.sh 32)")
-def test_reference_driver_with_hip_evolve_matches_pure_reference_run():
-    m = json.load(open(os.path.join(GOLDEN, "refrun32_onesrc.json")))
-    a = np.load(os.path.join(GOLDEN, "refrun32_onesrc.npz"))
+@pytest.mark.parametrize("case", ["refrun32_onesrc", "refrun32_std"])
+def test_reference_driver_with_hip_evolve_matches_pure_reference_run(case):
+    m = json.load(open(os.path.join(GOLDEN, case + ".json")))
+    a = np.load(os.path.join(GOLDEN, case + ".npz"))
     d = tempfile.mkdtemp(prefix="c2r_dropin_")
     try:
         os.makedirs(d + "/results")
@@ -43,7 +44,7 @@ def test_reference_driver_with_hip_evolve_matches_pure_reference_run():
         assert outs == m["outputs"]
         nonconv = [int(l.split(":")[1]) for l in open(d + "/results/C2Ray.log")
                    if "Number of non-converged points:" in l]
-        assert len(nonconv) == m["total_outer_iterations"]       # 648 outer iterations over 140 steps
+        assert len(nonconv) == m["total_outer_iterations"]       # e.g. 648 outer iterations over 140 steps
         assert nonconv == m["nonconv"]
         for f in m["kept"]:
             z = f[len("xfrac3D_"):-4]

@@ -12,12 +12,13 @@ from tests._util import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-def test_test_problem_run_matches_the_reference_outputs(tmp_path):
+@pytest.mark.parametrize("case", ["refrun32_onesrc", "refrun32_std"])
+def test_test_problem_run_matches_the_reference_outputs(tmp_path, case):
     import __graft_entry__ as g
     pkg = g.load_package()
     from c2ray3dm_amd.harness import run_test_problem
-    m = json.load(open(os.path.join(GOLDEN, "refrun32_onesrc.json")))
-    a = np.load(os.path.join(GOLDEN, "refrun32_onesrc.npz"))
+    m = json.load(open(os.path.join(GOLDEN, case + ".json")))
+    a = np.load(os.path.join(GOLDEN, case + ".npz"))
     src = str(tmp_path / "test_sources.dat")
     with open(src, "w") as f:
         f.write("%d\n" % len(m["sources"]))
