@@ -77,7 +77,11 @@ class HipBackend:
         self.params = p
         self.ctx = C.c_void_p()
         rc = self.lib.c2r_create(C.byref(self.ctx), C.byref(p))
-        self._check(rc, "c2r_create")
+        if rc != 0:                      # the context exists even on failure (for its error text): free it
+            try:
+                self._check(rc, "c2r_create")
+            finally:
+                self.close()
         thick = np.ascontiguousarray(thick, dtype=np.float64)
         thin = np.ascontiguousarray(thin, dtype=np.float64)
         self._check(self.lib.c2r_set_tables(self.ctx, thick.ctypes.data, thin.ctypes.data, thick.size),
