@@ -316,7 +316,7 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
         pending = nbox;
     }
     if (ctx->d_gbox)
-        hipLaunchKernelGGL(k_gamma_reduce, dim3((unsigned)((ctx->ncell + 255) / 256)), dim3(256), 0, st, k, count,
+        hipLaunchKernelGGL(k_gamma_reduce, dim3((p.mesh[0] + 255) / 256, p.mesh[1], p.mesh[2]), dim3(256), 0, st, k, count,
                            ctx->d_final_nbox, p.subboxsize, (double *)ctx->grid[4]);
     hipLaunchKernelGGL(k_batch_totals, dim3(1), dim3(64), 0, st, count, ctx->d_final_loss, ctx->d_final_nbox,
                        ctx->d_photon_loss, ctx->d_sum_nbox);

@@ -410,32 +410,32 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
 __global__ __launch_bounds__(256) void k_gamma_reduce(KParams p, int nsrc, const int *final_nbox, int subbox,
                                                       double *phih)
 {
+    // block = 256 cells along x of one (y,z) row: the y and z parts of the box test are block-uniform
+    const int c0 = blockIdx.x * 256 + threadIdx.x, c1 = blockIdx.y, c2 = blockIdx.z;
+    const bool live = c0 < p.n[0];
     const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
-    const unsigned id = blockIdx.x * 256u + threadIdx.x;
-    if (id >= ncell) return;
-    const int c0 = (int)(id % (unsigned)p.n[0]);
-    const unsigned r = id / (unsigned)p.n[0];
-    const int c1 = (int)(r % (unsigned)p.n[1]), c2 = (int)(r / (unsigned)p.n[1]);
+    const unsigned id = (unsigned)c0 + (unsigned)p.n[0] * ((unsigned)c1 + (unsigned)p.n[1] * (unsigned)c2);
     const unsigned id_t = (unsigned)c1 + (unsigned)p.n[1] * ((unsigned)c0 + (unsigned)p.n[0] * (unsigned)c2);
-    double acc = phih[id];
+    double acc = live ? phih[id] : 0.0;
     for (int s = 0; s < nsrc; ++s) {
         const int nb = final_nbox[s];                 // uniform
         if (nb <= 0) continue;
         const int ext = subbox * nb;
-        int d0 = c0 - p.srcw[3 * s + 0], d1 = c1 - p.srcw[3 * s + 1], d2 = c2 - p.srcw[3 * s + 2];
-        d0 -= (d0 > p.hr[0]) ? p.n[0] : 0;  d0 += (d0 < -p.hl[0]) ? p.n[0] : 0;
+        int d1 = c1 - p.srcw[3 * s + 1], d2 = c2 - p.srcw[3 * s + 2];
         d1 -= (d1 > p.hr[1]) ? p.n[1] : 0;  d1 += (d1 < -p.hl[1]) ? p.n[1] : 0;
         d2 -= (d2 > p.hr[2]) ? p.n[2] : 0;  d2 += (d2 < -p.hl[2]) ? p.n[2] : 0;
-        const bool in = d0 >= -min(ext, p.hl[0]) && d0 <= min(ext, p.hr[0]) &&
-                        d1 >= -min(ext, p.hl[1]) && d1 <= min(ext, p.hr[1]) &&
-                        d2 >= -min(ext, p.hl[2]) && d2 <= min(ext, p.hr[2]);
-        if (in) {
-            const bool xf = abs(d0) > abs(d1) && abs(d0) > abs(d2);      // cinterp branch priority z > y > x
+        if (d1 < -min(ext, p.hl[1]) || d1 > min(ext, p.hr[1]) || d2 < -min(ext, p.hl[2]) || d2 > min(ext, p.hr[2]))
+            continue;                                 // the whole row lies outside this source's box
+        const int m12 = max(abs(d1), abs(d2));
+        int d0 = c0 - p.srcw[3 * s + 0];
+        d0 -= (d0 > p.hr[0]) ? p.n[0] : 0;  d0 += (d0 < -p.hl[0]) ? p.n[0] : 0;
+        if (live && d0 >= -min(ext, p.hl[0]) && d0 <= min(ext, p.hr[0])) {
+            const bool xf = abs(d0) > m12;            // cinterp branch priority z > y > x
             const double *g = p.gbox + ((size_t)s * 2 + (xf ? 1 : 0)) * ncell;
             acc = acc + g[xf ? id_t : id];
         }
     }
-    phih[id] = acc;
+    if (live) phih[id] = acc;
 }
 
 // nhi[i,j,k] = max(1-max(xh_av,eps),eps) * ndens (ion%h_av(0)*ndens_p of evolve0D) and its (x,y)-transposed
