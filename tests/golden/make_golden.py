@@ -277,6 +277,29 @@ def case_refrun(name, n, sources):
     print(name, "outputs", len(outs), "outer iterations", len(nonconv))
 
 
+def case_evolve_planes(name, n, sources, dens_seed=None, xfield=None):
+    """One evolve3D step on a large mesh: three orthogonal planes through source 1 of xh_after and
+    phih_grid, checksums and the iteration history."""
+    dens = density_factor(n, dens_seed) if dens_seed is not None else None
+    d = run_driver(n, sources, {"mode": "'evolve'", "nsteps": 1, "dump_first": 1, "dump_last": 1}, dens=dens, xfield=xfield)
+    log = parse_log(d + "/results/C2Ray.log")
+    kv = read_kv(d + "/dump/step001_in.txt"); kv.update(read_kv(d + "/dump/step001_out.txt"))
+    kv["log"] = log[0]; kv["niter"] = len(log[0]["nonconv"])
+    xa = rd(d, "step001_xh_after.f64", n); ph = rd(d, "step001_phih_grid.f64", n)
+    s0 = [(p - 1) % n for p in kv["srcpos"][0]]
+    arrays = {"xh_px": xa[s0[0]], "xh_py": xa[:, s0[1]], "xh_pz": xa[:, :, s0[2]],
+              "phih_px": ph[s0[0]], "phih_py": ph[:, s0[1]], "phih_pz": ph[:, :, s0[2]]}
+    nd = rd(d, "step001_ndens.f32", n, np.float32); xb = rd(d, "step001_xh_before.f64", n)
+    arrays["ndens"] = nd.flat[0:1].copy() if np.all(nd == nd.flat[0]) else nd
+    arrays["xh_before"] = xb.flat[0:1].copy() if np.all(xb == xb.flat[0]) else xb
+    kv.update(xh_sum=float(np.sum(xa, dtype=np.longdouble)), xh_min=float(xa.min()), xh_max=float(xa.max()),
+              phih_sum=float(np.sum(ph, dtype=np.longdouble)), phih_max=float(ph.max()),
+              phih_nonzero=int(np.count_nonzero(ph)))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    json.dump({"n": n, **kv}, open(os.path.join(HERE, name + ".json"), "w"), indent=1)
+    print(name, "niter", kv["niter"], "phih_nonzero", kv["phih_nonzero"])
+
+
 def case_restart(name, n, sources, dens_seed, xfield, k_iter=2):
     """evolve3D(restart=3): the reference resumes a time step from an iteration dump
     (start_from_dump, evolve.F90:328).  The dump is a genuine mid-iteration state -- k_iter outer
@@ -354,6 +377,12 @@ def main():
         x = bubble_xfield(64, [(50, 50, 50), (20, 10, 10), (6, 8, 50), (20, 10, 26)], 14.0)
         srcs = SRC_STD[:8] + [(72, 72, 50, 1e58), (20, 10, 90, 1e54)]
         case_sweep("sweep64_bubbles", 64, srcs, dens_seed=64, xfield=x, ns_dump=9, full=False)
+    # BASELINE.json grid sizes, straight from the reference (planes + checksums)
+    if want("big"):
+        case_sweep("sweep128_std_x999", 128, SRC_STD, x_init=0.999, full=False)
+        case_evolve_planes("evolve128_std", 128, SRC_STD)
+        case_sweep("sweep256_3src_x999", 256, [(200, 30, 77, 1e56), (5, 250, 130, 3e55), (128, 128, 128, 1e57)],
+                   x_init=0.999, full=False, ns_dump=3)
     if want("evolve64"):
         x = bubble_xfield(64, [(50, 50, 50), (20, 10, 10), (6, 8, 50), (20, 10, 26)], 12.0)
         case_evolve("evolve64_std_bubbles", 64, SRC_STD, 1, [1], dens_seed=65, xfield=x,

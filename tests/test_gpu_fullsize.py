@@ -5,7 +5,7 @@ sub-box counts over disjoint source sets (which is also what sharding over ranks
 periodic translation of the whole problem."""
 import numpy as np
 import pytest
-from tests._util import F, oracle_for, relerr
+from tests._util import F, oracle_for, relerr, load_case, expand
 
 pytestmark = pytest.mark.gpu
 TOL_GAMMA, TOL_LOSS, TOL_X = 1e-9, 1e-10, 1e-9
@@ -135,3 +135,51 @@ def test_evolve3d_native_equals_python_loop_128(pkg, tables):
         b.close()
     assert out[0][0] == out[1][0]
     assert np.max(np.abs(out[0][1] - out[1][1])) < 1e-12
+
+
+def _planes(p3, m):
+    n = m["n"]
+    s = [(q - 1) % n for q in m["srcpos"][m.get("ns_dump", 1) - 1]]
+    return {"px": p3[s[0]], "py": p3[:, s[1]], "pz": p3[:, :, s[2]]}
+
+
+@pytest.mark.parametrize("name", ["sweep128_std_x999", "sweep256_3src_x999"])
+def test_sweep_vs_reference_fixture_at_baseline_sizes(pkg, tables, name):
+    """128^3 and 256^3 against values recorded from the Fortran reference itself (planes through a
+    source, number of cells with a rate, sum of the rates, sub-box counts, photon loss)."""
+    m, a = load_case(name)
+    n = m["n"]
+    nd, xh = F(expand(a["ndens"], n)), F(expand(a["xh"], n))
+    b = backend(pkg, tables, m, n, nd, xh, m["srcpos"], m["normflux"])
+    b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    assert nbox == m["sum_nbox"]
+    assert abs(loss - m["photon_loss"]) <= TOL_LOSS * abs(m["photon_loss"])
+    p3 = b.fetch("phih_grid").reshape((n, n, n), order="F")
+    assert np.count_nonzero(p3) == m["phih_nonzero"]
+    assert abs(float(np.sum(p3, dtype=np.longdouble)) / m["phih_sum"] - 1) < 1e-10
+    for tag, sl in _planes(p3, m).items():
+        assert relerr(sl, a["phih_" + tag], floor=1e-60) < TOL_GAMMA, tag
+    b.close()
+
+
+def test_evolve3d_128_vs_reference_fixture(pkg, tables):
+    """A whole cold-start time step at 128^3 with the reference's 10-source list: 53 outer iterations."""
+    m, a = load_case("evolve128_std")
+    n = m["n"]
+    b = backend(pkg, tables, m, n, F(expand(a["ndens"], n)), F(expand(a["xh_before"], n)), m["srcpos"], m["normflux"])
+    rep = b.evolve3d_native(m["dt"])
+    assert rep.converged and rep.niter == m["niter"]
+    assert list(rep.it_conv_flag[:rep.niter]) == m["log"]["nonconv"]
+    assert rep.sum_nbox_all == m["sum_nbox_all"]
+    x3 = b.fetch("xh").reshape((n, n, n), order="F")
+    p3 = b.fetch("phih_grid").reshape((n, n, n), order="F")
+    for tag, sl in _planes(x3, m).items():
+        assert np.max(np.abs(sl - a["xh_" + tag])) < TOL_X, tag
+    for tag, sl in _planes(p3, m).items():
+        assert relerr(sl, a["phih_" + tag], floor=1e-60) < 1e-8, tag
+    assert np.count_nonzero(p3) == m["phih_nonzero"]
+    assert abs(float(np.sum(x3, dtype=np.longdouble)) / m["xh_sum"] - 1) < 1e-12
+    for k in ("totrec", "totcollisions", "total_ion"):
+        assert abs(getattr(rep, k) / m[k] - 1) < 1e-9
+    b.close()

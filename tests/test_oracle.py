@@ -186,3 +186,45 @@ def test_evolve3d_physics_variants(tables, name):
     assert rep.sum_nbox_all == s["sum_nbox_all"] and rep.photon_loss_all == s["photon_loss_all"]
     for k in ("totrec", "totcollisions", "dh0", "total_ion"):
         assert getattr(rep, k) == s[k], k
+
+
+def _check_planes(p3, a, m, prefix, key, exact=True, tol=0.0):
+    n = m["n"]
+    s = [(q - 1) % n for q in m["srcpos"][m.get("ns_dump", 1) - 1]]
+    for tag, sl in (("px", p3[s[0]]), ("py", p3[:, s[1]]), ("pz", p3[:, :, s[2]])):
+        ref = a[prefix + "_" + tag]
+        if exact:
+            assert np.array_equal(sl, ref), (key, tag)
+        else:
+            assert relerr(sl, ref, floor=1e-60) < tol, (key, tag)
+
+
+@pytest.mark.parametrize("name", ["sweep128_std_x999", "sweep256_3src_x999"])
+def test_sweep_at_baseline_grid_sizes(tables, name):
+    """128^3 / 256^3 straight from the reference: planes through a source, checksums, and the known
+    answers SURVEY.md records for the 128^3 case (sum_nbox = 110, 2 028 081 cells with a rate)."""
+    m, a = load_case(name)
+    n = m["n"]
+    o = oracle_for(m, tables, n)
+    nd, xh = F(expand(a["ndens"], n)), F(expand(a["xh"], n))
+    phih = np.zeros(o.ncell)
+    loss, nb, vis = o.pass_sources(nd, xh, phih, m["srcpos"], m["normflux"])
+    assert nb == m["sum_nbox"] and loss == m["photon_loss"]
+    assert np.count_nonzero(phih) == m["phih_nonzero"]
+    _check_planes(phih.reshape((n, n, n), order="F"), a, m, "phih", name)
+    if name == "sweep128_std_x999":
+        assert m["sum_nbox"] == 110 and m["phih_nonzero"] == 2028081
+
+
+def test_evolve3d_128(tables):
+    m, a = load_case("evolve128_std")
+    n = m["n"]
+    o = oracle_for(m, tables, n)
+    xh = F(expand(a["xh_before"], n)); nd = F(expand(a["ndens"], n))
+    rep, xav, xint, phih = o.evolve3d(m["dt"], nd, xh, m["srcpos"], m["normflux"])
+    assert rep.niter == m["niter"] and list(rep.it_conv_flag[:rep.niter]) == m["log"]["nonconv"]
+    _check_planes(xh.reshape((n, n, n), order="F"), a, m, "xh", "xh")
+    _check_planes(phih.reshape((n, n, n), order="F"), a, m, "phih", "phih")
+    assert np.count_nonzero(phih) == m["phih_nonzero"]
+    for k in ("totrec", "totcollisions", "dh0", "total_ion"):
+        assert getattr(rep, k) == m[k]
