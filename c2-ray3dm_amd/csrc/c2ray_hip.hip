@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -69,6 +70,9 @@ struct Ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_sweep, ev_chem;
     size_t ev_sweep_used = 0, ev_chem_used = 0;
     double prof_sweep_ms = 0, prof_chem_ms = 0; long long prof_sweep_n = 0, prof_chem_n = 0;
+    // host arrays of the driver that c2r_evolve3d has page-locked (they are allocated once and live for
+    // the whole run: evolve_data.F90:75-90), so the per-step transfers run at DMA speed
+    std::map<const void *, size_t> pinned;
     std::string err;
 };
 
@@ -457,6 +461,7 @@ void c2r_destroy(c2r_ctx *c)
     if (!c) return;
     Ctx *ctx = C(c);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->pinned) hipHostUnregister(const_cast<void *>(kv.first));
     free_sweep_scratch(ctx);
     for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
     hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_nactive);
@@ -901,11 +906,28 @@ int c2r_evolve3d_restart_dev(c2r_ctx *c, double dt, int32_t niter, double photon
     return evolve3d_worker(c, dt, niter, photon_loss_all, rep);
 }
 
+static void pin_host_array(Ctx *ctx, const void *ptr, size_t bytes)
+{
+    if (!ptr) return;
+    auto it = ctx->pinned.find(ptr);
+    if (it != ctx->pinned.end() && it->second >= bytes) return;
+    if (it != ctx->pinned.end()) { hipHostUnregister(const_cast<void *>(ptr)); ctx->pinned.erase(it); }
+    // best effort: an array that cannot be registered is simply copied as pageable memory
+    if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) ctx->pinned[ptr] = bytes;
+    else (void)hipGetLastError();
+}
+
 int c2r_evolve3d(c2r_ctx *c, double dt, const float *ndens, double *xh, double *xh_av, double *xh_int,
                  double *phih, c2r_report *rep)
 {
     if (!c || !ndens || !xh) return C2R_EINVAL;
     int rc;
+    {
+        Ctx *ctx = C(c);
+        pin_host_array(ctx, ndens, grid_bytes(ctx, 0)); pin_host_array(ctx, xh, grid_bytes(ctx, 1));
+        pin_host_array(ctx, xh_av, grid_bytes(ctx, 2)); pin_host_array(ctx, xh_int, grid_bytes(ctx, 3));
+        pin_host_array(ctx, phih, grid_bytes(ctx, 4));
+    }
     if ((rc = c2r_upload(c, 0, ndens))) return rc;
     if ((rc = c2r_upload(c, 1, xh))) return rc;
     if ((rc = c2r_evolve3d_dev(c, dt, rep))) return rc;
