@@ -167,3 +167,60 @@ def read_iteration_dump(path, mesh):
             raise ValueError("iteration dump does not match the mesh")
         arrs.append(a.copy())
     return (niter, loss) + tuple(arrs)
+
+
+class PhotonCounts:
+    """results/PhotonCounts.out and PhotonCounts2.out (output.F90:149-168, 504-606) and the grand totals
+    of update_grandtotal_photonstatistics (photonstatistics.F90:286-293).  One line per output time,
+    holding the statistics of the most recent time step."""
+
+    def __init__(self, results_dir):
+        self.f1 = open(os.path.join(results_dir, "PhotonCounts.out"), "a")
+        self.f2 = open(os.path.join(results_dir, "PhotonCounts2.out"), "a")
+        self.f1.write(" Columns: redshift, total number of photons used on the grid, total number of photons produced "
+                      "on the grid, photon conservation number, fraction new ionization, fraction recombinations, "
+                      "fraction LLS losses (seems to be wrong), fraction photon losses, fraction collisional "
+                      "ionization, grand total photon conservation number\n")
+        self.f2.write(" Columns: redshift, total number of ions, grand total ionizing photons, mean ionization "
+                      "fraction (by volume and mass)\n")
+        self.grtotal_ion = 0.0
+        self.grtotal_src = 0.0
+        self.last = None
+
+    def update(self, phot, photon_loss_all, dt):
+        """After every evolve3D: photonstatistics.F90:286-293.  phot: the step's statistics (dict with
+        total_ion, totcollisions, totrec, dh0, totalsrc); photon_loss_all in photons/s."""
+        self.grtotal_src += phot["totalsrc"]
+        self.grtotal_ion += phot["total_ion"] - phot["totcollisions"]
+        self.last = dict(phot, photon_loss=photon_loss_all * dt)
+
+    @staticmethod
+    def _es(v):
+        return "%10.3E" % v
+
+    def write(self, zred, time, totions, volfrac, massfrac):
+        """output.F90:504-606 write_photonstatistics at an output time."""
+        p = self.last
+        if time > 0.0 and p is not None:
+            cols = [p["total_ion"], p["totalsrc"], (p["total_ion"] - p["totcollisions"]) / p["totalsrc"],
+                    p["dh0"] / p["total_ion"], p["totrec"] / p["total_ion"], 0.0, p["photon_loss"] / p["totalsrc"],
+                    p["totcollisions"] / p["total_ion"], self.grtotal_ion / self.grtotal_src]
+            self.f1.write("%6.3f" % zred + "".join(self._es(c) for c in cols) + "\n")
+            self.f1.flush()
+        self.f2.write("%6.3f" % zred + "".join(self._es(c) for c in (totions, self.grtotal_src, volfrac, massfrac)) + "\n")
+        self.f2.flush()
+
+    def close(self):
+        self.f1.close(); self.f2.close()
+
+
+def read_photon_counts(path):
+    """Numeric rows of a PhotonCounts(2).out file (header lines skipped)."""
+    rows = []
+    for line in open(path):
+        t = line.split()
+        try:
+            rows.append([float(v) for v in t])
+        except ValueError:
+            continue
+    return rows

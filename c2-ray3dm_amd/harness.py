@@ -29,9 +29,20 @@ def run_test_problem(mesh, source_file, results_dir, nslices=14, device=0, comm=
     ncell = mesh ** 3
     b.load(xh=np.full(ncell, XH_INITIAL))                  # ionfractions_module.F90:49
     reports = []
-    if rank == 0:                                          # C2Ray.F90:343: output at sim_time = 0
-        fileio.write_xfrac3D(results_dir, tp.zred_at(0.0), b.fetch("xh"), mesh)
-        fileio.write_IonRates3D(results_dir, tp.zred_at(0.0), b.fetch("phih_grid"), mesh)
+    counts = fileio.PhotonCounts(results_dir) if rank == 0 else None
+
+    def write_outputs(zred, time):                         # output.F90:175: streams 2, 3 and the photon statistics
+        if rank != 0:
+            return
+        fileio.write_xfrac3D(results_dir, zred, b.fetch("xh"), mesh)
+        fileio.write_IonRates3D(results_dir, zred, b.fetch("phih_grid"), mesh)
+        h0, h1, _, _ = b.photon_sums("xh", "xh")           # sum n(1-x), sum n x  (output.F90:573-581)
+        counts.write(zred, time, h1 * b.vol, float(b.xh.sum()) / ncell, h1 / (h0 + h1))
+
+    s0 = tp.at_time(0.0)
+    b.set_step(s0["dr1"], s0["vol"], s0["coldensh_LLS"])
+    b.load(ndens=np.full(ncell, s0["ndens"], dtype=np.float32))
+    write_outputs(tp.zred_at(0.0), 0.0)                    # C2Ray.F90:343: output at sim_time = 0
     step = 0
     for nz in range(nslices):
         for _ in range(STEPS_PER_SLICE):
@@ -42,15 +53,25 @@ def run_test_problem(mesh, source_file, results_dir, nslices=14, device=0, comm=
             if native_loop and comm is None:
                 rep = b.evolve3d_native(s["dt"])
                 reports.append(dict(niter=rep.niter, converged=bool(rep.converged), photcons=rep.photcons))
+                phot = {k: getattr(rep, k) for k in ("total_ion", "totcollisions", "totrec", "dh0", "totalsrc")}
+                loss_all = rep.photon_loss_all
             else:
                 r = ev.evolve3D((step - 1) * tp.dt, s["dt"], 0)
                 reports.append(dict(niter=r["niter"], converged=r["converged"],
                                     photcons=r["photon_statistics"].get("photcons")))
+                phot, loss_all = r["photon_statistics"], r["photon_loss_all"]
+            if counts is not None:
+                counts.update(phot, loss_all, s["dt"])
             if log:
                 log("step %d niter %d" % (step, reports[-1]["niter"]))
-        z_out = tp.zred_at(step * tp.dt)                   # C2Ray.F90:393-398: output at the end of the slice
-        if rank == 0:
-            fileio.write_xfrac3D(results_dir, z_out, b.fetch("xh"), mesh)
-            fileio.write_IonRates3D(results_dir, z_out, b.fetch("phih_grid"), mesh)
+        # C2Ray.F90:393-398: output at the end of the slice; the driver has rescaled ndens and vol to that
+        # redshift by then (C2Ray.F90:416-419), which enters the total number of ions
+        z_out = tp.zred_at(step * tp.dt)
+        s_end = tp.at_time(step * tp.dt)
+        b.set_step(s_end["dr1"], s_end["vol"], s_end["coldensh_LLS"])
+        b.load(ndens=np.full(ncell, s_end["ndens"], dtype=np.float32))
+        write_outputs(z_out, step * tp.dt)
+    if counts is not None:
+        counts.close()
     b.close()
     return reports

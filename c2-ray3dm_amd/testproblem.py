@@ -66,6 +66,18 @@ class TestProblem:
                     coldensh_LLS=coldensh_lls, clumping=1.0, S_star=S_STAR, zred=z_mid,
                     ndens=float(ndens), temper=1e4)
 
+    def at_time(self, t):
+        """Proper dr, vol, mean density and LLS column at simulation time t, i.e. what redshift_evol(t) +
+        cosmo_evol leave behind at the end of a slice (C2Ray.F90:416-419).  Used for the output-time
+        statistics only (the driver reaches the same values by incremental f32 rescaling; they agree
+        to ~1e-7)."""
+        z = self.zred_at(t)
+        dr = self.dr_comoving / (1.0 + z)
+        ndens = np.float32(RHO_CRIT_0 * OMEGA_B / (MU * M_P) * (1.0 + z) ** 3)
+        mfp_pmpc = max(LLS_CMFP_MPC / (1.0 + z), 1.0 / (1.0 + z))
+        return dict(dr1=dr, vol=dr * dr * dr, ndens=float(ndens), zred=z,
+                    coldensh_LLS=(1.0 / SIGMA_HI) * (dr / (mfp_pmpc * MPC)))
+
     def fields(self, step=1, x_init=XH_INITIAL):
         """Uniform ndens (f32) and xh (f64) as flat Fortran-order arrays."""
         s = self.step(step)

@@ -270,8 +270,18 @@ def case_refrun(name, n, sources):
     sha = {f: hashlib.sha256(open(d + "/results/" + f, "rb").read()).hexdigest()
            for f in keep + ["IonRates3D_" + keep[0][len("xfrac3D_"):]]}
     zs = [float(l.split()[2]) for l in open(d + "/results/C2Ray.log") if l.strip().startswith("Doing redshift:")]
+    def numeric_rows(path):
+        rows = []
+        for line in open(path):
+            try:
+                rows.append([float(v) for v in line.split()])
+            except ValueError:
+                pass
+        return rows
+    counts = {"PhotonCounts": numeric_rows(d + "/results/PhotonCounts.out"),
+              "PhotonCounts2": numeric_rows(d + "/results/PhotonCounts2.out")}
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
-    json.dump({"n": n, "outputs": outs, "kept": keep, "nonconv": nonconv, "sha256": sha, "slice_redshifts": zs, "total_outer_iterations": len(nonconv),
+    json.dump({"n": n, "outputs": outs, "kept": keep, "nonconv": nonconv, "sha256": sha, "slice_redshifts": zs, "photon_counts": counts, "total_outer_iterations": len(nonconv),
                "sources": [list(s) for s in sources], "answers": ANSWERS},
               open(os.path.join(HERE, name + ".json"), "w"), indent=1)
     print(name, "outputs", len(outs), "outer iterations", len(nonconv))
