@@ -44,6 +44,8 @@ struct Ctx {
     std::vector<int32_t> last_nbox;                              // final sub-box count per local source, last pass
     c2r_allreduce_fn ar = nullptr;
     void *ar_user = nullptr;
+    c2r_iteration_fn iter_hook = nullptr;
+    void *iter_user = nullptr;
     // sweep geometry
     int hl[3], hr[3], nbox_max = 0, Qmax = 0, R = 0, P = 1;
     size_t PP = 1;
@@ -717,6 +719,37 @@ int c2r_do_source(c2r_ctx *c, int32_t ns, double *cd_host, double *loss, int32_t
     return C2R_OK;
 }
 
+int c2r_do_source_host(c2r_ctx *c, int32_t ns, const float *ndens, const double *xh_av, double *phih_grid,
+                       double *coldensh_out, double *photon_loss_src, int32_t *nbox)
+{
+    if (!c || !ndens || !xh_av || !phih_grid) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    int rc;
+    if ((rc = c2r_upload(c, 0, ndens))) return rc;
+    if ((rc = c2r_upload(c, 2, xh_av))) return rc;
+    if ((rc = c2r_zero_rates(c))) return rc;
+    if ((rc = c2r_do_source(c, ns, coldensh_out, photon_loss_src, nbox, nullptr))) return rc;
+    // phih_grid(pos) = phih_grid(pos) + this source's rate (evolve_point.F90:283), on the host array
+    std::vector<double> g(ctx->ncell);
+    if ((rc = c2r_download(c, 4, g.data()))) return rc;
+    for (size_t i = 0; i < ctx->ncell; ++i) phih_grid[i] = phih_grid[i] + g[i];
+    return C2R_OK;
+}
+
+int c2r_global_pass_host(c2r_ctx *c, double dt, const float *ndens, const double *xh, double *xh_av,
+                         double *xh_intermed, const double *phih_grid, int64_t *conv_flag)
+{
+    if (!c || !ndens || !xh || !xh_av || !xh_intermed || !phih_grid) return C2R_EINVAL;
+    int rc;
+    if ((rc = c2r_upload(c, 0, ndens))) return rc;
+    if ((rc = c2r_upload(c, 1, xh))) return rc;
+    if ((rc = c2r_upload(c, 2, xh_av))) return rc;
+    if ((rc = c2r_upload(c, 4, phih_grid))) return rc;
+    if ((rc = c2r_global_pass(c, dt, conv_flag, nullptr))) return rc;
+    if ((rc = c2r_download(c, 2, xh_av))) return rc;
+    return c2r_download(c, 3, xh_intermed);
+}
+
 int c2r_sum(c2r_ctx *c, int32_t which, double *sum)
 {
     if (!c || !sum || which < 1 || which > 4) return C2R_EINVAL;
@@ -824,6 +857,8 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
         prev1 = prev0 = 0.0;
         rep->photon_loss_all = restart_loss;
         rc = c2r_global_pass(c, dt, &conv_flag, &sum1);
+        // logged in the slot of the iteration whose global pass this repeats
+        if (niter >= 1 && niter <= C2R_MAX_ITER_LOG) rep->it_conv_flag[niter - 1] = conv_flag;
     } else {
         rc = c2r_sum(c, 3, &sum1);                                                     // :183
     }
@@ -880,6 +915,11 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
             const double tion = trec + (before[0] * ctx->vol - after[0] * ctx->vol);
             rep->it_photcons[niter - 1] = totalsrc > 0.0 ? (tion - tcol) / totalsrc : 0.0;
         }
+        // evolve.F90:271-275: the place where the reference decides on an iteration dump
+        if (ctx->iter_hook) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (ctx->iter_hook(ctx->iter_user, niter, rep->photon_loss_all) != 0) FAIL(C2R_ECALLBACK, "iteration hook failed");
+        }
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     rep->niter = niter; rep->conv_flag = conv_flag;
@@ -904,6 +944,13 @@ int c2r_evolve3d_restart_dev(c2r_ctx *c, double dt, int32_t niter, double photon
 {
     if (niter < 0) return C2R_EINVAL;
     return evolve3d_worker(c, dt, niter, photon_loss_all, rep);
+}
+
+int c2r_set_iteration_hook(c2r_ctx *c, c2r_iteration_fn fn, void *user)
+{
+    if (!c) return C2R_EINVAL;
+    C(c)->iter_hook = fn; C(c)->iter_user = user;
+    return C2R_OK;
 }
 
 static void pin_host_array(Ctx *ctx, const void *ptr, size_t bytes)
@@ -936,6 +983,23 @@ int c2r_evolve3d(c2r_ctx *c, double dt, const float *ndens, double *xh, double *
     if (xh_int && (rc = c2r_download(c, 3, xh_int))) return rc;
     if (phih && (rc = c2r_download(c, 4, phih))) return rc;
     return C2R_OK;
+}
+
+int c2r_evolve3d_restart(c2r_ctx *c, double dt, int32_t niter, double photon_loss_all, const float *ndens,
+                         double *xh, double *xh_av, double *xh_int, double *phih, c2r_report *rep)
+{
+    if (!c || !ndens || !xh || !xh_av || !xh_int || !phih || niter < 0) return C2R_EINVAL;
+    int rc;
+    if ((rc = c2r_upload(c, 0, ndens))) return rc;
+    if ((rc = c2r_upload(c, 1, xh))) return rc;
+    if ((rc = c2r_upload(c, 2, xh_av))) return rc;
+    if ((rc = c2r_upload(c, 3, xh_int))) return rc;
+    if ((rc = c2r_upload(c, 4, phih))) return rc;
+    if ((rc = c2r_evolve3d_restart_dev(c, dt, niter, photon_loss_all, rep))) return rc;
+    if ((rc = c2r_download(c, 1, xh))) return rc;
+    if ((rc = c2r_download(c, 2, xh_av))) return rc;
+    if ((rc = c2r_download(c, 3, xh_int))) return rc;
+    return c2r_download(c, 4, phih);
 }
 
 int c2r_selftest(c2r_ctx *c, int64_t *mismatches)

@@ -1,5 +1,6 @@
-!> Drop-in replacement of the reference's `evolve` module (evolve.F90) for C2-Ray, backed by the
-!! MI355X HIP library (include/c2ray_hip.h) through ISO_C_BINDING.
+!> Drop-in replacement of the reference's `evolve` and `evolve_source` modules (evolve.F90,
+!! evolve_source.F90) for C2-Ray, backed by the MI355X HIP library (include/c2ray_hip.h) through
+!! ISO_C_BINDING.
 !!
 !! Link position: in the reference's makefile_core:31 replace
 !!     EVOLVE = evolve_data.o column_density.o evolve_point.o evolve_source.o master_slave.o evolve.o
@@ -7,24 +8,22 @@
 !!     EVOLVE = evolve_data.o evolve_hip.o            (and add  -L<dir> -lc2ray_hip  to the link line)
 !! `evolve_data` (the arrays C2Ray.F90:61 and output.F90:31 use) stays the reference's own file.
 !!
-!! The public surface is the one the driver uses: `evolve3D(time,dt,restart)` (evolve.F90:83, called
-!! from C2Ray.F90:379), plus `sum_nbox`/`sum_nbox_all` (evolve_source.F90:45-46).  All inputs are
-!! taken from the same module-global arrays the reference routine reads, by `use` association; the
-!! HIP side never keeps a host pointer after the call returns.
-module evolve
+!! Three modules:
+!!   c2ray_hip      the bind(C) mirror of include/c2ray_hip.h, the context, per-step state transfer
+!!   evolve_source  `do_source(dt,ns1,niter)`, `sum_nbox`, `sum_nbox_all`   (evolve_source.F90:45-58)
+!!   evolve         `evolve3D(time,dt,restart)`                              (evolve.F90:83, C2Ray.F90:379)
+!! All inputs are taken from the same module-global arrays the reference routines read, by `use`
+!! association; the HIP side never keeps a host pointer after a call returns.
+module c2ray_hip
 
   use, intrinsic :: iso_c_binding
   use precision, only: dp
-  use my_mpi, only: rank
-  use file_admin, only: logf, timefile
-  use clocks, only: timestamp_wallclock
+  use file_admin, only: logf
   use sizes, only: mesh
   use grid, only: dr, vol
-  use density_module, only: ndens
-  use ionfractions_module, only: xh
   use temperature_module, only: temper_val
-  use clumping_module, only: clumping
-  use lls_module, only: coldensh_LLS
+  use clumping_module, only: clumping, clumping_grid
+  use lls_module, only: coldensh_LLS, LLS_grid, R_max_LLS
   use sourceprops, only: NumSrc, srcpos, NormFlux_stellar
   use radiation_sizes, only: NumTau
   use radiation_tables, only: stellar_photo_thick_table, stellar_photo_thin_table, minlogtau, dlogtau
@@ -34,16 +33,14 @@ module evolve
   use mathconstants, only: pi
   use abundances, only: abu_c
   use c2ray_parameters, only: epsilon, convergence_fraction, minimum_fractional_change, &
-       minimum_fraction_of_atoms, loss_fraction, subboxsize, max_subbox
-  use photonstatistics, only: photon_loss, LLS_loss, state_before, calculate_photon_statistics, &
-       report_photonstatistics, update_grandtotal_photonstatistics
-  use evolve_data, only: phih_grid, xh_av, xh_intermed, photon_loss_all
+       minimum_fraction_of_atoms, loss_fraction, subboxsize, max_subbox, use_LLS, type_of_LLS, &
+       type_of_clumping
 
   implicit none
 
   save
 
-  private
+  public
 
   integer, parameter :: C2R_MAX_ITER_LOG = 128
 
@@ -119,14 +116,55 @@ module evolve
        real(c_double), intent(inout) :: xh(*), xh_av(*), xh_intermed(*), phih_grid(*)
        type(c2r_report), intent(out) :: rep
      end function c2r_evolve3d
+     integer(c_int) function c2r_evolve3d_restart(ctx, dt, niter, photon_loss_all, ndens, xh, xh_av, &
+          xh_intermed, phih_grid, rep) bind(C, name="c2r_evolve3d_restart")
+       import :: c_int, c_ptr, c_double, c_float, c_int32_t, c2r_report
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt, photon_loss_all
+       integer(c_int32_t), value :: niter
+       real(c_float), intent(in) :: ndens(*)
+       real(c_double), intent(inout) :: xh(*), xh_av(*), xh_intermed(*), phih_grid(*)
+       type(c2r_report), intent(out) :: rep
+     end function c2r_evolve3d_restart
+     integer(c_int) function c2r_set_lls(ctx, lls_type, lls_grid, R_max_LLS) bind(C, name="c2r_set_lls")
+       import :: c_int, c_ptr, c_double, c_float, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: lls_type
+       type(c_ptr), value :: lls_grid            ! const float* or NULL
+       real(c_double), value :: R_max_LLS
+     end function c2r_set_lls
+     integer(c_int) function c2r_set_clumping_grid(ctx, clump_grid) bind(C, name="c2r_set_clumping_grid")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       type(c_ptr), value :: clump_grid          ! const float* or NULL
+     end function c2r_set_clumping_grid
+     integer(c_int) function c2r_do_source_host(ctx, ns, ndens, xh_av, phih_grid, coldensh_out, &
+          photon_loss_src, nbox) bind(C, name="c2r_do_source_host")
+       import :: c_int, c_ptr, c_double, c_float, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: ns           ! 1..NumSrc, as ns1 of do_source
+       real(c_float), intent(in) :: ndens(*)
+       real(c_double), intent(in) :: xh_av(*)
+       real(c_double), intent(inout) :: phih_grid(*)
+       real(c_double), intent(out) :: coldensh_out(*)
+       real(c_double), intent(out) :: photon_loss_src
+       integer(c_int32_t), intent(out) :: nbox
+     end function c2r_do_source_host
+     integer(c_int) function c2r_set_iteration_hook(ctx, fn, user) bind(C, name="c2r_set_iteration_hook")
+       import :: c_int, c_ptr, c_funptr
+       type(c_ptr), value :: ctx
+       type(c_funptr), value :: fn
+       type(c_ptr), value :: user
+     end function c2r_set_iteration_hook
+     integer(c_int) function c2r_download(ctx, which, host) bind(C, name="c2r_download")
+       import :: c_int, c_ptr, c_double, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: which
+       real(c_double), intent(out) :: host(*)
+     end function c2r_download
   end interface
 
   type(c_ptr) :: ctx = c_null_ptr
-  integer, public :: sum_nbox      !< sum of all nboxes (this process)      evolve_source.F90:45
-  integer, public :: sum_nbox_all  !< sum of all nboxes (all processes)     evolve_source.F90:46
-  type(c2r_report), public :: last_report
-
-  public :: evolve3D, evolve_hip_end
 
 contains
 
@@ -149,7 +187,7 @@ contains
        endif
     endif
     flush(logf)
-    stop "c2ray_hip failure"
+    error stop "c2ray_hip failure"
   end subroutine check
 
   !> evolve_ini counterpart for the device side: created lazily on the first evolve3D
@@ -179,6 +217,117 @@ contains
     ctx = c_null_ptr
   end subroutine evolve_hip_end
 
+  !> What changes between calls and lives in host module variables of the driver: cell size,
+  !! LLS column / grid, clumping, temperature, source list.  Cheap (a few scalars; grids only when
+  !! the compile-time model uses them).
+  subroutine hip_step_state()
+    type(c_ptr) :: gridp
+    if (.not. c_associated(ctx)) call evolve_hip_ini()
+    call check(c2r_set_step(ctx, dr, vol, coldensh_LLS, real(clumping, c_float), &
+         real(temper_val, c_double)), "c2r_set_step")
+    if (use_LLS .and. type_of_LLS == 2) then                          ! LLS_point, LLS.F90:199
+       call check(c2r_set_lls(ctx, 2_c_int32_t, grid_address(LLS_grid), 0.0_c_double), "c2r_set_lls")
+    elseif (use_LLS .and. type_of_LLS == 3) then                      ! R_max_LLS, LLS.F90:186
+       call check(c2r_set_lls(ctx, 3_c_int32_t, c_null_ptr, R_max_LLS), "c2r_set_lls")
+    endif
+    if (type_of_clumping == 5) then                                   ! clumping_point, clumping_module.F90:106
+       gridp = grid_address(clumping_grid)
+       call check(c2r_set_clumping_grid(ctx, gridp), "c2r_set_clumping_grid")
+    endif
+    call check(c2r_set_sources(ctx, srcpos, NormFlux_stellar(1:NumSrc), int(NumSrc, c_int32_t)), &
+         "c2r_set_sources")
+  end subroutine hip_step_state
+
+  function grid_address(g) result(p)
+    real, dimension(:,:,:), allocatable, target, intent(in) :: g
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(g)) p = c_loc(g)
+  end function grid_address
+
+end module c2ray_hip
+
+! =============================================================================================
+
+!> `evolve_source` of the reference (evolve_source.F90): ray tracing for ONE source on the GPU,
+!! with the reference's side effects on the host module arrays.
+module evolve_source
+
+  use, intrinsic :: iso_c_binding
+  use precision, only: dp
+  use density_module, only: ndens
+  use photonstatistics, only: photon_loss
+  use evolve_data, only: phih_grid, xh_av, coldensh_out
+  use c2ray_hip, only: ctx, check, hip_step_state, c2r_do_source_host
+
+  implicit none
+
+  save
+
+  private
+
+  integer, public :: sum_nbox      !< sum of all nboxes (this process)      evolve_source.F90:45
+  integer, public :: sum_nbox_all  !< sum of all nboxes (all processes)     evolve_source.F90:46
+
+  public :: do_source
+
+contains
+
+  !> Ray tracing over the entire 3D grid for source ns1 (same contract as evolve_source.F90:58):
+  !! adds the source's photo-ionization rates into phih_grid, leaves its outgoing column densities
+  !! in coldensh_out, adds its escaping photons to photon_loss(1) and its sub-box count to sum_nbox.
+  subroutine do_source(dt,ns1,niter)
+
+    real(kind=dp),intent(in) :: dt !< time step (unused by the transfer, as in the reference)
+    integer,intent(in) :: ns1 !< number of the source being done
+    integer,intent(in) :: niter !< iteration counter
+
+    real(c_double) :: photon_loss_src
+    integer(c_int32_t) :: nbox
+
+    call hip_step_state()
+    call check(c2r_do_source_host(ctx, int(ns1, c_int32_t), ndens, xh_av, phih_grid, coldensh_out, &
+         photon_loss_src, nbox), "c2r_do_source_host")
+    photon_loss(1) = photon_loss(1) + photon_loss_src                 ! evolve_source.F90:216
+    sum_nbox = sum_nbox + nbox                                        ! evolve_source.F90:219
+
+  end subroutine do_source
+
+end module evolve_source
+
+! =============================================================================================
+
+module evolve
+
+  use, intrinsic :: iso_c_binding
+  use precision, only: dp
+  use my_mpi, only: rank
+  use file_admin, only: logf, timefile, iterdump, dump_dir
+  use clocks, only: timestamp_wallclock, iterdump_minutes
+  use sizes, only: mesh
+  use density_module, only: ndens
+  use ionfractions_module, only: xh
+  use sourceprops, only: NumSrc
+  use c2ray_parameters, only: convergence_fraction
+  use photonstatistics, only: photon_loss, LLS_loss, state_before, calculate_photon_statistics, &
+       report_photonstatistics, update_grandtotal_photonstatistics
+  use evolve_data, only: phih_grid, xh_av, xh_intermed, photon_loss_all
+  use evolve_source, only: sum_nbox, sum_nbox_all
+  use c2ray_hip
+
+  implicit none
+
+  save
+
+  private
+
+  type(c2r_report), public :: last_report
+  real :: wallclock_last_dump = 0.0
+
+  public :: evolve3D, evolve_hip_end
+
+contains
+
   !> Evolve the entire grid over a time step dt (same contract as evolve.F90:83)
   subroutine evolve3D (time,dt,restart)
 
@@ -186,32 +335,35 @@ contains
     real(kind=dp),intent(in) :: dt !< time step
     integer,intent(in) :: restart !< restart flag (iteration dumps are not supported here)
 
-    integer :: k
+    integer :: k, niter0
     real(kind=dp) :: ncell
-
-    if (restart /= 0) then
-       write(logf,*) "c2ray_hip: restart from iteration dump is not supported by the HIP evolve module"
-       stop "c2ray_hip: restart /= 0"
-    endif
-    if (.not. c_associated(ctx)) call evolve_hip_ini()
 
     call state_before (xh)                                            ! evolve.F90:136
 
-    call check(c2r_set_step(ctx, dr, vol, coldensh_LLS, real(clumping, c_float), &
-         real(temper_val, c_double)), "c2r_set_step")
-    call check(c2r_set_sources(ctx, srcpos, NormFlux_stellar(1:NumSrc), int(NumSrc, c_int32_t)), &
-         "c2r_set_sources")
+    call hip_step_state()
+    call check(c2r_set_iteration_hook(ctx, c_funloc(iteration_hook), c_null_ptr), &
+         "c2r_set_iteration_hook")
+    wallclock_last_dump = timestamp_wallclock ()
 
     if (rank == 0) write(timefile,"(A,F8.1)") "Time before starting iteration: ", timestamp_wallclock ()
 
-    call check(c2r_evolve3d(ctx, dt, ndens, xh, xh_av, xh_intermed, phih_grid, last_report), &
-         "c2r_evolve3d")
+    niter0 = 0
+    if (restart == 0) then
+       call check(c2r_evolve3d(ctx, dt, ndens, xh, xh_av, xh_intermed, phih_grid, last_report), &
+            "c2r_evolve3d")
+    else
+       call start_from_dump(restart, niter0)                          ! evolve.F90:153-157
+       call check(c2r_evolve3d_restart(ctx, dt, int(niter0, c_int32_t), photon_loss_all(1), ndens, &
+            xh, xh_av, xh_intermed, phih_grid, last_report), "c2r_evolve3d_restart")
+    endif
 
     ! what the reference logs per outer iteration (evolve.F90:205-210, 249-251, 559-566)
     ncell = real(mesh(1),dp)*real(mesh(2),dp)*real(mesh(3),dp)
     if (rank == 0) then
-       do k = 1, min(last_report%niter, C2R_MAX_ITER_LOG)
-          write(logf,*) "Average number of subboxes: ", real(last_report%it_sum_nbox(k))/real(NumSrc)
+       ! (after a restart the first entry is the global pass that start_from_dump is followed by)
+       do k = max(1, niter0), min(last_report%niter, C2R_MAX_ITER_LOG)
+          if (k > niter0) write(logf,*) "Average number of subboxes: ", &
+               real(last_report%it_sum_nbox(k))/real(NumSrc)
           write(logf,*) "Number of non-converged points: ", last_report%it_conv_flag(k)
           write(logf,*) "Intermediate result for mean H ionization fraction: ", &
                last_report%it_sum_xh1(k)/ncell
@@ -229,7 +381,7 @@ contains
             timestamp_wallclock ()
     endif
 
-    sum_nbox = int(last_report%sum_nbox_all)
+    sum_nbox = int(last_report%sum_nbox_all)                          ! last iteration, as evolve.F90:523
     sum_nbox_all = sum_nbox
     photon_loss_all(1) = last_report%photon_loss_all
     photon_loss(:) = photon_loss_all(:)/ncell                         ! evolve.F90:519
@@ -240,5 +392,75 @@ contains
     call update_grandtotal_photonstatistics (dt)
 
   end subroutine evolve3D
+
+  !> Called by the library after every outer iteration: the reference's dump decision
+  !! (evolve.F90:271-275: write an iteration dump when iterdump_minutes of wall clock have passed).
+  function iteration_hook(user, niter, loss_all) bind(C) result(rc)
+    type(c_ptr), value :: user
+    integer(c_int32_t), value :: niter
+    real(c_double), value :: loss_all
+    integer(c_int) :: rc
+    real :: now
+    rc = 0
+    now = timestamp_wallclock ()
+    if (rank == 0 .and. now - wallclock_last_dump > 60.0*iterdump_minutes) then
+       wallclock_last_dump = now
+       photon_loss_all(1) = loss_all
+       rc = c2r_download(ctx, 4_c_int32_t, phih_grid)
+       if (rc == 0) rc = c2r_download(ctx, 2_c_int32_t, xh_av)
+       if (rc == 0) rc = c2r_download(ctx, 3_c_int32_t, xh_intermed)
+       if (rc == 0) call write_iteration_dump(int(niter))
+    endif
+  end function iteration_hook
+
+  !> Same file layout as evolve.F90:285-324 (isothermal case: the only one on this path)
+  subroutine write_iteration_dump (niter)
+    integer,intent(in) :: niter
+    integer :: ndump=0
+    character(len=20) :: iterfile
+    write(timefile,"(A,F8.1)") "Time before writing iterdump: ", timestamp_wallclock ()
+    ndump = ndump + 1
+    if (mod(ndump,2) == 0) then
+       iterfile = "iterdump2.bin"
+    else
+       iterfile = "iterdump1.bin"
+    endif
+    open(unit=iterdump, file=trim(adjustl(dump_dir))//iterfile, form="unformatted", status="unknown")
+    write(iterdump) niter
+    write(iterdump) photon_loss_all
+    write(iterdump) phih_grid
+    write(iterdump) xh_av
+    write(iterdump) xh_intermed
+    close(iterdump)
+    write(timefile,"(A,F8.1)") "Time after writing iterdump: ", timestamp_wallclock ()
+  end subroutine write_iteration_dump
+
+  !> Reads the dump selected by the restart flag (evolve.F90:328-426, serial, isothermal)
+  subroutine start_from_dump (restart, niter)
+    integer,intent(in) :: restart
+    integer,intent(out) :: niter
+    character(len=20) :: iterfile
+    write(timefile,"(A,F8.1)") "Time before reading iterdump: ", timestamp_wallclock ()
+    select case (restart)
+    case (1)
+       iterfile = "iterdump1.bin"
+    case (2)
+       iterfile = "iterdump2.bin"
+    case default
+       iterfile = "iterdump.bin"
+    end select
+    open(unit=iterdump, file=trim(adjustl(dump_dir))//iterfile, form="unformatted", status="old")
+    read(iterdump) niter
+    read(iterdump) photon_loss_all
+    read(iterdump) phih_grid
+    read(iterdump) xh_av
+    read(iterdump) xh_intermed
+    close(iterdump)
+    write(logf,*) "Read iteration ",niter," from dump file"
+    write(logf,*) "photon loss counter: ",photon_loss_all
+    write(logf,*) "Intermediate result for mean ionization fraction: ", &
+         sum(xh_intermed(:,:,:))/real(mesh(1)*mesh(2)*mesh(3))
+    write(timefile,"(A,F8.1)") "Time after reading iterdump: ", timestamp_wallclock ()
+  end subroutine start_from_dump
 
 end module evolve

@@ -31,7 +31,7 @@ extern "C" {
 #define C2R_EINVAL      (-1)   /* bad argument */
 #define C2R_ESTATE      (-2)   /* call order: tables / step scalars / sources / buffers missing */
 #define C2R_ENOMEM      (-3)
-#define C2R_ECALLBACK   (-4)   /* the all-reduce callback failed */
+#define C2R_ECALLBACK   (-4)   /* the all-reduce callback or the iteration hook failed */
 
 #define C2R_MAX_ITER_LOG 128
 
@@ -82,7 +82,8 @@ typedef struct c2r_report {
     double  seconds_chem;            /* wall time inside global_pass, all iterations */
     int32_t chem_not_converged;      /* cells that hit max_chem_iter in the last global pass */
     int32_t reserved0;
-    int64_t it_conv_flag[C2R_MAX_ITER_LOG];
+    int64_t it_conv_flag[C2R_MAX_ITER_LOG];        /* [k]: global pass of iteration k+1; after a restart from
+                                                    * iteration r, [r-1] is the pass that follows the dump read */
     int64_t it_sum_nbox[C2R_MAX_ITER_LOG];
     double  it_rel_change_xh1[C2R_MAX_ITER_LOG];   /* Test-2 values seen before iteration k+2 */
     double  it_rel_change_xh0[C2R_MAX_ITER_LOG];
@@ -176,6 +177,17 @@ int  c2r_photon_sums(c2r_ctx *ctx, int32_t which_l, int32_t which_r, double out[
 /* sum() of one of the device arrays (evolve.F90:183) */
 int  c2r_sum(c2r_ctx *ctx, int32_t which, double *sum);
 
+/* ---- the path, piecewise, on the driver's host arrays (Fortran shim: do_source, global_pass) ----- */
+/* do_source(dt,ns1,niter) (evolve_source.F90:58) with the module arrays it touches as arguments:
+ * reads ndens, xh_av; ADDS the source's rates into phih_grid (evolve_point.F90:283); fills the
+ * source's coldensh_out (N^3, may be NULL); returns photon_loss_src (:216) and nbox (:219).
+ * ns = 1..NumSrc as in c2r_do_source. */
+int  c2r_do_source_host(c2r_ctx *ctx, int32_t ns, const float *ndens, const double *xh_av,
+                        double *phih_grid, double *coldensh_out, double *photon_loss_src, int32_t *nbox);
+/* global_pass(conv_flag,dt) (evolve.F90:499): evolve0D_global over the mesh with the host arrays. */
+int  c2r_global_pass_host(c2r_ctx *ctx, double dt, const float *ndens, const double *xh, double *xh_av,
+                          double *xh_intermed, const double *phih_grid, int64_t *conv_flag);
+
 /* ---- the path, whole ------------------------------------------------------------------- */
 /* evolve3D(time,dt,restart=0) (evolve.F90:83-281) on the device-resident arrays. */
 int  c2r_evolve3d_dev(c2r_ctx *ctx, double dt, c2r_report *rep);
@@ -189,6 +201,16 @@ int  c2r_evolve3d_restart_dev(c2r_ctx *ctx, double dt, int32_t niter, double pho
  * shim calls. */
 int  c2r_evolve3d(c2r_ctx *ctx, double dt, const float *ndens, double *xh, double *xh_av,
                   double *xh_intermed, double *phih_grid, c2r_report *rep);
+/* evolve3D(time,dt,restart/=0) on the driver's host arrays, after the shim's start_from_dump
+ * (evolve.F90:328-426) has read niter, photon_loss_all, phih_grid, xh_av, xh_intermed from the dump. */
+int  c2r_evolve3d_restart(c2r_ctx *ctx, double dt, int32_t niter, double photon_loss_all,
+                          const float *ndens, double *xh, double *xh_av, double *xh_intermed,
+                          double *phih_grid, c2r_report *rep);
+/* Called after every outer iteration (global pass done, stream idle) at the point where the
+ * reference checks the wall clock and writes an iteration dump (evolve.F90:271-275); the hook may
+ * c2r_download() arrays 2,3,4 (xh_av, xh_intermed, phih_grid).  Non-zero return aborts (C2R_ECALLBACK). */
+typedef int (*c2r_iteration_fn)(void *user, int32_t niter, double photon_loss_all);
+int  c2r_set_iteration_hook(c2r_ctx *ctx, c2r_iteration_fn fn, void *user);
 
 /* ---- rate tables (one-time set-up; host code, needs no GPU and no context) ------------------ */
 /* SED and table parameters: compile-time `parameter`s of sed_parameters.f90, radiation_sizes.f90,

@@ -74,28 +74,35 @@ build_variant () {   # $1 = mesh[:variant], $2 = subdir, $3 = extra flags
 
 # The reference's OWN program with its evolve modules swapped for the HIP drop-in
 # (c2-ray3dm_amd/fortran/evolve_hip.F90 + libc2ray_hip.so): the integration test of INTEGRATION.md.
-build_hip_dropin () {   # $1 = mesh
-  local N=$1 S=$HERE/_ref/N$1/serial B=$HERE/_ref/N$1/hip FLAGS="-DGFORT -O2"
-  local PKG=$HERE/../c2-ray3dm_amd
+build_hip_dropin () {   # $1 = mesh[:variant]
+  local N=${1%%:*} V="" FLAGS="-DGFORT -O2"
+  [ "$1" != "$N" ] && V=${1#*:}
+  local D=$HERE/_ref/N$N${V:+_$V}
+  local S=$D/serial B=$D/hip PKG=$HERE/../c2-ray3dm_amd
   [ -f "$PKG/libc2ray_hip.so" ] || { echo "libc2ray_hip.so not built: skipping drop-in program" >&2; return 0; }
   mkdir -p "$B"
+  # the shim's evolve.mod / evolve_source.mod land in $B and shadow the reference's ($B before $S)
   ( cd "$B" && $FC $FLAGS -I"$S" -c "$PKG/fortran/evolve_hip.F90" -o evolve_hip.o 2>>build.log \
-      && $FC $FLAGS -I"$B" -I"$S" -c "$REF/C2Ray.F90" -o C2Ray.o 2>>build.log )
+      && $FC $FLAGS -I"$B" -I"$S" -c "$REF/C2Ray.F90" -o C2Ray.o 2>>build.log \
+      && $FC $FLAGS -I"$B" -I"$S" -c "$HERE/ref_driver.F90" -o ref_driver.o 2>>build.log )
   local objs=""
   for o in "$S"/*.o; do
     case "$(basename "$o")" in
-      column_density.o|evolve_point.o|evolve_source.o|master_slave.o|evolve.o|C2Ray.o|ref_driver.o) ;;
+      evolve_point.o|evolve_source.o|master_slave.o|evolve.o|C2Ray.o|ref_driver.o) ;;
       *) objs="$objs $o" ;;
     esac
   done
-  ( cd "$B" && $FC $FLAGS -o c2ray_test_hip $objs evolve_hip.o C2Ray.o -L"$PKG" -lc2ray_hip \
-      -Wl,-rpath,'$ORIGIN/../../../../c2-ray3dm_amd' -Wl,-rpath,/opt/rocm/lib 2>>build.log )
+  local LINK="-L$PKG -lc2ray_hip -Wl,-rpath,\$ORIGIN/../../../../c2-ray3dm_amd -Wl,-rpath,/opt/rocm/lib"
+  # the reference's own program, and our fixture driver (ref_driver.F90: do_source / evolve3D / restart
+  # modes), both with the HIP modules in place of the reference's evolve modules
+  ( cd "$B" && $FC $FLAGS -o c2ray_test_hip $objs evolve_hip.o C2Ray.o $LINK 2>>build.log \
+      && $FC $FLAGS -o ref_driver_hip $objs evolve_hip.o ref_driver.o $LINK 2>>build.log )
 }
 
 for N in "$@"; do
   build_variant "$N" serial ""
-  if [ "${N%%:*}" = "$N" ]; then       # timing build and drop-in program only for the shipped parameters
-    build_hip_dropin "$N"
+  build_hip_dropin "$N"
+  if [ "${N%%:*}" = "$N" ]; then       # timing build only for the shipped parameters
     build_variant "$N" omp "-fopenmp -DMY_OPENMP"
   fi
   echo "built oracle/_ref/N${N/:/_}"

@@ -22,103 +22,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = os.path.join(ROOT, "oracle", "_ref")
-ANSWERS = "n\nn\n1\n7\n10\n1\n"     # inputs/input_example_test: no restart, slice 1, UV model 7 (Test)
-
-SRC_ONE = [(50, 50, 50, 1e57)]                                  # inputs/test_sources_onesrc.dat
-SRC_STD = [(50, 50, 50, 1e55), (51, 50, 50, 1e55), (52, 50, 50, 1e55), (53, 50, 50, 1e55),
-           (20, 10, 10, 1e57), (70, 70, 50, 1e55), (72, 70, 50, 1e55), (70, 72, 50, 1e55),
-           (72, 72, 50, 1e56), (20, 10, 90, 1e54)]              # inputs/test_sources_standard.dat
-
-
-def density_factor(n, seed, sigma=0.6):
-    """Log-normal multiplicative perturbation of the test problem's uniform density (f32)."""
-    rng = np.random.default_rng(seed)
-    g = rng.standard_normal((n, n, n))
-    f = np.exp(sigma * g - 0.5 * sigma * sigma)
-    return f.astype(np.float32)
-
-
-def bubble_xfield(n, centres, radius, x_in=0.9995, x_out=2e-4, seed=7):
-    """Initial ionized-fraction field: ionized spheres (periodic) in neutral gas, with jitter."""
-    rng = np.random.default_rng(seed)
-    ax = np.arange(1, n + 1)
-    x = np.full((n, n, n), x_out)
-    I, J, K = np.meshgrid(ax, ax, ax, indexing="ij")
-    for (ci, cj, ck) in centres:
-        d = [np.minimum(np.abs(A - c), n - np.abs(A - c)) for A, c in ((I, ci), (J, cj), (K, ck))]
-        r2 = d[0] ** 2 + d[1] ** 2 + d[2] ** 2
-        x[r2 <= radius * radius] = x_in
-    x = x * (1.0 + 1e-3 * rng.standard_normal(x.shape))
-    return np.clip(x, 1e-6, 1.0 - 1e-6)
-
-
-def run_driver(n, sources, nml, dens=None, xfield=None, extra_files=None, omp=False, threads=1, variant=None):
-    d = "/tmp/c2ray_golden_run"
-    shutil.rmtree(d, ignore_errors=True)
-    os.makedirs(d + "/results")
-    os.makedirs(d + "/dump")
-    with open(d + "/answers", "w") as f:
-        f.write(ANSWERS)
-    with open(d + "/test_sources.dat", "w") as f:
-        f.write("%d\n" % len(sources))
-        for (i, j, k, flux) in sources:
-            f.write("%d %d %d %.17e 0.0\n" % (i, j, k, flux))
-    nml = dict(nml)
-    if dens is not None:
-        dens.T.tofile(d + "/dens.f32")         # Fortran order on disk
-        nml["dens_file"] = "'dens.f32'"
-    if xfield is not None:
-        xfield.T.tofile(d + "/x.f64")
-        nml["x_file"] = "'x.f64'"
-    for name, writer in (extra_files or {}).items():
-        writer(os.path.join(d, name))
-    with open(d + "/driver.nml", "w") as f:
-        f.write("&ctl " + ", ".join("%s=%s" % kv for kv in nml.items()) + " /\n")
-    exe = os.path.join(REF, "N%d%s" % (n, "_" + variant if variant else ""), "omp" if omp else "serial", "ref_driver")
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads))
-    subprocess.check_call([exe, "answers"], cwd=d, env=env, stdout=subprocess.DEVNULL)
-    return d
-
-
-def read_kv(path):
-    out, srcs = {}, []
-    for line in open(path):
-        t = line.split()
-        if t[0] == "src":
-            srcs.append((int(t[1]), int(t[2]), int(t[3]), float(t[4])))
-        else:
-            out[t[0]] = float(t[1]) if ("E" in t[1] or "." in t[1]) else int(t[1])
-    if srcs:
-        out["srcpos"] = [s[:3] for s in srcs]
-        out["normflux"] = [s[3] for s in srcs]
-    return out
-
-
-def rd(d, name, n, dtype=np.float64):
-    return np.fromfile(os.path.join(d, "dump", name), dtype=dtype).reshape((n, n, n), order="F")
-
-
-def parse_log(path):
-    """Per-step, per-iteration values the reference logs (evolve.F90:205-210,249-251,559-566)."""
-    steps, cur = [], None
-    fl = r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[Ee][-+]?\d+)?"
-    for line in open(path):
-        if "REFDRIVER step" in line:
-            cur = {"test1": [], "test2": [], "nonconv": [], "avg_nbox": [], "mean_x": []}
-            steps.append(cur)
-        elif cur is None:
-            continue
-        elif "Test 1 values:" in line:
-            cur["test1"].append([int(v) for v in line.split(":")[1].split()])
-        elif "Test 2 values:" in line:
-            cur["test2"].append([float(v) for v in re.findall(fl, line.split(":")[1])][:2])
-        elif "Number of non-converged points:" in line:
-            cur["nonconv"].append(int(line.split(":")[1]))
-        elif "Average number of subboxes:" in line:
-            cur["avg_nbox"].append(float(re.findall(fl, line.split(":")[1])[0]))
-        elif "Intermediate result for mean H ionization fraction:" in line:
-            cur["mean_x"].append(float(re.findall(fl, line.split(":")[1])[0]))
-    return steps
+sys.path.insert(0, HERE)
+from inputs import ANSWERS, SRC_ONE, SRC_STD, density_factor, bubble_xfield, run_driver, \
+    read_kv, rd, parse_log   # noqa: E402
 
 
 def case_tables():

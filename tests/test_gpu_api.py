@@ -76,3 +76,94 @@ def test_host_pointer_evolve3d_is_what_the_shim_calls(pkg, tables):
     assert lib.c2r_evolve3d(ctx, s["dt"], nd.ctypes.data, xh2.ctypes.data, None, None, None, None) == 0
     assert np.max(np.abs(xh2 - xh)) < 1e-13
     lib.c2r_destroy(ctx)
+
+
+def _ctx_for(pkg, tables, s, n):
+    lib = pkg.load_library()
+    p = pkg.default_params(n)
+    ctx = C.c_void_p()
+    assert lib.c2r_create(C.byref(ctx), C.byref(p)) == 0
+    thick, thin = tables
+    assert lib.c2r_set_tables(ctx, thick.ctypes.data, thin.ctypes.data, 2001) == 0
+    dr = (C.c_double * 3)(s["dr1"], s["dr2"], s["dr3"])
+    assert lib.c2r_set_step(ctx, C.byref(dr), s["vol"], s["coldensh_LLS"], s["clumping"], 1e4) == 0
+    pos = np.ascontiguousarray(s["srcpos"], dtype=np.int32); nf = np.ascontiguousarray(s["normflux"], dtype=np.float64)
+    assert lib.c2r_set_sources(ctx, pos.ctypes.data, nf.ctypes.data, len(nf)) == 0
+    return lib, ctx
+
+
+def test_iteration_hook_sees_every_iteration_and_a_dumpable_state(pkg, tables):
+    """c2r_set_iteration_hook: the reference's iteration-dump point (evolve.F90:271-275).  A dump taken
+    in the hook at iteration k and handed to c2r_evolve3d_restart repeats that iteration's global pass
+    bit for bit -- after which, as in the reference (fixture restart32_std_bubbles), no cell has changed,
+    Test 1 passes at once and the step ends with the dump's xh_intermed."""
+    m, a = load_case("evolve32_std_bubbles")
+    s, n = m["steps"]["step001"], m["n"]
+    lib, ctx = _ctx_for(pkg, tables, s, n)
+    nd = F(a["step001_ndens"]); xh = F(a["step001_xh_before"])
+    seen, dump = [], {}
+    HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_double)
+
+    def hook(user, niter, loss):
+        seen.append((niter, loss))
+        if niter == 2:
+            for which, key in ((2, "xh_av"), (3, "xh_intermed"), (4, "phih")):
+                dump[key] = np.empty(n ** 3)
+                assert lib.c2r_download(ctx, which, dump[key].ctypes.data) == 0
+            dump["loss"] = loss
+        return 0
+    cb = HOOK(hook)
+    assert lib.c2r_set_iteration_hook(ctx, cb, None) == 0
+    xav, xint, phih = np.empty(n ** 3), np.empty(n ** 3), np.empty(n ** 3)
+    rep = pkg.Report()
+    assert lib.c2r_evolve3d(ctx, s["dt"], nd.ctypes.data, xh.ctypes.data, xav.ctypes.data, xint.ctypes.data,
+                            phih.ctypes.data, C.byref(rep)) == 0
+    assert [k for k, _ in seen] == list(range(1, rep.niter + 1))
+    assert seen[-1][1] == rep.photon_loss_all
+    # resume from the iteration-2 state in a fresh context
+    assert lib.c2r_set_iteration_hook(ctx, None, None) == 0
+    lib.c2r_destroy(ctx)
+    lib, ctx = _ctx_for(pkg, tables, s, n)
+    xh2 = F(a["step001_xh_before"])
+    rep2 = pkg.Report()
+    assert lib.c2r_evolve3d_restart(ctx, s["dt"], 2, dump["loss"], nd.ctypes.data, xh2.ctypes.data,
+                                    dump["xh_av"].ctypes.data, dump["xh_intermed"].ctypes.data,
+                                    dump["phih"].ctypes.data, C.byref(rep2)) == 0
+    assert rep2.niter == 2 and rep2.converged == 1 and rep2.conv_flag == 0
+    assert np.array_equal(xh2, dump["xh_intermed"])
+    assert rep2.photon_loss_all == dump["loss"]
+    # a failing hook aborts the step with C2R_ECALLBACK
+    bad = HOOK(lambda u, k, l: 1)
+    assert lib.c2r_set_iteration_hook(ctx, bad, None) == 0
+    xh3 = F(a["step001_xh_before"])
+    assert lib.c2r_evolve3d(ctx, s["dt"], nd.ctypes.data, xh3.ctypes.data, None, None, None, None) == -4
+    lib.c2r_destroy(ctx)
+
+
+def test_host_array_pieces_do_source_and_global_pass(pkg, tables):
+    """c2r_do_source_host / c2r_global_pass_host (what the Fortran shim's do_source calls, and the
+    global_pass counterpart) against the oracle on the same arrays."""
+    m, a = load_case("evolve32_std_bubbles")
+    s, n = m["steps"]["step001"], m["n"]
+    lib, ctx = _ctx_for(pkg, tables, s, n)
+    from tests._util import oracle_for
+    o = oracle_for(s, tables, n)
+    nd = F(a["step001_ndens"]); xh = F(a["step001_xh_before"]); xav = xh.copy()
+    phih = np.zeros(n ** 3); phih_o = np.zeros(n ** 3)
+    for ns in range(1, len(s["normflux"]) + 1):
+        cd = np.empty(n ** 3); loss = C.c_double(); nb = C.c_int32()
+        assert lib.c2r_do_source_host(ctx, ns, nd.ctypes.data, xav.ctypes.data, phih.ctypes.data, cd.ctypes.data,
+                                      C.byref(loss), C.byref(nb)) == 0
+        nbo, losso, _, cdo = o.do_source(nd, xav, phih_o, s["srcpos"][ns - 1], s["normflux"][ns - 1])
+        assert nb.value == nbo and abs(loss.value - losso) <= 1e-10 * abs(losso)
+        assert np.array_equal(cd == 0, cdo == 0)
+        assert np.max(np.abs(cd - cdo) / np.maximum(cdo, 1e-300)) < 1e-11
+    assert np.max(np.abs(phih - phih_o) / np.maximum(phih_o, 1e-60)) < 1e-9
+    xint = np.empty(n ** 3); conv = C.c_int64()
+    xav_o, xint_o = xav.copy(), np.empty(n ** 3)
+    assert lib.c2r_global_pass_host(ctx, s["dt"], nd.ctypes.data, xh.ctypes.data, xav.ctypes.data, xint.ctypes.data,
+                                    phih_o.ctypes.data, C.byref(conv)) == 0
+    conv_o = o.global_pass(s["dt"], nd, xh, xav_o, xint_o, phih_o)
+    assert conv.value == conv_o
+    assert np.max(np.abs(xint - xint_o)) < 1e-12 and np.max(np.abs(xav - xav_o)) < 1e-12
+    lib.c2r_destroy(ctx)

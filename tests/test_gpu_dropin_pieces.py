@@ -1,0 +1,112 @@
+"""GPU tests of the Fortran call surface piece by piece: oracle/ref_driver.F90 -- the program that
+produced the fixtures by calling the REFERENCE's do_source / evolve3D -- linked instead with the
+shim's modules `evolve_source` and `evolve` (c2-ray3dm_amd/fortran/evolve_hip.F90 + libc2ray_hip.so;
+oracle/ref_build.sh: ref_driver_hip).  Same inputs, same dumps, compared with the fixtures:
+  * do_source(dt,ns,niter) per source: phih_grid accumulation, coldensh_out of one source,
+    photon_loss(1), sum_nbox                                       (evolve_source.F90:58-221)
+  * evolve3D(time,dt,0) in builds with type_of_LLS=2,3 / type_of_clumping=5 (the shim forwards
+    LLS_grid / R_max_LLS / clumping_grid)
+  * evolve3D(time,dt,3): the shim's start_from_dump reads iterdump.bin (evolve.F90:328-426)
+The binaries contain compiled reference objects and live in the git-ignored oracle/_ref/."""
+import json
+import os
+import shutil
+import sys
+import tempfile
+import numpy as np
+import pytest
+from tests._util import GOLDEN, relerr
+
+sys.path.insert(0, GOLDEN)
+import inputs as gi      # noqa: E402  (tests/golden/inputs.py: seeded inputs + run-directory writer)
+
+pytestmark = pytest.mark.gpu
+
+
+def exe(n, variant=None):
+    return os.path.join(gi.REF, "N%d%s" % (n, "_" + variant if variant else ""), "hip", "ref_driver_hip")
+
+
+def need(n, variant=None):
+    if not os.path.exists(exe(n, variant)):
+        pytest.skip("ref_driver_hip not built (needs the reference: oracle/ref_build.sh %d%s)"
+                    % (n, ":" + variant if variant else ""))
+
+
+@pytest.fixture
+def rundir():
+    d = tempfile.mkdtemp(prefix="c2r_pieces_")
+    yield d
+    shutil.rmtree(d, ignore_errors=True)
+
+
+BUBBLES = [(18, 18, 18), (20, 10, 10), (6, 6, 18)]
+
+
+def test_fortran_do_source_matches_reference_sweep(rundir):
+    need(32)
+    m = json.load(open(os.path.join(GOLDEN, "sweep32_bubbles.json")))
+    a = np.load(os.path.join(GOLDEN, "sweep32_bubbles.npz"))
+    d = gi.run_driver(32, gi.SRC_STD, {"mode": "'sweep'", "ns_dump": m["ns_dump"]}, dens=gi.density_factor(32, 5),
+                      xfield=gi.bubble_xfield(32, BUBBLES, 7.0), hip=True, d=rundir)
+    assert np.array_equal(gi.rd(d, "step001_ndens.f32", 32, np.float32), a["ndens"])      # same inputs
+    assert np.array_equal(gi.rd(d, "step001_xh_before.f64", 32), a["xh"])
+    kv = gi.read_kv(d + "/dump/step001_sweep.txt")
+    assert kv["sum_nbox"] == m["sum_nbox"]
+    assert abs(kv["photon_loss"] - m["photon_loss"]) <= 1e-10 * abs(m["photon_loss"])
+    cd = gi.rd(d, "step001_coldensh_out.f64", 32)
+    assert np.array_equal(cd == 0.0, a["coldensh_out"] == 0.0)                            # same cells reached
+    assert relerr(cd, a["coldensh_out"]) < 1e-11
+    assert relerr(gi.rd(d, "step001_phih_grid.f64", 32), a["phih"]) < 1e-9
+
+
+@pytest.mark.parametrize("variant,name", [("lls2", "evolve32_lls2"), ("lls3", "evolve32_lls3"),
+                                          ("clump5", "evolve32_clump5")])
+def test_fortran_evolve3d_physics_variants(rundir, variant, name):
+    need(32, variant)
+    m = json.load(open(os.path.join(GOLDEN, name + ".json")))["steps"]["step001"]
+    a = np.load(os.path.join(GOLDEN, name + ".npz"))
+    nml = {"mode": "'evolve'", "nsteps": 1, "dump_first": 1, "dump_last": 1}
+    extra = {}
+    if "lls_grid" in a.files:
+        extra["lls.f32"] = lambda p: a["lls_grid"].T.tofile(p); nml["lls_file"] = "'lls.f32'"
+    if "clump_grid" in a.files:
+        extra["clump.f32"] = lambda p: a["clump_grid"].T.tofile(p); nml["clump_file"] = "'clump.f32'"
+    d = gi.run_driver(32, gi.SRC_STD, nml, dens=gi.density_factor(32, 11), xfield=gi.bubble_xfield(32, BUBBLES, 7.0),
+                      variant=variant, extra_files=extra, hip=True, d=rundir)
+    assert np.array_equal(gi.rd(d, "step001_xh_before.f64", 32), a["step001_xh_before"])
+    log = gi.parse_log(d + "/results/C2Ray.log")[0]
+    assert log["nonconv"] == m["log"]["nonconv"]                    # same iteration history
+    assert log["test1"] == m["log"]["test1"][1:]                    # (the reference also logs the test before iteration 1)
+    kv = gi.read_kv(d + "/dump/step001_out.txt")
+    assert kv["sum_nbox_all"] == m["sum_nbox_all"]
+    assert abs(kv["photon_loss_all"] - m["photon_loss_all"]) <= 1e-10 * abs(m["photon_loss_all"]) + 1e-300
+    assert np.max(np.abs(gi.rd(d, "step001_xh_after.f64", 32) - a["step001_xh_after"])) < 1e-9
+    assert np.max(np.abs(gi.rd(d, "step001_xh_av.f64", 32) - a["step001_xh_av"])) < 1e-9
+    assert relerr(gi.rd(d, "step001_phih_grid.f64", 32), a["step001_phih_grid"]) < 1e-9
+
+
+@pytest.mark.parametrize("name,sources,dens_seed,bubbles", [
+    ("restart32_onesrc", gi.SRC_ONE, 12, None), ("restart32_std_bubbles", gi.SRC_STD, 11, 6.0)])
+def test_fortran_evolve3d_restart_from_iteration_dump(rundir, name, sources, dens_seed, bubbles):
+    need(32)
+    m = json.load(open(os.path.join(GOLDEN, name + ".json")))
+    a = np.load(os.path.join(GOLDEN, name + ".npz"))
+
+    def w_dump(p):      # Fortran sequential unformatted: niter | photon_loss_all(1) | phih | xh_av | xh_intermed
+        with open(p, "wb") as f:
+            for rec in (np.array([m["dump_niter"]], np.int32), np.array([m["dump_photon_loss_all"]], np.float64),
+                        a["dump_phih"].ravel(order="F"), a["dump_xh_av"].ravel(order="F"),
+                        a["dump_xh_intermed"].ravel(order="F")):
+                b = rec.tobytes()
+                f.write(np.array([len(b)], np.int32).tobytes() + b + np.array([len(b)], np.int32).tobytes())
+
+    x = gi.bubble_xfield(32, BUBBLES, bubbles) if bubbles else None
+    d = gi.run_driver(32, sources, {"mode": "'restart'", "nsteps": 1, "dump_first": 1, "dump_last": 1},
+                      dens=gi.density_factor(32, dens_seed), xfield=x, extra_files={"iterdump.bin": w_dump},
+                      hip=True, d=rundir)
+    log = gi.parse_log(d + "/results/C2Ray.log")[0]
+    assert len(log["nonconv"]) == m["niter_after_restart"]
+    assert log["nonconv"] == m["log"]["nonconv"]
+    assert np.max(np.abs(gi.rd(d, "step001_xh_after.f64", 32) - a["xh_after"])) < 1e-9
+    assert relerr(gi.rd(d, "step001_phih_grid.f64", 32), a["phih_grid"]) < 1e-9
