@@ -55,9 +55,12 @@ struct Ctx {
     double *d_planes = nullptr;
     int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr;
     double *d_gbox = nullptr;   // deterministic mode: [batch_cap][2][ncell]
+    // one device block + one pinned staging block hold the small per-batch arrays below (one copy per batch)
+    char *d_batch = nullptr, *h_batch = nullptr; size_t batch_bytes = 0;
     int *d_active[2] = {nullptr, nullptr};
     int *d_nactive = nullptr;                                // [2]: length of d_active[0/1]
     int *h_nactive = nullptr;                                // pinned, one slot per sub-box
+    int *d_hnactive = nullptr;                               // the same slots as the device sees them
     std::vector<hipEvent_t> ev_box;                          // 'slot written' events
     double *d_loss_partial = nullptr, *d_loss_acc = nullptr, *d_final_loss = nullptr;
     int *d_final_nbox = nullptr;
@@ -65,7 +68,8 @@ struct Ctx {
     // reductions
     double *d_sum_partial = nullptr, *d_sum_out = nullptr;
     unsigned long long *d_conv = nullptr; unsigned int *d_chemfail = nullptr;
-    struct HostScalars { double sum; double photon_loss; long long sum_nbox; unsigned long long conv; unsigned int chemfail; double pair[2]; double four[4]; } *h_sc = nullptr;  // pinned
+    struct HostScalars { double sum; double photon_loss; long long sum_nbox; unsigned long long conv; unsigned int chemfail; double pair[2]; double four[4]; } *h_sc = nullptr,  // pinned
+      *d_hsc = nullptr;                       // ... and its device alias: kernels store results there directly
     double *d_dbg = nullptr, *d_pair = nullptr;
     // profiling
     bool prof = false;
@@ -99,10 +103,9 @@ size_t grid_bytes(const Ctx *ctx, int which) { return ctx->ncell * (which == 0 ?
 
 void free_sweep_scratch(Ctx *ctx)
 {
-    hipFree(ctx->d_planes); hipFree(ctx->d_gbox); hipFree(ctx->d_srcpos_b); hipFree(ctx->d_srcw_b); hipFree(ctx->d_nflux_b);
-    hipFree(ctx->d_active[0]); hipFree(ctx->d_active[1]);
-    hipFree(ctx->d_loss_partial); hipFree(ctx->d_loss_acc); hipFree(ctx->d_final_loss);
-    hipFree(ctx->d_final_nbox);
+    hipFree(ctx->d_planes); hipFree(ctx->d_gbox); hipFree(ctx->d_batch); hipFree(ctx->d_loss_partial);
+    if (ctx->h_batch) hipHostFree(ctx->h_batch);
+    ctx->d_batch = ctx->h_batch = nullptr; ctx->d_nactive = nullptr;
     ctx->d_planes = nullptr; ctx->d_gbox = nullptr; ctx->d_srcpos_b = nullptr; ctx->d_srcw_b = nullptr; ctx->d_nflux_b = nullptr;
     ctx->d_active[0] = ctx->d_active[1] = nullptr;
     ctx->d_loss_partial = ctx->d_loss_acc = ctx->d_final_loss = nullptr; ctx->d_final_nbox = nullptr;
@@ -135,15 +138,19 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
     cap = std::min(cap, 65535);                 // grid.z of k_sweep_shell
     HIP_TRY(hipMalloc(&ctx->d_planes, (size_t)cap * 2 * 6 * ctx->PP * sizeof(double)));
     if (ctx->prm.deterministic_rates) HIP_TRY(hipMalloc(&ctx->d_gbox, (size_t)cap * 2 * ctx->ncell * sizeof(double)));
-    HIP_TRY(hipMalloc(&ctx->d_srcpos_b, (size_t)cap * 3 * sizeof(int)));
-    HIP_TRY(hipMalloc(&ctx->d_srcw_b, (size_t)cap * 3 * sizeof(int)));
-    HIP_TRY(hipMalloc(&ctx->d_nflux_b, (size_t)cap * sizeof(double)));
-    HIP_TRY(hipMalloc(&ctx->d_active[0], (size_t)cap * sizeof(int)));
-    HIP_TRY(hipMalloc(&ctx->d_active[1], (size_t)cap * sizeof(int)));
     HIP_TRY(hipMalloc(&ctx->d_loss_partial, (size_t)cap * 6 * ctx->tiles_cap * sizeof(double)));
-    HIP_TRY(hipMalloc(&ctx->d_loss_acc, (size_t)cap * sizeof(double)));
-    HIP_TRY(hipMalloc(&ctx->d_final_loss, (size_t)cap * sizeof(double)));
-    HIP_TRY(hipMalloc(&ctx->d_final_nbox, (size_t)cap * sizeof(int)));
+    // small per-batch arrays: doubles first, then ints
+    //   nflux[cap] final_loss[cap] loss_acc[cap] | srcpos[3cap] srcw[3cap] active0[cap] active1[cap] final_nbox[cap] nactive[2]
+    ctx->batch_bytes = (size_t)cap * 3 * sizeof(double) + ((size_t)cap * 9 + 2) * sizeof(int);
+    HIP_TRY(hipMalloc(&ctx->d_batch, ctx->batch_bytes));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_batch, ctx->batch_bytes));
+    {
+        double *d = reinterpret_cast<double *>(ctx->d_batch);
+        ctx->d_nflux_b = d; ctx->d_final_loss = d + cap; ctx->d_loss_acc = d + 2 * (size_t)cap;
+        int *i = reinterpret_cast<int *>(d + 3 * (size_t)cap);
+        ctx->d_srcpos_b = i; ctx->d_srcw_b = i + 3 * (size_t)cap; ctx->d_active[0] = i + 6 * (size_t)cap;
+        ctx->d_active[1] = i + 7 * (size_t)cap; ctx->d_final_nbox = i + 8 * (size_t)cap; ctx->d_nactive = i + 9 * (size_t)cap;
+    }
     ctx->batch_cap = cap;
     ctx->batch_want = want;
     return C2R_OK;
@@ -219,13 +226,18 @@ void prof_collect(Ctx *ctx)
 
 // Sweep one batch: local sources [first, first+count) of this rank's list.
 // dbg: optional device N^3 array receiving coldensh_out (single-source test path).
-int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *nbox_out,
+int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg, std::vector<int> *nbox_out,
                 std::vector<double> *loss_out)
 {
     const c2r_params &p = ctx->prm;
-    std::vector<int> h_pos(3 * (size_t)count), h_posw(3 * (size_t)count), h_act, h_fn(count, 0);
-    std::vector<double> h_nf(count), h_fl(count, 0.0);
+    // fill the pinned staging block (layout of ensure_sweep_scratch) and send it with one copy
+    const size_t cap = (size_t)ctx->batch_cap;
+    memset(ctx->h_batch, 0, ctx->batch_bytes);                     // loss_acc = 0, final_nbox = 0, active lists
+    double *h_nf = reinterpret_cast<double *>(ctx->h_batch), *h_fl = h_nf + cap;
+    int *h_pos = reinterpret_cast<int *>(h_nf + 3 * cap), *h_posw = h_pos + 3 * cap, *h_act = h_pos + 6 * cap,
+        *h_na = h_pos + 9 * cap;
     const bool can_trace = ctx->hr[2] > 0 && ctx->hl[2] > 0;       // while condition, evolve_source.F90:130-131
+    int n_active = 0;
     for (int i = 0; i < count; ++i) {
         const int g = ctx->explicit_share ? ctx->share[first + i]
                                           : ctx->rank + (first + i) * ctx->nranks;      // master_slave.F90:85
@@ -236,20 +248,13 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
         }
         h_nf[i] = ctx->nflux[g];
         const double flux = h_nf[i] * p.S_star;
-        if (flux > p.loss_fraction * flux && can_trace) h_act.push_back(i);
+        if (flux > p.loss_fraction * flux && can_trace) h_act[n_active++] = i;
         else h_fl[i] = flux;                                       // loop never entered: loss = initial value
     }
-    int n_active = (int)h_act.size();
+    h_na[0] = n_active; h_na[1] = 0;
     hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(ctx->d_srcpos_b, h_pos.data(), h_pos.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ctx->d_srcw_b, h_posw.data(), h_posw.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ctx->d_nflux_b, h_nf.data(), h_nf.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ctx->d_final_loss, h_fl.data(), h_fl.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ctx->d_final_nbox, h_fn.data(), h_fn.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(ctx->d_loss_acc, 0, (size_t)count * sizeof(double), st));
-    if (n_active) HIP_TRY(hipMemcpyAsync(ctx->d_active[0], h_act.data(), (size_t)n_active * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ctx->d_nactive, &n_active, sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));      // host vectors go out of scope below
+    // (the staging block is next written by the next sweep_batch, after this one's final synchronize)
+    HIP_TRY(hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st));
 
     KParams k = make_kparams(ctx);
     int cur = 0;
@@ -309,9 +314,8 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
         }
         const int can_grow = (p.subboxsize * nbox < ctx->hr[2]) && (p.subboxsize * nbox < ctx->hl[2]);
         hipLaunchKernelGGL(k_box_decide, dim3(1), dim3(1024), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
-                           ctx->d_active[1 - cur], ctx->d_nactive + (1 - cur), ctx->d_nflux_b, p.S_star, p.loss_fraction,
-                           can_grow, nbox, ctx->d_loss_acc, ctx->d_final_loss, ctx->d_final_nbox);
-        HIP_TRY(hipMemcpyAsync(ctx->h_nactive + nbox, ctx->d_nactive + (1 - cur), sizeof(int), hipMemcpyDeviceToHost, st));
+                           ctx->d_active[1 - cur], ctx->d_nactive + (1 - cur), ctx->d_hnactive + nbox, ctx->d_nflux_b,
+                           p.S_star, p.loss_fraction, can_grow, nbox, ctx->d_loss_acc, ctx->d_final_loss, ctx->d_final_nbox);
         HIP_TRY(hipEventRecord(ctx->ev_box[nbox], st));
         cur = 1 - cur;
         // read the count of the PREVIOUS sub-box (its copy was enqueued a whole box of launches ago)
@@ -325,7 +329,8 @@ int sweep_batch(Ctx *ctx, int first, int count, double *dbg, std::vector<int> *n
         hipLaunchKernelGGL(k_gamma_reduce, dim3((p.mesh[0] + 255) / 256, p.mesh[1], p.mesh[2]), dim3(256), 0, st, k, count,
                            ctx->d_final_nbox, p.subboxsize, (double *)ctx->grid[4]);
     hipLaunchKernelGGL(k_batch_totals, dim3(1), dim3(64), 0, st, count, ctx->d_final_loss, ctx->d_final_nbox,
-                       ctx->d_photon_loss, ctx->d_sum_nbox);
+                       ctx->d_photon_loss, ctx->d_sum_nbox, first_of_pass ? 1 : 0, &ctx->d_hsc->photon_loss,
+                       &ctx->d_hsc->sum_nbox);
     HIP_TRY(hipGetLastError());
     if (nbox_out) {
         nbox_out->resize(count);
@@ -430,7 +435,6 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipMalloc(&ctx->d_phih_T, grid_bytes(ctx, 4)));
     HIP_TRY(hipMalloc(&ctx->d_thick, (size_t)(p->numtau + 1) * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_thin, (size_t)(p->numtau + 1) * sizeof(double)));
-    HIP_TRY(hipMalloc(&ctx->d_nactive, 2 * sizeof(int)));
     HIP_TRY(hipMalloc(&ctx->d_photon_loss, sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_sum_nbox, sizeof(long long)));
     HIP_TRY(hipMalloc(&ctx->d_sum_partial, 4 * kSumBlocks * sizeof(double)));
@@ -438,7 +442,12 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipMalloc(&ctx->d_conv, sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&ctx->d_chemfail, sizeof(unsigned int)));
     HIP_TRY(hipMalloc(&ctx->d_pair, 2 * sizeof(double)));
-    HIP_TRY(hipHostMalloc((void **)&ctx->h_sc, sizeof(*ctx->h_sc)));
+    HIP_TRY(hipMemset(ctx->d_conv, 0, sizeof(unsigned long long)));     // k_pass_final leaves them at zero again
+    HIP_TRY(hipMemset(ctx->d_chemfail, 0, sizeof(unsigned int)));
+    // pinned host scalars that kernels write straight through their mapped device pointers
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_sc, sizeof(*ctx->h_sc), hipHostMallocMapped));
+    memset(ctx->h_sc, 0, sizeof(*ctx->h_sc));
+    HIP_TRY(hipHostGetDevicePointer((void **)&ctx->d_hsc, ctx->h_sc, 0));
     // trace limits (evolve_source.F90:100-102), identical for every source
     int zlim = 0;
     for (int d = 0; d < 3; ++d) {
@@ -452,7 +461,8 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     ctx->Qmax = std::min(ctx->nbox_max * p->subboxsize, reach);
     ctx->R = ctx->Qmax; ctx->P = 2 * ctx->R + 1; ctx->PP = (size_t)ctx->P * ctx->P;
     ctx->tiles_cap = (int)((ctx->PP + kBlock - 1) / kBlock);
-    HIP_TRY(hipHostMalloc((void **)&ctx->h_nactive, (size_t)(ctx->nbox_max + 2) * sizeof(int)));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_nactive, (size_t)(ctx->nbox_max + 2) * sizeof(int), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void **)&ctx->d_hnactive, ctx->h_nactive, 0));
     ctx->ev_box.resize(ctx->nbox_max + 2);
     for (auto &e : ctx->ev_box) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return C2R_OK;
@@ -466,7 +476,7 @@ void c2r_destroy(c2r_ctx *c)
     for (auto &kv : ctx->pinned) hipHostUnregister(const_cast<void *>(kv.first));
     free_sweep_scratch(ctx);
     for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
-    hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_nactive);
+    hipFree(ctx->d_thick); hipFree(ctx->d_thin);
     hipFree(ctx->d_nhi); hipFree(ctx->d_nhi_T); hipFree(ctx->d_phih_T);
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
@@ -644,10 +654,9 @@ int c2r_pass_sources(c2r_ctx *c, double *photon_loss, int64_t *sum_nbox, int64_t
     Ctx *ctx = C(c);
     int rc = check_ready(ctx);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->d_photon_loss, 0, sizeof(double), ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_sum_nbox, 0, sizeof(long long), ctx->stream));
     const int nloc = n_local_sources(ctx);
     long long vis = 0;
+    ctx->h_sc->photon_loss = 0.0; ctx->h_sc->sum_nbox = 0;      // (the stream is idle between calls)
     if (nloc > 0) {
         rc = ensure_sweep_scratch(ctx, nloc);
         if (rc) return rc;
@@ -656,15 +665,13 @@ int c2r_pass_sources(c2r_ctx *c, double *photon_loss, int64_t *sum_nbox, int64_t
         ctx->last_nbox.clear();
         for (int first = 0; first < nloc; first += ctx->batch_cap) {
             const int count = std::min(ctx->batch_cap, nloc - first);
-            rc = sweep_batch(ctx, first, count, nullptr, &nb, nullptr);
+            rc = sweep_batch(ctx, first, count, first == 0, nullptr, &nb, nullptr);
             if (rc) return rc;
             for (int v : nb) { vis += visited_for_nbox(ctx, v); ctx->last_nbox.push_back(v); }
         }
         if ((rc = sweep_finish(ctx))) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(&ctx->h_sc->photon_loss, ctx->d_photon_loss, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(&ctx->h_sc->sum_nbox, ctx->d_sum_nbox, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));                 // k_batch_totals stored the totals in h_sc
     prof_collect(ctx);
     if (photon_loss) *photon_loss = ctx->h_sc->photon_loss;
     if (sum_nbox) *sum_nbox = ctx->h_sc->sum_nbox;
@@ -696,15 +703,13 @@ int c2r_do_source(c2r_ctx *c, int32_t ns, double *cd_host, double *loss, int32_t
         HIP_TRY(hipMemsetAsync(ctx->d_dbg, 0, ctx->ncell * sizeof(double), ctx->stream));   // evolve_source.F90:91
         dbg = ctx->d_dbg;
     }
-    HIP_TRY(hipMemsetAsync(ctx->d_photon_loss, 0, sizeof(double), ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_sum_nbox, 0, sizeof(long long), ctx->stream));
     // address the source directly, whatever the rank layout
     const int sr = ctx->rank, sn = ctx->nranks;
     const bool se = ctx->explicit_share;
     ctx->rank = 0; ctx->nranks = 1; ctx->explicit_share = false;
     std::vector<int> nb; std::vector<double> fl;
     rc = sweep_prepare(ctx);
-    if (!rc) rc = sweep_batch(ctx, ns - 1, 1, dbg, &nb, &fl);
+    if (!rc) rc = sweep_batch(ctx, ns - 1, 1, true, dbg, &nb, &fl);
     if (!rc) rc = sweep_finish(ctx);
     ctx->rank = sr; ctx->nranks = sn; ctx->explicit_share = se;
     if (rc) return rc;
@@ -756,8 +761,7 @@ int c2r_sum(c2r_ctx *c, int32_t which, double *sum)
     Ctx *ctx = C(c);
     hipLaunchKernelGGL(k_sum_partial, dim3(kSumBlocks), dim3(256), 0, ctx->stream, ctx->ncell,
                        (const double *)ctx->grid[which], ctx->d_sum_partial);
-    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, ctx->d_sum_out);
-    HIP_TRY(hipMemcpyAsync(&ctx->h_sc->sum, ctx->d_sum_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, &ctx->d_hsc->sum);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     *sum = ctx->h_sc->sum;
     return C2R_OK;
@@ -776,10 +780,7 @@ int c2r_photon_sums(c2r_ctx *c, int32_t which_l, int32_t which_r, double out[4])
                        (const double *)ctx->grid[which_r], p.abu_c, (double)ctx->clumping, (const float *)ctx->d_clump,
                        p.bh00, pow(ctx->temper / 1e4, p.albpow), p.colh0, sqrt(ctx->temper),
                        exp(-p.temph0 / ctx->temper), ctx->d_sum_partial);
-    for (int m = 0; m < 4; ++m)
-        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks,
-                           ctx->d_sum_partial + (size_t)m * kSumBlocks, ctx->d_sum_out + m);
-    HIP_TRY(hipMemcpyAsync(ctx->h_sc->four, ctx->d_sum_out, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(k_sum_final, dim3(4), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, ctx->d_hsc->four);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int m = 0; m < 4; ++m) out[m] = ctx->h_sc->four[m];
     return C2R_OK;
@@ -801,18 +802,14 @@ int c2r_global_pass(c2r_ctx *c, double dt, int64_t *conv_flag, double *sum_xh1)
     cp.brech0 = (double)ctx->clumping * p.bh00 * pow(ctx->temper / 1e4, p.albpow);
     cp.bh00 = p.bh00; cp.recpow = pow(ctx->temper / 1e4, p.albpow); cp.clump = ctx->d_clump;
     cp.acolh0 = p.colh0 * sqrt(ctx->temper) * exp(-p.temph0 / ctx->temper);
-    HIP_TRY(hipMemsetAsync(ctx->d_conv, 0, sizeof(unsigned long long), ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_chemfail, 0, sizeof(unsigned int), ctx->stream));
     prof_begin(ctx, ctx->ev_chem, ctx->ev_chem_used);
     hipLaunchKernelGGL(k_global_pass, dim3(kSumBlocks), dim3(256), 0, ctx->stream, cp, ctx->ncell,
                        (const float *)ctx->grid[0], (const double *)ctx->grid[1], (double *)ctx->grid[2],
                        (double *)ctx->grid[3], (const double *)ctx->grid[4], ctx->d_sum_partial, ctx->d_conv,
                        ctx->d_chemfail);
     prof_end(ctx, ctx->ev_chem, ctx->ev_chem_used);
-    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, ctx->d_sum_out);
-    HIP_TRY(hipMemcpyAsync(&ctx->h_sc->sum, ctx->d_sum_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(&ctx->h_sc->conv, ctx->d_conv, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(&ctx->h_sc->chemfail, ctx->d_chemfail, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(k_pass_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, ctx->d_conv,
+                       ctx->d_chemfail, &ctx->d_hsc->sum, &ctx->d_hsc->conv, &ctx->d_hsc->chemfail);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
     if (conv_flag) *conv_flag = (int64_t)ctx->h_sc->conv;

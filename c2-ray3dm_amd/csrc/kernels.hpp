@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const int *active, const in
 // loss_fraction of its photons leave the box and the box can still grow in z.  Compacts the
 // active list (stable), finalises the others.  One block of 1024 threads.
 __global__ __launch_bounds__(1024) void k_box_decide(const int *active_in, const int *n_in_dev, int *active_out,
-                                                     int *n_out, const double *normflux, double S_star,
+                                                     int *n_out, int *n_out_host, const double *normflux, double S_star,
                                                      double loss_fraction, int can_grow, int nbox,
                                                      double *loss_acc, double *final_loss, int *final_nbox)
 {
@@ -562,17 +562,22 @@ __global__ __launch_bounds__(1024) void k_box_decide(const int *active_in, const
         if (threadIdx.x == 1023) base += scan[1023];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *n_out = base;
+    // n_out_host: the schedule's pinned slot for this sub-box, written straight through the mapped pointer
+    if (threadIdx.x == 0) { *n_out = base; *n_out_host = base; }
 }
 
 // photon_loss(1) += photon_loss_src, in source order (evolve_source.F90:216); sum_nbox (:219).
+// first: first batch of a pass (the running totals restart from zero).  The totals so far are also
+// written to the host's pinned scalars through their mapped pointers.
 __global__ void k_batch_totals(int nsrc, const double *final_loss, const int *final_nbox,
-                               double *photon_loss, long long *sum_nbox)
+                               double *photon_loss, long long *sum_nbox, int first,
+                               double *host_loss, long long *host_nbox)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double l = *photon_loss; long long nb = *sum_nbox;
+        double l = first ? 0.0 : *photon_loss; long long nb = first ? 0 : *sum_nbox;
         for (int s = 0; s < nsrc; ++s) { l = l + final_loss[s]; nb += final_nbox[s]; }
         *photon_loss = l; *sum_nbox = nb;
+        *host_loss = l; *host_nbox = nb;
     }
 }
 
@@ -683,13 +688,31 @@ __global__ __launch_bounds__(256) void k_sum_partial(size_t n, const double *__r
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// out[m] = sum of partial[m][0..n) in a fixed order, m = blockIdx.x; `out` may be mapped host memory.
 __global__ __launch_bounds__(256) void k_sum_final(int n, const double *partial, double *out)
+{
+    __shared__ double sm[4];
+    partial += (size_t)blockIdx.x * n;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
+    const double tot = block_sum_256(v, sm);
+    if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}
+
+// End of a global pass: the sum of xh_intermed and the two counters go to the host's pinned scalars
+// (mapped pointers); the counters are left at zero for the next pass.
+__global__ __launch_bounds__(256) void k_pass_final(int n, const double *partial, unsigned long long *conv,
+                                                    unsigned int *chem_fail, double *host_sum,
+                                                    unsigned long long *host_conv, unsigned int *host_fail)
 {
     __shared__ double sm[4];
     double v = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
     const double tot = block_sum_256(v, sm);
-    if (threadIdx.x == 0) *out = tot;
+    if (threadIdx.x == 0) {
+        *host_sum = tot; *host_conv = *conv; *host_fail = *chem_fail;
+        *conv = 0ULL; *chem_fail = 0u;
+    }
 }
 
 }  // namespace c2r

@@ -230,7 +230,7 @@ contains
     elseif (use_LLS .and. type_of_LLS == 3) then                      ! R_max_LLS, LLS.F90:186
        call check(c2r_set_lls(ctx, 3_c_int32_t, c_null_ptr, R_max_LLS), "c2r_set_lls")
     endif
-    if (type_of_clumping == 5) then                                   ! clumping_point, clumping_module.F90:106
+    if (type_of_clumping >= 3 .and. type_of_clumping <= 5) then       ! clumping_point, evolve_point.F90:442, clumping_module.F90:106
        gridp = grid_address(clumping_grid)
        call check(c2r_set_clumping_grid(ctx, gridp), "c2r_set_clumping_grid")
     endif
