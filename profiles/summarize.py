@@ -8,7 +8,11 @@ wide coalesced read, so the read side is doubled ("fetch_corrected"); WRITE_SIZE
 The guide calibrates that factor for 16-B-per-lane streams; this kernel reads 8 B and 4 B per
 lane, so both the raw and the corrected figure are kept.
 
-usage: summarize.py <dir with kernel_stats.csv pmc_FETCH_SIZE.csv pmc_WRITE_SIZE.csv> <visited cell-sources in the pmc run>
+usage: summarize.py <dir> [visited cell-sources in the pmc run]
+<dir> holds kernel_stats.csv, pmc_FETCH_SIZE.csv, pmc_WRITE_SIZE.csv, optionally pmc_SQ.csv, and the bench.py
+lines printed by the profiled runs: kt_bench.json (kernel-trace run), pmc_bench.json (a PMC run; supplies
+the visited count when it is not given).  Also records whether rocprof's average k_sweep_shell duration
+agrees with the HIP-event average bench.py measured in the same run.
 """
 import collections
 import csv
@@ -35,6 +39,9 @@ def per_kernel(path):
 def main():
     d = sys.argv[1]
     visited = float(sys.argv[2]) if len(sys.argv) > 2 else None
+    pb = os.path.join(d, "pmc_bench.json")
+    if visited is None and os.path.exists(pb):
+        visited = json.load(open(pb))["config"]["visited_cell_sources_whole_run_rank0"]
     out = {"kernels": {}}
     for r in csv.DictReader(open(os.path.join(d, "kernel_stats.csv"))):
         k = kname(r["Name"])
@@ -59,6 +66,37 @@ def main():
             "fetch_corrected": sw["fetch_corrected_bytes_per_launch"] / vis_per_launch,
             "write": sw["write_bytes_per_launch"] / vis_per_launch,
             "visited_in_pmc_run": visited}
+    kb = os.path.join(d, "kt_bench.json")
+    if sw and os.path.exists(kb):
+        ev_ms = json.load(open(kb))["roofline"]["avg_launch_ms"]
+        kbj = json.load(open(kb))
+        out["agreement"] = {"rocprof_stats_avg_ms_all_launches": sw["avg_ns"] * 1e-6,
+                            "hip_event_avg_ms_timed_steps": ev_ms,
+                            "note": "--stats averages every launch of the process; the very first pass (input "
+                                    "preparation, uniform x) stops 18 shells earlier than all later ones, so "
+                                    "its launches are the smaller ones"}
+        tr = os.path.join(d, "kernel_trace.csv")
+        if os.path.exists(tr):     # like with like: the launches of the timed region are the last ones
+            n = int(kbj["roofline"]["launches"])
+            durs = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(tr))
+                    if kname(r["Kernel_Name"]) == "c2r::k_sweep_shell"]
+            last = durs[-n:]
+            out["agreement"].update(rocprof_trace_avg_ms_timed_launches=sum(last) / len(last) * 1e-6,
+                                    timed_launches=n, ratio_trace_over_events=sum(last) / len(last) * 1e-6 / ev_ms)
+    sq = os.path.join(d, "pmc_SQ.csv")
+    if os.path.exists(sq):
+        agg = collections.defaultdict(float)
+        dur = {}
+        for r in csv.DictReader(open(sq)):
+            if kname(r["Kernel_Name"]) == "c2r::k_sweep_shell":
+                agg[r["Counter_Name"]] += float(r["Counter_Value"])
+                dur[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        if agg.get("SQ_WAVES"):
+            # SIMD-cycles available while the kernel ran: 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md)
+            simd_cycles = sum(dur.values()) * 2.4 * 1024
+            out["sweep_sq"] = {"valu_insts_per_wave": agg["SQ_INSTS_VALU"] / agg["SQ_WAVES"],
+                               "valu_busy_frac_of_simd_cycles": 4 * agg["SQ_ACTIVE_INST_VALU"] / simd_cycles,
+                               "kernel_ns_in_this_pass": sum(dur.values()), "raw": dict(agg)}
     json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
