@@ -380,6 +380,8 @@ long long visited_for_nbox(const Ctx *ctx, int nbox)
 
 int check_ready(Ctx *ctx)
 {
+    // the context's allocations and launches belong to its device, whatever the caller made current since
+    HIP_TRY(hipSetDevice(ctx->prm.device));
     if (!ctx->have_tables) FAIL(C2R_ESTATE, "c2r_set_tables has not been called");
     if (!ctx->have_step) FAIL(C2R_ESTATE, "c2r_set_step has not been called");
     return C2R_OK;
@@ -535,6 +537,7 @@ int c2r_set_lls(c2r_ctx *c, int32_t type, const float *lls_grid, double R_max_LL
     if (type < 1 || type > 3) FAIL(C2R_EINVAL, "type_of_LLS must be 1, 2 or 3");
     if (type == 2 && !lls_grid) FAIL(C2R_EINVAL, "type_of_LLS=2 needs the LLS grid");
     if (type == 3 && !(R_max_LLS > 0.0)) FAIL(C2R_EINVAL, "type_of_LLS=3 needs R_max_LLS > 0");
+    HIP_TRY(hipSetDevice(ctx->prm.device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (type == 2) {
         const c2r_params &p = ctx->prm;
@@ -553,6 +556,7 @@ int c2r_set_clumping_grid(c2r_ctx *c, const float *clump_grid)
 {
     if (!c) return C2R_EINVAL;
     Ctx *ctx = C(c);
+    HIP_TRY(hipSetDevice(ctx->prm.device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (!clump_grid) { hipFree(ctx->d_clump); ctx->d_clump = nullptr; return C2R_OK; }
     if (!ctx->d_clump) HIP_TRY(hipMalloc(&ctx->d_clump, grid_bytes(ctx, 0)));
