@@ -18,6 +18,7 @@ using namespace c2r;
 namespace {
 
 constexpr int kSumBlocks = 1024;      // fixed grid of every deterministic reduction
+constexpr int kFusedQmax = 10;        // sub-boxes ending at q <= this run in k_sweep_box_fused (one launch per sub-box)
 
 struct Ctx {
     c2r_params prm{};
@@ -52,6 +53,7 @@ struct Ctx {
     int tiles_cap = 0;          // ceil(P*P/256): most tiles any face plane needs
     // sweep scratch (one batch of sources)
     int batch_cap = 0, batch_want = 0;
+    bool fuse_small = true;     // C2R_FUSE_SMALL=0 disables the fused first sub-boxes (experiments, A/B tests)
     double *d_planes = nullptr;
     int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr;
     double *d_gbox = nullptr;   // deterministic mode: [batch_cap][2][ncell]
@@ -276,12 +278,12 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                                ctx->d_loss_acc, dbg);
         }
         const int q0 = p.subboxsize * (nbox - 1) + 1, q1 = std::min(p.subboxsize * nbox, ctx->Qmax);
-        for (int q = q0; q <= q1; ++q) {
+        const bool det = ctx->d_gbox != nullptr;
+        auto shell_args = [&](int q) {
             ShellArgs sa{};
             sa.q = q;
             sa.tiles_max = 0;
             for (int f = 0; f < 6; ++f) { sa.face[f] = face_rect(ctx, f, q); sa.tiles_max = std::max(sa.tiles_max, sa.face[f].ntiles); }
-            if (sa.tiles_max == 0) continue;
             sa.has_boundary = 0;
             for (int d = 0; d < 3; ++d) {
                 sa.boxR[d] = boxR[d]; sa.boxL[d] = boxL[d];
@@ -292,10 +294,45 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             for (int d = 0; d < 3; ++d) { const double t = ctx->dr[d] * (double)q; sa.d2axis[d] = t * t; }   // sign drops out
             sa.active = ctx->d_active[cur]; sa.n_active = ctx->d_nactive + cur;
             sa.loss_partial = ctx->d_loss_partial; sa.dbg_cdout = dbg;
+            return sa;
+        };
+        if (ctx->fuse_small && q1 <= kFusedQmax && q1 - q0 + 1 <= kMaxFused) {
+            // near the source: the whole sub-box of every active source in ONE launch (k_sweep_box_fused)
+            BoxArgs ba{};
+            int most = 0;
+            for (int q = q0; q <= q1; ++q) {
+                ShellArgs sa = shell_args(q);
+                if (sa.tiles_max == 0) continue;
+                const int k = ba.nshell++;
+                int off = 0;
+                for (int f = 0; f < 6; ++f) { ba.face_off[k][f] = off; off += sa.face[f].ntiles ? sa.face[f].wa * sa.face[f].wb : 0; }
+                ba.face_off[k][6] = ba.face_off[k][7] = off;
+                ba.ncell[k] = off; most = std::max(most, off);
+                ba.sh[k] = sa;
+            }
+            if (ba.nshell > 0) {
+                ba.active = ctx->d_active[cur]; ba.n_active = ctx->d_nactive + cur; ba.loss_acc = ctx->d_loss_acc;
+                const dim3 grid(bound), blk(most <= 256 ? 256 : (most <= 512 ? 512 : 1024));
+                prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
+#define C2R_LAUNCH_FUSED(D, L) hipLaunchKernelGGL((k_sweep_box_fused<D, L>), grid, blk, 0, st, k, ba)
+                switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
+                    case 2: C2R_LAUNCH_FUSED(false, 1); break;
+                    case 3: C2R_LAUNCH_FUSED(true, 1); break;
+                    case 4: C2R_LAUNCH_FUSED(false, 2); break;
+                    case 5: C2R_LAUNCH_FUSED(true, 2); break;
+                    case 6: C2R_LAUNCH_FUSED(false, 3); break;
+                    default: C2R_LAUNCH_FUSED(true, 3); break;
+                }
+#undef C2R_LAUNCH_FUSED
+                prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
+            }
+        } else
+        for (int q = q0; q <= q1; ++q) {
+            ShellArgs sa = shell_args(q);
+            if (sa.tiles_max == 0) continue;
             prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
             {
                 const dim3 grid(sa.tiles_max, 6, bound), blk(kBlock);
-                const bool det = ctx->d_gbox != nullptr;
 #define C2R_LAUNCH_SWEEP(D, L) hipLaunchKernelGGL((k_sweep_shell<D, L>), grid, blk, 0, st, k, sa)
                 switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
                     case 2: C2R_LAUNCH_SWEEP(false, 1); break;
@@ -328,7 +365,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
     if (ctx->d_gbox)
         hipLaunchKernelGGL(k_gamma_reduce, dim3((p.mesh[0] + 255) / 256, p.mesh[1], p.mesh[2]), dim3(256), 0, st, k, count,
                            ctx->d_final_nbox, p.subboxsize, (double *)ctx->grid[4]);
-    hipLaunchKernelGGL(k_batch_totals, dim3(1), dim3(64), 0, st, count, ctx->d_final_loss, ctx->d_final_nbox,
+    hipLaunchKernelGGL(k_batch_totals, dim3(1), dim3(1024), 0, st, count, ctx->d_final_loss, ctx->d_final_nbox,
                        ctx->d_photon_loss, ctx->d_sum_nbox, first_of_pass ? 1 : 0, &ctx->d_hsc->photon_loss,
                        &ctx->d_hsc->sum_nbox);
     HIP_TRY(hipGetLastError());
@@ -419,6 +456,7 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     if (p->mesh[0] < 1 || p->mesh[1] < 1 || p->mesh[2] < 1 || p->numtau < 1 || p->subboxsize < 1) return C2R_EINVAL;
     Ctx *ctx = new Ctx();
     ctx->prm = *p;
+    if (const char *e = getenv("C2R_FUSE_SMALL")) ctx->fuse_small = atoi(e) != 0;
     *out = reinterpret_cast<c2r_ctx *>(ctx);     // returned even on failure so c2r_last_error works
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));

@@ -245,9 +245,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
+template <int AUX = 0>      // AUX 1 = glc: read through to L2 (planes written by other waves of the same launch)
 __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
 {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0));
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, AUX));
 }
 __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
 {
@@ -268,25 +269,18 @@ __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned
 // unit-stride axis of the arrays the face reads (x for z/y faces, y in the transposed replicas
 // for x faces).
 // DET: deterministic_rates mode (per-source Gamma grids instead of atomics); LLS: type_of_LLS (1,2,3)
-template <bool DET, int LLS>
-__global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
+// One cell (a,b) of face `face` in shell sa.q of source s: everything evolve0D does for it.  Returns the
+// cell's photon-loss contribution (0 unless it lies on the sub-box surface).  Shared by the
+// shell-per-launch kernel (face block-uniform) and the fused first-sub-box kernel (face per thread).
+template <bool DET, int LLS, int GLC>
+__device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &sa, const int face, const int s,
+                                             const int a, const int b)
 {
-    __shared__ double sm[16];
-    const int face = blockIdx.y;
-    const int sl = blockIdx.z;
-    const int tile = blockIdx.x;
-    if (sl >= *sa.n_active) return;              // block-uniform: this source retired after the launch was sized
-    const FaceRect fr = sa.face[face];
     double loss = 0.0;
-    const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
-    const unsigned bi = fr.magic ? __umulhi(t, fr.magic) : t;
-    if (tile < fr.ntiles && bi < (unsigned)fr.wb) {
-        const int s = sa.active[sl];
+    {
         const int q = sa.q;
         const int axis = 2 - (face >> 1);            // 2:z 1:y 0:x
         const int pd = (face & 1) ? -q : q;
-        const int a = fr.a_lo + (int)(t - bi * (unsigned)fr.wa);
-        const int b = fr.b_lo + (int)bi;
         // mesh-axis deltas and the source coordinates seen along (a,b); all block-uniform selects
         const int d0 = (axis == 0) ? pd : a;
         const int d1 = (axis == 2) ? b : ((axis == 1) ? pd : a);
@@ -322,10 +316,10 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         const bool ina = abs(a) <= qm, inam = abs(am) <= qm, inb = abs(b) <= qm, inbm = abs(bm) <= qm;
         const int o = (b + p.R) * p.P + (a + p.R);
         const unsigned o8 = (unsigned)o * 8u, da8 = (unsigned)(sga * 8), db8 = (unsigned)(sgb * p.P * 8);
-        const double c1v = buf_load_f64(r_prev, (inam && inbm) ? o8 - db8 - da8 : kOOB);
-        const double c2v = buf_load_f64(r_prev, (ina && inbm) ? o8 - db8 : kOOB);
-        const double c3v = buf_load_f64(r_prev, (inam && inb) ? o8 - da8 : kOOB);
-        const double c4v = buf_load_f64(r_prev, (ina && inb) ? o8 : kOOB);
+        const double c1v = buf_load_f64<GLC>(r_prev, (inam && inbm) ? o8 - db8 - da8 : kOOB);
+        const double c2v = buf_load_f64<GLC>(r_prev, (ina && inbm) ? o8 - db8 : kOOB);
+        const double c3v = buf_load_f64<GLC>(r_prev, (inam && inb) ? o8 - da8 : kOOB);
+        const double c4v = buf_load_f64<GLC>(r_prev, (ina && inb) ? o8 : kOOB);
 
         // cinterp, generic in (a,b,pd): the three branches differ only by which axes play (u,v).
         // real(int) conversions of the reference are f32 but exact (|.| < 2^24): cvt i32->f64.
@@ -397,10 +391,76 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         // deterministic mode: every visited cell records its rate (zero included) for k_gamma_reduce
         if (DET) p.gbox[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + id] = gamma;
     }
+    return loss;
+}
+
+template <bool DET, int LLS>
+__global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
+{
+    __shared__ double sm[16];
+    const int face = blockIdx.y;
+    const int sl = blockIdx.z;
+    const int tile = blockIdx.x;
+    if (sl >= *sa.n_active) return;              // block-uniform: this source retired after the launch was sized
+    const FaceRect fr = sa.face[face];
+    double loss = 0.0;
+    const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
+    const unsigned bi = fr.magic ? __umulhi(t, fr.magic) : t;
+    if (tile < fr.ntiles && bi < (unsigned)fr.wb) {
+        const int a = fr.a_lo + (int)(t - bi * (unsigned)fr.wa);
+        const int b = fr.b_lo + (int)bi;
+        loss = shell_cell<DET, LLS, 0>(p, sa, face, sa.active[sl], a, b);
+    }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
         if (threadIdx.x == 0)
             sa.loss_partial[((size_t)sl * 6 + face) * sa.tiles_max + tile] = tot;
+    }
+}
+
+// ---- the first sub-boxes, fused: one workgroup per source, all shells of the sub-box in one launch -----
+// Near the source a shell has few cells (24q^2+2: 26 ... 602 for q = 1..5) and a launch per shell is
+// nothing but latency, with the six faces' 256-thread tiles mostly empty.  Here the cells of a shell are
+// packed over the six faces (face_off = prefix sums of the owned rectangles) and a source's workgroup walks
+// the shells itself, a barrier between them; its photon loss through the box surface is summed in a fixed
+// order and added to loss_acc[source] (no k_loss_reduce).  Same per-cell code as k_sweep_shell.
+constexpr int kMaxFused = 5;
+struct BoxArgs {
+    int nshell;
+    int ncell[kMaxFused];            // packed cells of each shell
+    int face_off[kMaxFused][8];      // [f]: first packed index of face f; [6] = ncell
+    ShellArgs sh[kMaxFused];
+    const int *active;
+    const int *n_active;
+    double *loss_acc;
+};
+
+template <bool DET, int LLS>
+__global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
+{
+    __shared__ double sm[16];
+    const int sl = blockIdx.x;
+    if (sl >= *ba.n_active) return;
+    const int s = ba.active[sl];
+    for (int k = 0; k < ba.nshell; ++k) {
+        const ShellArgs &sa = ba.sh[k];
+        double loss = 0.0;
+        for (int t = threadIdx.x; t < ba.ncell[k]; t += blockDim.x) {
+            int f = 0;
+#pragma unroll
+            for (int g = 1; g < 6; ++g) f += (t >= ba.face_off[k][g]) ? 1 : 0;
+            const FaceRect fr = sa.face[f];
+            const unsigned lt = (unsigned)(t - ba.face_off[k][f]);
+            const unsigned bi = fr.magic ? __umulhi(lt, fr.magic) : lt;
+            const int a = fr.a_lo + (int)(lt - bi * (unsigned)fr.wa);
+            const int b = fr.b_lo + (int)bi;
+            loss = loss + shell_cell<DET, LLS, 0>(p, sa, f, s, a, b);
+        }
+        if (sa.has_boundary) {
+            const double tot = block_sum_256(loss, sm);       // contains a barrier
+            if (threadIdx.x == 0) ba.loss_acc[s] += tot;      // what k_loss_reduce does for the per-shell launches
+        }
+        __syncthreads();        // workgroup-scope release/acquire: this shell's planes are visible to every wave of the group
     }
 }
 
@@ -569,15 +629,26 @@ __global__ __launch_bounds__(1024) void k_box_decide(const int *active_in, const
 // photon_loss(1) += photon_loss_src, in source order (evolve_source.F90:216); sum_nbox (:219).
 // first: first batch of a pass (the running totals restart from zero).  The totals so far are also
 // written to the host's pinned scalars through their mapped pointers.
-__global__ void k_batch_totals(int nsrc, const double *final_loss, const int *final_nbox,
-                               double *photon_loss, long long *sum_nbox, int first,
-                               double *host_loss, long long *host_nbox)
+__global__ __launch_bounds__(1024) void k_batch_totals(int nsrc, const double *final_loss, const int *final_nbox,
+                                                       double *photon_loss, long long *sum_nbox, int first,
+                                                       double *host_loss, long long *host_nbox)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double l = first ? 0.0 : *photon_loss; long long nb = first ? 0 : *sum_nbox;
-        for (int s = 0; s < nsrc; ++s) { l = l + final_loss[s]; nb += final_nbox[s]; }
-        *photon_loss = l; *sum_nbox = nb;
-        *host_loss = l; *host_nbox = nb;
+    // thread t sums the contiguous run [t*c, (t+1)*c) in order, thread 0 the runs in order: for up to 1024
+    // sources (c = 1) that IS the sequential source-order sum of the reference; beyond, a fixed two-level order
+    __shared__ double sl[1024];
+    __shared__ long long sn[1024];
+    const int c = (nsrc + 1023) / 1024;
+    const int i0 = (int)threadIdx.x * c, i1 = min(nsrc, i0 + c);
+    double l = 0.0; long long nb = 0;
+    for (int i = i0; i < i1; ++i) { l = l + final_loss[i]; nb += final_nbox[i]; }
+    sl[threadIdx.x] = l; sn[threadIdx.x] = nb;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double L = first ? 0.0 : *photon_loss; long long NB = first ? 0 : *sum_nbox;
+        const int used = c > 0 ? (nsrc + c - 1) / c : 0;
+        for (int t = 0; t < used; ++t) { L = L + sl[t]; NB += sn[t]; }
+        *photon_loss = L; *sum_nbox = NB;
+        *host_loss = L; *host_nbox = NB;
     }
 }
 

@@ -178,6 +178,29 @@ def test_small_scratch_batches_equal_one_batch(pkg, tables):
     assert relerr(res[0][1], res[1][1], floor=1e-60) < 1e-12
 
 
+def test_fused_first_subboxes_equal_per_shell_launches(pkg, tables, monkeypatch):
+    """k_sweep_box_fused (sub-boxes ending at q <= 10: one launch per sub-box, one workgroup per source)
+    runs the same per-cell code as the per-shell launches: identical column densities and sub-box
+    counts, rates equal to rounding (atomics), the loss equal up to its summation order."""
+    n, nsrc = 48, 9
+    s, nd, xh, pos, nf = _random_case(n, nsrc, 21, pkg)
+    res = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("C2R_FUSE_SMALL", fuse)          # read by c2r_create
+        b = make_backend(pkg, tables, dict(s, srcpos=pos, normflux=nf), n, nd, xh)
+        b.begin_step(); b.zero_rates()
+        out = b.pass_sources()
+        cds = [b.do_source(k + 1, want_coldens=True) for k in range(nsrc)]
+        res.append((out, b.fetch("phih_grid"), cds))
+        b.close()
+    assert res[0][0][1:] == res[1][0][1:]                                        # sum_nbox, visited
+    assert abs(res[0][0][0] - res[1][0][0]) <= 1e-13 * abs(res[0][0][0])        # photon loss
+    for (nb0, l0, v0, cd0), (nb1, l1, v1, cd1) in zip(res[0][2], res[1][2]):
+        assert nb0 == nb1 and v0 == v1
+        assert np.array_equal(cd0, cd1)                                          # bit for bit
+        assert abs(l0 - l1) <= 1e-13 * abs(l0) + 1e-300
+
+
 def test_edge_cases(pkg, tables):
     """No sources; a zero-flux source; a source outside [1,N] (wrapped); error codes."""
     n = 16
