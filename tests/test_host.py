@@ -34,6 +34,19 @@ def test_library_exports_every_declared_symbol(pkg):
     assert declared <= exported
 
 
+def test_rccl_binding_exports_its_header(pkg):
+    """include/c2ray_rccl.h (optional RCCL all-reduce callback) against libc2ray_rccl.so."""
+    hdr = open(os.path.join(ROOT, "include", "c2ray_rccl.h")).read()
+    declared = set(re.findall(r"\b(c2r_rccl_\w+)\s*\(", hdr))
+    assert declared == {"c2r_rccl_unique_id", "c2r_rccl_attach", "c2r_rccl_allreduce", "c2r_rccl_detach"}
+    lib = os.path.join(os.path.dirname(pkg.LIB_PATH), "libc2ray_rccl.so")
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib]).decode()
+    assert declared <= set(re.findall(r"\bT (c2r_rccl_\w+)", out))
+    # the core library itself must not depend on RCCL
+    needed = subprocess.check_output(["readelf", "-d", pkg.LIB_PATH]).decode()
+    assert "rccl" not in needed
+
+
 def test_struct_layout_matches_header(pkg):
     """sizeof() of the two ABI structs as the C compiler sees them."""
     src = '#include <stdio.h>\n#include "c2ray_hip.h"\nint main(){printf("%zu %zu\\n",sizeof(c2r_params),sizeof(c2r_report));return 0;}\n'
