@@ -92,9 +92,21 @@ def main():
                 agg[r["Counter_Name"]] += float(r["Counter_Value"])
                 dur[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         if agg.get("SQ_WAVES"):
-            # SIMD-cycles available while the kernel ran: 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md)
-            simd_cycles = sum(dur.values()) * 2.4 * 1024
+            # SIMD-cycles available while the kernel ran: 256 CUs x 4 SIMDs at the measured engine clock
+            # (pmc_GRBM.csv: GRBM_COUNT summed over the 8 XCDs / kernel time), else the nominal 2.4 GHz
+            ghz = 2.4
+            gr = os.path.join(d, "pmc_GRBM.csv")
+            if os.path.exists(gr):
+                cnt, gd = 0.0, {}
+                for r in csv.DictReader(open(gr)):
+                    if kname(r["Kernel_Name"]) == "c2r::k_sweep_shell" and r["Counter_Name"] == "GRBM_COUNT":
+                        cnt += float(r["Counter_Value"])
+                        gd[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                if gd:
+                    ghz = cnt / 8 / sum(gd.values())
+            simd_cycles = sum(dur.values()) * ghz * 1024
             out["sweep_sq"] = {"valu_insts_per_wave": agg["SQ_INSTS_VALU"] / agg["SQ_WAVES"],
+                               "engine_clock_ghz_during_kernel": ghz,
                                "valu_busy_frac_of_simd_cycles": 4 * agg["SQ_ACTIVE_INST_VALU"] / simd_cycles,
                                "kernel_ns_in_this_pass": sum(dur.values()), "raw": dict(agg)}
     json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
