@@ -314,8 +314,9 @@ __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &
             make_rsrc(p.planes + ((size_t)s * 2 + ((q - 1) & 1)) * 6 * p.PP + (size_t)face * p.PP, plane_bytes);
         const int qm = q - 1;
         const bool ina = abs(a) <= qm, inam = abs(am) <= qm, inb = abs(b) <= qm, inbm = abs(bm) <= qm;
-        const int o = (b + p.R) * p.P + (a + p.R);
-        const unsigned o8 = (unsigned)o * 8u, da8 = (unsigned)(sga * 8), db8 = (unsigned)(sgb * p.P * 8);
+        const int o = (int)__umul24((unsigned)(b + p.R), (unsigned)p.P) + (a + p.R);          // factors in [0, 2^24)
+        const unsigned p8 = (unsigned)p.P * 8u;
+        const unsigned o8 = (unsigned)o * 8u, da8 = (unsigned)(sga * 8), db8 = b < 0 ? 0u - p8 : p8;
         const double c1v = buf_load_f64<GLC>(r_prev, (inam && inbm) ? o8 - db8 - da8 : kOOB);
         const double c2v = buf_load_f64<GLC>(r_prev, (ina && inbm) ? o8 - db8 : kOOB);
         const double c3v = buf_load_f64<GLC>(r_prev, (inam && inb) ? o8 - da8 : kOOB);
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
     const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
     const unsigned bi = fr.magic ? __umulhi(t, fr.magic) : t;
     if (tile < fr.ntiles && bi < (unsigned)fr.wb) {
-        const int a = fr.a_lo + (int)(t - bi * (unsigned)fr.wa);
+        const int a = fr.a_lo + (int)(t - __umul24(bi, (unsigned)fr.wa));
         const int b = fr.b_lo + (int)bi;
         loss = shell_cell<DET, LLS, 0>(p, sa, face, sa.active[sl], a, b);
     }
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
             const FaceRect fr = sa.face[f];
             const unsigned lt = (unsigned)(t - ba.face_off[k][f]);
             const unsigned bi = fr.magic ? __umulhi(lt, fr.magic) : lt;
-            const int a = fr.a_lo + (int)(lt - bi * (unsigned)fr.wa);
+            const int a = fr.a_lo + (int)(lt - __umul24(bi, (unsigned)fr.wa));
             const int b = fr.b_lo + (int)bi;
             loss = loss + shell_cell<DET, LLS, 0>(p, sa, f, s, a, b);
         }
