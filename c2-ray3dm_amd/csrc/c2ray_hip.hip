@@ -35,6 +35,7 @@ struct Ctx {
     float *d_lls = nullptr, *d_lls_T = nullptr, *d_clump = nullptr;
     bool  own[5] = {false, false, false, false, false};
     double *d_thick = nullptr, *d_thin = nullptr;
+    v2f64 *d_logtab = nullptr;                               // log10_tab's {r_i, -log10 r_i}
     bool have_tables = false, have_step = false;
     double dr[3] = {0, 0, 0}, vol = 0, lls = 0, temper = 0;
     float clumping = 1.0f;
@@ -200,7 +201,7 @@ KParams make_kparams(const Ctx *ctx)
     k.nhi = ctx->d_nhi; k.nhi_T = ctx->d_nhi_T; k.phih = (double *)ctx->grid[4]; k.phih_T = ctx->d_phih_T;
     k.gbox = ctx->d_gbox;
     k.lls_type = ctx->lls_type; k.R_max2 = ctx->R_max_LLS * ctx->R_max_LLS; k.lls = ctx->d_lls; k.lls_T = ctx->d_lls_T;
-    k.thick = ctx->d_thick; k.thin = ctx->d_thin;
+    k.thick = ctx->d_thick; k.thin = ctx->d_thin; k.logtab = ctx->d_logtab;
     k.srcpos = ctx->d_srcpos_b; k.srcw = ctx->d_srcw_b; k.normflux = ctx->d_nflux_b; k.planes = ctx->d_planes;
     return k;
 }
@@ -475,6 +476,16 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipMalloc(&ctx->d_phih_T, grid_bytes(ctx, 4)));
     HIP_TRY(hipMalloc(&ctx->d_thick, (size_t)(p->numtau + 1) * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_thin, (size_t)(p->numtau + 1) * sizeof(double)));
+    {   // log10_tab: interval i of m in [0.5,1) has centre c_i = (1 + (i+1/2)/64)/2; r_i = RN(1/c_i), T_i = RN(-log10 r_i)
+        double tab[2 * kLogTab];
+        for (int i = 0; i < kLogTab; ++i) {
+            const long double c = 0.5L * (1.0L + ((long double)i + 0.5L) / (long double)kLogTab);
+            const double r = (double)(1.0L / c);
+            tab[2 * i] = r; tab[2 * i + 1] = (double)(-log10l((long double)r));
+        }
+        HIP_TRY(hipMalloc(&ctx->d_logtab, sizeof tab));
+        HIP_TRY(hipMemcpy(ctx->d_logtab, tab, sizeof tab, hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMalloc(&ctx->d_photon_loss, sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_sum_nbox, sizeof(long long)));
     HIP_TRY(hipMalloc(&ctx->d_sum_partial, 4 * kSumBlocks * sizeof(double)));
@@ -516,7 +527,7 @@ void c2r_destroy(c2r_ctx *c)
     for (auto &kv : ctx->pinned) hipHostUnregister(const_cast<void *>(kv.first));
     free_sweep_scratch(ctx);
     for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
-    hipFree(ctx->d_thick); hipFree(ctx->d_thin);
+    hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_logtab);
     hipFree(ctx->d_nhi); hipFree(ctx->d_nhi_T); hipFree(ctx->d_phih_T);
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);

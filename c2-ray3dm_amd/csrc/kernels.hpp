@@ -20,6 +20,9 @@ namespace c2r {
 #endif
 constexpr int kBlock = C2R_BLOCK;   // threads per block of the sweep; a face's owned rectangle is flattened into tiles of kBlock
 
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+constexpr int kLogTab = 64;              // intervals of the log10 table (log10_tab)
+
 struct KParams {
     int n[3];
     int hl[3], hr[3];          // trace limits around a source: -hl..+hr (evolve_source.F90:100-102)
@@ -48,6 +51,7 @@ struct KParams {
     double *gbox;              // deterministic mode: [S_batch][2][ncell] per-source Gamma ([0] x-fastest cells of
                                // z/y faces, [1] y-fastest cells of x faces); null: atomics into phih/phih_T
     const double *thick, *thin;
+    const v2f64 *logtab;      // [kLogTab] {r_i, -log10 r_i} for log10_tab
     const int    *srcpos;      // 3 x S_batch (unwrapped, 1-based: cinterp's real(i0) needs it)
     const int    *srcw;        // 3 x S_batch wrapped to 0..N-1
     const double *normflux;    // S_batch
@@ -151,11 +155,47 @@ __device__ __forceinline__ double log10_pos(double x)      // x > 0, normal
 #endif
 }
 
+// The same log10 with a 64-interval table held in LDS (one private copy per wave, filled by
+// wave_log_table): x = 2^e * m, m in [0.5,1); interval i = top 6 fraction bits of m; with r_i ~ 1/c_i
+// (c_i the interval centre) z = m*r_i - 1 is exact to an fma rounding and |z| <= 2^-7, so
+// log(m) = -log(r_i) + log1p(z) needs a degree-7 series only: 17 VALU instructions and one 16-byte LDS
+// read instead of 32 VALU -- the LDS port is otherwise idle in this kernel, the VALU port is what binds it.
+// Entries: .x = r_i, .y = -log10(r_i) (host, long double).  Error <= ~1 ulp of the result like log10_pos.
+__device__ __forceinline__ double log10_tab(double x, const v2f64 *__restrict__ tab)   // x > 0, normal; tab in LDS
+{
+    const double m = __builtin_amdgcn_frexp_mant(x);        // [0.5, 1)
+    const int e = __builtin_amdgcn_frexp_exp(x);
+    const unsigned i = ((unsigned)__double2hiint(m) >> 14) & 63u;
+    const v2f64 rt = tab[i];
+    const double z = __builtin_fma(m, rt.x, -1.0);
+    // log1p(z) = z + z^2 * (-1/2 + z/3 - z^2/4 + z^3/5 - z^4/6 + z^5/7); next term z^8/8 < 2^-59
+    double P = __builtin_fma(z, 1.0 / 7.0, -1.0 / 6.0);
+    P = __builtin_fma(z, P, 0.2);
+    P = __builtin_fma(z, P, -0.25);
+    P = __builtin_fma(z, P, 1.0 / 3.0);
+    P = __builtin_fma(z, P, -0.5);
+    const double l1p = __builtin_fma(z * z, P, z);
+    return __builtin_fma((double)e, 3.01029995663981198017e-01, __builtin_fma(l1p, 4.34294481903251816668e-01, rt.y));
+}
+// Every wave keeps its own copy of the table in LDS: filled with all 64 lanes active at the top of the
+// kernel, read later by the same wave only, so no barrier is needed (same-wave LDS accesses are ordered).
+__device__ __forceinline__ const v2f64 *wave_log_table(const v2f64 *__restrict__ g, v2f64 *lds /* [waves][64] */)
+{
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    v2f64 *mine = lds + (tid & ~63u);
+    mine[lane] = g[lane];
+    return mine;
+}
+
 // radiation_photoionrates.F90:184-208  set_tau_table_positions
 struct TauPos { int ip, ip1; double res; };
-__device__ __forceinline__ TauPos tau_pos(double tau, const KParams &p)
+__device__ __forceinline__ TauPos tau_pos(double tau, const KParams &p, const v2f64 *__restrict__ ltab)
 {
+#ifdef C2R_LOG10_NOTAB
     const double lt = log10_pos(fmax(1.0e-20, tau));
+#else
+    const double lt = log10_tab(fmax(1.0e-20, tau), ltab);
+#endif
     const double od = fmin(p.numtau_d, fmax(0.0, 1.0 + udiv(lt - p.minlogtau, p.dlogtau, p.inv_dlogtau, p.exact_udiv)));
     TauPos t;
     t.ip = (int)od;
@@ -172,15 +212,15 @@ __device__ __forceinline__ double read_table(const double *__restrict__ tab, con
 
 // radiation_photoionrates.F90:71-179, :233-317 for NumFreqBnd=1, stellar table.
 // Returns photo_cell_HI (already divided by vol_ph); out = photo_out.
-__device__ __forceinline__ double photoion(const KParams &p, double cd_in, double cd_out,
+__device__ __forceinline__ double photoion(const KParams &p, const v2f64 *__restrict__ ltab, double cd_in, double cd_out,
                                            double vol_ph, double nflux, double &p_out)
 {
     const double tau_in = cd_in * p.sigma, tau_out = cd_out * p.sigma;
-    const TauPos pin = tau_pos(tau_in, p);
+    const TauPos pin = tau_pos(tau_in, p, ltab);
     const double p_in = nflux * read_table(p.thick, pin);
     double p_cell;
     if (fabs(tau_out - tau_in) > p.tau_limit) {
-        p_out = nflux * read_table(p.thick, tau_pos(tau_out, p));
+        p_out = nflux * read_table(p.thick, tau_pos(tau_out, p, ltab));
         p_cell = p_in - p_out;
     } else {
         p_cell = nflux * (tau_out - tau_in) * read_table(p.thin, pin);
@@ -207,6 +247,8 @@ __device__ __forceinline__ double block_sum_256(double v, double *sm /* >= 4 dou
 __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0, int boxR1, int boxR2,
                                int boxL0, int boxL1, int boxL2, double *loss_acc, double *dbg_cdout)
 {
+    __shared__ v2f64 s_log[kLogTab];                          // blocks of one wave
+    const v2f64 *ltab = wave_log_table(p.logtab, s_log);
     const int sl = blockIdx.x * blockDim.x + threadIdx.x;
     if (sl >= nsrc) return;
     const int s = active[sl];
@@ -226,7 +268,7 @@ __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0
     const double nflux = p.normflux[s];
     double p_out = 0.0, gamma = 0.0;
     if (nflux > 0.0) {      // cd_in = 0 is never above max_coldensh
-        gamma = photoion(p, cd_in, cd_out, vol_ph, nflux, p_out) / nhi;
+        gamma = photoion(p, ltab, cd_in, cd_out, vol_ph, nflux, p_out) / nhi;
         if (!p.gbox) atomicAdd(&p.phih[id], gamma);
     }
     if (p.gbox) p.gbox[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = gamma;
@@ -273,8 +315,8 @@ __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned
 // cell's photon-loss contribution (0 unless it lies on the sub-box surface).  Shared by the
 // shell-per-launch kernel (face block-uniform) and the fused first-sub-box kernel (face per thread).
 template <bool DET, int LLS, int GLC>
-__device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &sa, const int face, const int s,
-                                             const int a, const int b)
+__device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
+                                             const int face, const int s, const int a, const int b)
 {
     double loss = 0.0;
     {
@@ -381,7 +423,7 @@ __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &
         double gamma = 0.0;
         if (!stop_far && !(cd_in > p.max_coldensh) && nflux > 0.0) {
             double p_out;
-            gamma = fdiv(photoion(p, cd_in, cd_out, vol_ph, nflux, p_out), nhi);
+            gamma = fdiv(photoion(p, ltab, cd_in, cd_out, vol_ph, nflux, p_out), nhi);
             if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id], gamma);
             if (sa.has_boundary) {
                 const bool bnd = d0 == sa.boxR[0] || d1 == sa.boxR[1] || d2 == sa.boxR[2] ||
@@ -399,18 +441,21 @@ template <bool DET, int LLS>
 __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
 {
     __shared__ double sm[16];
+    __shared__ v2f64 s_log[kBlock];                      // kBlock/64 waves x 64 entries
     const int face = blockIdx.y;
     const int sl = blockIdx.z;
     const int tile = blockIdx.x;
     if (sl >= *sa.n_active) return;              // block-uniform: this source retired after the launch was sized
     const FaceRect fr = sa.face[face];
+    if (tile >= fr.ntiles && !sa.has_boundary) return;   // block-uniform: nothing to do and no partial to write
+    const v2f64 *ltab = wave_log_table(p.logtab, s_log);
     double loss = 0.0;
     const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
     const unsigned bi = fr.magic ? __umulhi(t, fr.magic) : t;
     if (tile < fr.ntiles && bi < (unsigned)fr.wb) {
         const int a = fr.a_lo + (int)(t - __umul24(bi, (unsigned)fr.wa));
         const int b = fr.b_lo + (int)bi;
-        loss = shell_cell<DET, LLS, 0>(p, sa, face, sa.active[sl], a, b);
+        loss = shell_cell<DET, LLS, 0>(p, sa, ltab, face, sa.active[sl], a, b);
     }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
@@ -440,9 +485,11 @@ template <bool DET, int LLS>
 __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
 {
     __shared__ double sm[16];
+    __shared__ v2f64 s_log[1024];
     const int sl = blockIdx.x;
     if (sl >= *ba.n_active) return;
     const int s = ba.active[sl];
+    const v2f64 *ltab = wave_log_table(p.logtab, s_log);
     for (int k = 0; k < ba.nshell; ++k) {
         const ShellArgs &sa = ba.sh[k];
         double loss = 0.0;
@@ -455,7 +502,7 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
             const unsigned bi = fr.magic ? __umulhi(lt, fr.magic) : lt;
             const int a = fr.a_lo + (int)(lt - __umul24(bi, (unsigned)fr.wa));
             const int b = fr.b_lo + (int)bi;
-            loss = loss + shell_cell<DET, LLS, 0>(p, sa, f, s, a, b);
+            loss = loss + shell_cell<DET, LLS, 0>(p, sa, ltab, f, s, a, b);
         }
         if (sa.has_boundary) {
             const double tot = block_sum_256(loss, sm);       // contains a barrier
