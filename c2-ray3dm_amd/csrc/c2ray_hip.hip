@@ -314,7 +314,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             if (ba.nshell > 0) {
                 ba.active = ctx->d_active[cur]; ba.n_active = ctx->d_nactive + cur; ba.loss_acc = ctx->d_loss_acc;
                 const dim3 grid(bound), blk(most <= 256 ? 256 : (most <= 512 ? 512 : 1024));
-                prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
+                // (not in the k_sweep_shell launch timing of c2r_profile: a different kernel, 21^3 cells per source)
 #define C2R_LAUNCH_FUSED(D, L) hipLaunchKernelGGL((k_sweep_box_fused<D, L>), grid, blk, 0, st, k, ba)
                 switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
                     case 2: C2R_LAUNCH_FUSED(false, 1); break;
@@ -325,7 +325,6 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                     default: C2R_LAUNCH_FUSED(true, 3); break;
                 }
 #undef C2R_LAUNCH_FUSED
-                prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
             }
         } else
         for (int q = q0; q <= q1; ++q) {
