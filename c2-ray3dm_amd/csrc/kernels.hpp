@@ -63,7 +63,8 @@ struct KParams {
 struct FaceRect {
     int a_lo, wa, b_lo, wb;
     unsigned magic;            // t / wa == umulhi(t, magic) for t < wa*wb (0: wa == 1)
-    int ntiles;                // 0: face absent from this shell
+    int ntiles;                // tiles of k_sweep_shell (pairs of rows); 0: face absent from this shell
+    int pp, npr;               // row pairs of the rows b >= 0; row pairs in all (k_sweep_shell walks wa x npr pairs)
 };
 
 struct ShellArgs {
@@ -331,129 +332,210 @@ __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned
 // unit-stride axis of the arrays the face reads (x for z/y faces, y in the transposed replicas
 // for x faces).
 // DET: deterministic_rates mode (per-source Gamma grids instead of atomics); LLS: type_of_LLS (1,2,3)
-// One cell (a,b) of face `face` in shell sa.q of source s: everything evolve0D does for it.  Returns the
-// cell's photon-loss contribution (0 unless it lies on the sub-box surface).  Shared by the
-// shell-per-launch kernel (face block-uniform) and the fused first-sub-box kernel (face per thread).
+// ---- one cell, in two phases so that a thread can interleave two cells ---------------------------------
+// CellState: everything evolve0D computes for cell (a,b) of face `face` in shell sa.q of source s before it
+// touches memory for writing; cell_commit: the stores, the photo-ionization rate, the atomic and the
+// photon loss.  The four upstream corners arrive as values (c*) with their weight reciprocals
+// r* = 1/max(0.6, c*sigma) (weightf, column_density.f90:276-293), because neighbouring cells share them.
+struct CellState {
+    int d0, d1, d2;
+    unsigned c0, c1, c2, id, o8;
+    double nhi, cd_in, cd_out, vol_ph;
+    bool stop_far;
+};
+
+// plane offset of (a,b) in bytes and the in-range test of a plane coordinate against shell q-1
+__device__ __forceinline__ unsigned plane_off8(const KParams &p, int a, int b)
+{
+    return ((unsigned)((int)__umul24((unsigned)(b + p.R), (unsigned)p.P) + (a + p.R))) * 8u;   // factors in [0, 2^24)
+}
+
+template <int LLS>
+__device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArgs &sa, const int face, const int s,
+                                                const int a, const int b, const double c1v, const double c2v,
+                                                const double c3v, const double c4v, const double r1, const double r2,
+                                                const double r3, const double r4)
+{
+    CellState cs;
+    const int q = sa.q;
+    const int axis = 2 - (face >> 1);            // 2:z 1:y 0:x
+    const int pd = (face & 1) ? -q : q;
+    // mesh-axis deltas and the source coordinates seen along (a,b); all block-uniform selects
+    cs.d0 = (axis == 0) ? pd : a;
+    cs.d1 = (axis == 2) ? b : ((axis == 1) ? pd : a);
+    cs.d2 = (axis == 2) ? pd : b;
+    const int s0 = p.srcpos[3 * s + 0], s1 = p.srcpos[3 * s + 1], s2 = p.srcpos[3 * s + 2];
+    const int su = (axis == 0) ? s1 : s0;
+    const int sv = (axis == 2) ? s1 : s2;
+    // periodic wrap (evolve_point.F90:122): srcw + d + n lies in [n/2, 5n/2); min(c, c-n) as
+    // unsigned folds [n, 2n) onto [0, n), twice
+    unsigned c0 = (unsigned)(p.srcw[3 * s + 0] + p.n[0] + cs.d0);
+    unsigned c1 = (unsigned)(p.srcw[3 * s + 1] + p.n[1] + cs.d1);
+    unsigned c2 = (unsigned)(p.srcw[3 * s + 2] + p.n[2] + cs.d2);
+    c0 = min(c0, c0 - (unsigned)p.n[0]);  c0 = min(c0, c0 - (unsigned)p.n[0]);
+    c1 = min(c1, c1 - (unsigned)p.n[1]);  c1 = min(c1, c1 - (unsigned)p.n[1]);
+    c2 = min(c2, c2 - (unsigned)p.n[2]);  c2 = min(c2, c2 - (unsigned)p.n[2]);
+    cs.c0 = c0; cs.c1 = c1; cs.c2 = c2;
+    // cell index in the array this face reads: x-fastest, or y-fastest in the transposed replicas
+    // (block-uniform choice; 24-bit multiplies: every factor is below 2^24)
+    const bool xf = (axis == 0);
+    const unsigned ca = xf ? c1 : c0, cb = xf ? c0 : c1;
+    const unsigned na = xf ? (unsigned)p.n[1] : (unsigned)p.n[0], nb = xf ? (unsigned)p.n[0] : (unsigned)p.n[1];
+    cs.id = ca + __umul24(na, cb + __umul24(nb, c2));
+    const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(xf ? p.nhi_T : p.nhi, ncell * 8u);
+    cs.nhi = buf_load_f64(r_x, cs.id * 8u);
+    cs.o8 = plane_off8(p, a, b);
+
+    // cinterp, generic in (a,b,pd): the three branches differ only by which axes play (u,v).
+    // real(int) conversions of the reference are f32 but exact (|.| < 2^24): cvt i32->f64.
+    const int sga = a < 0 ? -1 : 1, sgb = b < 0 ? -1 : 1;
+    const int am = a - sga, bm = b - sgb;
+    const double du = (double)a, dv = (double)b;
+    const double uc = sa.alam * du + (double)su;
+    const double vc = sa.alam * dv + (double)sv;
+    // real(im)+0.5*sgni (column_density.f90:117) is a half-integer: one conversion of 2*im+sgni
+    const double ddu = 2.0 * fabs(uc - 0.5 * (double)(2 * (su + am) + sga));
+    const double ddv = 2.0 * fabs(vc - 0.5 * (double)(2 * (sv + bm) + sgb));
+    const double w1 = ((1. - ddu) * (1. - ddv)) * r1;
+    const double w2 = ((1. - ddv) * ddu) * r2;
+    const double w3 = ((1. - ddu) * ddv) * r3;
+    const double w4 = (ddu * ddv) * r4;
+    double cdi = fdiv(c1v * w1 + c2v * w2 + c3v * w3 + c4v * w4, w1 + w2 + w3 + w4);
+    if (q == 1 && (abs(a) == 1 || abs(b) == 1))
+        cdi = (abs(a) == 1 && abs(b) == 1) ? p.sqrt3 * cdi : p.sqrt2 * cdi;
+    double path = fsqrt(udiv(du * du + dv * dv, sa.dp2, sa.inv_dp2, p.exact_udiv) + 1.0);
+
+    // evolve0D
+    path = path * p.dr[0];
+    // dist2 = xs*xs + ys*ys + zs*zs (evolve_point.F90:171-174); the term of the face's own axis
+    // is the same for the whole launch (sa.d2axis = (dr_axis * q)^2)
+    const double xs = p.dr[0] * (double)cs.d0;
+    const double ys = p.dr[1] * (double)cs.d1;
+    const double zs = p.dr[2] * (double)cs.d2;
+    const double xx = (axis == 0) ? sa.d2axis[0] : xs * xs;
+    const double yy = (axis == 1) ? sa.d2axis[1] : ys * ys;
+    const double zz = (axis == 2) ? sa.d2axis[2] : zs * zs;
+    const double dist2 = xx + yy + zz;
+    cs.vol_ph = p.fourpi * dist2 * path;
+    // LLS opacity (evolve_point.F90:186-196): homogeneous column, per-cell column (LLS_point), or a
+    // hard barrier at R_max that only stops the transfer
+    cs.cd_in = cdi;
+    cs.stop_far = false;
+    if (LLS == 3) {
+        cs.stop_far = dist2 > p.R_max2;
+    } else {
+        const double lls = (LLS == 2) ? (double)(xf ? p.lls_T : p.lls)[cs.id] : p.coldensh_LLS;
+        cs.cd_in = cdi + udiv(lls * path, p.dr[0], p.inv_dr0, p.exact_udiv);
+    }
+    cs.cd_out = cs.cd_in + cs.nhi * path;
+    return cs;
+}
+
+// Returns the cell's photon-loss contribution (0 unless it lies on the sub-box surface).
+template <bool DET, int LLS>
+__device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
+                                              const int face, const int s, const int a, const int b, const CellState &cs)
+{
+    double loss = 0.0;
+    const int q = sa.q;
+    const int axis = 2 - (face >> 1);
+    const int pd = (face & 1) ? -q : q;
+    const bool xf = (axis == 0);
+    const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
+    const unsigned plane_bytes = (unsigned)p.PP * 8u;
+    const double cd_out = cs.cd_out;
+    // store into this face's plane and into the planes of the faces sharing the cell
+    const __amdgpu_buffer_rsrc_t r_cur = make_rsrc(p.planes + ((size_t)s * 2 + (q & 1)) * 6 * p.PP, 6u * plane_bytes);
+    buf_store_f64(r_cur, (unsigned)face * plane_bytes + cs.o8, cd_out);
+    if (axis == 2) {
+        if (abs(a) == q)   // x-face (u=y=b, v=z=pd)
+            buf_store_f64(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((pd + p.R) * p.P + (b + p.R)) * 8u, cd_out);
+        if (abs(b) == q)   // y-face (u=x=a, v=z=pd)
+            buf_store_f64(r_cur, (b > 0 ? 2u : 3u) * plane_bytes + (unsigned)((pd + p.R) * p.P + (a + p.R)) * 8u, cd_out);
+    } else if (axis == 1) {
+        if (abs(a) == q)   // x-face (u=y=pd, v=z=b)
+            buf_store_f64(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((b + p.R) * p.P + (pd + p.R)) * 8u, cd_out);
+    }
+    if (sa.dbg_cdout) sa.dbg_cdout[cs.c0 + (unsigned)p.n[0] * (cs.c1 + (unsigned)p.n[1] * cs.c2)] = cd_out;
+
+    const double nflux = p.normflux[s];
+    double gamma = 0.0;
+    if (!cs.stop_far && !(cs.cd_in > p.max_coldensh) && nflux > 0.0) {
+        double p_out;
+        gamma = fdiv(photoion(p, ltab, cs.cd_in, cd_out, cs.vol_ph, nflux, p_out), cs.nhi);
+        if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[cs.id], gamma);
+        if (sa.has_boundary) {
+            const bool bnd = cs.d0 == sa.boxR[0] || cs.d1 == sa.boxR[1] || cs.d2 == sa.boxR[2] ||
+                             cs.d0 == -sa.boxL[0] || cs.d1 == -sa.boxL[1] || cs.d2 == -sa.boxL[2];
+            if (bnd) loss = fdiv(p_out * p.vol, cs.vol_ph);
+        }
+    }
+    // deterministic mode: every visited cell records its rate (zero included) for k_gamma_reduce
+    if (DET) p.gbox[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + cs.id] = gamma;
+    return loss;
+}
+
+__device__ __forceinline__ double weight_rcp(const KParams &p, double c) { return frcp(fmax(p.wfloor, c * p.sigma)); }
+
+// One cell (a,b): four upstream corners of plane q-1 (zero weight and value outside |.| <= q-1: an
+// out-of-range offset reads 0), state, commit.  Used by the fused first-sub-box kernel.
 template <bool DET, int LLS, int GLC>
 __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                              const int face, const int s, const int a, const int b)
 {
-    double loss = 0.0;
-    {
-        const int q = sa.q;
-        const int axis = 2 - (face >> 1);            // 2:z 1:y 0:x
-        const int pd = (face & 1) ? -q : q;
-        // mesh-axis deltas and the source coordinates seen along (a,b); all block-uniform selects
-        const int d0 = (axis == 0) ? pd : a;
-        const int d1 = (axis == 2) ? b : ((axis == 1) ? pd : a);
-        const int d2 = (axis == 2) ? pd : b;
-        const int s0 = p.srcpos[3 * s + 0], s1 = p.srcpos[3 * s + 1], s2 = p.srcpos[3 * s + 2];
-        const int su = (axis == 0) ? s1 : s0;
-        const int sv = (axis == 2) ? s1 : s2;
-        // periodic wrap (evolve_point.F90:122): srcw + d + n lies in [n/2, 5n/2); min(c, c-n) as
-        // unsigned folds [n, 2n) onto [0, n), twice
-        unsigned c0 = (unsigned)(p.srcw[3 * s + 0] + p.n[0] + d0);
-        unsigned c1 = (unsigned)(p.srcw[3 * s + 1] + p.n[1] + d1);
-        unsigned c2 = (unsigned)(p.srcw[3 * s + 2] + p.n[2] + d2);
-        c0 = min(c0, c0 - (unsigned)p.n[0]);  c0 = min(c0, c0 - (unsigned)p.n[0]);
-        c1 = min(c1, c1 - (unsigned)p.n[1]);  c1 = min(c1, c1 - (unsigned)p.n[1]);
-        c2 = min(c2, c2 - (unsigned)p.n[2]);  c2 = min(c2, c2 - (unsigned)p.n[2]);
-        // cell index in the array this face reads: x-fastest, or y-fastest in the transposed replicas
-        // (block-uniform choice; 24-bit multiplies: every factor is below 2^24)
-        const bool xf = (axis == 0);
-        const unsigned ca = xf ? c1 : c0, cb = xf ? c0 : c1;
-        const unsigned na = xf ? (unsigned)p.n[1] : (unsigned)p.n[0], nb = xf ? (unsigned)p.n[0] : (unsigned)p.n[1];
-        const unsigned id = ca + __umul24(na, cb + __umul24(nb, c2));
-        const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
-        const __amdgpu_buffer_rsrc_t r_x = make_rsrc(xf ? p.nhi_T : p.nhi, ncell * 8u);
-        const double nhi = buf_load_f64(r_x, id * 8u);
+    const int q = sa.q, qm = q - 1;
+    const int sga = a < 0 ? -1 : 1, sgb = b < 0 ? -1 : 1;
+    const int am = a - sga, bm = b - sgb;
+    const unsigned plane_bytes = (unsigned)p.PP * 8u;
+    const __amdgpu_buffer_rsrc_t r_prev =
+        make_rsrc(p.planes + ((size_t)s * 2 + (qm & 1)) * 6 * p.PP + (size_t)face * p.PP, plane_bytes);
+    const bool ina = abs(a) <= qm, inam = abs(am) <= qm, inb = abs(b) <= qm, inbm = abs(bm) <= qm;
+    const unsigned p8 = (unsigned)p.P * 8u;
+    const unsigned o8 = plane_off8(p, a, b), da8 = (unsigned)(sga * 8), db8 = b < 0 ? 0u - p8 : p8;
+    const double c1v = buf_load_f64<GLC>(r_prev, (inam && inbm) ? o8 - db8 - da8 : kOOB);
+    const double c2v = buf_load_f64<GLC>(r_prev, (ina && inbm) ? o8 - db8 : kOOB);
+    const double c3v = buf_load_f64<GLC>(r_prev, (inam && inb) ? o8 - da8 : kOOB);
+    const double c4v = buf_load_f64<GLC>(r_prev, (ina && inb) ? o8 : kOOB);
+    const CellState cs = cell_state<LLS>(p, sa, face, s, a, b, c1v, c2v, c3v, c4v, weight_rcp(p, c1v), weight_rcp(p, c2v),
+                                         weight_rcp(p, c3v), weight_rcp(p, c4v));
+    return cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b, cs);
+}
 
-        // upstream corners in plane q-1 of this face (zero weight outside |.| <= q-1)
-        const int sga = a < 0 ? -1 : 1, sgb = b < 0 ? -1 : 1;
-        const int am = a - sga, bm = b - sgb;
-        const unsigned plane_bytes = (unsigned)p.PP * 8u;
-        const __amdgpu_buffer_rsrc_t r_prev =
-            make_rsrc(p.planes + ((size_t)s * 2 + ((q - 1) & 1)) * 6 * p.PP + (size_t)face * p.PP, plane_bytes);
-        const int qm = q - 1;
-        const bool ina = abs(a) <= qm, inam = abs(am) <= qm, inb = abs(b) <= qm, inbm = abs(bm) <= qm;
-        const int o = (int)__umul24((unsigned)(b + p.R), (unsigned)p.P) + (a + p.R);          // factors in [0, 2^24)
-        const unsigned p8 = (unsigned)p.P * 8u;
-        const unsigned o8 = (unsigned)o * 8u, da8 = (unsigned)(sga * 8), db8 = b < 0 ? 0u - p8 : p8;
-        const double c1v = buf_load_f64<GLC>(r_prev, (inam && inbm) ? o8 - db8 - da8 : kOOB);
-        const double c2v = buf_load_f64<GLC>(r_prev, (ina && inbm) ? o8 - db8 : kOOB);
-        const double c3v = buf_load_f64<GLC>(r_prev, (inam && inb) ? o8 - da8 : kOOB);
-        const double c4v = buf_load_f64<GLC>(r_prev, (ina && inb) ? o8 : kOOB);
-
-        // cinterp, generic in (a,b,pd): the three branches differ only by which axes play (u,v).
-        // real(int) conversions of the reference are f32 but exact (|.| < 2^24): cvt i32->f64.
-        const double du = (double)a, dv = (double)b;
-        const double uc = sa.alam * du + (double)su;
-        const double vc = sa.alam * dv + (double)sv;
-        // real(im)+0.5*sgni (column_density.f90:117) is a half-integer: one conversion of 2*im+sgni
-        const double ddu = 2.0 * fabs(uc - 0.5 * (double)(2 * (su + am) + sga));
-        const double ddv = 2.0 * fabs(vc - 0.5 * (double)(2 * (sv + bm) + sgb));
-        const double w1 = ((1. - ddu) * (1. - ddv)) * frcp(fmax(p.wfloor, c1v * p.sigma));
-        const double w2 = ((1. - ddv) * ddu) * frcp(fmax(p.wfloor, c2v * p.sigma));
-        const double w3 = ((1. - ddu) * ddv) * frcp(fmax(p.wfloor, c3v * p.sigma));
-        const double w4 = (ddu * ddv) * frcp(fmax(p.wfloor, c4v * p.sigma));
-        double cdi = fdiv(c1v * w1 + c2v * w2 + c3v * w3 + c4v * w4, w1 + w2 + w3 + w4);
-        if (q == 1 && (abs(a) == 1 || abs(b) == 1))
-            cdi = (abs(a) == 1 && abs(b) == 1) ? p.sqrt3 * cdi : p.sqrt2 * cdi;
-        double path = fsqrt(udiv(du * du + dv * dv, sa.dp2, sa.inv_dp2, p.exact_udiv) + 1.0);
-
-        // evolve0D
-        path = path * p.dr[0];
-        // dist2 = xs*xs + ys*ys + zs*zs (evolve_point.F90:171-174); the term of the face's own axis
-        // is the same for the whole launch (sa.d2axis = (dr_axis * q)^2)
-        const double xs = p.dr[0] * (double)d0;
-        const double ys = p.dr[1] * (double)d1;
-        const double zs = p.dr[2] * (double)d2;
-        const double xx = (axis == 0) ? sa.d2axis[0] : xs * xs;
-        const double yy = (axis == 1) ? sa.d2axis[1] : ys * ys;
-        const double zz = (axis == 2) ? sa.d2axis[2] : zs * zs;
-        const double dist2 = xx + yy + zz;
-        const double vol_ph = p.fourpi * dist2 * path;
-        // LLS opacity (evolve_point.F90:186-196): homogeneous column, per-cell column (LLS_point), or a
-        // hard barrier at R_max that only stops the transfer
-        double cd_in = cdi;
-        bool stop_far = false;
-        if (LLS == 3) {
-            stop_far = dist2 > p.R_max2;
-        } else {
-            const double lls = (LLS == 2) ? (double)(xf ? p.lls_T : p.lls)[id] : p.coldensh_LLS;
-            cd_in = cdi + udiv(lls * path, p.dr[0], p.inv_dr0, p.exact_udiv);
-        }
-        const double cd_out = cd_in + nhi * path;
-
-        // store into this face's plane and into the planes of the faces sharing the cell
-        const __amdgpu_buffer_rsrc_t r_cur = make_rsrc(p.planes + ((size_t)s * 2 + (q & 1)) * 6 * p.PP, 6u * plane_bytes);
-        buf_store_f64(r_cur, (unsigned)face * plane_bytes + o8, cd_out);
-        if (axis == 2) {
-            if (abs(a) == q)   // x-face (u=y=b, v=z=pd)
-                buf_store_f64(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((pd + p.R) * p.P + (b + p.R)) * 8u, cd_out);
-            if (abs(b) == q)   // y-face (u=x=a, v=z=pd)
-                buf_store_f64(r_cur, (b > 0 ? 2u : 3u) * plane_bytes + (unsigned)((pd + p.R) * p.P + (a + p.R)) * 8u, cd_out);
-        } else if (axis == 1) {
-            if (abs(a) == q)   // x-face (u=y=pd, v=z=b)
-                buf_store_f64(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((b + p.R) * p.P + (pd + p.R)) * 8u, cd_out);
-        }
-        if (sa.dbg_cdout) sa.dbg_cdout[c0 + (unsigned)p.n[0] * (c1 + (unsigned)p.n[1] * c2)] = cd_out;
-
-        const double nflux = p.normflux[s];
-        double gamma = 0.0;
-        if (!stop_far && !(cd_in > p.max_coldensh) && nflux > 0.0) {
-            double p_out;
-            gamma = fdiv(photoion(p, ltab, cd_in, cd_out, vol_ph, nflux, p_out), nhi);
-            if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id], gamma);
-            if (sa.has_boundary) {
-                const bool bnd = d0 == sa.boxR[0] || d1 == sa.boxR[1] || d2 == sa.boxR[2] ||
-                                 d0 == -sa.boxL[0] || d1 == -sa.boxL[1] || d2 == -sa.boxL[2];
-                if (bnd) loss = fdiv(p_out * p.vol, vol_ph);
-            }
-        }
-        // deterministic mode: every visited cell records its rate (zero included) for k_gamma_reduce
-        if (DET) p.gbox[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + id] = gamma;
-    }
+// Two cells of one column: (a,b0) and (a,b0+sgb), sgb = the sign class of both rows (rows are paired
+// outward from 0 within each sign class, see FaceRect).  Cell 1's upstream row is cell 0's own row, so the
+// pair needs six corners instead of eight -- and six of the seven-instruction weight reciprocals -- and
+// everything that depends on `a` alone (its sign, the u-interpolation factor, the wrap of that mesh axis)
+// is computed once; the two cells' dependency chains interleave in one thread.  Per-cell arithmetic is
+// exactly shell_cell's.
+template <bool DET, int LLS>
+__device__ __forceinline__ double shell_pair(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
+                                             const int face, const int s, const int a, const int b0, const int sgb,
+                                             const bool valid1)
+{
+    const int q = sa.q, qm = q - 1;
+    const int sga = a < 0 ? -1 : 1;
+    const int am = a - sga;
+    const int b1 = b0 + sgb, bu = b0 - sgb;
+    const unsigned plane_bytes = (unsigned)p.PP * 8u;
+    const __amdgpu_buffer_rsrc_t r_prev =
+        make_rsrc(p.planes + ((size_t)s * 2 + (qm & 1)) * 6 * p.PP + (size_t)face * p.PP, plane_bytes);
+    const bool ina = abs(a) <= qm, inam = abs(am) <= qm;
+    const bool inu = abs(bu) <= qm, in0 = abs(b0) <= qm, in1 = abs(b1) <= qm;
+    const unsigned p8 = (unsigned)p.P * 8u;
+    const unsigned o0 = plane_off8(p, a, b0), da8 = (unsigned)(sga * 8), db8 = sgb < 0 ? 0u - p8 : p8;
+    const double u_m = buf_load_f64(r_prev, (inam && inu) ? o0 - db8 - da8 : kOOB);
+    const double u_a = buf_load_f64(r_prev, (ina && inu) ? o0 - db8 : kOOB);
+    const double m_m = buf_load_f64(r_prev, (inam && in0) ? o0 - da8 : kOOB);
+    const double m_a = buf_load_f64(r_prev, (ina && in0) ? o0 : kOOB);
+    const double d_m = buf_load_f64(r_prev, (inam && in1) ? o0 + db8 - da8 : kOOB);
+    const double d_a = buf_load_f64(r_prev, (ina && in1) ? o0 + db8 : kOOB);
+    const double ru_m = weight_rcp(p, u_m), ru_a = weight_rcp(p, u_a), rm_m = weight_rcp(p, m_m), rm_a = weight_rcp(p, m_a);
+    const double rd_m = weight_rcp(p, d_m), rd_a = weight_rcp(p, d_a);
+    const CellState cs0 = cell_state<LLS>(p, sa, face, s, a, b0, u_m, u_a, m_m, m_a, ru_m, ru_a, rm_m, rm_a);
+    const CellState cs1 = cell_state<LLS>(p, sa, face, s, a, b1, m_m, m_a, d_m, d_a, rm_m, rm_a, rd_m, rd_a);
+    double loss = cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b0, cs0);
+    if (valid1) loss = loss + cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b1, cs1);
     return loss;
 }
 
@@ -471,11 +553,17 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
     const v2f64 *ltab = wave_log_table(p.logtab, s_log);
     double loss = 0.0;
     const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
-    const unsigned bi = fr.magic ? __umulhi(t, fr.magic) : t;
-    if (tile < fr.ntiles && bi < (unsigned)fr.wb) {
+    const unsigned bi = fr.magic ? __umulhi(t, fr.magic) : t;       // pair-row index
+    if (tile < fr.ntiles && bi < (unsigned)fr.npr) {
         const int a = fr.a_lo + (int)(t - __umul24(bi, (unsigned)fr.wa));
-        const int b = fr.b_lo + (int)bi;
-        loss = shell_cell<DET, LLS, 0>(p, sa, ltab, face, sa.active[sl], a, b);
+        // rows are paired outward from 0 within each sign class: (0,1),(2,3),... then (-1,-2),(-3,-4),...
+        const bool pos = bi < (unsigned)fr.pp;
+        const int k2 = 2 * (pos ? (int)bi : (int)bi - fr.pp);
+        const int sgb = pos ? 1 : -1;
+        const int b0 = pos ? k2 : -1 - k2;
+        const int b1 = b0 + sgb;
+        const bool valid1 = pos ? (b1 <= fr.b_lo + fr.wb - 1) : (b1 >= fr.b_lo);
+        loss = shell_pair<DET, LLS>(p, sa, ltab, face, sa.active[sl], a, b0, sgb, valid1);
     }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
