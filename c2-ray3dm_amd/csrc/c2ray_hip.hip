@@ -476,8 +476,9 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipMalloc(&ctx->d_nhi, grid_bytes(ctx, 2)));
     HIP_TRY(hipMalloc(&ctx->d_nhi_T, grid_bytes(ctx, 2)));
     HIP_TRY(hipMalloc(&ctx->d_phih_T, grid_bytes(ctx, 4)));
-    HIP_TRY(hipMalloc(&ctx->d_thick, (size_t)(p->numtau + 1) * sizeof(double)));
-    HIP_TRY(hipMalloc(&ctx->d_thin, (size_t)(p->numtau + 1) * sizeof(double)));
+    // one spare element after each table: a copy of the last, so that tab[ip+1] exists for ip = numtau
+    HIP_TRY(hipMalloc(&ctx->d_thick, (size_t)(p->numtau + 2) * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_thin, (size_t)(p->numtau + 2) * sizeof(double)));
     {   // log10_tab: interval i of m in [0.5,1) has centre c_i = (1 + (i+1/2)/64)/2; r_i = RN(1/c_i), T_i = RN(-log10 r_i)
         double tab[2 * kLogTab];
         for (int i = 0; i < kLogTab; ++i) {
@@ -566,6 +567,8 @@ int c2r_set_tables(c2r_ctx *c, const double *thick, const double *thin, int32_t 
     if (n != ctx->prm.numtau + 1) FAIL(C2R_EINVAL, "table length must be numtau+1");
     HIP_TRY(hipMemcpy(ctx->d_thick, thick, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_thin, thin, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_thick + n, thick + n - 1, sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_thin + n, thin + n - 1, sizeof(double), hipMemcpyHostToDevice));
     ctx->have_tables = true;
     return C2R_OK;
 }

@@ -227,8 +227,11 @@ __device__ __forceinline__ TauPos tau_pos(double tau, const KParams &p, const v2
 // radiation_photoionrates.F90:212-228  read_table
 __device__ __forceinline__ double read_table(const double *__restrict__ tab, const TauPos &t)
 {
-    const double t0 = tab[t.ip], t1 = tab[t.ip1];
-    return t0 + (t1 - t0) * t.res;
+    // the device tables carry one extra element equal to the last (tab[numtau+1] = tab[numtau]), so the
+    // two neighbours tab(ip), tab(ip1 = min(numtau, ip+1)) are always tab[ip], tab[ip+1]: one 16-byte load
+    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+    const d2u v = *reinterpret_cast<const d2u *>(tab + t.ip);
+    return v.x + (v.y - v.x) * t.res;
 }
 
 // radiation_photoionrates.F90:71-179, :233-317 for NumFreqBnd=1, stellar table.
