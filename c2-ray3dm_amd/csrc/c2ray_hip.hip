@@ -181,8 +181,8 @@ FaceRect face_rect(const Ctx *ctx, int f, int q)
     r.a_lo = a_lo; r.wa = a_hi - a_lo + 1; r.b_lo = b_lo; r.wb = b_hi - b_lo + 1;
     r.magic = r.wa > 1 ? (unsigned)((1ULL << 32) / (unsigned)r.wa + 1ULL) : 0u;
     // k_sweep_shell gives a thread two rows of the same sign: (0,1),(2,3),... and (-1,-2),(-3,-4),...
-    r.pp = (b_hi + 2) / 2;                      // rows 0..b_hi
-    r.npr = r.pp + (-b_lo + 1) / 2;             // rows -1..b_lo
+    r.pp = (b_hi + kRows) / kRows;              // groups of the rows 0..b_hi
+    r.npr = r.pp + (-b_lo + kRows - 1) / kRows; // + groups of the rows -1..b_lo
     r.ntiles = (int)(((long long)r.wa * r.npr + kBlock - 1) / kBlock);
     return r;
 }

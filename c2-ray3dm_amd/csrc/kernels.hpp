@@ -340,12 +340,30 @@ __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned
 // touches memory for writing; cell_commit: the stores, the photo-ionization rate, the atomic and the
 // photon loss.  The four upstream corners arrive as values (c*) with their weight reciprocals
 // r* = 1/max(0.6, c*sigma) (weightf, column_density.f90:276-293), because neighbouring cells share them.
-struct CellState {
-    int d0, d1, d2;
-    unsigned c0, c1, c2, id, o8;
+struct CellState {                 // kept small: it is live while the thread's other cell is worked on
+    unsigned id, o8;
     double nhi, cd_in, cd_out, vol_ph;
     bool stop_far;
 };
+
+// mesh-axis deltas of plane cell (a,b) on a face normal to `axis` at signed distance pd (block-uniform selects)
+struct Delta3 { int d0, d1, d2; };
+__device__ __forceinline__ Delta3 mesh_delta(int axis, int pd, int a, int b)
+{
+    Delta3 d;
+    d.d0 = (axis == 0) ? pd : a;
+    d.d1 = (axis == 2) ? b : ((axis == 1) ? pd : a);
+    d.d2 = (axis == 2) ? pd : b;
+    return d;
+}
+// periodic wrap (evolve_point.F90:122): srcw + d + n lies in [n/2, 5n/2); min(c, c-n) as unsigned folds
+// [n, 2n) onto [0, n), twice
+__device__ __forceinline__ unsigned wrap_pos(int srcw, int n, int d)
+{
+    unsigned c = (unsigned)(srcw + n + d);
+    c = min(c, c - (unsigned)n);
+    return min(c, c - (unsigned)n);
+}
 
 // plane offset of (a,b) in bytes and the in-range test of a plane coordinate against shell q-1
 __device__ __forceinline__ unsigned plane_off8(const KParams &p, int a, int b)
@@ -363,22 +381,14 @@ __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArg
     const int q = sa.q;
     const int axis = 2 - (face >> 1);            // 2:z 1:y 0:x
     const int pd = (face & 1) ? -q : q;
-    // mesh-axis deltas and the source coordinates seen along (a,b); all block-uniform selects
-    cs.d0 = (axis == 0) ? pd : a;
-    cs.d1 = (axis == 2) ? b : ((axis == 1) ? pd : a);
-    cs.d2 = (axis == 2) ? pd : b;
+    // mesh-axis deltas and the source coordinates seen along (a,b)
+    const Delta3 dl = mesh_delta(axis, pd, a, b);
     const int s0 = p.srcpos[3 * s + 0], s1 = p.srcpos[3 * s + 1], s2 = p.srcpos[3 * s + 2];
     const int su = (axis == 0) ? s1 : s0;
     const int sv = (axis == 2) ? s1 : s2;
-    // periodic wrap (evolve_point.F90:122): srcw + d + n lies in [n/2, 5n/2); min(c, c-n) as
-    // unsigned folds [n, 2n) onto [0, n), twice
-    unsigned c0 = (unsigned)(p.srcw[3 * s + 0] + p.n[0] + cs.d0);
-    unsigned c1 = (unsigned)(p.srcw[3 * s + 1] + p.n[1] + cs.d1);
-    unsigned c2 = (unsigned)(p.srcw[3 * s + 2] + p.n[2] + cs.d2);
-    c0 = min(c0, c0 - (unsigned)p.n[0]);  c0 = min(c0, c0 - (unsigned)p.n[0]);
-    c1 = min(c1, c1 - (unsigned)p.n[1]);  c1 = min(c1, c1 - (unsigned)p.n[1]);
-    c2 = min(c2, c2 - (unsigned)p.n[2]);  c2 = min(c2, c2 - (unsigned)p.n[2]);
-    cs.c0 = c0; cs.c1 = c1; cs.c2 = c2;
+    const unsigned c0 = wrap_pos(p.srcw[3 * s + 0], p.n[0], dl.d0);
+    const unsigned c1 = wrap_pos(p.srcw[3 * s + 1], p.n[1], dl.d1);
+    const unsigned c2 = wrap_pos(p.srcw[3 * s + 2], p.n[2], dl.d2);
     // cell index in the array this face reads: x-fastest, or y-fastest in the transposed replicas
     // (block-uniform choice; 24-bit multiplies: every factor is below 2^24)
     const bool xf = (axis == 0);
@@ -413,9 +423,9 @@ __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArg
     path = path * p.dr[0];
     // dist2 = xs*xs + ys*ys + zs*zs (evolve_point.F90:171-174); the term of the face's own axis
     // is the same for the whole launch (sa.d2axis = (dr_axis * q)^2)
-    const double xs = p.dr[0] * (double)cs.d0;
-    const double ys = p.dr[1] * (double)cs.d1;
-    const double zs = p.dr[2] * (double)cs.d2;
+    const double xs = p.dr[0] * (double)dl.d0;
+    const double ys = p.dr[1] * (double)dl.d1;
+    const double zs = p.dr[2] * (double)dl.d2;
     const double xx = (axis == 0) ? sa.d2axis[0] : xs * xs;
     const double yy = (axis == 1) ? sa.d2axis[1] : ys * ys;
     const double zz = (axis == 2) ? sa.d2axis[2] : zs * zs;
@@ -460,7 +470,12 @@ __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs 
         if (abs(a) == q)   // x-face (u=y=pd, v=z=b)
             buf_store_f64(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((b + p.R) * p.P + (pd + p.R)) * 8u, cd_out);
     }
-    if (sa.dbg_cdout) sa.dbg_cdout[cs.c0 + (unsigned)p.n[0] * (cs.c1 + (unsigned)p.n[1] * cs.c2)] = cd_out;
+    const Delta3 dl = mesh_delta(axis, pd, a, b);          // recomputed, not carried in CellState
+    if (sa.dbg_cdout) {                                     // single-source test path: the N^3 coldensh_out
+        const unsigned c0 = wrap_pos(p.srcw[3 * s + 0], p.n[0], dl.d0), c1 = wrap_pos(p.srcw[3 * s + 1], p.n[1], dl.d1),
+                       c2 = wrap_pos(p.srcw[3 * s + 2], p.n[2], dl.d2);
+        sa.dbg_cdout[c0 + (unsigned)p.n[0] * (c1 + (unsigned)p.n[1] * c2)] = cd_out;
+    }
 
     const double nflux = p.normflux[s];
     double gamma = 0.0;
@@ -469,8 +484,8 @@ __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs 
         gamma = fdiv(photoion(p, ltab, cs.cd_in, cd_out, cs.vol_ph, nflux, p_out), cs.nhi);
         if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[cs.id], gamma);
         if (sa.has_boundary) {
-            const bool bnd = cs.d0 == sa.boxR[0] || cs.d1 == sa.boxR[1] || cs.d2 == sa.boxR[2] ||
-                             cs.d0 == -sa.boxL[0] || cs.d1 == -sa.boxL[1] || cs.d2 == -sa.boxL[2];
+            const bool bnd = dl.d0 == sa.boxR[0] || dl.d1 == sa.boxR[1] || dl.d2 == sa.boxR[2] ||
+                             dl.d0 == -sa.boxL[0] || dl.d1 == -sa.boxL[1] || dl.d2 == -sa.boxL[2];
             if (bnd) loss = fdiv(p_out * p.vol, cs.vol_ph);
         }
     }
@@ -505,40 +520,58 @@ __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &
     return cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b, cs);
 }
 
-// Two cells of one column: (a,b0) and (a,b0+sgb), sgb = the sign class of both rows (rows are paired
-// outward from 0 within each sign class, see FaceRect).  Cell 1's upstream row is cell 0's own row, so the
-// pair needs six corners instead of eight -- and six of the seven-instruction weight reciprocals -- and
-// everything that depends on `a` alone (its sign, the u-interpolation factor, the wrap of that mesh axis)
-// is computed once; the two cells' dependency chains interleave in one thread.  Per-cell arithmetic is
-// exactly shell_cell's.
+// kRows cells of one column: (a,b0), (a,b0+sgb), ... with sgb the sign class of all their rows (rows are
+// grouped outward from 0 within each sign class, see FaceRect).  Cell k+1's upstream row is cell k's own
+// row, so the group needs 2(kRows+1) corners instead of 4 kRows -- and as many of the seven-instruction
+// weight reciprocals -- and everything that depends on `a` alone (its sign, the u-interpolation factor,
+// the wrap of that mesh axis) is computed once; the cells' dependency chains interleave in one thread and
+// a wave's start-up is paid once for 64 kRows cells.  Per-cell arithmetic is exactly shell_cell's.
+// Same-box A/B at 256^3 x 1000: 1 row 231 ms, 2 rows 206, 3 rows 194, 4 rows 203 (86 VGPRs, occupancy 5).
+#ifndef C2R_ROWS
+#define C2R_ROWS 3
+#endif
+constexpr int kRows = C2R_ROWS;
 template <bool DET, int LLS>
-__device__ __forceinline__ double shell_pair(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
+__device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                              const int face, const int s, const int a, const int b0, const int sgb,
-                                             const bool valid1)
+                                             const int nvalid)
 {
     const int q = sa.q, qm = q - 1;
     const int sga = a < 0 ? -1 : 1;
     const int am = a - sga;
-    const int b1 = b0 + sgb, bu = b0 - sgb;
     const unsigned plane_bytes = (unsigned)p.PP * 8u;
     const __amdgpu_buffer_rsrc_t r_prev =
         make_rsrc(p.planes + ((size_t)s * 2 + (qm & 1)) * 6 * p.PP + (size_t)face * p.PP, plane_bytes);
     const bool ina = abs(a) <= qm, inam = abs(am) <= qm;
-    const bool inu = abs(bu) <= qm, in0 = abs(b0) <= qm, in1 = abs(b1) <= qm;
     const unsigned p8 = (unsigned)p.P * 8u;
-    const unsigned o0 = plane_off8(p, a, b0), da8 = (unsigned)(sga * 8), db8 = sgb < 0 ? 0u - p8 : p8;
-    const double u_m = buf_load_f64(r_prev, (inam && inu) ? o0 - db8 - da8 : kOOB);
-    const double u_a = buf_load_f64(r_prev, (ina && inu) ? o0 - db8 : kOOB);
-    const double m_m = buf_load_f64(r_prev, (inam && in0) ? o0 - da8 : kOOB);
-    const double m_a = buf_load_f64(r_prev, (ina && in0) ? o0 : kOOB);
-    const double d_m = buf_load_f64(r_prev, (inam && in1) ? o0 + db8 - da8 : kOOB);
-    const double d_a = buf_load_f64(r_prev, (ina && in1) ? o0 + db8 : kOOB);
-    const double ru_m = weight_rcp(p, u_m), ru_a = weight_rcp(p, u_a), rm_m = weight_rcp(p, m_m), rm_a = weight_rcp(p, m_a);
-    const double rd_m = weight_rcp(p, d_m), rd_a = weight_rcp(p, d_a);
-    const CellState cs0 = cell_state<LLS>(p, sa, face, s, a, b0, u_m, u_a, m_m, m_a, ru_m, ru_a, rm_m, rm_a);
-    const CellState cs1 = cell_state<LLS>(p, sa, face, s, a, b1, m_m, m_a, d_m, d_a, rm_m, rm_a, rd_m, rd_a);
-    double loss = cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b0, cs0);
-    if (valid1) loss = loss + cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b1, cs1);
+    const unsigned da8 = (unsigned)(sga * 8), db8 = sgb < 0 ? 0u - p8 : p8;
+    unsigned o = plane_off8(p, a, b0) - db8;                 // row b0 - sgb
+    double vm[kRows + 1], va[kRows + 1], rm[kRows + 1], ra[kRows + 1];
+#pragma unroll
+    for (int r = 0; r <= kRows; ++r) {                       // rows b0-sgb, b0, ..., b0+(kRows-1)sgb
+        const bool inr = abs(b0 + (r - 1) * sgb) <= qm;
+        vm[r] = buf_load_f64(r_prev, (inam && inr) ? o - da8 : kOOB);
+        va[r] = buf_load_f64(r_prev, (ina && inr) ? o : kOOB);
+        o += db8;
+    }
+#pragma unroll
+    for (int r = 0; r <= kRows; ++r) { rm[r] = weight_rcp(p, vm[r]); ra[r] = weight_rcp(p, va[r]); }
+    const CellState c0 = cell_state<LLS>(p, sa, face, s, a, b0, vm[0], va[0], vm[1], va[1], rm[0], ra[0], rm[1], ra[1]);
+    const CellState c1 = cell_state<LLS>(p, sa, face, s, a, b0 + sgb, vm[1], va[1], vm[2], va[2], rm[1], ra[1], rm[2], ra[2]);
+#if C2R_ROWS >= 3
+    const CellState c2 = cell_state<LLS>(p, sa, face, s, a, b0 + 2 * sgb, vm[2], va[2], vm[3], va[3], rm[2], ra[2], rm[3], ra[3]);
+#endif
+#if C2R_ROWS >= 4
+    const CellState c3 = cell_state<LLS>(p, sa, face, s, a, b0 + 3 * sgb, vm[3], va[3], vm[4], va[4], rm[3], ra[3], rm[4], ra[4]);
+#endif
+    double loss = cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b0, c0);
+    if (nvalid > 1) loss = loss + cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b0 + sgb, c1);
+#if C2R_ROWS >= 3
+    if (nvalid > 2) loss = loss + cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b0 + 2 * sgb, c2);
+#endif
+#if C2R_ROWS >= 4
+    if (nvalid > 3) loss = loss + cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b0 + 3 * sgb, c3);
+#endif
     return loss;
 }
 
@@ -556,17 +589,16 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
     const v2f64 *ltab = wave_log_table(p.logtab, s_log);
     double loss = 0.0;
     const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
-    const unsigned bi = fr.magic ? __umulhi(t, fr.magic) : t;       // pair-row index
+    const unsigned bi = fr.magic ? __umulhi(t, fr.magic) : t;       // row-group index
     if (tile < fr.ntiles && bi < (unsigned)fr.npr) {
         const int a = fr.a_lo + (int)(t - __umul24(bi, (unsigned)fr.wa));
-        // rows are paired outward from 0 within each sign class: (0,1),(2,3),... then (-1,-2),(-3,-4),...
+        // rows are grouped outward from 0 within each sign class: (0..kRows-1), ... then (-1..-kRows), ...
         const bool pos = bi < (unsigned)fr.pp;
-        const int k2 = 2 * (pos ? (int)bi : (int)bi - fr.pp);
+        const int k0 = kRows * (pos ? (int)bi : (int)bi - fr.pp);
         const int sgb = pos ? 1 : -1;
-        const int b0 = pos ? k2 : -1 - k2;
-        const int b1 = b0 + sgb;
-        const bool valid1 = pos ? (b1 <= fr.b_lo + fr.wb - 1) : (b1 >= fr.b_lo);
-        loss = shell_pair<DET, LLS>(p, sa, ltab, face, sa.active[sl], a, b0, sgb, valid1);
+        const int b0 = pos ? k0 : -1 - k0;
+        const int left = pos ? (fr.b_lo + fr.wb - b0) : (b0 - fr.b_lo + 1);     // rows from b0 to the end of the class
+        loss = shell_rows<DET, LLS>(p, sa, ltab, face, sa.active[sl], a, b0, sgb, min(left, kRows));
     }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
