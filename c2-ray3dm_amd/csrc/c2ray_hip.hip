@@ -75,7 +75,8 @@ struct Ctx {
       *d_hsc = nullptr;                       // ... and its device alias: kernels store results there directly
     double *d_dbg = nullptr, *d_pair = nullptr;
     // profiling
-    bool prof = false;
+    int prof = 0;               // 0 off; 1 an event pair around every k_sweep_shell launch; 2 one pair per sub-box
+    std::vector<int> ev_sweep_cnt;   // k_sweep_shell launches covered by each pair
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_sweep, ev_chem;
     size_t ev_sweep_used = 0, ev_chem_used = 0;
     double prof_sweep_ms = 0, prof_chem_ms = 0; long long prof_sweep_n = 0, prof_chem_n = 0;
@@ -226,7 +227,9 @@ void prof_collect(Ctx *ctx)
     if (!ctx->prof) return;
     for (size_t i = 0; i < ctx->ev_sweep_used; ++i) { float ms = 0; hipEventElapsedTime(&ms, ctx->ev_sweep[i].first, ctx->ev_sweep[i].second); ctx->prof_sweep_ms += ms; }
     for (size_t i = 0; i < ctx->ev_chem_used; ++i) { float ms = 0; hipEventElapsedTime(&ms, ctx->ev_chem[i].first, ctx->ev_chem[i].second); ctx->prof_chem_ms += ms; }
-    ctx->prof_sweep_n += (long long)ctx->ev_sweep_used; ctx->prof_chem_n += (long long)ctx->ev_chem_used;
+    for (size_t i = 0; i < ctx->ev_sweep_used; ++i) ctx->prof_sweep_n += i < ctx->ev_sweep_cnt.size() ? ctx->ev_sweep_cnt[i] : 1;
+    ctx->ev_sweep_cnt.clear();
+    ctx->prof_chem_n += (long long)ctx->ev_chem_used;
     ctx->ev_sweep_used = ctx->ev_chem_used = 0;
 }
 
@@ -329,11 +332,14 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                 }
 #undef C2R_LAUNCH_FUSED
             }
-        } else
+        } else {
+        int in_box = 0;                         // k_sweep_shell launches of this sub-box (coarse timing)
+        if (ctx->prof == 2) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
         for (int q = q0; q <= q1; ++q) {
             ShellArgs sa = shell_args(q);
             if (sa.tiles_max == 0) continue;
-            prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
+            ++in_box;
+            if (ctx->prof == 1) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
             {
                 const dim3 grid(sa.tiles_max, 6, bound), blk(kBlock);
 #define C2R_LAUNCH_SWEEP(D, L) hipLaunchKernelGGL((k_sweep_shell<D, L>), grid, blk, 0, st, k, sa)
@@ -347,10 +353,12 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                 }
 #undef C2R_LAUNCH_SWEEP
             }
-            prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
+            if (ctx->prof == 1) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(1); }
             if (sa.has_boundary)
                 hipLaunchKernelGGL(k_loss_reduce, dim3(bound), dim3(256), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
                                    ctx->d_loss_partial, 6 * sa.tiles_max, ctx->d_loss_acc);
+        }
+        if (ctx->prof == 2) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(in_box); }
         }
         const int can_grow = (p.subboxsize * nbox < ctx->hr[2]) && (p.subboxsize * nbox < ctx->hl[2]);
         hipLaunchKernelGGL(k_box_decide, dim3(1), dim3(1024), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
@@ -1081,7 +1089,7 @@ int c2r_profile(c2r_ctx *c, int32_t enable)
 {
     if (!c) return C2R_EINVAL;
     Ctx *ctx = C(c);
-    ctx->prof = enable != 0;
+    ctx->prof = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     ctx->prof_sweep_ms = ctx->prof_chem_ms = 0; ctx->prof_sweep_n = ctx->prof_chem_n = 0;
     return C2R_OK;
 }

@@ -263,8 +263,9 @@ class HipBackend:
         self._check(self.lib.c2r_selftest(self.ctx, C.byref(bad)), "c2r_selftest")
         return bad.value
 
-    def profile(self, enable=True):
-        self._check(self.lib.c2r_profile(self.ctx, 1 if enable else 0), "c2r_profile")
+    def profile(self, mode=1):
+        """0/False off, 1/True per-launch events, 2 one event pair per sub-box (see c2r_profile)."""
+        self._check(self.lib.c2r_profile(self.ctx, int(mode)), "c2r_profile")
 
     def profile_read(self):
         a, b, c, d = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()

@@ -236,8 +236,11 @@ int  c2r_selftest(c2r_ctx *ctx, int64_t *mismatches);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 /* HIP-event timing of the two hot kernels on the context's stream (bench.py's roofline leg).
- * enable!=0 resets the counters.  Times are sums of per-launch event intervals. */
-int  c2r_profile(c2r_ctx *ctx, int32_t enable);
+ * mode 0: off; 1: an event pair around every k_sweep_shell launch (the roofline measurement; the extra
+ * barrier packets cost ~3 % when launches are short, e.g. 125 sources per GPU); 2: one pair per sub-box
+ * (5 launches plus the small kernels between them: cheaper, slightly pessimistic).  Any mode resets the
+ * counters.  sweep_ms is the sum of the intervals, sweep_launches the k_sweep_shell launches they cover. */
+int  c2r_profile(c2r_ctx *ctx, int32_t mode);
 int  c2r_profile_read(c2r_ctx *ctx, double *sweep_ms, int64_t *sweep_launches,
                       double *chem_ms, int64_t *chem_launches);
 
