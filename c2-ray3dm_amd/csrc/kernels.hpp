@@ -63,8 +63,8 @@ struct KParams {
 struct FaceRect {
     int a_lo, wa, b_lo, wb;
     unsigned magic;            // t / wa == umulhi(t, magic) for t < wa*wb (0: wa == 1)
-    int ntiles;                // tiles of k_sweep_shell (pairs of rows); 0: face absent from this shell
-    int pp, npr;               // row pairs of the rows b >= 0; row pairs in all (k_sweep_shell walks wa x npr pairs)
+    int ntiles;                // tiles of k_sweep_shell (groups of kRows rows); 0: face absent from this shell
+    int pp, npr;               // row groups of the rows b >= 0; row groups in all (k_sweep_shell walks wa x npr groups)
 };
 
 struct ShellArgs {
