@@ -54,6 +54,7 @@ struct Ctx {
     int tiles_cap = 0;          // ceil(P*P/256): most tiles any face plane needs
     // sweep scratch (one batch of sources)
     int batch_cap = 0, batch_want = 0;
+    bool stream_hint = false;   // non-temporal cache policy of k_sweep_shell: meshes whose n_HI array outgrows the L2s
     bool fuse_small = true;     // C2R_FUSE_SMALL=0 disables the fused first sub-boxes (experiments, A/B tests)
     double *d_planes = nullptr;
     int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr;
@@ -342,7 +343,8 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             if (ctx->prof == 1) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
             {
                 const dim3 grid(sa.tiles_max, 6, bound), blk(kBlock);
-#define C2R_LAUNCH_SWEEP(D, L) hipLaunchKernelGGL((k_sweep_shell<D, L>), grid, blk, 0, st, k, sa)
+#define C2R_LAUNCH_SWEEP(D, L) do { if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_shell<D, L, true>), grid, blk, 0, st, k, sa); \
+                                    else hipLaunchKernelGGL((k_sweep_shell<D, L, false>), grid, blk, 0, st, k, sa); } while (0)
                 switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
                     case 2: C2R_LAUNCH_SWEEP(false, 1); break;
                     case 3: C2R_LAUNCH_SWEEP(true, 1); break;
@@ -476,6 +478,8 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipStreamCreate(&ctx->stream));
     ctx->own_stream = true;
     ctx->ncell = (size_t)p->mesh[0] * p->mesh[1] * p->mesh[2];
+    ctx->stream_hint = ctx->ncell * sizeof(double) >= ((size_t)64 << 20);      // 8 x 4 MB of L2; neutral at 128^3, +2.8 % at 256^3
+    if (const char *e = getenv("C2R_STREAM_HINT")) ctx->stream_hint = atoi(e) != 0;
     for (int w = 0; w < 5; ++w) { HIP_TRY(hipMalloc(&ctx->grid[w], grid_bytes(ctx, w))); ctx->own[w] = true; }
     HIP_TRY(hipMemset(ctx->grid[4], 0, grid_bytes(ctx, 4)));      // evolve_data.F90:76 phih_grid=0.0
     if (ctx->ncell >= (1ULL << 31) || p->mesh[0] >= (1 << 23) || p->mesh[1] >= (1 << 23) || p->mesh[2] >= (1 << 23) ||

@@ -324,6 +324,9 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned
 // planes are written once and read once, one launch later, after every other source's shell has gone by; the
 // n_HI replica is read once per (cell, source).  Marking them non-temporal keeps the L2 for the Gamma
 // atomics and the rate tables: +2.8 % in a same-box A/B (stores only +1 %, stores + planes +1 %, all three).
+// Only in k_sweep_shell and only on large meshes (STREAM): at 128^3 the hint is neutral, at 64^3 -- everything
+// fits the L2s -- it costs 3 %; the fused first sub-boxes re-read their planes within the same workgroup a
+// shell later and never use it.
 #ifndef C2R_STORE_AUX
 #define C2R_STORE_AUX 2
 #endif
@@ -333,9 +336,10 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned
 #ifndef C2R_PLANE_AUX
 #define C2R_PLANE_AUX 2
 #endif
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double v)
 {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, v), r, (int)byte_off, 0, C2R_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, v), r, (int)byte_off, 0, AUX);
 }
 
 // ---- one Chebyshev shell of every active source ------------------------------------------------
@@ -384,7 +388,7 @@ __device__ __forceinline__ unsigned plane_off8(const KParams &p, int a, int b)
     return ((unsigned)((int)__umul24((unsigned)(b + p.R), (unsigned)p.P) + (a + p.R))) * 8u;   // factors in [0, 2^24)
 }
 
-template <int LLS>
+template <int LLS, bool STREAM>
 __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArgs &sa, const int face, const int s,
                                                 const int a, const int b, const double c1v, const double c2v,
                                                 const double c3v, const double c4v, const double r1, const double r2,
@@ -410,7 +414,7 @@ __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArg
     cs.id = ca + __umul24(na, cb + __umul24(nb, c2));
     const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
     const __amdgpu_buffer_rsrc_t r_x = make_rsrc(xf ? p.nhi_T : p.nhi, ncell * 8u);
-    cs.nhi = buf_load_f64<C2R_NHI_AUX>(r_x, cs.id * 8u);
+    cs.nhi = buf_load_f64<STREAM ? C2R_NHI_AUX : 0>(r_x, cs.id * 8u);
     cs.o8 = plane_off8(p, a, b);
 
     // cinterp, generic in (a,b,pd): the three branches differ only by which axes play (u,v).
@@ -459,7 +463,7 @@ __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArg
 }
 
 // Returns the cell's photon-loss contribution (0 unless it lies on the sub-box surface).
-template <bool DET, int LLS>
+template <bool DET, int LLS, bool STREAM>
 __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                               const int face, const int s, const int a, const int b, const CellState &cs)
 {
@@ -473,15 +477,16 @@ __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs 
     const double cd_out = cs.cd_out;
     // store into this face's plane and into the planes of the faces sharing the cell
     const __amdgpu_buffer_rsrc_t r_cur = make_rsrc(p.planes + ((size_t)s * 2 + (q & 1)) * 6 * p.PP, 6u * plane_bytes);
-    buf_store_f64(r_cur, (unsigned)face * plane_bytes + cs.o8, cd_out);
+    constexpr int SA = STREAM ? C2R_STORE_AUX : 0;
+    buf_store_f64<SA>(r_cur, (unsigned)face * plane_bytes + cs.o8, cd_out);
     if (axis == 2) {
         if (abs(a) == q)   // x-face (u=y=b, v=z=pd)
-            buf_store_f64(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((pd + p.R) * p.P + (b + p.R)) * 8u, cd_out);
+            buf_store_f64<SA>(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((pd + p.R) * p.P + (b + p.R)) * 8u, cd_out);
         if (abs(b) == q)   // y-face (u=x=a, v=z=pd)
-            buf_store_f64(r_cur, (b > 0 ? 2u : 3u) * plane_bytes + (unsigned)((pd + p.R) * p.P + (a + p.R)) * 8u, cd_out);
+            buf_store_f64<SA>(r_cur, (b > 0 ? 2u : 3u) * plane_bytes + (unsigned)((pd + p.R) * p.P + (a + p.R)) * 8u, cd_out);
     } else if (axis == 1) {
         if (abs(a) == q)   // x-face (u=y=pd, v=z=b)
-            buf_store_f64(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((b + p.R) * p.P + (pd + p.R)) * 8u, cd_out);
+            buf_store_f64<SA>(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((b + p.R) * p.P + (pd + p.R)) * 8u, cd_out);
     }
     const Delta3 dl = mesh_delta(axis, pd, a, b);          // recomputed, not carried in CellState
     if (sa.dbg_cdout) {                                     // single-source test path: the N^3 coldensh_out
@@ -528,9 +533,9 @@ __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &
     const double c2v = buf_load_f64<GLC>(r_prev, (ina && inbm) ? o8 - db8 : kOOB);
     const double c3v = buf_load_f64<GLC>(r_prev, (inam && inb) ? o8 - da8 : kOOB);
     const double c4v = buf_load_f64<GLC>(r_prev, (ina && inb) ? o8 : kOOB);
-    const CellState cs = cell_state<LLS>(p, sa, face, s, a, b, c1v, c2v, c3v, c4v, weight_rcp(p, c1v), weight_rcp(p, c2v),
+    const CellState cs = cell_state<LLS, false>(p, sa, face, s, a, b, c1v, c2v, c3v, c4v, weight_rcp(p, c1v), weight_rcp(p, c2v),
                                          weight_rcp(p, c3v), weight_rcp(p, c4v));
-    return cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b, cs);
+    return cell_commit<DET, LLS, false>(p, sa, ltab, face, s, a, b, cs);
 }
 
 // kRows cells of one column: (a,b0), (a,b0+sgb), ... with sgb the sign class of all their rows (rows are
@@ -544,7 +549,7 @@ __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &
 #define C2R_ROWS 3
 #endif
 constexpr int kRows = C2R_ROWS;
-template <bool DET, int LLS>
+template <bool DET, int LLS, bool STREAM>
 __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                              const int face, const int s, const int a, const int b0, const int sgb,
                                              const int nvalid)
@@ -563,32 +568,33 @@ __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &
 #pragma unroll
     for (int r = 0; r <= kRows; ++r) {                       // rows b0-sgb, b0, ..., b0+(kRows-1)sgb
         const bool inr = abs(b0 + (r - 1) * sgb) <= qm;
-        vm[r] = buf_load_f64<C2R_PLANE_AUX>(r_prev, (inam && inr) ? o - da8 : kOOB);
-        va[r] = buf_load_f64<C2R_PLANE_AUX>(r_prev, (ina && inr) ? o : kOOB);
+        vm[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (inam && inr) ? o - da8 : kOOB);
+        va[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (ina && inr) ? o : kOOB);
         o += db8;
     }
 #pragma unroll
     for (int r = 0; r <= kRows; ++r) { rm[r] = weight_rcp(p, vm[r]); ra[r] = weight_rcp(p, va[r]); }
-    const CellState c0 = cell_state<LLS>(p, sa, face, s, a, b0, vm[0], va[0], vm[1], va[1], rm[0], ra[0], rm[1], ra[1]);
-    const CellState c1 = cell_state<LLS>(p, sa, face, s, a, b0 + sgb, vm[1], va[1], vm[2], va[2], rm[1], ra[1], rm[2], ra[2]);
+    const CellState c0 = cell_state<LLS, STREAM>(p, sa, face, s, a, b0, vm[0], va[0], vm[1], va[1], rm[0], ra[0], rm[1], ra[1]);
+    const CellState c1 = cell_state<LLS, STREAM>(p, sa, face, s, a, b0 + sgb, vm[1], va[1], vm[2], va[2], rm[1], ra[1], rm[2], ra[2]);
 #if C2R_ROWS >= 3
-    const CellState c2 = cell_state<LLS>(p, sa, face, s, a, b0 + 2 * sgb, vm[2], va[2], vm[3], va[3], rm[2], ra[2], rm[3], ra[3]);
+    const CellState c2 = cell_state<LLS, STREAM>(p, sa, face, s, a, b0 + 2 * sgb, vm[2], va[2], vm[3], va[3], rm[2], ra[2], rm[3], ra[3]);
 #endif
 #if C2R_ROWS >= 4
-    const CellState c3 = cell_state<LLS>(p, sa, face, s, a, b0 + 3 * sgb, vm[3], va[3], vm[4], va[4], rm[3], ra[3], rm[4], ra[4]);
+    const CellState c3 = cell_state<LLS, STREAM>(p, sa, face, s, a, b0 + 3 * sgb, vm[3], va[3], vm[4], va[4], rm[3], ra[3], rm[4], ra[4]);
 #endif
-    double loss = cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b0, c0);
-    if (nvalid > 1) loss = loss + cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b0 + sgb, c1);
+    double loss = cell_commit<DET, LLS, STREAM>(p, sa, ltab, face, s, a, b0, c0);
+    if (nvalid > 1) loss = loss + cell_commit<DET, LLS, STREAM>(p, sa, ltab, face, s, a, b0 + sgb, c1);
 #if C2R_ROWS >= 3
-    if (nvalid > 2) loss = loss + cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b0 + 2 * sgb, c2);
+    if (nvalid > 2) loss = loss + cell_commit<DET, LLS, STREAM>(p, sa, ltab, face, s, a, b0 + 2 * sgb, c2);
 #endif
 #if C2R_ROWS >= 4
-    if (nvalid > 3) loss = loss + cell_commit<DET, LLS>(p, sa, ltab, face, s, a, b0 + 3 * sgb, c3);
+    if (nvalid > 3) loss = loss + cell_commit<DET, LLS, STREAM>(p, sa, ltab, face, s, a, b0 + 3 * sgb, c3);
 #endif
     return loss;
 }
 
-template <bool DET, int LLS>
+// STREAM: the non-temporal cache policy above (the host turns it on for meshes whose n_HI array outgrows the L2s)
+template <bool DET, int LLS, bool STREAM>
 __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
 {
     __shared__ double sm[16];
@@ -611,7 +617,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         const int sgb = pos ? 1 : -1;
         const int b0 = pos ? k0 : -1 - k0;
         const int left = pos ? (fr.b_lo + fr.wb - b0) : (b0 - fr.b_lo + 1);     // rows from b0 to the end of the class
-        loss = shell_rows<DET, LLS>(p, sa, ltab, face, sa.active[sl], a, b0, sgb, min(left, kRows));
+        loss = shell_rows<DET, LLS, STREAM>(p, sa, ltab, face, sa.active[sl], a, b0, sgb, min(left, kRows));
     }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
