@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--x-init", type=float, default=0.999)
     ap.add_argument("--density", choices=["uniform", "lognormal"], default="uniform",
                     help="lognormal: sigma_ln=1, mean 1 times the same mean density (SURVEY.md s8d, config 5)")
+    ap.add_argument("--sweep-mode", choices=["exact", "fast"], default=os.environ.get("C2R_BENCH_SWEEP_MODE", "exact"),
+                    help="c2r_params.sweep_mode: exact = the reference's f64 operation order (column densities bit-identical "
+                         "to the Fortran), fast = re-associated arithmetic within the stated tolerance (include/c2ray_hip.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--balance", action="store_true",
                     help="cost-balanced source shares (by the previous pass) instead of the static stride")
@@ -128,7 +131,7 @@ def main():
         nd = (nd * np.exp(rng.standard_normal(nd.size, dtype=np.float32) - 0.5)).astype(np.float32)
     srcpos, normflux = pkg.seeded_sources(n, S)
     thick, thin, _ = pkg.build_tables()          # rad_ini on the host (c2r_build_tables)
-    b = pkg.HipBackend(n, thick, thin, device=local_rank, deterministic=args.deterministic)
+    b = pkg.HipBackend(n, thick, thin, device=local_rank, deterministic=args.deterministic, fast=args.sweep_mode == "fast")
     b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], s["clumping"], s["temper"])
     b.set_sources(srcpos, normflux)
     b.load(ndens=nd, xh=xh)
@@ -204,7 +207,7 @@ def main():
             "config": {"workload": "%d^3 mesh, %d sources (seeded), reference test problem at z=9 pre-ionised to "
                                    "x=%.3f, %s density, one evolve3D outer iteration per step (sweep all sources + "
                                    "all-reduce + global chemistry pass)" % (n, S, args.x_init, args.density),
-                       "mesh": n, "sources": S, "gamma_accumulation": "ordered" if args.deterministic else "atomic", "sources_per_gpu": len(pkg.static_source_share(S, 0, world)),
+                       "mesh": n, "sources": S, "sweep_mode": args.sweep_mode, "gamma_accumulation": "ordered" if args.deterministic else "atomic", "sources_per_gpu": len(pkg.static_source_share(S, 0, world)),
                        "parallelism": "sources sharded over %d GPU(s), RCCL all-reduce of Gamma" % world,
                        "visited_cell_sources_per_step": visited_all / args.steps,
                        "visited_per_s": visited_all / dt_wall,

@@ -17,6 +17,7 @@ class Params(C.Structure):
     _fields_ = [("mesh", C.c_int32 * 3), ("device", C.c_int32), ("subboxsize", C.c_int32),
                 ("max_subbox", C.c_int32), ("numtau", C.c_int32), ("max_outer_iter", C.c_int32),
                 ("max_chem_iter", C.c_int32), ("deterministic_rates", C.c_int32),
+                ("sweep_mode", C.c_int32), ("reserved1", C.c_int32),
                 ("epsilon", C.c_double), ("convergence_fraction", C.c_double),
                 ("minimum_fractional_change", C.c_double), ("minimum_fraction_of_atoms", C.c_double),
                 ("loss_fraction", C.c_double), ("max_coldensh", C.c_double),
@@ -53,6 +54,7 @@ class SedParams(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ITERATION_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_double)
 
 # every symbol include/c2ray_hip.h declares: (name, restype, argtypes)
 _P, _I32, _I64, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_double

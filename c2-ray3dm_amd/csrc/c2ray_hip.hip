@@ -36,6 +36,8 @@ struct Ctx {
     bool  own[5] = {false, false, false, false, false};
     double *d_thick = nullptr, *d_thin = nullptr;
     v2f64 *d_logtab = nullptr;                               // log10_tab's {r_i, -log10 r_i}
+    v2f64 *d_odtab = nullptr;                                // fast mode: {r_i, table position of tau = 1/r_i} (tau_od)
+    bool fast = false;                                       // c2r_params.sweep_mode == C2R_SWEEP_FAST
     bool have_tables = false, have_step = false;
     double dr[3] = {0, 0, 0}, vol = 0, lls = 0, temper = 0;
     float clumping = 1.0f;
@@ -207,6 +209,10 @@ KParams make_kparams(const Ctx *ctx)
     k.gbox = ctx->d_gbox;
     k.lls_type = ctx->lls_type; k.R_max2 = ctx->R_max_LLS * ctx->R_max_LLS; k.lls = ctx->d_lls; k.lls_T = ctx->d_lls_T;
     k.thick = ctx->d_thick; k.thin = ctx->d_thin; k.logtab = ctx->d_logtab;
+    k.odtab = ctx->d_odtab;
+    k.od_per_e = (double)(0.301029995663981195213738894724493027L / (long double)p.dlogtau);
+    k.od_per_ln = (double)(0.434294481903251827651128918916605082L / (long double)p.dlogtau);
+    for (int d = 0; d < 3; ++d) k.dr2[d] = ctx->dr[d] * ctx->dr[d];
     k.srcpos = ctx->d_srcpos_b; k.srcw = ctx->d_srcw_b; k.normflux = ctx->d_nflux_b; k.planes = ctx->d_planes;
     return k;
 }
@@ -300,6 +306,8 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             sa.alam = (double)((float)(q - 1) + 0.5f) / (double)(float)q;
             sa.dp2 = (double)q * (double)q; sa.inv_dp2 = 1.0 / sa.dp2;
             for (int d = 0; d < 3; ++d) { const double t = ctx->dr[d] * (double)q; sa.d2axis[d] = t * t; }   // sign drops out
+            sa.inv_q = 1.0 / (double)q; sa.path_scale = ctx->dr[0] / (double)q;
+            sa.lls_scale = ctx->lls_type == 2 ? 1.0 / (double)q : ctx->lls / (double)q;
             sa.active = ctx->d_active[cur]; sa.n_active = ctx->d_nactive + cur;
             sa.loss_partial = ctx->d_loss_partial; sa.dbg_cdout = dbg;
             return sa;
@@ -322,7 +330,8 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                 ba.active = ctx->d_active[cur]; ba.n_active = ctx->d_nactive + cur; ba.loss_acc = ctx->d_loss_acc;
                 const dim3 grid(bound), blk(most <= 256 ? 256 : (most <= 512 ? 512 : 1024));
                 // (not in the k_sweep_shell launch timing of c2r_profile: a different kernel, 21^3 cells per source)
-#define C2R_LAUNCH_FUSED(D, L) hipLaunchKernelGGL((k_sweep_box_fused<D, L>), grid, blk, 0, st, k, ba)
+#define C2R_LAUNCH_FUSED(D, L) do { if (ctx->fast) hipLaunchKernelGGL((k_sweep_box_fused<D, L, true>), grid, blk, 0, st, k, ba); \
+                                    else hipLaunchKernelGGL((k_sweep_box_fused<D, L, false>), grid, blk, 0, st, k, ba); } while (0)
                 switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
                     case 2: C2R_LAUNCH_FUSED(false, 1); break;
                     case 3: C2R_LAUNCH_FUSED(true, 1); break;
@@ -343,8 +352,11 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             if (ctx->prof == 1) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
             {
                 const dim3 grid(sa.tiles_max, 6, bound), blk(kBlock);
-#define C2R_LAUNCH_SWEEP(D, L) do { if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_shell<D, L, true>), grid, blk, 0, st, k, sa); \
-                                    else hipLaunchKernelGGL((k_sweep_shell<D, L, false>), grid, blk, 0, st, k, sa); } while (0)
+#define C2R_LAUNCH_SWEEP(D, L) do { \
+    if (ctx->fast) { if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_shell_fast<D, L, true>), grid, blk, 0, st, k, sa); \
+                     else hipLaunchKernelGGL((k_sweep_shell_fast<D, L, false>), grid, blk, 0, st, k, sa); } \
+    else if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_shell<D, L, true>), grid, blk, 0, st, k, sa); \
+    else hipLaunchKernelGGL((k_sweep_shell<D, L, false>), grid, blk, 0, st, k, sa); } while (0)
                 switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
                     case 2: C2R_LAUNCH_SWEEP(false, 1); break;
                     case 3: C2R_LAUNCH_SWEEP(true, 1); break;
@@ -458,6 +470,7 @@ int c2r_default_params(c2r_params *p)
     p->sqrt2 = C2R_SQRT2; p->sqrt3 = C2R_SQRT3; p->pi = C2R_PI; p->abu_c = C2R_ABU_C;
     p->bh00 = C2R_BH00; p->albpow = C2R_ALBPOW; p->colh0 = C2R_COLH0; p->temph0 = C2R_TEMPH0;
     p->S_star = C2R_S_STAR;
+    p->sweep_mode = C2R_SWEEP_EXACT;
     p->scratch_bytes = 0;
     return C2R_OK;
 }
@@ -470,6 +483,9 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     Ctx *ctx = new Ctx();
     ctx->prm = *p;
     if (const char *e = getenv("C2R_FUSE_SMALL")) ctx->fuse_small = atoi(e) != 0;
+    if (p->sweep_mode != C2R_SWEEP_EXACT && p->sweep_mode != C2R_SWEEP_FAST) { delete ctx; return C2R_EINVAL; }
+    ctx->fast = p->sweep_mode == C2R_SWEEP_FAST;
+    if (const char *e = getenv("C2R_SWEEP_MODE")) ctx->fast = atoi(e) != 0;         // experiments, A/B runs
     *out = reinterpret_cast<c2r_ctx *>(ctx);     // returned even on failure so c2r_last_error works
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -480,11 +496,16 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     ctx->ncell = (size_t)p->mesh[0] * p->mesh[1] * p->mesh[2];
     ctx->stream_hint = ctx->ncell * sizeof(double) >= ((size_t)64 << 20);      // 8 x 4 MB of L2; neutral at 128^3, +2.8 % at 256^3
     if (const char *e = getenv("C2R_STREAM_HINT")) ctx->stream_hint = atoi(e) != 0;
+    // The sweep addresses cells through buffer descriptors with 32-bit BYTE offsets (cell id * 8 and a
+    // num_records of ncell * 8, kernels.hpp cell_state / shell_rows_fast): ncell * 8 must stay below 2^32,
+    // i.e. ncell < 2^29 (a cubic mesh up to 812^3).  Checked before anything is allocated.
+    if (ctx->ncell >= (1ULL << 29) || p->mesh[0] >= (1 << 23) || p->mesh[1] >= (1 << 23) || p->mesh[2] >= (1 << 23) ||
+        (uint64_t)p->mesh[1] * p->mesh[2] >= (1ULL << 24) || (uint64_t)p->mesh[0] * p->mesh[2] >= (1ULL << 24) ||
+        (uint64_t)p->mesh[0] * p->mesh[1] >= (1ULL << 24))
+        FAIL(C2R_EINVAL, "mesh too large: the sweep's 32-bit byte offsets need mesh(1)*mesh(2)*mesh(3) < 2^29 cells "
+                         "(812^3) and every pair product < 2^24");
     for (int w = 0; w < 5; ++w) { HIP_TRY(hipMalloc(&ctx->grid[w], grid_bytes(ctx, w))); ctx->own[w] = true; }
     HIP_TRY(hipMemset(ctx->grid[4], 0, grid_bytes(ctx, 4)));      // evolve_data.F90:76 phih_grid=0.0
-    if (ctx->ncell >= (1ULL << 31) || p->mesh[0] >= (1 << 23) || p->mesh[1] >= (1 << 23) || p->mesh[2] >= (1 << 23) ||
-        (uint64_t)p->mesh[1] * p->mesh[2] >= (1ULL << 24) || (uint64_t)p->mesh[0] * p->mesh[2] >= (1ULL << 24))
-        FAIL(C2R_EINVAL, "mesh too large for the 32-bit / 24-bit index arithmetic of the sweep");
     HIP_TRY(hipMalloc(&ctx->d_nhi, grid_bytes(ctx, 2)));
     HIP_TRY(hipMalloc(&ctx->d_nhi_T, grid_bytes(ctx, 2)));
     HIP_TRY(hipMalloc(&ctx->d_phih_T, grid_bytes(ctx, 4)));
@@ -500,6 +521,11 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
         }
         HIP_TRY(hipMalloc(&ctx->d_logtab, sizeof tab));
         HIP_TRY(hipMemcpy(ctx->d_logtab, tab, sizeof tab, hipMemcpyHostToDevice));
+        // tau_od (fast mode): the same intervals, holding the table position 1 + (log10(1/r_i) - minlogtau)/dlogtau
+        for (int i = 0; i < kLogTab; ++i)
+            tab[2 * i + 1] = (double)(1.0L + (-log10l((long double)tab[2 * i]) - (long double)p->minlogtau) / (long double)p->dlogtau);
+        HIP_TRY(hipMalloc(&ctx->d_odtab, sizeof tab));
+        HIP_TRY(hipMemcpy(ctx->d_odtab, tab, sizeof tab, hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMalloc(&ctx->d_photon_loss, sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_sum_nbox, sizeof(long long)));
@@ -542,7 +568,7 @@ void c2r_destroy(c2r_ctx *c)
     for (auto &kv : ctx->pinned) hipHostUnregister(const_cast<void *>(kv.first));
     free_sweep_scratch(ctx);
     for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
-    hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_logtab);
+    hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_logtab); hipFree(ctx->d_odtab);
     hipFree(ctx->d_nhi); hipFree(ctx->d_nhi_T); hipFree(ctx->d_phih_T);
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
@@ -829,9 +855,11 @@ int c2r_sum(c2r_ctx *c, int32_t which, double *sum)
 {
     if (!c || !sum || which < 1 || which > 4) return C2R_EINVAL;
     Ctx *ctx = C(c);
+    HIP_TRY(hipSetDevice(ctx->prm.device));
     hipLaunchKernelGGL(k_sum_partial, dim3(kSumBlocks), dim3(256), 0, ctx->stream, ctx->ncell,
                        (const double *)ctx->grid[which], ctx->d_sum_partial);
     hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, &ctx->d_hsc->sum);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     *sum = ctx->h_sc->sum;
     return C2R_OK;
@@ -851,6 +879,7 @@ int c2r_photon_sums(c2r_ctx *c, int32_t which_l, int32_t which_r, double out[4])
                        p.bh00, pow(ctx->temper / 1e4, p.albpow), p.colh0, sqrt(ctx->temper),
                        exp(-p.temph0 / ctx->temper), ctx->d_sum_partial);
     hipLaunchKernelGGL(k_sum_final, dim3(4), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, ctx->d_hsc->four);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int m = 0; m < 4; ++m) out[m] = ctx->h_sc->four[m];
     return C2R_OK;
@@ -880,6 +909,7 @@ int c2r_global_pass(c2r_ctx *c, double dt, int64_t *conv_flag, double *sum_xh1)
     prof_end(ctx, ctx->ev_chem, ctx->ev_chem_used);
     hipLaunchKernelGGL(k_pass_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, ctx->d_conv,
                        ctx->d_chemfail, &ctx->d_hsc->sum, &ctx->d_hsc->conv, &ctx->d_hsc->chemfail);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
     if (conv_flag) *conv_flag = (int64_t)ctx->h_sc->conv;

@@ -52,6 +52,10 @@ struct KParams {
                                // z/y faces, [1] y-fastest cells of x faces); null: atomics into phih/phih_T
     const double *thick, *thin;
     const v2f64 *logtab;      // [kLogTab] {r_i, -log10 r_i} for log10_tab
+    // tolerance ("fast") mode of the sweep (c2r_params.sweep_mode = 1, k_sweep_shell_fast)
+    const v2f64 *odtab;       // [kLogTab] {r_i, 1 + (-log10 r_i - minlogtau)/dlogtau}: table position of tau = 1/r_i
+    double od_per_e, od_per_ln; // log10(2)/dlogtau, log10(e)/dlogtau
+    double dr2[3];            // dr_d^2
     const int    *srcpos;      // 3 x S_batch (unwrapped, 1-based: cinterp's real(i0) needs it)
     const int    *srcw;        // 3 x S_batch wrapped to 0..N-1
     const double *normflux;    // S_batch
@@ -75,6 +79,7 @@ struct ShellArgs {
     double alam;                 // (q-0.5)/q, column_density.f90:112 (sign cancels)
     double dp2, inv_dp2;         // q*q and its correctly rounded reciprocal
     double d2axis[3];            // (dr_d * q)^2: the own-axis term of dist2 for faces normal to d
+    double inv_q, path_scale, lls_scale;   // fast mode: 1/q, dr[0]/q, coldensh_LLS/q
     FaceRect face[6];
     const int *active;           // compacted list of local source indices
     const int *n_active;         // its length on the device: the grid may be sized by an older, larger count
@@ -626,6 +631,217 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
     }
 }
 
+// ==== tolerance ("fast") mode of the sweep =======================================================
+// Same physics, same schedule, same integer decisions; the f64 arithmetic of one (cell, source) is
+// re-associated where algebra allows, giving up bit-identity of the column densities with the
+// Fortran (c2r_params.sweep_mode = 1; the exact kernel above stays the default).  Against the exact
+// kernel: ~1e-13 relative on column densities and rates (stated and tested in tests/: integers exact,
+// xh 1e-9).  What changes, with the reference lines each form restates:
+//  * cinterp weights (column_density.f90:112-140): dx = 2|xc-(im+sgn/2)| is 1-|a|/q identically, so the
+//    four weights factor into column and row parts; with t = c/max(0.6,c sigma), r = 1/max(0.6,c sigma)
+//    per corner, cdensi = [omv(omu t1+ddu t2)+ddv(omu t3+ddu t4)] / [same in r]: the column sums of a row
+//    are shared by the two cells above and below it (3 rows per thread: 4 rows of sums for 3 cells);
+//  * reciprocals by v_rcp_f64 + one Newton step (2^-48) instead of the correctly rounded quotient;
+//  * path = sqrt(q^2+a^2+b^2) dr/q from the exact integer (column_density.f90:168), dist2 by two FMAs
+//    (evolve_point.F90:171-174), Gamma = (T_in-T_out) NormFlux / (4 pi dist2 n_HI path) with one
+//    reciprocal (radiation_photoionrates.F90:262-263, evolve_point.F90:262);
+//  * the table position 1+(log10 tau-minlogtau)/dlogtau (radiation_photoionrates.F90:195-199) comes
+//    straight out of the log evaluation: the LDS table holds positions instead of logarithms.
+__device__ __forceinline__ double rcp1(double d)        // 1/d to 2^-48
+{
+    const double r = __builtin_amdgcn_rcp(d);
+    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+}
+__device__ __forceinline__ double sqrt_pos(double x)    // sqrt(x), x >= 1 normal: Goldschmidt step + one correction (~1 ulp)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    const double h = 0.5 * y;
+    g = __builtin_fma(g, __builtin_fma(-h, g, 0.5), g);
+    return __builtin_fma(__builtin_fma(-g, g, x), h, g);
+}
+// table position od = min(numtau, 1 + (log10(max(1e-20,tau)) - minlogtau)/dlogtau); tab = wave's LDS copy of p.odtab
+__device__ __forceinline__ double tau_od(double tau, const KParams &p, const v2f64 *__restrict__ tab)
+{
+    const double x = fmax(1.0e-20, tau);
+    const double m = __builtin_amdgcn_frexp_mant(x);        // [0.5, 1)
+    const int e = __builtin_amdgcn_frexp_exp(x);
+    const unsigned i = ((unsigned)__double2hiint(m) >> 14) & 63u;
+    const v2f64 rt = tab[i];
+    const double z = __builtin_fma(m, rt.x, -1.0);
+    double P = __builtin_fma(z, 1.0 / 7.0, -1.0 / 6.0);
+    P = __builtin_fma(z, P, 0.2);
+    P = __builtin_fma(z, P, -0.25);
+    P = __builtin_fma(z, P, 1.0 / 3.0);
+    P = __builtin_fma(z, P, -0.5);
+    const double l1p = __builtin_fma(z * z, P, z);
+    const double od = __builtin_fma((double)e, p.od_per_e, __builtin_fma(l1p, p.od_per_ln, rt.y));
+    return fmin(p.numtau_d, od);
+}
+// read_table at position od >= 1 (radiation_photoionrates.F90:212-228); tables padded by one element
+__device__ __forceinline__ double table_at(const double *__restrict__ tab, double od)
+{
+    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+    const d2u v = *reinterpret_cast<const d2u *>(tab + (int)od);
+    return __builtin_fma(v.y - v.x, __builtin_amdgcn_fract(od), v.x);
+}
+
+template <bool DET, int LLS, bool STREAM, int NR>
+__device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
+                                                  const int face, const int s, const int a, const int b0, const int sgb,
+                                                  const int nvalid)
+{
+    const int q = sa.q, qm = q - 1;
+    const int axis = 2 - (face >> 1);            // 2:z 1:y 0:x  (block-uniform)
+    const int pd = (face & 1) ? -q : q;
+    const bool xf = (axis == 0);
+    const int ua = xf ? 1 : 0, va = (axis == 2) ? 1 : 2;      // mesh axes of the plane coordinates (a, b)
+    const int sga = a < 0 ? -1 : 1;
+    const int am = a - sga;
+    const unsigned plane_bytes = (unsigned)p.PP * 8u;
+    const __amdgpu_buffer_rsrc_t r_prev =
+        make_rsrc(p.planes + ((size_t)s * 2 + (qm & 1)) * 6 * p.PP + (size_t)face * p.PP, plane_bytes);
+    const bool ina = abs(a) <= qm, inam = abs(am) <= qm;
+    const unsigned p8 = (unsigned)p.P * 8u;
+    const unsigned da8 = (unsigned)(sga * 8), db8 = sgb < 0 ? 0u - p8 : p8;
+    const unsigned o_first = plane_off8(p, a, b0);
+    unsigned o = o_first - db8;                               // row b0 - sgb
+    double vm[NR + 1], va_[NR + 1];
+#pragma unroll
+    for (int r = 0; r <= NR; ++r) {                        // rows b0-sgb, b0, ..., b0+(NR-1)sgb
+        const bool inr = abs(b0 + (r - 1) * sgb) <= qm;
+        vm[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (inam && inr) ? o - da8 : kOOB);
+        va_[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (ina && inr) ? o : kOOB);
+        o += db8;
+    }
+    // cell indices: id = ca + base_p + stride_b * cb (x-fastest array, or the (x,y)-transposed replica for x faces)
+    const unsigned na = (unsigned)p.n[ua], nmid = xf ? (unsigned)p.n[0] : (unsigned)p.n[1];
+    const unsigned ca = wrap_pos(p.srcw[3 * s + ua], p.n[ua], a);
+    const unsigned cp = wrap_pos(p.srcw[3 * s + axis], p.n[axis], pd);          // block-uniform
+    const unsigned stride_b = (axis == 2) ? na : na * nmid;
+    const unsigned base_p = (axis == 2) ? na * nmid * cp : na * cp;
+    const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(xf ? p.nhi_T : p.nhi, ncell * 8u);
+    unsigned id[NR];
+    double nhi[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const unsigned cb = wrap_pos(p.srcw[3 * s + va], p.n[va], b0 + k * sgb);
+        id[k] = ca + base_p + __umul24(stride_b, cb);
+        nhi[k] = buf_load_f64<STREAM ? C2R_NHI_AUX : 0>(r_x, id[k] * 8u);
+    }
+    // column part of the interpolation and of the geometry
+    const double omu = (double)abs(a) * sa.inv_q, ddu = 1.0 - omu;   // weights of columns am and a
+    const int a2 = a * a;
+    const double du2 = p.dr2[ua] * (double)a2;
+    // row sums over the two columns: R = omu r(am) + ddu r(a), T likewise with t = c r
+    double R[NR + 1], T[NR + 1];
+#pragma unroll
+    for (int r = 0; r <= NR; ++r) {
+        const double rm = rcp1(fmax(p.wfloor, vm[r] * p.sigma)), ra = rcp1(fmax(p.wfloor, va_[r] * p.sigma));
+        R[r] = __builtin_fma(omu, rm, ddu * ra);
+        T[r] = __builtin_fma(omu, vm[r] * rm, ddu * (va_[r] * ra));
+    }
+    const double nflux = p.normflux[s];
+    const __amdgpu_buffer_rsrc_t r_cur = make_rsrc(p.planes + ((size_t)s * 2 + (q & 1)) * 6 * p.PP, 6u * plane_bytes);
+    constexpr int SA = STREAM ? C2R_STORE_AUX : 0;
+    const bool bnd_col = sa.has_boundary && (a == sa.boxR[ua] || a == -sa.boxL[ua] || pd == sa.boxR[axis] || pd == -sa.boxL[axis]);
+    double loss = 0.0;
+    unsigned o8 = o_first;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int b = b0 + k * sgb;
+        if (k < nvalid) {
+            const double omv = (double)abs(b) * sa.inv_q, ddv = 1.0 - omv;      // weights of rows b-sgb and b
+            const double den = __builtin_fma(omv, R[k], ddv * R[k + 1]);
+            const double num = __builtin_fma(omv, T[k], ddv * T[k + 1]);
+            double cdi = num * rcp1(den);
+            if (q == 1 && (abs(a) == 1 || abs(b) == 1))
+                cdi = (abs(a) == 1 && abs(b) == 1) ? p.sqrt3 * cdi : p.sqrt2 * cdi;
+            const double pq = sqrt_pos((double)(q * q + a2 + b * b));             // |delta| in cells
+            const double path = pq * sa.path_scale;
+            const double dist2 = __builtin_fma(p.dr2[va], (double)(b * b), du2 + sa.d2axis[axis]);
+            bool stop = false;
+            double cd_in;
+            if (LLS == 3) { stop = dist2 > p.R_max2; cd_in = cdi; }
+            else if (LLS == 2) cd_in = __builtin_fma((double)(xf ? p.lls_T : p.lls)[id[k]] * sa.inv_q, pq, cdi);
+            else cd_in = __builtin_fma(sa.lls_scale, pq, cdi);
+            const double np = nhi[k] * path;                                      // n_HI path: the cell's own column
+            const double cd_out = cd_in + np;
+            // the cell's column density, also into the planes of the faces sharing the cell
+            buf_store_f64<SA>(r_cur, (unsigned)face * plane_bytes + o8, cd_out);
+            if (axis == 2) {
+                if (abs(a) == q)
+                    buf_store_f64<SA>(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((pd + p.R) * p.P + (b + p.R)) * 8u, cd_out);
+                if (abs(b) == q)
+                    buf_store_f64<SA>(r_cur, (b > 0 ? 2u : 3u) * plane_bytes + (unsigned)((pd + p.R) * p.P + (a + p.R)) * 8u, cd_out);
+            } else if (axis == 1) {
+                if (abs(a) == q)
+                    buf_store_f64<SA>(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((b + p.R) * p.P + (pd + p.R)) * 8u, cd_out);
+            }
+            if (sa.dbg_cdout) {
+                const Delta3 dl = mesh_delta(axis, pd, a, b);
+                const unsigned c0 = wrap_pos(p.srcw[3 * s + 0], p.n[0], dl.d0), c1 = wrap_pos(p.srcw[3 * s + 1], p.n[1], dl.d1),
+                               c2 = wrap_pos(p.srcw[3 * s + 2], p.n[2], dl.d2);
+                sa.dbg_cdout[c0 + (unsigned)p.n[0] * (c1 + (unsigned)p.n[1] * c2)] = cd_out;
+            }
+            double gamma = 0.0;
+            if (!stop && !(cd_in > p.max_coldensh) && nflux > 0.0) {
+                const double tau_in = cd_in * p.sigma, tau_out = cd_out * p.sigma;
+                const double od_in = tau_od(tau_in, p, ltab);
+                const double t_in = table_at(p.thick, od_in);
+                double dT, t_out;
+                if (fabs(tau_out - tau_in) > p.tau_limit) {
+                    t_out = table_at(p.thick, tau_od(tau_out, p, ltab));
+                    dT = t_in - t_out;
+                } else {
+                    dT = (tau_out - tau_in) * table_at(p.thin, od_in);
+                    t_out = t_in - dT;
+                }
+                const double area = p.fourpi * dist2;                             // vol_ph = area path
+                gamma = (nflux * dT) * rcp1(area * np);                           // photo_cell_HI / (n_HI vol_ph)
+                if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id[k]], gamma);
+                if (sa.has_boundary && (bnd_col || b == sa.boxR[va] || b == -sa.boxL[va]))
+                    loss = loss + fdiv((nflux * t_out) * p.vol, area * path);
+            }
+            if (DET) p.gbox[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + id[k]] = gamma;
+        }
+        o8 += db8;
+    }
+    return loss;
+}
+
+template <bool DET, int LLS, bool STREAM>
+__global__ __launch_bounds__(kBlock) void k_sweep_shell_fast(KParams p, ShellArgs sa)
+{
+    __shared__ double sm[16];
+    __shared__ v2f64 s_log[kBlock];                      // kBlock/64 waves x 64 entries
+    const int face = blockIdx.y;
+    const int sl = blockIdx.z;
+    const int tile = blockIdx.x;
+    if (sl >= *sa.n_active) return;
+    const FaceRect fr = sa.face[face];
+    if (tile >= fr.ntiles && !sa.has_boundary) return;
+    const v2f64 *ltab = wave_log_table(p.odtab, s_log);
+    double loss = 0.0;
+    const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
+    const unsigned bi = fr.magic ? __umulhi(t, fr.magic) : t;
+    if (tile < fr.ntiles && bi < (unsigned)fr.npr) {
+        const int a = fr.a_lo + (int)(t - __umul24(bi, (unsigned)fr.wa));
+        const bool pos = bi < (unsigned)fr.pp;
+        const int k0 = kRows * (pos ? (int)bi : (int)bi - fr.pp);
+        const int sgb = pos ? 1 : -1;
+        const int b0 = pos ? k0 : -1 - k0;
+        const int left = pos ? (fr.b_lo + fr.wb - b0) : (b0 - fr.b_lo + 1);
+        loss = shell_rows_fast<DET, LLS, STREAM, kRows>(p, sa, ltab, face, sa.active[sl], a, b0, sgb, min(left, kRows));
+    }
+    if (sa.has_boundary) {
+        const double tot = block_sum_256(loss, sm);
+        if (threadIdx.x == 0)
+            sa.loss_partial[((size_t)sl * 6 + face) * sa.tiles_max + tile] = tot;
+    }
+}
+
 // ---- the first sub-boxes, fused: one workgroup per source, all shells of the sub-box in one launch -----
 // Near the source a shell has few cells (24q^2+2: 26 ... 602 for q = 1..5) and a launch per shell is
 // nothing but latency, with the six faces' 256-thread tiles mostly empty.  Here the cells of a shell are
@@ -643,7 +859,7 @@ struct BoxArgs {
     double *loss_acc;
 };
 
-template <bool DET, int LLS>
+template <bool DET, int LLS, bool FAST>
 __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
 {
     __shared__ double sm[16];
@@ -651,7 +867,7 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
     const int sl = blockIdx.x;
     if (sl >= *ba.n_active) return;
     const int s = ba.active[sl];
-    const v2f64 *ltab = wave_log_table(p.logtab, s_log);
+    const v2f64 *ltab = wave_log_table(FAST ? p.odtab : p.logtab, s_log);
     for (int k = 0; k < ba.nshell; ++k) {
         const ShellArgs &sa = ba.sh[k];
         double loss = 0.0;
@@ -664,7 +880,8 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
             const unsigned bi = fr.magic ? __umulhi(lt, fr.magic) : lt;
             const int a = fr.a_lo + (int)(lt - __umul24(bi, (unsigned)fr.wa));
             const int b = fr.b_lo + (int)bi;
-            loss = loss + shell_cell<DET, LLS, 0>(p, sa, ltab, f, s, a, b);
+            if (FAST) loss = loss + shell_rows_fast<DET, LLS, false, 1>(p, sa, ltab, f, s, a, b, b < 0 ? -1 : 1, 1);
+            else loss = loss + shell_cell<DET, LLS, 0>(p, sa, ltab, f, s, a, b);
         }
         if (sa.has_boundary) {
             const double tot = block_sum_256(loss, sm);       // contains a barrier

@@ -61,7 +61,7 @@ def balanced_source_shares(cost, npr):
 class HipBackend:
     """The HIP path: owns a c2r context on one GPU and the device-resident arrays."""
 
-    def __init__(self, mesh, thick, thin, device=0, scratch_bytes=0, deterministic=False):
+    def __init__(self, mesh, thick, thin, device=0, scratch_bytes=0, deterministic=False, fast=None):
         import torch
         self.torch = torch
         self.lib = _capi.load_library()
@@ -74,6 +74,9 @@ class HipBackend:
         p = _capi.default_params(self.mesh, device)
         p.scratch_bytes = scratch_bytes
         p.deterministic_rates = 1 if deterministic else 0
+        # fast=None: the library default (C2R_SWEEP_EXACT unless the C2R_SWEEP_MODE experiment switch is set)
+        if fast is not None:
+            p.sweep_mode = 1 if fast else 0
         self.params = p
         self.ctx = C.c_void_p()
         rc = self.lib.c2r_create(C.byref(self.ctx), C.byref(p))
@@ -178,7 +181,12 @@ class HipBackend:
                     t = known.get(ptr)
                     if t is None:
                         t = torch.as_tensor(_DevView(ptr, count), device=self.device)
-                    allreduce(t)
+                    # reduce ON the stream the library hands over (its kernels before and after are ordered on it)
+                    if stream:
+                        with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+                            allreduce(t)
+                    else:
+                        allreduce(t)
                     return 0
                 except Exception as exc:      # never unwind through C
                     import traceback
@@ -258,6 +266,26 @@ class HipBackend:
                                                           C.byref(rep)), "c2r_evolve3d_restart_dev")
         return rep
 
+    def set_iteration_hook(self, fn=None):
+        """fn(niter, photon_loss_all) -> None, called by the native loop after every outer iteration at the point
+        where the reference decides on an iteration dump (evolve.F90:271-275; c2r_set_iteration_hook).  The arrays
+        xh_av, xh_intermed, phih_grid of that iteration are in place.  None removes the hook."""
+        if fn is None:
+            self._hook = None
+            self._check(self.lib.c2r_set_iteration_hook(self.ctx, None, None), "c2r_set_iteration_hook")
+            return
+
+        def _cb(user, niter, loss):
+            try:
+                fn(niter, loss)
+                return 0
+            except Exception:                 # never unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._hook = _capi.ITERATION_FN(_cb)
+        self._check(self.lib.c2r_set_iteration_hook(self.ctx, C.cast(self._hook, C.c_void_p), None), "c2r_set_iteration_hook")
+
     def selftest(self):
         bad = C.c_int64()
         self._check(self.lib.c2r_selftest(self.ctx, C.byref(bad)), "c2r_selftest")
@@ -323,9 +351,15 @@ class Evolve:
     # master_slave.F90:53 -> :74 do_grid_static; the per-source loop and do_source live in the
     # backend (c2r_pass_sources), which traces this rank's share 1+rank, 1+rank+npr, ...
     def do_grid(self, dt, niter):
+        if self.nbox_per_source is not None and len(self.nbox_per_source) != self.b.nsrc:
+            self.nbox_per_source = None        # the source list changed (new slice): back to the static rule for one pass
         if self.balance and self.npr > 1 and self.nbox_per_source is not None:
             cost = box_cost(self.nbox_per_source, self.b.mesh)
-            self.b.set_source_share(balanced_source_shares(cost, self.npr)[self.rank])
+            shares = balanced_source_shares(cost, self.npr)
+            assert sorted(i for sh in shares for i in sh) == list(range(self.b.nsrc))
+            self.b.set_source_share(shares[self.rank])
+        elif self.balance and getattr(self.b, "share", None) is not None:
+            self.b.set_source_share(None)
         loss, nb, vis = self.b.pass_sources()
         if self.balance and self.npr > 1:
             # every rank learns every source's sub-box count: own entries, zero elsewhere, summed

@@ -18,17 +18,43 @@ import numpy as np
 S_STAR = 1.00000000000000004e+48
 
 
-def _rec(f, payload):
-    n = np.int32(len(payload)).tobytes()
-    f.write(n); f.write(payload); f.write(n)
+MAX_SUBRECORD = 2147483639        # libgfortran: records longer than 2^31-9 bytes are split into subrecords
+
+
+def _rec(f, payload, max_sub=None):
+    """One Fortran sequential record with gfortran's 4-byte markers.  A record longer than 2^31-9 bytes (an N^3
+    f64 array from mesh 646^3 up: xfrac3D, iteration dumps) is written as subrecords, as libgfortran does
+    (io/transfer.c next_record_w_unf): the LEADING marker of a subrecord is negative when another subrecord
+    follows, the TRAILING marker is negative when one preceded it."""
+    max_sub = max_sub or MAX_SUBRECORD
+    payload = memoryview(payload)
+    total, off, first = len(payload), 0, True
+    while True:
+        n = min(max_sub, total - off)
+        more = off + n < total
+        f.write(np.int32(-n if more else n).tobytes())
+        f.write(payload[off:off + n])
+        f.write(np.int32(n if first else -n).tobytes())
+        off += n
+        first = False
+        if not more:
+            break
 
 
 def _read_rec(raw, off):
-    n = int(np.frombuffer(raw, dtype=np.int32, count=1, offset=off)[0])
-    body = raw[off + 4: off + 4 + n]
-    if int(np.frombuffer(raw, dtype=np.int32, count=1, offset=off + 4 + n)[0]) != n:
-        raise ValueError("corrupt Fortran record")
-    return body, off + 8 + n
+    """Returns (payload, offset behind the record); joins gfortran subrecords (see _rec)."""
+    parts = []
+    while True:
+        m = int(np.frombuffer(raw, dtype=np.int32, count=1, offset=off)[0])
+        n = abs(m)
+        parts.append(raw[off + 4: off + 4 + n])
+        t = int(np.frombuffer(raw, dtype=np.int32, count=1, offset=off + 4 + n)[0])
+        if abs(t) != n or (t < 0) != (len(parts) > 1):
+            raise ValueError("corrupt Fortran record")
+        off += 8 + n
+        if m >= 0:
+            break
+    return (parts[0] if len(parts) == 1 else b"".join(parts)), off
 
 
 def write_sm3d(path, a):

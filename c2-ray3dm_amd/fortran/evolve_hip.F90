@@ -47,7 +47,7 @@ module c2ray_hip
   !> mirror of struct c2r_params (include/c2ray_hip.h)
   type, bind(C) :: c2r_params
      integer(c_int32_t) :: mesh(3), device, subboxsize, max_subbox, numtau, max_outer_iter, &
-          max_chem_iter, deterministic_rates
+          max_chem_iter, deterministic_rates, sweep_mode, reserved1
      real(c_double) :: epsilon, convergence_fraction, minimum_fractional_change, &
           minimum_fraction_of_atoms, loss_fraction, max_coldensh, tau_photo_limit, sigma_HI, &
           minlogtau, dlogtau, weight_floor, sqrt2, sqrt3, pi, abu_c, bh00, albpow, colh0, temph0, S_star

@@ -35,6 +35,9 @@ extern "C" {
 
 #define C2R_MAX_ITER_LOG 128
 
+#define C2R_SWEEP_EXACT   0
+#define C2R_SWEEP_FAST    1
+
 typedef struct c2r_ctx c2r_ctx;
 
 /* Numerical parameters of the path: compile-time `parameter`s in the reference, run-time here
@@ -52,6 +55,14 @@ typedef struct c2r_params {
                                       * 1: per-source Gamma grids reduced in source order: bit-reproducible, and
                                       *    the summation order of the serial reference (evolve_point.F90:283);
                                       *    costs 16 B x N^3 of scratch per source in flight */
+    int32_t sweep_mode;              /* C2R_SWEEP_EXACT (0, default): every f64 operation of evolve0D/cinterp/photoion_rates
+                                      *    in the reference's order, IEEE-exact division and sqrt: column densities
+                                      *    bit-identical to the Fortran;
+                                      * C2R_SWEEP_FAST (1): algebraically re-associated arithmetic (factored
+                                      *    interpolation weights, 2^-48 reciprocals, fused table position): same
+                                      *    integer results, column densities and rates within ~1e-13 of the exact mode
+                                      *    (tolerances stated in tests/test_gpu_fast.py), ~1.5x the throughput */
+    int32_t reserved1;
     double  epsilon;                 /* c2ray_parameters.f90:31 */
     double  convergence_fraction;    /* :25 */
     double  minimum_fractional_change; /* :34 */

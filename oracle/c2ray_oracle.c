@@ -36,6 +36,13 @@ typedef struct {
     double R_max_LLS;         /* LLS.F90:191  R_max/(1+z), proper cm (type 3)                  */
     const float *lls_grid;    /* LLS.F90:208  LLS_grid (f32), type 2                           */
     const float *clump_grid;  /* clumping_module.F90:116 clumping_grid (f32), type_of_clumping 3-5 */
+    /* Checker-side diagnostic, not part of the reference's algorithm (NULL = off): per cell
+     *   W = sum over sources of (1 + tau_in) * photo_in / (vol_ph * n_HI),
+     * the rate the cell would have if it absorbed every arriving photon, weighted by the optical depth
+     * in front of it.  The tests bound the rate error by RTOL*Gamma + WTOL*W: Gamma = (T(tau_in)-T(tau_out))
+     * NormFlux/(vol_ph n_HI) is a difference of two table values whose own rounding error (log10 and the
+     * table position, ~1e-16 od per unit of tau) does not shrink with the difference. */
+    double *tolw;
 } oracle_cfg;
 
 static inline int pmod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
@@ -224,6 +231,7 @@ static void evolve0d(sweep_t *s, const int rt[3])
     if (!stop) {
         oracle_photoion_rates(c->thick, c->thin, cd_in, cd_out, vol_ph, s->normflux, phi);
         phi[0] = phi[0] / (xav0 * nd);                                         /* :262 */
+        if (c->tolw) c->tolw[id] += (1.0 + cd_in * C2R_SIGMA_HI) * phi[1] / (vol_ph * (xav0 * nd));
     }
     s->phih[id] = s->phih[id] + phi[0];                                        /* :283 */
     if (rt[0] == s->last_l[0] || rt[1] == s->last_l[1] || rt[2] == s->last_l[2] ||
@@ -438,6 +446,7 @@ void oracle_evolve3d_x(const oracle_cfg *c, double dt, const float *ndens, doubl
         prev1 = sum1; prev0 = sum0;
         niter++;
         memset(phih, 0, ncell * sizeof(double));                               /* :243 */
+        if (c->tolw) memset(c->tolw, 0, ncell * sizeof(double));               /* checker diagnostic: last pass only */
         double loss; long nb, vis;
         oracle_pass_sources(c, ndens, xh_av, phih, srcpos, normflux, nsrc, 0, 1, &loss, &nb, &vis);
         rep->photon_loss_all = loss; rep->sum_nbox_all = nb; rep->visited += vis;

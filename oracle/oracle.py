@@ -23,7 +23,7 @@ class Cfg(C.Structure):
                 ("coldensh_LLS", C.c_double), ("clumping", C.c_double), ("temper", C.c_double),
                 ("S_star", C.c_double), ("thick", C.c_void_p), ("thin", C.c_void_p),
                 ("lls_type", C.c_int), ("R_max_LLS", C.c_double), ("lls_grid", C.c_void_p),
-                ("clump_grid", C.c_void_p)]
+                ("clump_grid", C.c_void_p), ("tolw", C.c_void_p)]
 
 
 class Report(C.Structure):
@@ -68,9 +68,17 @@ class Oracle:
         self.cfg = Cfg((C.c_int * 3)(*n), (C.c_double * 3)(*dr), vol, coldensh_LLS, clumping,
                        temper, S_star, _p(self.thick), _p(self.thin), lls_type, R_max_LLS,
                        None if self.lls_grid is None else _p(self.lls_grid),
-                       None if self.clump_grid is None else _p(self.clump_grid))
+                       None if self.clump_grid is None else _p(self.clump_grid), None)
+        self.tolw = None
         self.n = n
         self.ncell = n[0] * n[1] * n[2]
+
+    def enable_tolerance_weight(self):
+        """Checker diagnostic (see oracle_cfg.tolw): accumulate, from now on, W = sum_s (1+tau_in) photo_in /
+        (vol_ph n_HI) per cell into self.tolw (zeroed here)."""
+        self.tolw = np.zeros(self.ncell, dtype=np.float64)
+        self.cfg.tolw = self.tolw.ctypes.data
+        return self.tolw
 
     # -- point functions ------------------------------------------------------------------
     def cinterp(self, cdout, pos, src):

@@ -1,0 +1,67 @@
+"""Randomized GPU-vs-oracle cases shared by tests/test_gpu_fuzz.py (asserting, 25 cases per mode) and
+tests/fuzz_gpu.py (the long run by hand).  Random non-cubic meshes (every extent 3..44, odd and even), 1..12
+sources anywhere (also outside [1,N]), rates over 6 decades, density and ionization fields with structure,
+both fully and barely ionized gas, so that sub-boxes end anywhere between the first and the clipped last; the
+row-group tiling of k_sweep_shell (three rows per thread, groups per sign class) meets every remainder."""
+import numpy as np
+
+
+def make_case(seed, pkg):
+    rng = np.random.default_rng(seed)
+    s = pkg.TestProblem(32).step(1)
+    mesh = tuple(int(v) for v in rng.integers(3, 45, 3))
+    ncell = mesh[0] * mesh[1] * mesh[2]
+    scale = 10.0 ** rng.uniform(-0.3, 0.6)
+    dr = tuple(float(s["dr1"] * scale * f) for f in rng.uniform(0.7, 1.4, 3))
+    nd = (s["ndens"] * np.exp(0.7 * rng.standard_normal(ncell))).astype(np.float32)
+    if seed % 3 == 0:       # mostly neutral gas: everything ends in the first sub-boxes
+        lo = rng.choice([-5.0, -2.0, -0.5])
+        xh = np.clip(10.0 ** rng.uniform(lo, 0, ncell) * 0.99999, 1e-7, 0.99999)
+    else:                   # highly ionized with neutral clumps: rays run to the trace limits
+        xh = 1.0 - 10.0 ** rng.uniform(-6.5, -3.0, ncell)
+        clumps = rng.random(ncell) < 0.02
+        xh[clumps] = 10.0 ** rng.uniform(-4, -0.3, int(clumps.sum()))
+        nd = (nd * 10.0 ** rng.uniform(-1.5, 0.0)).astype(np.float32)
+    nsrc = int(rng.integers(1, 13))
+    pos = np.stack([rng.integers(-3, mesh[d] + 5, nsrc) for d in range(3)], axis=1).astype(np.int32)
+    nf = 10.0 ** rng.uniform(4, 10, nsrc)
+    if rng.random() < 0.2:
+        nf[rng.integers(0, nsrc)] = 0.0
+    lls = s["coldensh_LLS"] * 10.0 ** rng.uniform(-1, 1)
+    k = int(rng.integers(0, nsrc))          # the source whose column densities are compared
+    return dict(mesh=mesh, dr=dr, vol=dr[0] * dr[1] * dr[2], nd=nd, xh=xh, pos=pos, nf=nf, lls=lls, k=k)
+
+
+def run_case(seed, pkg, tables, fast):
+    """One pass of all sources on the GPU and in the oracle.  Returns the comparison metrics; integer
+    results and zero patterns are asserted here (they are exact in both sweep modes)."""
+    from oracle.oracle import Oracle
+    c = make_case(seed, pkg)
+    mesh, ncell = c["mesh"], c["nd"].size
+    o = Oracle(mesh, c["dr"], c["vol"], c["lls"], *tables)
+    w = o.enable_tolerance_weight()
+    phih_o = np.zeros(ncell)
+    oloss, onb, ovis = o.pass_sources(c["nd"], c["xh"], phih_o, c["pos"], c["nf"])
+    w = w.copy()
+    b = pkg.HipBackend(mesh, *tables, device=0, fast=fast)
+    b.set_step(c["dr"], c["vol"], c["lls"], 1.0)
+    b.set_sources(c["pos"], c["nf"]); b.set_rank(0, 1); b.load(ndens=c["nd"], xh=c["xh"])
+    b.begin_step(); b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    phih = b.fetch("phih_grid")
+    assert (nbox, vis) == (onb, ovis), (seed, mesh, nbox, onb, vis, ovis)
+    assert np.array_equal(phih == 0, phih_o == 0), (seed, mesh)
+    k = c["k"]
+    nb1, l1, v1, cd = b.do_source(k + 1, want_coldens=True)
+    nbo, lo1, vo, cdo = o.do_source(c["nd"], c["xh"], np.zeros(ncell), c["pos"][k], c["nf"][k])
+    b.close()
+    assert nb1 == nbo and v1 == vo, (seed, mesh, k)
+    assert np.array_equal(cd == 0, cdo == 0), (seed, mesh, k)
+    d = np.abs(phih - phih_o)
+    nz = phih_o != 0
+    return dict(mesh=mesh, nsrc=len(c["nf"]), nbox=nbox, visited=vis,
+                loss=abs(loss - oloss) / max(abs(oloss), 1e-300),
+                cd=float(np.max(np.abs(cd - cdo) / np.maximum(cdo, 1e-300))),
+                gamma_rel=float(np.max(d[nz] / phih_o[nz])) if nz.any() else 0.0,
+                gamma_w=float(np.max(d[nz] / w[nz])) if nz.any() else 0.0,        # |dGamma| / W, see oracle_cfg.tolw
+                dgamma=d, gamma_ref=phih_o, w=w)

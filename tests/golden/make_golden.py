@@ -193,7 +193,7 @@ def case_refrun(name, n, sources):
     print(name, "outputs", len(outs), "outer iterations", len(nonconv))
 
 
-def case_evolve_planes(name, n, sources, dens_seed=None, xfield=None):
+def case_evolve_planes(name, n, sources, dens_seed=None, xfield=None, store_inputs=True, xfield_recipe=None):
     """One evolve3D step on a large mesh: three orthogonal planes through source 1 of xh_after and
     phih_grid, checksums and the iteration history."""
     dens = density_factor(n, dens_seed) if dens_seed is not None else None
@@ -207,7 +207,15 @@ def case_evolve_planes(name, n, sources, dens_seed=None, xfield=None):
               "phih_px": ph[s0[0]], "phih_py": ph[:, s0[1]], "phih_pz": ph[:, :, s0[2]]}
     nd = rd(d, "step001_ndens.f32", n, np.float32); xb = rd(d, "step001_xh_before.f64", n)
     arrays["ndens"] = nd.flat[0:1].copy() if np.all(nd == nd.flat[0]) else nd
-    arrays["xh_before"] = xb.flat[0:1].copy() if np.all(xb == xb.flat[0]) else xb
+    if np.all(xb == xb.flat[0]):
+        arrays["xh_before"] = xb.flat[0:1].copy()
+    elif store_inputs:
+        arrays["xh_before"] = xb
+    else:       # too large to commit: the test regenerates the field from its recipe and checks these
+        kv["xh_before_recipe"] = xfield_recipe
+        kv["xh_before_sum"] = float(np.sum(xb, dtype=np.longdouble))
+        import hashlib
+        kv["xh_before_sha256"] = hashlib.sha256(np.ascontiguousarray(xb.ravel(order="F")).tobytes()).hexdigest()
     kv.update(xh_sum=float(np.sum(xa, dtype=np.longdouble)), xh_min=float(xa.min()), xh_max=float(xa.max()),
               phih_sum=float(np.sum(ph, dtype=np.longdouble)), phih_max=float(ph.max()),
               phih_nonzero=int(np.count_nonzero(ph)))
@@ -299,6 +307,20 @@ def main():
         case_evolve_planes("evolve128_std", 128, SRC_STD)
         case_sweep("sweep256_3src_x999", 256, [(200, 30, 77, 1e56), (5, 250, 130, 3e55), (128, 128, 128, 1e57)],
                    x_init=0.999, full=False, ns_dump=3)
+    # BASELINE.json configs[2]: 256^3 x 100 sources as WHOLE evolve3D steps: the cold
+    # start (x = 2e-4) and a late field (ionized bubbles of 14 cells around every source, sub-boxes grow)
+    if want("evolve256"):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+        pos, nf = g.load_package().seeded_sources(256, 100)
+        srcs = [(int(p[0]), int(p[1]), int(p[2]), float(f) * 1.00000000000000004e+48) for p, f in zip(pos, nf)]
+        only = os.environ.get("C2R_GOLDEN_ONLY", "")
+        if only in ("", "cold"):
+            case_evolve_planes("evolve256_100src_cold", 256, srcs)
+        if only in ("", "late"):
+            x = bubble_xfield(256, [tuple(int(v) for v in p) for p in pos], 14.0)
+            case_evolve_planes("evolve256_100src_late", 256, srcs, xfield=x, store_inputs=False,
+                               xfield_recipe="inputs.bubble_xfield(256, seeded_sources(256,100) positions, 14.0)")
     if want("evolve64"):
         x = bubble_xfield(64, [(50, 50, 50), (20, 10, 10), (6, 8, 50), (20, 10, 26)], 12.0)
         case_evolve("evolve64_std_bubbles", 64, SRC_STD, 1, [1], dens_seed=65, xfield=x,

@@ -81,3 +81,34 @@ def test_density_file_round_trip(fio, tmp_path, access):
     assert np.array_equal(back, nd)
     with pytest.raises(ValueError):
         fio.read_density(p, mesh=(6, 5, 5), access=access)
+
+
+def test_records_beyond_2GiB_are_gfortran_subrecords(tmp_path, monkeypatch):
+    """A sequential record longer than 2^31-9 bytes (N^3 f64 from mesh 646^3 up) is split into subrecords by
+    libgfortran: leading marker negative while another subrecord follows, trailing marker negative when one
+    preceded.  Exercised with a small subrecord limit; the default limit is gfortran's."""
+    import io
+    import __graft_entry__ as g
+    fio = g.load_package().fileio
+    assert fio.MAX_SUBRECORD == 2 ** 31 - 9
+    payload = np.arange(25, dtype=np.float64).tobytes()          # 200 bytes
+    f = io.BytesIO()
+    fio._rec(f, payload, max_sub=64)                             # 64 + 64 + 64 + 8
+    raw = f.getvalue()
+    marks = []
+    off = 0
+    while off < len(raw):
+        m = int(np.frombuffer(raw, np.int32, 1, off)[0]); n = abs(m)
+        t = int(np.frombuffer(raw, np.int32, 1, off + 4 + n)[0])
+        marks.append((m, t)); off += 8 + n
+    assert marks == [(-64, 64), (-64, -64), (-64, -64), (8, -8)]
+    body, end = fio._read_rec(raw, 0)
+    assert bytes(body) == payload and end == len(raw)
+    # an ordinary record is unchanged: [n][payload][n]
+    f = io.BytesIO(); fio._rec(f, payload)
+    assert f.getvalue() == np.int32(200).tobytes() + payload + np.int32(200).tobytes()
+    # whole files written with a small limit read back identically
+    monkeypatch.setattr(fio, "MAX_SUBRECORD", 1000)
+    a = np.random.default_rng(3).random((9, 8, 7))
+    fio.write_sm3d(str(tmp_path / "x.bin"), a)
+    assert np.array_equal(fio.read_sm3d(str(tmp_path / "x.bin")), a)

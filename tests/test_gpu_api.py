@@ -41,6 +41,15 @@ def test_call_order_and_argument_errors(pkg, tables):
     lib.c2r_destroy(ctx)
     bad = pkg.default_params(0)
     assert lib.c2r_create(C.byref(ctx), C.byref(bad)) == -1
+    # the sweep addresses cells with 32-bit byte offsets: meshes of 2^29 cells and more (813^3, 1024^3 -- which
+    # would fit the 288 GB of HBM) are refused before anything is allocated; 812^3 is the largest cube
+    for n in (813, 1024):
+        ctx = C.c_void_p()
+        assert lib.c2r_create(C.byref(ctx), C.byref(pkg.default_params(n))) == -1
+        assert b"mesh too large" in lib.c2r_last_error(ctx)
+        lib.c2r_destroy(ctx)
+    big = pkg.default_params(16); big.sweep_mode = 7
+    assert lib.c2r_create(C.byref(ctx), C.byref(big)) == -1                                # unknown sweep mode
 
 
 def test_host_pointer_evolve3d_is_what_the_shim_calls(pkg, tables):

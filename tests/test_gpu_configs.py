@@ -1,0 +1,152 @@
+"""GPU parity tests on BASELINE.json's own configurations, once per sweep mode:
+
+  configs[2]  256^3 x 100 sources as WHOLE evolve3D steps against fixtures recorded from the Fortran reference
+              (cold start and a late field: tests/golden/evolve256_100src_{cold,late});
+  configs[3]  the bench workload itself -- 256^3 x 1000 seeded sources, x = 0.999 -- one pass: a 16-source subset
+              against the oracle, the other 984 through additivity (Gamma, loss, sub-box counts and visited cells of a
+              pass are sums over sources), and the expected trace-to-the-limit sub-box count;
+  configs[4]  504^3 (log-normal density, sigma = 1): two sources traced to the limits against the oracle.
+
+The serial oracle needs ~0.15 us per visited (cell, source) pair, so its results are computed once and shared by
+the two modes (module cache)."""
+import hashlib
+import numpy as np
+import pytest
+from tests._util import F, load_case, oracle_for, expand, tol, assert_gamma, oracle_pass, STATE_RTOL
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("sweep_mode")]
+
+_cache = {}
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+def backend(pkg, tables, s, n, nd, xh, pos, nf):
+    b = pkg.HipBackend(n, *tables, device=0)
+    b.set_step((s["dr1"], s["dr2"], s["dr3"]), s["vol"], s["coldensh_LLS"], s["clumping"])
+    b.set_sources(pos, nf)
+    b.set_rank(0, 1)
+    b.load(ndens=nd, xh=xh)
+    return b
+
+
+def _planes(p3, m):
+    n = m["n"]
+    s = [(q - 1) % n for q in m["srcpos"][0]]
+    return {"px": p3[s[0]], "py": p3[:, s[1]], "pz": p3[:, :, s[2]]}
+
+
+@pytest.mark.parametrize("name", ["evolve256_100src_cold", "evolve256_100src_late"])
+def test_evolve3d_256_100src_vs_reference_fixture(pkg, tables, name):
+    """BASELINE configs[2] as a whole time step (evolve.F90:83-281): outer-iteration count, the sequence of
+    non-converged-cell counts, sum_nbox, photon statistics, planes of xh and Gamma through source 1, checksums."""
+    from tests.golden.inputs import bubble_xfield
+    m, a = load_case(name)
+    n = m["n"]
+    nd = F(expand(a["ndens"], n))
+    pos, nf = pkg.seeded_sources(n, 100)
+    assert [tuple(p) for p in pos.tolist()] == [tuple(p) for p in m["srcpos"]]
+    if "xh_before" in a:
+        xh0 = F(expand(a["xh_before"], n))
+    else:       # too large to commit: regenerate from the recipe and prove it is the field the reference ran on
+        xh0 = F(bubble_xfield(n, [tuple(int(v) for v in p) for p in pos], 14.0))
+        assert hashlib.sha256(xh0.tobytes()).hexdigest() == m["xh_before_sha256"]
+    b = backend(pkg, tables, m, n, nd, xh0, m["srcpos"], m["normflux"])
+    # keep the xh_av each pass started from (ping-pong): the state before the LAST pass gives the tolerance weight
+    import torch
+    keep = [torch.empty_like(b.xh_av), torch.empty_like(b.xh_av)]
+    b.set_iteration_hook(lambda niter, loss: keep[niter % 2].copy_(b.xh_av))
+    rep = b.evolve3d_native(m["dt"])
+    b.set_iteration_hook(None)
+    assert rep.converged and rep.niter == m["niter"]
+    assert list(rep.it_conv_flag[:rep.niter]) == m["log"]["nonconv"]
+    assert rep.sum_nbox_all == m["sum_nbox_all"]
+    assert abs(rep.photon_loss_all - m["photon_loss_all"]) <= tol("loss") * abs(m["photon_loss_all"]) + 1e-300
+    x3 = b.fetch("xh").reshape((n, n, n), order="F")
+    p3 = b.fetch("phih_grid").reshape((n, n, n), order="F")
+    for tag, sl in _planes(x3, m).items():
+        assert np.max(np.abs(sl - a["xh_" + tag])) < tol("x"), tag
+    assert np.count_nonzero(p3) == m["phih_nonzero"]
+    assert abs(float(np.sum(x3, dtype=np.longdouble)) / m["xh_sum"] - 1) < 1e-12
+    assert abs(x3.min() - m["xh_min"]) < tol("x") and abs(x3.max() - m["xh_max"]) < tol("x")
+    for k in ("totrec", "totcollisions"):
+        assert abs(getattr(rep, k) / m[k] - 1) < 1e-9
+    assert abs(rep.total_ion - m["total_ion"]) < n ** 3 * 2.3e-16 * rep.h0_before
+    # Gamma of the last pass: the oracle's pass over the state that pass started from (the GPU's own xh_av of
+    # the iteration before, equal to the reference's to ~1e-14) gives the rates and the tolerance weight
+    xav_prev = keep[(rep.niter - 1) % 2].cpu().numpy() if rep.niter > 1 else xh0
+    oloss, onb, ovis, ophih, w = oracle_pass(oracle_for(m, tables, n), nd, xav_prev, m["srcpos"], m["normflux"])
+    assert onb == m["sum_nbox_all"]
+    wp = _planes(w.reshape((n, n, n), order="F"), m)
+    for tag, sl in _planes(p3, m).items():
+        assert_gamma(sl, a["phih_" + tag], wp[tag], name + " " + tag, state_rtol=STATE_RTOL)       # the Fortran's planes
+    assert_gamma(p3.ravel(order="F"), ophih, w, name + " whole mesh vs oracle")
+    b.close()
+
+
+def test_bench_workload_256_x_1000(pkg, tables):
+    """The workload bench.py times (256^3, 1000 seeded sources, x = 0.999, first pass) is checked here."""
+    n, S, nsub = 256, 1000, 16
+    tp = pkg.TestProblem(n)
+    s = tp.step(1)
+    nd, xh = tp.fields(1, 0.999)
+    pos, nf = pkg.seeded_sources(n, S)
+    b = backend(pkg, tables, s, n, nd, xh, pos, nf)
+    b.begin_step()
+    b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    whole = b.fetch("phih_grid")
+    per_src = b.last_nbox()
+    assert per_src.sum() == nbox and int(np.sum(pkg.box_cost(per_src, (n, n, n)))) == vis
+    assert np.all(whole > 0)                       # every cell is reached by some source
+    # subset against the oracle
+    if "bench" not in _cache:
+        _cache["bench"] = oracle_pass(oracle_for(s, tables, n), nd, xh, pos[:nsub], nf[:nsub])
+    oloss, onb, ovis, ophih, w = _cache["bench"]
+    b.set_sources(pos[:nsub], nf[:nsub])
+    b.zero_rates()
+    l_a, nb_a, v_a = b.pass_sources()
+    g_a = b.fetch("phih_grid")
+    assert (nb_a, v_a) == (onb, ovis)
+    assert np.array_equal(b.last_nbox(), per_src[:nsub])
+    assert abs(l_a - oloss) <= tol("loss") * abs(oloss)
+    assert_gamma(g_a, ophih, w, "16-source subset")
+    # the other 984 sources: additivity
+    b.set_sources(pos[nsub:], nf[nsub:])
+    b.zero_rates()
+    l_b, nb_b, v_b = b.pass_sources()
+    g_b = b.fetch("phih_grid")
+    assert np.array_equal(b.last_nbox(), per_src[nsub:])
+    assert (nb_a + nb_b, v_a + v_b) == (nbox, vis)
+    assert abs(l_a + l_b - loss) <= 1e-12 * abs(loss)
+    assert np.max(np.abs(g_a + g_b - whole) / whole) < 1e-12       # order of the atomic adds only
+    b.close()
+
+
+def test_504_lognormal_two_sources_vs_oracle(pkg, tables):
+    """BASELINE configs[4]'s mesh (504^3, log-normal density sigma = 1, HBM-resident): two sources traced out to
+    q = 252 against the oracle; 24-bit index arithmetic, plane pitch 505, 1.0 GB grids."""
+    n = 504
+    tp = pkg.TestProblem(n)        # the 100 Mpc/h box: 0.028 of an LLS mean free path per cell, rays reach the limits
+    s = tp.step(1)
+    nd, xh = tp.fields(1, 0.9995)
+    rng = np.random.default_rng(20261003)
+    nd = (nd * np.exp(rng.standard_normal(nd.size, dtype=np.float32) - 0.5)).astype(np.float32)
+    pos = np.array([[17, 480, 252], [300, 301, 302]], dtype=np.int32)
+    nf = np.array([3e8, 1e9])
+    if "504" not in _cache:
+        _cache["504"] = oracle_pass(oracle_for(s, tables, n), nd, xh, pos, nf)
+    oloss, onb, ovis, ophih, w = _cache["504"]
+    b = backend(pkg, tables, s, n, nd, xh, pos, nf)
+    b.begin_step()
+    b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    assert (nbox, vis) == (onb, ovis)
+    assert list(b.last_nbox()) == [51, 51] and vis == 2 * n ** 3          # both traced out to q = 252: the whole mesh
+    assert abs(loss - oloss) <= tol("loss") * abs(oloss) + 1e-300
+    assert_gamma(b.fetch("phih_grid"), ophih, w, "504^3")
+    b.close()

@@ -5,10 +5,9 @@ sub-box counts over disjoint source sets (which is also what sharding over ranks
 periodic translation of the whole problem."""
 import numpy as np
 import pytest
-from tests._util import F, oracle_for, relerr, load_case, expand
+from tests._util import F, oracle_for, relerr, load_case, expand, tol, assert_gamma, oracle_pass, oracle_step, STATE_RTOL
 
-pytestmark = pytest.mark.gpu
-TOL_GAMMA, TOL_LOSS, TOL_X = 1e-9, 1e-10, 1e-9
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("sweep_mode")]      # every test once per sweep mode
 
 
 @pytest.fixture(scope="module")
@@ -48,21 +47,19 @@ def test_pass_vs_oracle_at_full_size(pkg, tables, n, nsrc, x_mode, seed):
     s, nd, xh = field_case(pkg, n, seed, x_mode)
     pos, nf = pkg.seeded_sources(n, nsrc, seed=seed)
     o = oracle_for(s, tables, n)
-    phih_o = np.zeros(o.ncell)
-    oloss, onb, ovis = o.pass_sources(nd, xh, phih_o, pos, nf)
+    oloss, onb, ovis, phih_o, w = oracle_pass(o, nd, xh, pos, nf)
     b = backend(pkg, tables, s, n, nd, xh, pos, nf)
     b.zero_rates()
     loss, nbox, vis = b.pass_sources()
     assert (nbox, vis) == (onb, ovis)
-    assert abs(loss - oloss) <= TOL_LOSS * abs(oloss) + 1e-300
+    assert abs(loss - oloss) <= tol("loss") * abs(oloss) + 1e-300
     phih = b.fetch("phih_grid")
-    assert np.array_equal(phih == 0, phih_o == 0)
-    assert relerr(phih, phih_o, floor=1e-60) < TOL_GAMMA
+    assert_gamma(phih, phih_o, w)
     xav, xint = xh.copy(), xh.copy()
     oconv = o.global_pass(s["dt"], nd, xh, xav, xint, phih_o)
     conv, _ = b.global_pass(s["dt"])
     assert conv == oconv
-    assert np.max(np.abs(b.fetch("xh_intermed") - xint)) < TOL_X
+    assert np.max(np.abs(b.fetch("xh_intermed") - xint)) < tol("x")
     b.close()
 
 
@@ -111,7 +108,8 @@ def test_periodic_translation_128(pkg, tables):
     g1 = b.fetch("phih_grid").reshape((n, n, n), order="F")
     assert r0[1:] == r1[1:]
     assert abs(r0[0] - r1[0]) <= 1e-10 * abs(r0[0])
-    assert relerr(g1, np.roll(g0, sh, axis=(0, 1, 2)), floor=1e-60) < 1e-9
+    w3 = oracle_pass(oracle_for(s, tables, n), nd, xh, pos, nf)[4].reshape((n, n, n), order="F")
+    assert_gamma(g1, np.roll(g0, sh, axis=(0, 1, 2)), np.roll(w3, sh, axis=(0, 1, 2)))
     b.close()
 
 
@@ -154,12 +152,14 @@ def test_sweep_vs_reference_fixture_at_baseline_sizes(pkg, tables, name):
     b.zero_rates()
     loss, nbox, vis = b.pass_sources()
     assert nbox == m["sum_nbox"]
-    assert abs(loss - m["photon_loss"]) <= TOL_LOSS * abs(m["photon_loss"])
+    assert abs(loss - m["photon_loss"]) <= tol("loss") * abs(m["photon_loss"])
     p3 = b.fetch("phih_grid").reshape((n, n, n), order="F")
     assert np.count_nonzero(p3) == m["phih_nonzero"]
     assert abs(float(np.sum(p3, dtype=np.longdouble)) / m["phih_sum"] - 1) < 1e-10
+    w3 = oracle_pass(oracle_for(m, tables, n), nd, xh, m["srcpos"], m["normflux"])[4].reshape((n, n, n), order="F")
+    wp = _planes(w3, m)
     for tag, sl in _planes(p3, m).items():
-        assert relerr(sl, a["phih_" + tag], floor=1e-60) < TOL_GAMMA, tag
+        assert_gamma(sl, a["phih_" + tag], wp[tag], tag)
     b.close()
 
 
@@ -175,9 +175,13 @@ def test_evolve3d_128_vs_reference_fixture(pkg, tables):
     x3 = b.fetch("xh").reshape((n, n, n), order="F")
     p3 = b.fetch("phih_grid").reshape((n, n, n), order="F")
     for tag, sl in _planes(x3, m).items():
-        assert np.max(np.abs(sl - a["xh_" + tag])) < TOL_X, tag
+        assert np.max(np.abs(sl - a["xh_" + tag])) < tol("x"), tag
+    nd, xh0 = F(expand(a["ndens"], n)), F(expand(a["xh_before"], n))
+    orep, oxh, oxav, ophih, w = oracle_step(oracle_for(m, tables, n), m["dt"], nd, xh0, m["srcpos"], m["normflux"])
+    assert orep.niter == m["niter"]
+    wp = _planes(w.reshape((n, n, n), order="F"), m)
     for tag, sl in _planes(p3, m).items():
-        assert relerr(sl, a["phih_" + tag], floor=1e-60) < 1e-8, tag
+        assert_gamma(sl, a["phih_" + tag], wp[tag], tag, state_rtol=STATE_RTOL)
     assert np.count_nonzero(p3) == m["phih_nonzero"]
     assert abs(float(np.sum(x3, dtype=np.longdouble)) / m["xh_sum"] - 1) < 1e-12
     for k in ("totrec", "totcollisions"):

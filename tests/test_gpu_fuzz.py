@@ -1,0 +1,25 @@
+"""A 25-case cut of the randomized GPU-vs-oracle run (tests/_fuzz.py; the long run by hand is tests/fuzz_gpu.py),
+once per sweep mode: non-cubic meshes of every remainder class, sources inside and outside the mesh, neutral and
+highly ionized gas.  Integers and zero patterns exact (asserted in run_case), column densities, photon loss and
+rates within the mode's stated tolerances (tests/_util.TOL)."""
+import pytest
+from tests._util import tol, gamma_ok
+from tests._fuzz import run_case
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("sweep_mode")]
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+@pytest.mark.parametrize("seed", range(1000, 1025))
+def test_random_pass_vs_oracle(pkg, tables, sweep_mode, seed):
+    r = run_case(seed, pkg, tables, sweep_mode == "fast")
+    assert r["loss"] <= tol("loss"), (seed, r["mesh"], r["loss"])
+    assert r["cd"] <= tol("cd"), (seed, r["mesh"], r["cd"])
+    if sweep_mode == "exact":
+        assert r["cd"] == 0.0          # column densities bit for bit
+    assert gamma_ok(r["dgamma"], r["gamma_ref"], r["w"], sweep_mode == "fast"), (seed, r["mesh"], r["gamma_rel"], r["gamma_w"])
