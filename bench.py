@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--x-init", type=float, default=0.999)
     ap.add_argument("--density", choices=["uniform", "lognormal"], default="uniform",
                     help="lognormal: sigma_ln=1, mean 1 times the same mean density (SURVEY.md s8d, config 5)")
-    ap.add_argument("--sweep-mode", choices=["exact", "fast"], default=os.environ.get("C2R_BENCH_SWEEP_MODE", "exact"),
+    ap.add_argument("--sweep-mode", choices=["exact", "fast"], default=os.environ.get("C2R_BENCH_SWEEP_MODE", "fast"),
                     help="c2r_params.sweep_mode: exact = the reference's f64 operation order (column densities bit-identical "
                          "to the Fortran), fast = re-associated arithmetic within the stated tolerance (include/c2ray_hip.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -213,7 +213,7 @@ def main():
                        "visited_per_s": visited_all / dt_wall,
                        "visited_cell_sources_whole_run_rank0": float(ev.visited + visited_before),
                        "mean_subboxes_per_source": [x / S for x in nbox_hist]},
-            "roofline": {"bound": "hbm", "kernel": "k_sweep_shell", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_sweep_shell_fast" if args.sweep_mode == "fast" else "k_sweep_shell", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": SWEEP_BYTES_PER_VISIT * vis_rank / launches,

@@ -681,11 +681,20 @@ __device__ __forceinline__ double tau_od(double tau, const KParams &p, const v2f
 // read_table at position od >= 1 (radiation_photoionrates.F90:212-228); tables padded by one element
 __device__ __forceinline__ double table_at(const double *__restrict__ tab, double od)
 {
+#if defined(C2R_ABLATE) && (C2R_ABLATE & 8)
+    return 1.0e48 / od;
+#endif
     typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
     const d2u v = *reinterpret_cast<const d2u *>(tab + (int)od);
     return __builtin_fma(v.y - v.x, __builtin_amdgcn_fract(od), v.x);
 }
 
+// Timing experiments only (profiles/micro/ablate.sh; results are WRONG with any bit set): -DC2R_ABLATE=<mask>
+//   1 no Gamma atomics   2 no plane stores   4 no n_HI loads   8 no rate-table reads   16 no plane loads
+//   32 plane stores and loads only on even shells (upper bound of what a two-shell on-chip hand-off could save)
+#ifndef C2R_ABLATE
+#define C2R_ABLATE 0
+#endif
 template <bool DET, int LLS, bool STREAM, int NR>
 __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                                   const int face, const int s, const int a, const int b0, const int sgb,
@@ -710,8 +719,11 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
 #pragma unroll
     for (int r = 0; r <= NR; ++r) {                        // rows b0-sgb, b0, ..., b0+(NR-1)sgb
         const bool inr = abs(b0 + (r - 1) * sgb) <= qm;
+        if ((C2R_ABLATE & 16) || ((C2R_ABLATE & 32) && (q & 1))) { vm[r] = 1e17 * (double)(o & 7u); va_[r] = 2e17; }
+        else {
         vm[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (inam && inr) ? o - da8 : kOOB);
         va_[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (ina && inr) ? o : kOOB);
+        }
         o += db8;
     }
     // cell indices: id = ca + base_p + stride_b * cb (x-fastest array, or the (x,y)-transposed replica for x faces)
@@ -728,7 +740,7 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
     for (int k = 0; k < NR; ++k) {
         const unsigned cb = wrap_pos(p.srcw[3 * s + va], p.n[va], b0 + k * sgb);
         id[k] = ca + base_p + __umul24(stride_b, cb);
-        nhi[k] = buf_load_f64<STREAM ? C2R_NHI_AUX : 0>(r_x, id[k] * 8u);
+        nhi[k] = (C2R_ABLATE & 4) ? 1e-7 * (double)(1u + (id[k] & 3u)) : buf_load_f64<STREAM ? C2R_NHI_AUX : 0>(r_x, id[k] * 8u);
     }
     // column part of the interpolation and of the geometry
     const double omu = (double)abs(a) * sa.inv_q, ddu = 1.0 - omu;   // weights of columns am and a
@@ -769,8 +781,10 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
             const double np = nhi[k] * path;                                      // n_HI path: the cell's own column
             const double cd_out = cd_in + np;
             // the cell's column density, also into the planes of the faces sharing the cell
+            if (!(C2R_ABLATE & 2) && !((C2R_ABLATE & 32) && !(q & 1)))
             buf_store_f64<SA>(r_cur, (unsigned)face * plane_bytes + o8, cd_out);
-            if (axis == 2) {
+            if (C2R_ABLATE & 2) { if (cd_out == 1.2345e-300) buf_store_f64<SA>(r_cur, o8, cd_out); }
+            else if (axis == 2) {
                 if (abs(a) == q)
                     buf_store_f64<SA>(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((pd + p.R) * p.P + (b + p.R)) * 8u, cd_out);
                 if (abs(b) == q)
@@ -800,6 +814,8 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
                 }
                 const double area = p.fourpi * dist2;                             // vol_ph = area path
                 gamma = (nflux * dT) * rcp1(area * np);                           // photo_cell_HI / (n_HI vol_ph)
+                if (C2R_ABLATE & 1) { if (gamma == 1.2345e-300) atomicAdd(&p.phih[id[k]], gamma); }
+                else
                 if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id[k]], gamma);
                 if (sa.has_boundary && (bnd_col || b == sa.boxR[va] || b == -sa.boxL[va]))
                     loss = loss + fdiv((nflux * t_out) * p.vol, area * path);
@@ -811,8 +827,11 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
     return loss;
 }
 
+#ifndef C2R_FAST_ATTR
+#define C2R_FAST_ATTR __launch_bounds__(kBlock)
+#endif
 template <bool DET, int LLS, bool STREAM>
-__global__ __launch_bounds__(kBlock) void k_sweep_shell_fast(KParams p, ShellArgs sa)
+__global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
 {
     __shared__ double sm[16];
     __shared__ v2f64 s_log[kBlock];                      // kBlock/64 waves x 64 entries

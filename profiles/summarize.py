@@ -58,7 +58,10 @@ def main():
         if k in w:
             n, kib = w[k]
             out["kernels"][k].update(write_bytes_per_launch=kib * 1024 / n)
-    sw = out["kernels"].get("c2r::k_sweep_shell")
+    # the sweep kernel of the run: the tolerance-mode kernel when bench.py ran with --sweep-mode fast
+    SWEEP = "c2r::k_sweep_shell_fast" if "c2r::k_sweep_shell_fast" in out["kernels"] else "c2r::k_sweep_shell"
+    out["sweep_kernel"] = SWEEP
+    sw = out["kernels"].get(SWEEP)
     if sw and visited and "pmc_launches" in sw:
         vis_per_launch = visited / sw["pmc_launches"]
         out["sweep_bytes_per_visit"] = {
@@ -79,7 +82,7 @@ def main():
         if os.path.exists(tr):     # like with like: the launches of the timed region are the last ones
             n = int(kbj["roofline"]["launches"])
             durs = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(tr))
-                    if kname(r["Kernel_Name"]) == "c2r::k_sweep_shell"]
+                    if kname(r["Kernel_Name"]) == SWEEP]
             last = durs[-n:]
             out["agreement"].update(rocprof_trace_avg_ms_timed_launches=sum(last) / len(last) * 1e-6,
                                     timed_launches=n, ratio_trace_over_events=sum(last) / len(last) * 1e-6 / ev_ms)
@@ -88,7 +91,7 @@ def main():
         agg = collections.defaultdict(float)
         dur = {}
         for r in csv.DictReader(open(sq)):
-            if kname(r["Kernel_Name"]) == "c2r::k_sweep_shell":
+            if kname(r["Kernel_Name"]) == SWEEP:
                 agg[r["Counter_Name"]] += float(r["Counter_Value"])
                 dur[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         if agg.get("SQ_WAVES"):
@@ -99,16 +102,33 @@ def main():
             if os.path.exists(gr):
                 cnt, gd = 0.0, {}
                 for r in csv.DictReader(open(gr)):
-                    if kname(r["Kernel_Name"]) == "c2r::k_sweep_shell" and r["Counter_Name"] == "GRBM_COUNT":
+                    if kname(r["Kernel_Name"]) == SWEEP and r["Counter_Name"] == "GRBM_COUNT":
                         cnt += float(r["Counter_Value"])
                         gd[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
                 if gd:
                     ghz = cnt / 8 / sum(gd.values())
             simd_cycles = sum(dur.values()) * ghz * 1024
+            sq2 = os.path.join(d, "pmc_SQ2.csv")
+            if os.path.exists(sq2):
+                a2 = collections.defaultdict(float)
+                for r in csv.DictReader(open(sq2)):
+                    if kname(r["Kernel_Name"]) == SWEEP:
+                        a2[r["Counter_Name"]] += float(r["Counter_Value"])
+                if a2.get("SQ_WAVES"):
+                    out["sweep_sq2_per_wave"] = {k: v / a2["SQ_WAVES"] for k, v in a2.items() if k != "SQ_WAVES"}
             out["sweep_sq"] = {"valu_insts_per_wave": agg["SQ_INSTS_VALU"] / agg["SQ_WAVES"],
                                "engine_clock_ghz_during_kernel": ghz,
                                "valu_busy_frac_of_simd_cycles": 4 * agg["SQ_ACTIVE_INST_VALU"] / simd_cycles,
                                "kernel_ns_in_this_pass": sum(dur.values()), "raw": dict(agg)}
+    # every other counter pass (pmc_TCC*.csv, pmc_TCP*.csv): totals of the sweep kernel per visited pair
+    extra = {}
+    for fn in sorted(os.listdir(d)):
+        if fn.startswith("pmc_TC") and fn.endswith(".csv"):
+            for r in csv.DictReader(open(os.path.join(d, fn))):
+                if kname(r["Kernel_Name"]) == SWEEP:
+                    extra[r["Counter_Name"]] = extra.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    if extra and visited:
+        out["sweep_counters_per_visit"] = {k: v / visited for k, v in sorted(extra.items())}
     json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
