@@ -72,6 +72,10 @@ SYMBOLS = [
     ("c2r_set_rank", C.c_int, [_P, _I32, _I32, ALLREDUCE_FN, _P]),
     ("c2r_set_source_share", C.c_int, [_P, _P, _I32]),
     ("c2r_last_nbox", C.c_int, [_P, _P, _I32]),
+    ("c2r_set_balance", C.c_int, [_P, _I32]),
+    ("c2r_source_share", C.c_int, [_P, _P, _I32, C.POINTER(_I32)]),
+    ("c2r_balanced_shares", C.c_int, [_P, _I32, _I32, _I32, _P, C.POINTER(_I32)]),
+    ("c2r_get_device", C.c_int, [_P, C.POINTER(_I32)]),
     ("c2r_bind_device_buffers", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("c2r_device_ptr", C.c_int, [_P, _I32, C.POINTER(_P)]),
     ("c2r_upload", C.c_int, [_P, _I32, _P]),

@@ -46,6 +46,11 @@ struct Ctx {
     int nsrc = 0, rank = 0, nranks = 1;
     bool explicit_share = false; std::vector<int32_t> share;   // c2r_set_source_share: this rank's sources
     std::vector<int32_t> last_nbox;                              // final sub-box count per local source, last pass
+    // cost-balanced distribution inside the library (c2r_set_balance): every rank learns every source's last
+    // sub-box count through the all-reduce callback and computes the same LPT partition
+    bool balance = false, auto_share = false;                    // auto_share: `share` was set by the balancer, not the caller
+    std::vector<int32_t> nbox_all;                               // [nsrc] after a balanced pass (empty: not known yet)
+    double *d_nbox_all = nullptr, *h_nbox_all = nullptr; int nbox_all_cap = 0;   // device buffer + pinned staging
     c2r_allreduce_fn ar = nullptr;
     void *ar_user = nullptr;
     c2r_iteration_fn iter_hook = nullptr;
@@ -394,15 +399,13 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                        ctx->d_photon_loss, ctx->d_sum_nbox, first_of_pass ? 1 : 0, &ctx->d_hsc->photon_loss,
                        &ctx->d_hsc->sum_nbox);
     HIP_TRY(hipGetLastError());
-    if (nbox_out) {
-        nbox_out->resize(count);
-        HIP_TRY(hipMemcpyAsync(nbox_out->data(), ctx->d_final_nbox, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, st));
-    }
-    if (loss_out) {
-        loss_out->resize(count);
-        HIP_TRY(hipMemcpyAsync(loss_out->data(), ctx->d_final_loss, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
-    }
+    // results come back through the pinned staging block (same layout as the device block): no pageable async copies
+    int *h_fnb = h_pos + 8 * cap;
+    if (nbox_out) HIP_TRY(hipMemcpyAsync(h_fnb, ctx->d_final_nbox, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (loss_out) HIP_TRY(hipMemcpyAsync(h_fl, ctx->d_final_loss, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (nbox_out) nbox_out->assign(h_fnb, h_fnb + count);
+    if (loss_out) loss_out->assign(h_fl, h_fl + count);
     return C2R_OK;
 }
 
@@ -449,6 +452,72 @@ int check_ready(Ctx *ctx)
     return C2R_OK;
 }
 
+// Longest-processing-time partition of the sources over the ranks by cost (deterministic: ties by source
+// index, then by rank); every share in ascending source order.  The role of the reference's master/worker
+// scheduler (master_slave.F90:124-330) without a master: cost = cells of the sub-box the source ended with in
+// the previous pass (+1: every source costs something).
+void lpt_shares(const std::vector<long long> &cost, int nranks, std::vector<std::vector<int32_t>> &shares)
+{
+    const int n = (int)cost.size();
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    std::vector<long long> load(nranks, 0);
+    shares.assign(nranks, {});
+    for (int i : order) {
+        int r = 0;
+        for (int k = 1; k < nranks; ++k) if (load[k] < load[r]) r = k;
+        shares[r].push_back(i);
+        load[r] += cost[i] + 1;
+    }
+    for (auto &sh : shares) std::sort(sh.begin(), sh.end());
+}
+
+// Before a pass: this rank's share from the sub-box counts every rank learnt after the previous pass.
+void balance_before_pass(Ctx *ctx)
+{
+    if (!ctx->balance || ctx->nranks <= 1 || (ctx->explicit_share && !ctx->auto_share)) return;
+    if ((int)ctx->nbox_all.size() != ctx->nsrc) {            // nothing known yet (first pass, new source list): static rule
+        if (ctx->auto_share) { ctx->explicit_share = false; ctx->auto_share = false; ctx->share.clear(); }
+        return;
+    }
+    std::vector<long long> cost(ctx->nsrc);
+    for (int i = 0; i < ctx->nsrc; ++i) cost[i] = visited_for_nbox(ctx, ctx->nbox_all[i]);
+    std::vector<std::vector<int32_t>> shares;
+    lpt_shares(cost, ctx->nranks, shares);
+    ctx->share = shares[ctx->rank];
+    ctx->explicit_share = true; ctx->auto_share = true;
+}
+
+// After a pass: every rank contributes the sub-box counts of the sources it swept (zero elsewhere); the sum over
+// ranks through the all-reduce callback is the full list (exact in f64).
+int balance_after_pass(Ctx *ctx)
+{
+    if (!ctx->balance || ctx->nranks <= 1 || !ctx->ar || (ctx->explicit_share && !ctx->auto_share) || ctx->nsrc == 0) return C2R_OK;
+    if (ctx->nbox_all_cap < ctx->nsrc) {
+        hipFree(ctx->d_nbox_all); ctx->d_nbox_all = nullptr; ctx->nbox_all_cap = 0;
+        if (ctx->h_nbox_all) { hipHostFree(ctx->h_nbox_all); ctx->h_nbox_all = nullptr; }
+        HIP_TRY(hipMalloc(&ctx->d_nbox_all, (size_t)ctx->nsrc * sizeof(double)));
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_nbox_all, (size_t)ctx->nsrc * sizeof(double)));
+        ctx->nbox_all_cap = ctx->nsrc;
+    }
+    double *mine = ctx->h_nbox_all;                          // pinned: both copies below are true async DMA
+    for (int i = 0; i < ctx->nsrc; ++i) mine[i] = 0.0;
+    const int nloc = n_local_sources(ctx);
+    for (int i = 0; i < nloc && i < (int)ctx->last_nbox.size(); ++i) {
+        const int g = ctx->explicit_share ? ctx->share[i] : ctx->rank + i * ctx->nranks;
+        mine[g] = (double)ctx->last_nbox[i];
+    }
+    const size_t bytes = (size_t)ctx->nsrc * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(ctx->d_nbox_all, mine, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->ar(ctx->ar_user, ctx->d_nbox_all, (size_t)ctx->nsrc, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-reduce callback failed");
+    HIP_TRY(hipMemcpyAsync(mine, ctx->d_nbox_all, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->nbox_all.resize(ctx->nsrc);
+    for (int i = 0; i < ctx->nsrc; ++i) ctx->nbox_all[i] = (int32_t)llround(mine[i]);
+    return C2R_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -490,7 +559,17 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev < 1) FAIL(C2R_ESTATE, "no HIP device: the c2ray_hip path needs a GPU (there is no CPU fallback)");
-    HIP_TRY(hipSetDevice(p->device));
+    if (p->device < 0) {
+        // C2R_DEVICE_AUTO: one process per GPU -- this process's local rank as its launcher exports it
+        // (the MPI builds of the driver, mpi.F90:83-160, know only the global rank), modulo the visible devices
+        static const char *const names[] = {"C2R_DEVICE", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK",
+                                            "MPI_LOCALRANKID", "PMI_LOCAL_RANK", "SLURM_LOCALID"};
+        int dev = 0;
+        for (const char *nm : names)
+            if (const char *e = getenv(nm)) { dev = atoi(e); break; }
+        ctx->prm.device = ((dev % ndev) + ndev) % ndev;
+    } else if (p->device >= ndev) FAIL(C2R_EINVAL, "device ordinal beyond the visible HIP devices");
+    HIP_TRY(hipSetDevice(ctx->prm.device));
     HIP_TRY(hipStreamCreate(&ctx->stream));
     ctx->own_stream = true;
     ctx->ncell = (size_t)p->mesh[0] * p->mesh[1] * p->mesh[2];
@@ -573,7 +652,8 @@ void c2r_destroy(c2r_ctx *c)
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
     hipFree(ctx->d_photon_loss); hipFree(ctx->d_sum_nbox); hipFree(ctx->d_sum_partial); hipFree(ctx->d_sum_out);
-    hipFree(ctx->d_conv); hipFree(ctx->d_chemfail); hipFree(ctx->d_dbg); hipFree(ctx->d_pair);
+    hipFree(ctx->d_conv); hipFree(ctx->d_chemfail); hipFree(ctx->d_dbg); hipFree(ctx->d_pair); hipFree(ctx->d_nbox_all);
+    if (ctx->h_nbox_all) hipHostFree(ctx->h_nbox_all);
     if (ctx->h_sc) hipHostFree(ctx->h_sc);
     for (auto &e : ctx->ev_box) hipEventDestroy(e);
     for (auto &e : ctx->ev_sweep) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -663,7 +743,7 @@ int c2r_set_sources(c2r_ctx *c, const int32_t *srcpos, const double *normflux, i
     ctx->srcpos.assign(srcpos, srcpos + 3 * (size_t)nsrc);
     ctx->nflux.assign(normflux, normflux + nsrc);
     ctx->nsrc = nsrc;
-    ctx->explicit_share = false; ctx->share.clear(); ctx->last_nbox.clear();
+    ctx->explicit_share = false; ctx->auto_share = false; ctx->share.clear(); ctx->last_nbox.clear(); ctx->nbox_all.clear();
     return C2R_OK;
 }
 
@@ -674,6 +754,8 @@ int c2r_set_rank(c2r_ctx *c, int32_t rank, int32_t nranks, c2r_allreduce_fn fn, 
     if (nranks < 1 || rank < 0 || rank >= nranks) FAIL(C2R_EINVAL, "need 0 <= rank < nranks");
     if (nranks > 1 && !fn) FAIL(C2R_EINVAL, "nranks > 1 needs an all-reduce callback");
     ctx->rank = rank; ctx->nranks = nranks; ctx->ar = fn; ctx->ar_user = user;
+    if (ctx->auto_share) { ctx->explicit_share = false; ctx->auto_share = false; ctx->share.clear(); }
+    ctx->nbox_all.clear();
     return C2R_OK;
 }
 
@@ -681,10 +763,10 @@ int c2r_set_source_share(c2r_ctx *c, const int32_t *idx, int32_t n)
 {
     if (!c) return C2R_EINVAL;
     Ctx *ctx = C(c);
-    if (!idx || n < 0) { ctx->explicit_share = false; ctx->share.clear(); return C2R_OK; }
+    if (!idx || n < 0) { ctx->explicit_share = false; ctx->auto_share = false; ctx->share.clear(); return C2R_OK; }
     for (int i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= ctx->nsrc) FAIL(C2R_EINVAL, "source index out of range");
     ctx->share.assign(idx, idx + n);
-    ctx->explicit_share = true;
+    ctx->explicit_share = true; ctx->auto_share = false;
     return C2R_OK;
 }
 
@@ -694,6 +776,44 @@ int c2r_last_nbox(c2r_ctx *c, int32_t *nbox, int32_t n)
     Ctx *ctx = C(c);
     if (n != (int32_t)ctx->last_nbox.size()) FAIL(C2R_EINVAL, "length must equal the number of sources this rank swept");
     for (int i = 0; i < n; ++i) nbox[i] = ctx->last_nbox[i];
+    return C2R_OK;
+}
+
+int c2r_get_device(const c2r_ctx *c, int32_t *device)
+{
+    if (!c || !device) return C2R_EINVAL;
+    *device = C(c)->prm.device;
+    return C2R_OK;
+}
+
+int c2r_set_balance(c2r_ctx *c, int32_t on)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    ctx->balance = on != 0;
+    if (!ctx->balance && ctx->auto_share) { ctx->explicit_share = false; ctx->auto_share = false; ctx->share.clear(); }
+    ctx->nbox_all.clear();
+    return C2R_OK;
+}
+
+int c2r_source_share(c2r_ctx *c, int32_t *idx, int32_t cap, int32_t *n)
+{
+    if (!c || !n || (cap > 0 && !idx)) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    const int nloc = n_local_sources(ctx);
+    *n = nloc;
+    for (int i = 0; i < nloc && i < cap; ++i) idx[i] = ctx->explicit_share ? ctx->share[i] : ctx->rank + i * ctx->nranks;
+    return C2R_OK;
+}
+
+int c2r_balanced_shares(const int64_t *cost, int32_t nsrc, int32_t nranks, int32_t rank, int32_t *idx, int32_t *n)
+{
+    if (nsrc < 0 || nranks < 1 || rank < 0 || rank >= nranks || !n || (nsrc > 0 && (!cost || !idx))) return C2R_EINVAL;
+    std::vector<long long> c(cost, cost + nsrc);
+    std::vector<std::vector<int32_t>> shares;
+    lpt_shares(c, nranks, shares);
+    *n = (int32_t)shares[rank].size();
+    for (size_t i = 0; i < shares[rank].size(); ++i) idx[i] = shares[rank][i];
     return C2R_OK;
 }
 
@@ -750,15 +870,16 @@ int c2r_pass_sources(c2r_ctx *c, double *photon_loss, int64_t *sum_nbox, int64_t
     Ctx *ctx = C(c);
     int rc = check_ready(ctx);
     if (rc) return rc;
+    balance_before_pass(ctx);
     const int nloc = n_local_sources(ctx);
     long long vis = 0;
+    ctx->last_nbox.clear();
     ctx->h_sc->photon_loss = 0.0; ctx->h_sc->sum_nbox = 0;      // (the stream is idle between calls)
     if (nloc > 0) {
         rc = ensure_sweep_scratch(ctx, nloc);
         if (rc) return rc;
         if ((rc = sweep_prepare(ctx))) return rc;
         std::vector<int> nb;
-        ctx->last_nbox.clear();
         for (int first = 0; first < nloc; first += ctx->batch_cap) {
             const int count = std::min(ctx->batch_cap, nloc - first);
             rc = sweep_batch(ctx, first, count, first == 0, nullptr, &nb, nullptr);
@@ -769,6 +890,7 @@ int c2r_pass_sources(c2r_ctx *c, double *photon_loss, int64_t *sum_nbox, int64_t
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));                 // k_batch_totals stored the totals in h_sc
     prof_collect(ctx);
+    if ((rc = balance_after_pass(ctx))) return rc;
     if (photon_loss) *photon_loss = ctx->h_sc->photon_loss;
     if (sum_nbox) *sum_nbox = ctx->h_sc->sum_nbox;
     if (visited) *visited = vis;

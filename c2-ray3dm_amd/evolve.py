@@ -159,9 +159,17 @@ class HipBackend:
             self._check(self.lib.c2r_set_source_share(self.ctx, idx.ctypes.data, len(idx)), "c2r_set_source_share")
             self.share = idx
 
+    def set_balance(self, on=True):
+        """Cost-balanced source shares computed inside the library from the previous pass (c2r_set_balance)."""
+        self._check(self.lib.c2r_set_balance(self.ctx, 1 if on else 0), "c2r_set_balance")
+
     def local_sources(self):
-        sh = getattr(self, "share", None)
-        return np.asarray(sh if sh is not None else static_source_share(self.nsrc, self.rank, self.npr), dtype=np.int64)
+        """0-based global indices of the sources this rank sweeps (swept in the last pass): static stride,
+        explicit share or the library's balanced share (c2r_source_share)."""
+        n = C.c_int32()
+        idx = np.zeros(max(1, self.nsrc), dtype=np.int32)
+        self._check(self.lib.c2r_source_share(self.ctx, idx.ctypes.data, idx.size, C.byref(n)), "c2r_source_share")
+        return idx[:n.value].astype(np.int64)
 
     def last_nbox(self):
         n = len(self.local_sources())
@@ -333,6 +341,12 @@ class Evolve:
         self.npr = comm.get_world_size() if comm is not None else 1
         if hasattr(backend, "set_rank"):
             backend.set_rank(self.rank, self.npr, (lambda t: comm.all_reduce(t)) if comm is not None else None)
+        # the HIP backend balances inside the library (c2r_set_balance: the same LPT rule, one small all-reduce
+        # through the same callback), so the Fortran/C hosts get it too; do_grid's Python version below serves
+        # backends without it (the CPU test double)
+        self._lib_balance = balance and hasattr(backend, "set_balance")
+        if hasattr(backend, "set_balance"):
+            backend.set_balance(self._lib_balance)
         self.sum_nbox = 0
         self.sum_nbox_all = 0
         self.photon_loss = 0.0
@@ -351,6 +365,12 @@ class Evolve:
     # master_slave.F90:53 -> :74 do_grid_static; the per-source loop and do_source live in the
     # backend (c2r_pass_sources), which traces this rank's share 1+rank, 1+rank+npr, ...
     def do_grid(self, dt, niter):
+        if self._lib_balance:
+            loss, nb, vis = self.b.pass_sources()
+            self.photon_loss += loss
+            self.sum_nbox += nb
+            self.visited += vis
+            return
         if self.nbox_per_source is not None and len(self.nbox_per_source) != self.b.nsrc:
             self.nbox_per_source = None        # the source list changed (new slice): back to the static rule for one pass
         if self.balance and self.npr > 1 and self.nbox_per_source is not None:

@@ -35,8 +35,16 @@ module c2ray_hip
   use c2ray_parameters, only: epsilon, convergence_fraction, minimum_fractional_change, &
        minimum_fraction_of_atoms, loss_fraction, subboxsize, max_subbox, use_LLS, type_of_LLS, &
        type_of_clumping
+#ifdef MPI
+  ! -DMPI builds of the driver (mpi.F90:83-160): one rank per GPU; sources are distributed over the ranks inside the
+  ! library (master_slave.F90:74-96 / :124-330) and Gamma is summed with RCCL over xGMI (evolve.F90:577-616)
+  use my_mpi, only: rank, npr, MPI_COMM_NEW
+#endif
 
   implicit none
+#ifdef MPI
+  include 'mpif.h'
+#endif
 
   save
 
@@ -156,6 +164,42 @@ module c2ray_hip
        type(c_funptr), value :: fn
        type(c_ptr), value :: user
      end function c2r_set_iteration_hook
+     integer(c_int) function c2r_set_balance(ctx, on) bind(C, name="c2r_set_balance")
+       import :: c_int, c_ptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: on
+     end function c2r_set_balance
+     integer(c_int) function c2r_get_device(ctx, device) bind(C, name="c2r_get_device")
+       import :: c_int, c_ptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), intent(out) :: device
+     end function c2r_get_device
+     !> c2r_allreduce_fn of include/c2ray_hip.h as a C function pointer (c_funloc of a bind(C) function, or
+     !! the RCCL binding's own callback installed by c2r_rccl_attach)
+     integer(c_int) function c2r_set_rank(ctx, rank, nranks, fn, user) bind(C, name="c2r_set_rank")
+       import :: c_int, c_ptr, c_funptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: rank, nranks
+       type(c_funptr), value :: fn
+       type(c_ptr), value :: user
+     end function c2r_set_rank
+#ifdef MPI
+     ! libc2ray_rccl.so (include/c2ray_rccl.h): link with -lc2ray_rccl
+     integer(c_int) function c2r_rccl_unique_id(id) bind(C, name="c2r_rccl_unique_id")
+       import :: c_int, c_char
+       character(kind=c_char), intent(out) :: id(128)          ! C2R_RCCL_ID_BYTES
+     end function c2r_rccl_unique_id
+     integer(c_int) function c2r_rccl_attach(ctx, id, rank, nranks) bind(C, name="c2r_rccl_attach")
+       import :: c_int, c_ptr, c_char, c_int32_t
+       type(c_ptr), value :: ctx
+       character(kind=c_char), intent(in) :: id(128)
+       integer(c_int32_t), value :: rank, nranks
+     end function c2r_rccl_attach
+     integer(c_int) function c2r_rccl_detach(ctx) bind(C, name="c2r_rccl_detach")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_rccl_detach
+#endif
      integer(c_int) function c2r_download(ctx, which, host) bind(C, name="c2r_download")
        import :: c_int, c_ptr, c_double, c_int32_t
        type(c_ptr), value :: ctx
@@ -193,9 +237,18 @@ contains
   !> evolve_ini counterpart for the device side: created lazily on the first evolve3D
   subroutine evolve_hip_ini()
     type(c2r_params) :: p
+    integer(c_int32_t) :: dev
+#ifdef MPI
+    character(kind=c_char) :: uid(128)
+    integer :: mympierror
+#endif
     call check(c2r_default_params(p), "c2r_default_params")
     p%mesh = mesh
+#ifdef MPI
+    p%device = -1_c_int32_t            ! C2R_DEVICE_AUTO: this rank's LOCAL rank (from the launcher) modulo the node's GPUs
+#else
     p%device = 0
+#endif
     ! the parameters this build of the driver was compiled with
     p%subboxsize = subboxsize; p%max_subbox = max_subbox; p%numtau = NumTau
     p%epsilon = epsilon; p%convergence_fraction = convergence_fraction
@@ -210,10 +263,31 @@ contains
     call check(c2r_create(ctx, p), "c2r_create")
     call check(c2r_set_tables(ctx, stellar_photo_thick_table(:,1), stellar_photo_thin_table(:,1), &
          int(NumTau+1, c_int32_t)), "c2r_set_tables")
+    call check(c2r_get_device(ctx, dev), "c2r_get_device")
+    write(logf,*) "c2ray_hip: evolve hot path on HIP device ", dev
+#ifdef MPI
+    ! Join the RCCL communicator: rank 0 makes the 128-byte token, one broadcast next to those of mpi.F90 hands it
+    ! out, every rank attaches on its own device.  From here on c2r_evolve3d sweeps this rank's share of the sources
+    ! (static 1+rank,NumSrc,npr for the first pass, master_slave.F90:85; cost-balanced afterwards: the role of
+    ! do_grid_master/do_grid_slave, :124-330) and sums phih_grid, photon_loss and sum_nbox over the ranks
+    ! (mpi_accumulate_grid_quantities, evolve.F90:577-616) on the GPUs.
+    if (npr > 1) then
+       if (rank == 0) call check(c2r_rccl_unique_id(uid), "c2r_rccl_unique_id")
+       call MPI_BCAST(uid, 128, MPI_BYTE, 0, MPI_COMM_NEW, mympierror)
+       call check(c2r_rccl_attach(ctx, uid, int(rank, c_int32_t), int(npr, c_int32_t)), "c2r_rccl_attach")
+       call check(c2r_set_balance(ctx, 1_c_int32_t), "c2r_set_balance")
+    endif
+#endif
   end subroutine evolve_hip_ini
 
   subroutine evolve_hip_end()
-    if (c_associated(ctx)) call c2r_destroy(ctx)
+    integer(c_int) :: rc
+    if (c_associated(ctx)) then
+#ifdef MPI
+       if (npr > 1) rc = c2r_rccl_detach(ctx)
+#endif
+       call c2r_destroy(ctx)
+    endif
     ctx = c_null_ptr
   end subroutine evolve_hip_end
 
@@ -413,49 +487,63 @@ contains
     endif
   end function iteration_hook
 
-  !> Same file layout as evolve.F90:285-324 (isothermal case: the only one on this path)
-  subroutine write_iteration_dump (niter)
-    integer,intent(in) :: niter
-    integer :: ndump=0
-    character(len=20) :: iterfile
-    write(timefile,"(A,F8.1)") "Time before writing iterdump: ", timestamp_wallclock ()
-    ndump = ndump + 1
-    if (mod(ndump,2) == 0) then
-       iterfile = "iterdump2.bin"
+  !> Name of the dump file a restart flag / a running dump number selects: the reference alternates
+  !! iterdump1.bin and iterdump2.bin while it runs and reads iterdump.bin for restart=3 (evolve.F90:296-300, 346-353).
+  function dump_path(which) result(path)
+    integer, intent(in) :: which        !< 1, 2: the alternating files; anything else: iterdump.bin
+    character(len=512) :: path
+    character(len=16) :: leaf
+    leaf = "iterdump.bin"
+    if (which == 1) leaf = "iterdump1.bin"
+    if (which == 2) leaf = "iterdump2.bin"
+    path = trim(adjustl(dump_dir))//trim(leaf)
+  end function dump_path
+
+  !> One pass over the five unformatted records of an iteration dump, in the reference's order
+  !! (evolve.F90:303-311 write, :358-416 read; isothermal runs have no temperature record):
+  !! niter | photon_loss_all | phih_grid | xh_av | xh_intermed.
+  subroutine dump_records (path, writing, niter)
+    character(len=*), intent(in) :: path
+    logical, intent(in) :: writing
+    integer, intent(inout) :: niter
+    if (writing) then
+       open(unit=iterdump, file=trim(path), form="unformatted", status="unknown")
+       write(iterdump) niter
+       write(iterdump) photon_loss_all
+       write(iterdump) phih_grid
+       write(iterdump) xh_av
+       write(iterdump) xh_intermed
     else
-       iterfile = "iterdump1.bin"
+       open(unit=iterdump, file=trim(path), form="unformatted", status="old")
+       read(iterdump) niter
+       read(iterdump) photon_loss_all
+       read(iterdump) phih_grid
+       read(iterdump) xh_av
+       read(iterdump) xh_intermed
     endif
-    open(unit=iterdump, file=trim(adjustl(dump_dir))//iterfile, form="unformatted", status="unknown")
-    write(iterdump) niter
-    write(iterdump) photon_loss_all
-    write(iterdump) phih_grid
-    write(iterdump) xh_av
-    write(iterdump) xh_intermed
     close(iterdump)
+  end subroutine dump_records
+
+  !> The state of outer iteration `niter` to the next of the two alternating dump files (evolve.F90:285-324)
+  subroutine write_iteration_dump (niter)
+    integer, intent(in) :: niter
+    integer, save :: dumps_written = 0
+    integer :: n
+    n = niter
+    write(timefile,"(A,F8.1)") "Time before writing iterdump: ", timestamp_wallclock ()
+    dumps_written = dumps_written + 1
+    call dump_records (dump_path(2 - mod(dumps_written, 2)), .true., n)       ! 1, 2, 1, 2, ...
     write(timefile,"(A,F8.1)") "Time after writing iterdump: ", timestamp_wallclock ()
   end subroutine write_iteration_dump
 
-  !> Reads the dump selected by the restart flag (evolve.F90:328-426, serial, isothermal)
+  !> Load the dump the restart flag selects into the driver's arrays (evolve.F90:328-426; every rank reads the
+  !! file itself) and log what the reference logs about it (:418-422).
   subroutine start_from_dump (restart, niter)
-    integer,intent(in) :: restart
-    integer,intent(out) :: niter
-    character(len=20) :: iterfile
+    integer, intent(in) :: restart
+    integer, intent(out) :: niter
+    niter = 0
     write(timefile,"(A,F8.1)") "Time before reading iterdump: ", timestamp_wallclock ()
-    select case (restart)
-    case (1)
-       iterfile = "iterdump1.bin"
-    case (2)
-       iterfile = "iterdump2.bin"
-    case default
-       iterfile = "iterdump.bin"
-    end select
-    open(unit=iterdump, file=trim(adjustl(dump_dir))//iterfile, form="unformatted", status="old")
-    read(iterdump) niter
-    read(iterdump) photon_loss_all
-    read(iterdump) phih_grid
-    read(iterdump) xh_av
-    read(iterdump) xh_intermed
-    close(iterdump)
+    call dump_records (dump_path(restart), .false., niter)
     write(logf,*) "Read iteration ",niter," from dump file"
     write(logf,*) "photon loss counter: ",photon_loss_all
     write(logf,*) "Intermediate result for mean ionization fraction: ", &

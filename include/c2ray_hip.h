@@ -35,6 +35,7 @@ extern "C" {
 
 #define C2R_MAX_ITER_LOG 128
 
+#define C2R_DEVICE_AUTO  (-1)
 #define C2R_SWEEP_EXACT   0
 #define C2R_SWEEP_FAST    1
 
@@ -45,7 +46,9 @@ typedef struct c2r_ctx c2r_ctx;
  * c2ray_constants.h cites each defining line). */
 typedef struct c2r_params {
     int32_t mesh[3];                 /* sizes.f90:33  mesh(1:3) */
-    int32_t device;                  /* HIP device ordinal */
+    int32_t device;                  /* HIP device ordinal, or C2R_DEVICE_AUTO: the process's local rank as the launcher
+                                      * exports it (C2R_DEVICE, LOCAL_RANK, OMPI_COMM_WORLD_LOCAL_RANK, MV2_COMM_WORLD_LOCAL_RANK,
+                                      * MPI_LOCALRANKID, PMI_LOCAL_RANK, SLURM_LOCALID; first one set) modulo the visible devices */
     int32_t subboxsize;              /* c2ray_parameters.f90:54 */
     int32_t max_subbox;              /* c2ray_parameters.f90:61 */
     int32_t numtau;                  /* radiation_sizes.f90:14 (tables hold numtau+1 entries) */
@@ -152,6 +155,20 @@ int  c2r_set_rank(c2r_ctx *ctx, int32_t rank, int32_t nranks, c2r_allreduce_fn f
  * ended with in the last c2r_pass_sources (its cost is the volume of that box). */
 int  c2r_set_source_share(c2r_ctx *ctx, const int32_t *idx, int32_t n);
 int  c2r_last_nbox(c2r_ctx *ctx, int32_t *nbox, int32_t n);
+/* The same cost balancing INSIDE the library, for hosts that only call c2r_evolve3d (the Fortran shim): after
+ * every pass each rank contributes the sub-box counts of the sources it swept to one small all-reduce (through the
+ * callback of c2r_set_rank), and before the next pass every rank computes the same longest-processing-time
+ * partition by the cell count of each source's last sub-box.  The first pass after c2r_set_sources / c2r_set_rank
+ * uses the static rule.  An explicit c2r_set_source_share takes precedence while it is in force. */
+int  c2r_set_balance(c2r_ctx *ctx, int32_t on);
+/* The 0-based global indices of the sources this rank sweeps (swept in the last pass, once one has run):
+ * *n receives their number, idx (capacity cap) the first min(*n, cap) of them. */
+int  c2r_source_share(c2r_ctx *ctx, int32_t *idx, int32_t cap, int32_t *n);
+/* The partition c2r_set_balance uses, as a pure host function (no context, no GPU): rank `rank`'s share of
+ * nsrc sources with the given costs over nranks ranks; idx has room for nsrc entries. */
+int  c2r_balanced_shares(const int64_t *cost, int32_t nsrc, int32_t nranks, int32_t rank, int32_t *idx, int32_t *n);
+/* The device the context runs on (resolves C2R_DEVICE_AUTO). */
+int  c2r_get_device(const c2r_ctx *ctx, int32_t *device);
 
 /* ---- device buffers -------------------------------------------------------------------- */
 /* Use caller-owned device arrays (N^3 each; ndens f32, the rest f64) instead of the

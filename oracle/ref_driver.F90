@@ -15,6 +15,7 @@
 !! and driver.nml:
 !!   &ctl mode='evolve'|'sweep'|'point'|'tables', nsteps=, x_init=, dens_file=,
 !!        x_file=, dump_first=, dump_last=, ns_dump=, nrep=, out_dir= /
+!!   (mode 'sweep' also writes <tag>_nbox.txt: the sub-box count each source ended with)
 !! usage: ref_driver <answers-file>
 program ref_driver
 
@@ -59,6 +60,7 @@ program ref_driver
 
   character(len=512) :: answers
   integer :: restart = 0, nz0 = 1, ierror = 0, nz, u, istep, ns, irep
+  integer :: nbox_before, nbox_src(4096) = 0
   real(kind=dp) :: end_time, sim_time, output_time, dt, actual_dt
   real(kind=dp) :: t_sweep
   integer(kind=8) :: c0, c1, crate
@@ -162,7 +164,9 @@ program ref_driver
               photon_loss = 0.0
               sum_nbox = 0
               do ns = 1, NumSrc
+                 nbox_before = sum_nbox
                  call do_source(actual_dt, ns, 1)
+                 if (irep == 1 .and. ns <= size(nbox_src)) nbox_src(ns) = sum_nbox - nbox_before
                  if (ns == ns_dump .and. irep == 1) &
                       call dump_r8(trim(tag)//'_coldensh_out', coldensh_out)
               enddo
@@ -175,6 +179,12 @@ program ref_driver
            write(u,'(A,1X,I12)') 'sum_nbox', sum_nbox
            write(u,'(A,1X,ES26.17E3)') 'seconds_per_pass', t_sweep
            write(u,'(A,1X,I12)') 'nthreads', nthreads
+           close(u)
+           ! sub-boxes each source ended with (evolve_source.F90:219 adds them to sum_nbox): the cost of a source
+           open(newunit=u, file=trim(out_dir)//trim(tag)//'_nbox.txt', status='replace')
+           do ns = 1, min(NumSrc, size(nbox_src))
+              write(u,'(I8)') nbox_src(ns)
+           enddo
            close(u)
            stop
         endif

@@ -1,0 +1,146 @@
+// TEST INFRASTRUCTURE: a host WITHOUT Python, torch or MPI that drives the C ABI (include/c2ray_hip.h) with several
+// ranks in one process -- one thread per rank, one context per rank -- the way an MPI build of the Fortran driver
+// does with one process per rank (mpi.F90:83-160, master_slave.F90:74-96, evolve.F90:577-616):
+//     c2r_create(device = rank mod visible devices) / c2r_set_rank + all-reduce callback / c2r_set_balance /
+//     c2r_evolve3d (host-pointer entry, what the Fortran shim calls).
+// Collective:  "rccl"  libc2ray_rccl.so (ncclAllReduce over xGMI; needs one device per rank),
+//              "host"  a rank-ordered sum staged through host memory (any device count, also 1 GPU).
+// usage: mgpu_harness <in.bin> <out.bin> <nranks> <host|rccl> <balance 0|1>
+//   in.bin : int32 mesh, nsrc | f64 dr, vol, lls, dt | f32 ndens[N^3] | f64 xh[N^3] | int32 srcpos[3 nsrc] | f64 normflux[nsrc]
+//   out.bin: int32 niter, converged, nranks_used_rccl | int64 sum_nbox, conv_flag[niter] | f64 loss | f64 xh[N^3] | f64 phih[N^3]
+#include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/c2ray_hip.h"
+#include "../../include/c2ray_rccl.h"
+
+struct Problem {
+    int32_t mesh, nsrc; double dr, vol, lls, dt;
+    std::vector<float> ndens; std::vector<double> xh, normflux; std::vector<int32_t> srcpos;
+    std::vector<double> thick, thin;
+};
+struct Shared {
+    int nranks; bool rccl, balance; const Problem *pb;
+    pthread_barrier_t bar;
+    std::vector<double *> stage; std::vector<size_t> stage_cap;   // host all-reduce: one PINNED staging buffer per rank
+    unsigned char uid[C2R_RCCL_ID_BYTES];
+    std::vector<int> rc; std::vector<std::string> err;
+    c2r_report rep0; std::vector<double> xh0, phih0;
+};
+struct RankArg { Shared *sh; int rank; };
+
+// c2r_allreduce_fn: sum over the ranks (threads) in rank order, staged through host memory
+static int host_allreduce(void *user, void *dev_buf, size_t count, void *stream)
+{
+    RankArg *a = static_cast<RankArg *>(user);
+    Shared *sh = a->sh;
+    if (sh->stage_cap[a->rank] < count) {                      // (re)allocate between collectives only: no one reads it now
+        if (sh->stage[a->rank]) hipHostFree(sh->stage[a->rank]);
+        if (hipHostMalloc((void **)&sh->stage[a->rank], 2 * count * sizeof(double)) != hipSuccess) return 1;   // [0,count) mine, [count,2count) sum
+        sh->stage_cap[a->rank] = count;
+    }
+    double *mine = sh->stage[a->rank], *sum = mine + sh->stage_cap[a->rank];
+    if (hipMemcpyAsync(mine, dev_buf, count * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return 1;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;
+    pthread_barrier_wait(&sh->bar);
+    for (size_t i = 0; i < count; ++i) sum[i] = 0.0;
+    for (int r = 0; r < sh->nranks; ++r)
+        for (size_t i = 0; i < count; ++i) sum[i] = sum[i] + sh->stage[r][i];
+    pthread_barrier_wait(&sh->bar);                  // everyone has read every staging buffer
+    if (hipMemcpyAsync(dev_buf, sum, count * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return 1;
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : 1;
+}
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != 0) { sh->rc[rank] = rc_; sh->err[rank] = std::string(#expr) + ": " + (ctx ? c2r_last_error(ctx) : ""); goto done; } } while (0)
+
+static void *rank_main(void *p)
+{
+    RankArg *a = static_cast<RankArg *>(p);
+    Shared *sh = a->sh;
+    const Problem &pb = *sh->pb;
+    const int rank = a->rank;
+    c2r_ctx *ctx = nullptr;
+    int ndev = 0;
+    hipGetDeviceCount(&ndev);
+    const size_t ncell = (size_t)pb.mesh * pb.mesh * pb.mesh;
+    // every rank owns its arrays, as every MPI process does (the library page-locks the arrays it is handed)
+    std::vector<float> ndens = pb.ndens;
+    std::vector<double> xh = pb.xh, xh_av(ncell), xh_int(ncell), phih(ncell);
+    c2r_report rep;
+    {
+        c2r_params prm;
+        c2r_default_params(&prm);
+        prm.mesh[0] = prm.mesh[1] = prm.mesh[2] = pb.mesh;
+        prm.device = rank % ndev;
+        if (const char *e = getenv("C2R_SWEEP_MODE")) prm.sweep_mode = atoi(e) ? C2R_SWEEP_FAST : C2R_SWEEP_EXACT;
+        TRY(c2r_create(&ctx, &prm));
+        TRY(c2r_set_tables(ctx, pb.thick.data(), pb.thin.data(), (int32_t)pb.thick.size()));
+        const double dr[3] = {pb.dr, pb.dr, pb.dr};
+        TRY(c2r_set_step(ctx, dr, pb.vol, pb.lls, 1.0f, 1.0e4));
+        TRY(c2r_set_sources(ctx, pb.srcpos.data(), pb.normflux.data(), pb.nsrc));
+        if (sh->nranks > 1) {
+            if (sh->rccl) {
+                if (rank == 0) TRY(c2r_rccl_unique_id(sh->uid));
+                pthread_barrier_wait(&sh->bar);
+                TRY(c2r_rccl_attach(ctx, sh->uid, rank, sh->nranks));
+            } else {
+                TRY(c2r_set_rank(ctx, rank, sh->nranks, host_allreduce, a));
+            }
+            TRY(c2r_set_balance(ctx, sh->balance ? 1 : 0));
+        }
+        TRY(c2r_evolve3d(ctx, pb.dt, ndens.data(), xh.data(), xh_av.data(), xh_int.data(), phih.data(), &rep));
+        if (rank == 0) { sh->rep0 = rep; sh->xh0 = xh; sh->phih0 = phih; }
+        if (sh->rccl && sh->nranks > 1) c2r_rccl_detach(ctx);
+    }
+done:
+    if (ctx) c2r_destroy(ctx);
+    return nullptr;
+}
+
+template <typename T> static void rd(FILE *f, T *p, size_t n) { if (fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "short input\n"); exit(2); } }
+
+int main(int argc, char **argv)
+{
+    if (argc < 6) { fprintf(stderr, "usage: %s in.bin out.bin nranks host|rccl balance\n", argv[0]); return 2; }
+    Problem pb;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) { perror(argv[1]); return 2; }
+    rd(f, &pb.mesh, 1); rd(f, &pb.nsrc, 1); rd(f, &pb.dr, 1); rd(f, &pb.vol, 1); rd(f, &pb.lls, 1); rd(f, &pb.dt, 1);
+    const size_t ncell = (size_t)pb.mesh * pb.mesh * pb.mesh;
+    pb.ndens.resize(ncell); pb.xh.resize(ncell); pb.srcpos.resize(3 * (size_t)pb.nsrc); pb.normflux.resize(pb.nsrc);
+    rd(f, pb.ndens.data(), ncell); rd(f, pb.xh.data(), ncell); rd(f, pb.srcpos.data(), pb.srcpos.size()); rd(f, pb.normflux.data(), pb.normflux.size());
+    fclose(f);
+    c2r_sed_params sed;
+    c2r_default_sed(&sed);
+    pb.thick.resize(sed.numtau + 1); pb.thin.resize(sed.numtau + 1);
+    if (c2r_build_tables(&sed, pb.thick.data(), pb.thin.data(), sed.numtau + 1, nullptr) != 0) { fprintf(stderr, "c2r_build_tables failed\n"); return 1; }
+    Shared sh;
+    sh.nranks = atoi(argv[3]); sh.rccl = strcmp(argv[4], "rccl") == 0; sh.balance = atoi(argv[5]) != 0; sh.pb = &pb;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { fprintf(stderr, "no HIP device\n"); return 1; }
+    if (sh.rccl && ndev < sh.nranks) { printf("SKIP: %d ranks over RCCL need %d devices, %d visible\n", sh.nranks, sh.nranks, ndev); return 77; }
+    pthread_barrier_init(&sh.bar, nullptr, sh.nranks);
+    sh.stage.assign(sh.nranks, nullptr); sh.stage_cap.assign(sh.nranks, 0); sh.rc.assign(sh.nranks, 0); sh.err.resize(sh.nranks);
+    std::vector<pthread_t> th(sh.nranks);
+    std::vector<RankArg> args(sh.nranks);
+    for (int r = 0; r < sh.nranks; ++r) { args[r] = {&sh, r}; pthread_create(&th[r], nullptr, rank_main, &args[r]); }
+    for (int r = 0; r < sh.nranks; ++r) pthread_join(th[r], nullptr);
+    for (int r = 0; r < sh.nranks; ++r)
+        if (sh.rc[r]) { fprintf(stderr, "rank %d failed (%d): %s\n", r, sh.rc[r], sh.err[r].c_str()); return 1; }
+    f = fopen(argv[2], "wb");
+    const int32_t head[3] = {sh.rep0.niter, sh.rep0.converged, sh.rccl ? sh.nranks : 0};
+    fwrite(head, sizeof(int32_t), 3, f);
+    fwrite(&sh.rep0.sum_nbox_all, sizeof(int64_t), 1, f);
+    fwrite(sh.rep0.it_conv_flag, sizeof(int64_t), sh.rep0.niter, f);
+    fwrite(&sh.rep0.photon_loss_all, sizeof(double), 1, f);
+    fwrite(sh.xh0.data(), sizeof(double), ncell, f);
+    fwrite(sh.phih0.data(), sizeof(double), ncell, f);
+    fclose(f);
+    printf("ok: %d rank(s) on %d device(s), %s all-reduce, balance %d: niter %d sum_nbox %lld\n", sh.nranks, ndev < sh.nranks ? ndev : sh.nranks,
+           sh.rccl ? "rccl" : "host", (int)sh.balance, sh.rep0.niter, (long long)sh.rep0.sum_nbox_all);
+    return 0;
+}

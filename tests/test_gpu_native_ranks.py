@@ -1,0 +1,79 @@
+"""Multi-rank runs BELOW Python: tests/native/mgpu_harness (C++, no torch, no MPI) drives the C ABI with one thread and
+one context per rank, the way an MPI build of the Fortran driver does with one process per rank -- c2r_set_rank with an
+all-reduce callback, c2r_set_balance, c2r_evolve3d on host arrays (mpi.F90:83-160, master_slave.F90:74-96 and
+:124-330, evolve.F90:577-616).  On the one-GPU box every rank's context sits on device 0 and the collective is a
+rank-ordered sum staged through host memory; where at least two devices are visible the same run goes through
+libc2ray_rccl.so (ncclAllReduce), otherwise that case is skipped."""
+import os
+import subprocess
+import numpy as np
+import pytest
+from tests._util import F, load_case, tol
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("sweep_mode")]
+HARNESS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "mgpu_harness")
+
+
+def write_input(path, n, s, nd, xh):
+    with open(path, "wb") as f:
+        np.array([n, len(s["normflux"])], dtype=np.int32).tofile(f)
+        np.array([s["dr1"], s["vol"], s["coldensh_LLS"], s["dt"]], dtype=np.float64).tofile(f)
+        np.asarray(nd, dtype=np.float32).tofile(f)
+        np.asarray(xh, dtype=np.float64).tofile(f)
+        np.asarray(s["srcpos"], dtype=np.int32).tofile(f)
+        np.asarray(s["normflux"], dtype=np.float64).tofile(f)
+
+
+def read_output(path, n):
+    with open(path, "rb") as f:
+        niter, converged, rccl_ranks = np.fromfile(f, np.int32, 3)
+        sum_nbox = int(np.fromfile(f, np.int64, 1)[0])
+        conv = np.fromfile(f, np.int64, niter)
+        loss = float(np.fromfile(f, np.float64, 1)[0])
+        xh = np.fromfile(f, np.float64, n ** 3)
+        phih = np.fromfile(f, np.float64, n ** 3)
+    return dict(niter=int(niter), converged=int(converged), rccl_ranks=int(rccl_ranks), sum_nbox=sum_nbox, conv=list(conv), loss=loss, xh=xh, phih=phih)
+
+
+def run(tmp_path, tag, nranks, coll, balance):
+    out = str(tmp_path / ("out_%s.bin" % tag))
+    p = subprocess.run([HARNESS, str(tmp_path / "in.bin"), out, str(nranks), coll, str(int(balance))],
+                       capture_output=True, text=True, timeout=600)
+    if p.returncode == 77:
+        pytest.skip(p.stdout.strip())
+    assert p.returncode == 0, p.stdout + p.stderr
+    return out
+
+
+@pytest.mark.parametrize("case", ["evolve32_std_bubbles", "evolve64_std_bubbles"])
+def test_ranks_as_threads_match_the_reference_step(tmp_path, case):
+    assert os.path.exists(HARNESS), "build it: make -C tests/native (or __graft_entry__.build())"
+    m, a = load_case(case)
+    n, s = m["n"], m["steps"]["step001"]
+    write_input(str(tmp_path / "in.bin"), n, s, F(a["step001_ndens"]), F(a["step001_xh_before"]))
+    ref = F(a["step001_xh_after"])
+    res = {}
+    for tag, nranks, coll, bal in (("1", 1, "host", 0), ("2", 2, "host", 0), ("3b", 3, "host", 1), ("4b", 4, "host", 1)):
+        r = read_output(run(tmp_path, tag, nranks, coll, bal), n)
+        assert r["converged"] and r["niter"] == s["niter"], tag
+        assert r["conv"] == s["log"]["nonconv"], tag
+        assert r["sum_nbox"] == s["sum_nbox_all"], tag
+        assert abs(r["loss"] - s["photon_loss_all"]) <= tol("loss") * abs(s["photon_loss_all"]) + 1e-300, tag
+        assert np.max(np.abs(r["xh"] - ref)) < tol("x"), tag
+        res[tag] = r
+    for tag in ("2", "3b", "4b"):        # the partition changes only the order of the sums
+        assert np.max(np.abs(res[tag]["xh"] - res["1"]["xh"])) < 1e-12
+        nz = res["1"]["phih"] != 0
+        assert np.array_equal(res[tag]["phih"] != 0, nz)
+        assert np.max(np.abs(res[tag]["phih"][nz] / res["1"]["phih"][nz] - 1)) < 1e-10
+
+
+def test_two_ranks_over_rccl(tmp_path):
+    """ncclAllReduce of phih_grid between two devices of the node (libc2ray_rccl.so); skipped on a one-GPU box."""
+    assert os.path.exists(HARNESS)
+    m, a = load_case("evolve32_std_bubbles")
+    n, s = m["n"], m["steps"]["step001"]
+    write_input(str(tmp_path / "in.bin"), n, s, F(a["step001_ndens"]), F(a["step001_xh_before"]))
+    r = read_output(run(tmp_path, "rccl", 2, "rccl", 1), n)
+    assert r["rccl_ranks"] == 2 and r["niter"] == s["niter"] and r["conv"] == s["log"]["nonconv"]
+    assert np.max(np.abs(r["xh"] - F(a["step001_xh_after"]))) < tol("x")

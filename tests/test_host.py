@@ -178,6 +178,27 @@ def test_balanced_source_shares(pkg):
     assert load.max() / load.mean() < 1.02 < static.max() / static.mean()
 
 
+def test_library_partition_equals_python_partition(pkg):
+    """c2r_balanced_shares -- the partition c2r_set_balance uses inside the library, so that hosts which only call
+    c2r_evolve3d (the Fortran shim) are balanced too -- is the same function as evolve.balanced_source_shares
+    (pure host code: needs no GPU)."""
+    import ctypes as C
+    lib = pkg.load_library()
+    rng = np.random.default_rng(1)
+    for trial in range(40):
+        n, npr = int(rng.integers(0, 300)), int(rng.integers(1, 12))
+        cost = (rng.integers(0, 1000, n) * rng.integers(0, 2, n)).astype(np.int64)      # many ties and zeros
+        ref = pkg.balanced_source_shares(cost, npr)
+        seen = []
+        for r in range(npr):
+            idx, m = np.zeros(max(n, 1), dtype=np.int32), C.c_int32()
+            assert lib.c2r_balanced_shares(cost.ctypes.data, n, npr, r, idx.ctypes.data, C.byref(m)) == 0
+            assert idx[:m.value].tolist() == ref[r]
+            seen += idx[:m.value].tolist()
+        assert sorted(seen) == list(range(n))
+    assert lib.c2r_balanced_shares(None, 3, 2, 2, None, None) == -1
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("mode", ["static", "balance"])
 def test_two_ranks_gloo_equals_one_rank(pkg, tmp_path, mode):
