@@ -46,6 +46,7 @@ struct Ctx {
     int nsrc = 0, rank = 0, nranks = 1;
     bool explicit_share = false; std::vector<int32_t> share;   // c2r_set_source_share: this rank's sources
     std::vector<int32_t> last_nbox;                              // final sub-box count per local source, last pass
+    int box_hint = 0;                                            // largest of them: how far the next pass is expected to go
     // cost-balanced distribution inside the library (c2r_set_balance): every rank learns every source's last
     // sub-box count through the all-reduce callback and computes the same LPT partition
     bool balance = false, auto_share = false;                    // auto_share: `share` was set by the balancer, not the caller
@@ -63,6 +64,7 @@ struct Ctx {
     int batch_cap = 0, batch_want = 0;
     bool stream_hint = false;   // non-temporal cache policy of k_sweep_shell: meshes whose n_HI array outgrows the L2s
     bool fuse_small = true;     // C2R_FUSE_SMALL=0 disables the fused first sub-boxes (experiments, A/B tests)
+    bool sched_hint = true;     // C2R_SCHED_HINT=0: always one sub-box ahead (experiments, see sweep_batch)
     double *d_planes = nullptr;
     int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr;
     double *d_gbox = nullptr;   // deterministic mode: [batch_cap][2][ncell]
@@ -82,6 +84,7 @@ struct Ctx {
     struct HostScalars { double sum; double photon_loss; long long sum_nbox; unsigned long long conv; unsigned int chemfail; double pair[2]; double four[4]; } *h_sc = nullptr,  // pinned
       *d_hsc = nullptr;                       // ... and its device alias: kernels store results there directly
     double *d_dbg = nullptr, *d_pair = nullptr;
+    double *h_it4 = nullptr, *d_hit4 = nullptr;   // pinned [C2R_MAX_ITER_LOG][4]: per-iteration photon-statistics sums, written by the device
     // profiling
     int prof = 0;               // 0 off; 1 an event pair around every k_sweep_shell launch; 2 one pair per sub-box
     std::vector<int> ev_sweep_cnt;   // k_sweep_shell launches covered by each pair
@@ -278,13 +281,23 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
     HIP_TRY(hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st));
 
     KParams k = make_kparams(ctx);
-    int cur = 0;
+    int cur = 0, last_bps = 0;     // last_bps: size of the last shell's loss partials per source (0: none), for k_box_decide
     // The active count lives on the device (d_nactive[cur]); the host only needs an upper bound to
     // size the grids.  It runs ONE sub-box ahead: box n+1 is enqueued (sized by the count known
     // after box n-1) before the count after box n is read back, so the GPU never drains while the
     // host waits; blocks of sources that retired in between return at once.
     int bound = n_active;          // upper bound of the device count for the launches being enqueued
-    int pending = 0;               // sub-box whose count has been requested but not read yet (0: none)
+    int known = 0;                 // sub-boxes whose resulting count has been read back
+    // How far ahead of the device the host runs.  Normally ONE sub-box: box n+1 is enqueued, sized by the count known
+    // after box n-1, before the count after box n is read back -- the GPU never drains while the host waits, and
+    // blocks of sources that retired in between return at once.  A batch of FEW sources (<= kFewSources) is nothing but
+    // launch latency, and every wait is a host round trip with the GPU idle: there the host does not wait at all up to
+    // the sub-box the previous pass ended at (box_hint: in the steady state of an outer iteration the sources retire
+    // where they did last time), only picking up counts that have already arrived; at that sub-box it waits for the
+    // box's own count (normally zero: done).  Measured (profiles/r02_launch_bound/): 128^3 x 1 source 0.80 -> 0.73 ms per
+    // outer iteration; with 1000 sources the same rule costs 5-20 % (stale large grids), hence the limit.
+    constexpr int kFewSources = 32;
+    const int hint = (ctx->sched_hint && n_active <= kFewSources) ? std::max(1, ctx->box_hint) : 1;
     for (int nbox = 1; nbox <= ctx->nbox_max && bound > 0; ++nbox) {
         int boxR[3], boxL[3];
         for (int d = 0; d < 3; ++d) {
@@ -317,6 +330,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             sa.loss_partial = ctx->d_loss_partial; sa.dbg_cdout = dbg;
             return sa;
         };
+        last_bps = 0;
         if (ctx->fuse_small && q1 <= kFusedQmax && q1 - q0 + 1 <= kMaxFused) {
             // near the source: the whole sub-box of every active source in ONE launch (k_sweep_box_fused)
             BoxArgs ba{};
@@ -349,6 +363,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             }
         } else {
         int in_box = 0;                         // k_sweep_shell launches of this sub-box (coarse timing)
+        last_bps = 0;
         if (ctx->prof == 2) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
         for (int q = q0; q <= q1; ++q) {
             ShellArgs sa = shell_args(q);
@@ -373,24 +388,29 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
 #undef C2R_LAUNCH_SWEEP
             }
             if (ctx->prof == 1) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(1); }
-            if (sa.has_boundary)
+            // the partials of the sub-box's last shell are summed by k_box_decide itself
+            if (sa.has_boundary && q < q1)
                 hipLaunchKernelGGL(k_loss_reduce, dim3(bound), dim3(256), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
                                    ctx->d_loss_partial, 6 * sa.tiles_max, ctx->d_loss_acc);
+            if (q == q1 && sa.has_boundary) last_bps = 6 * sa.tiles_max;
         }
         if (ctx->prof == 2) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(in_box); }
         }
         const int can_grow = (p.subboxsize * nbox < ctx->hr[2]) && (p.subboxsize * nbox < ctx->hl[2]);
         hipLaunchKernelGGL(k_box_decide, dim3(1), dim3(1024), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
                            ctx->d_active[1 - cur], ctx->d_nactive + (1 - cur), ctx->d_hnactive + nbox, ctx->d_nflux_b,
-                           p.S_star, p.loss_fraction, can_grow, nbox, ctx->d_loss_acc, ctx->d_final_loss, ctx->d_final_nbox);
+                           p.S_star, p.loss_fraction, can_grow, nbox, ctx->d_loss_acc, ctx->d_final_loss, ctx->d_final_nbox,
+                           (const double *)ctx->d_loss_partial, last_bps);
         HIP_TRY(hipEventRecord(ctx->ev_box[nbox], st));
         cur = 1 - cur;
-        // read the count of the PREVIOUS sub-box (its copy was enqueued a whole box of launches ago)
-        if (pending) {
-            HIP_TRY(hipEventSynchronize(ctx->ev_box[pending]));
-            bound = ctx->h_nactive[pending];
+        // counts that have already arrived (never blocks)
+        while (known < nbox && hipEventQuery(ctx->ev_box[known + 1]) == hipSuccess) bound = ctx->h_nactive[++known];
+        // blocking read-back: the box's own count where the previous pass ended, the previous box's beyond
+        const int need = nbox == hint ? nbox : (nbox > hint ? nbox - 1 : 0);
+        if (need > known) {
+            HIP_TRY(hipEventSynchronize(ctx->ev_box[need]));
+            known = need; bound = ctx->h_nactive[need];
         }
-        pending = nbox;
     }
     if (ctx->d_gbox)
         hipLaunchKernelGGL(k_gamma_reduce, dim3((p.mesh[0] + 255) / 256, p.mesh[1], p.mesh[2]), dim3(256), 0, st, k, count,
@@ -552,6 +572,7 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     Ctx *ctx = new Ctx();
     ctx->prm = *p;
     if (const char *e = getenv("C2R_FUSE_SMALL")) ctx->fuse_small = atoi(e) != 0;
+    if (const char *e = getenv("C2R_SCHED_HINT")) ctx->sched_hint = atoi(e) != 0;
     if (p->sweep_mode != C2R_SWEEP_EXACT && p->sweep_mode != C2R_SWEEP_FAST) { delete ctx; return C2R_EINVAL; }
     ctx->fast = p->sweep_mode == C2R_SWEEP_FAST;
     if (const char *e = getenv("C2R_SWEEP_MODE")) ctx->fast = atoi(e) != 0;         // experiments, A/B runs
@@ -619,6 +640,8 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipHostMalloc((void **)&ctx->h_sc, sizeof(*ctx->h_sc), hipHostMallocMapped));
     memset(ctx->h_sc, 0, sizeof(*ctx->h_sc));
     HIP_TRY(hipHostGetDevicePointer((void **)&ctx->d_hsc, ctx->h_sc, 0));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_it4, (size_t)C2R_MAX_ITER_LOG * 4 * sizeof(double), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void **)&ctx->d_hit4, ctx->h_it4, 0));
     // trace limits (evolve_source.F90:100-102), identical for every source
     int zlim = 0;
     for (int d = 0; d < 3; ++d) {
@@ -655,6 +678,7 @@ void c2r_destroy(c2r_ctx *c)
     hipFree(ctx->d_conv); hipFree(ctx->d_chemfail); hipFree(ctx->d_dbg); hipFree(ctx->d_pair); hipFree(ctx->d_nbox_all);
     if (ctx->h_nbox_all) hipHostFree(ctx->h_nbox_all);
     if (ctx->h_sc) hipHostFree(ctx->h_sc);
+    if (ctx->h_it4) hipHostFree(ctx->h_it4);
     for (auto &e : ctx->ev_box) hipEventDestroy(e);
     for (auto &e : ctx->ev_sweep) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : ctx->ev_chem) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -743,7 +767,7 @@ int c2r_set_sources(c2r_ctx *c, const int32_t *srcpos, const double *normflux, i
     ctx->srcpos.assign(srcpos, srcpos + 3 * (size_t)nsrc);
     ctx->nflux.assign(normflux, normflux + nsrc);
     ctx->nsrc = nsrc;
-    ctx->explicit_share = false; ctx->auto_share = false; ctx->share.clear(); ctx->last_nbox.clear(); ctx->nbox_all.clear();
+    ctx->explicit_share = false; ctx->auto_share = false; ctx->share.clear(); ctx->last_nbox.clear(); ctx->nbox_all.clear(); ctx->box_hint = 0;
     return C2R_OK;
 }
 
@@ -885,8 +909,11 @@ int c2r_pass_sources(c2r_ctx *c, double *photon_loss, int64_t *sum_nbox, int64_t
             rc = sweep_batch(ctx, first, count, first == 0, nullptr, &nb, nullptr);
             if (rc) return rc;
             for (int v : nb) { vis += visited_for_nbox(ctx, v); ctx->last_nbox.push_back(v); }
+            
         }
         if ((rc = sweep_finish(ctx))) return rc;
+        ctx->box_hint = 0;
+        for (int v : ctx->last_nbox) ctx->box_hint = std::max(ctx->box_hint, v);
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));                 // k_batch_totals stored the totals in h_sc
     prof_collect(ctx);
@@ -987,12 +1014,9 @@ int c2r_sum(c2r_ctx *c, int32_t which, double *sum)
     return C2R_OK;
 }
 
-int c2r_photon_sums(c2r_ctx *c, int32_t which_l, int32_t which_r, double out[4])
+// the four mesh sums of photonstatistics.F90 into dst[4] (device-visible: mapped pinned memory), no host wait
+static int photon_sums_launch(Ctx *ctx, int which_l, int which_r, double *dst)
 {
-    if (!c || !out || which_l < 1 || which_l > 3 || which_r < 1 || which_r > 3) return C2R_EINVAL;
-    Ctx *ctx = C(c);
-    int rc = check_ready(ctx);
-    if (rc) return rc;
     const c2r_params &p = ctx->prm;
     // photonstatistics.F90:166-172: same rate coefficients as doric, host libm
     hipLaunchKernelGGL(k_photon_sums, dim3(kSumBlocks), dim3(256), 0, ctx->stream, ctx->ncell,
@@ -1000,8 +1024,18 @@ int c2r_photon_sums(c2r_ctx *c, int32_t which_l, int32_t which_r, double out[4])
                        (const double *)ctx->grid[which_r], p.abu_c, (double)ctx->clumping, (const float *)ctx->d_clump,
                        p.bh00, pow(ctx->temper / 1e4, p.albpow), p.colh0, sqrt(ctx->temper),
                        exp(-p.temph0 / ctx->temper), ctx->d_sum_partial);
-    hipLaunchKernelGGL(k_sum_final, dim3(4), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, ctx->d_hsc->four);
+    hipLaunchKernelGGL(k_sum_final, dim3(4), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, dst);
     HIP_TRY(hipGetLastError());
+    return C2R_OK;
+}
+
+int c2r_photon_sums(c2r_ctx *c, int32_t which_l, int32_t which_r, double out[4])
+{
+    if (!c || !out || which_l < 1 || which_l > 3 || which_r < 1 || which_r > 3) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    if ((rc = photon_sums_launch(ctx, which_l, which_r, ctx->d_hsc->four))) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int m = 0; m < 4; ++m) out[m] = ctx->h_sc->four[m];
     return C2R_OK;
@@ -1128,11 +1162,9 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
         rep->chem_not_converged = (int32_t)ctx->h_sc->chemfail;
         if (niter <= C2R_MAX_ITER_LOG) {
             rep->it_conv_flag[niter - 1] = conv_flag; rep->it_sum_nbox[niter - 1] = nb;
-            // evolve.F90:570 calculate_photon_statistics(dt,xh_intermed,xh_av) + report: conservation line
-            if ((rc = c2r_photon_sums(c, 3, 2, after))) return rc;
-            const double trec = after[2] * ctx->vol * dt, tcol = after[3] * ctx->vol * dt;
-            const double tion = trec + (before[0] * ctx->vol - after[0] * ctx->vol);
-            rep->it_photcons[niter - 1] = totalsrc > 0.0 ? (tion - tcol) / totalsrc : 0.0;
+            // evolve.F90:570 calculate_photon_statistics(dt,xh_intermed,xh_av) + report: the conservation line.  The
+            // sums land in this iteration's pinned slot; nobody waits for them before the step ends.
+            if ((rc = photon_sums_launch(ctx, 3, 2, ctx->d_hit4 + 4 * (size_t)(niter - 1)))) return rc;
         }
         // evolve.F90:271-275: the place where the reference decides on an iteration dump
         if (ctx->iter_hook) {
@@ -1142,6 +1174,12 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     rep->niter = niter; rep->conv_flag = conv_flag;
+    for (int k = (restart_niter > 0 ? restart_niter : 0); k < niter && k < C2R_MAX_ITER_LOG; ++k) {
+        const double *a4 = ctx->h_it4 + 4 * (size_t)k;
+        const double trec = a4[2] * ctx->vol * dt, tcol = a4[3] * ctx->vol * dt;
+        const double tion = trec + (before[0] * ctx->vol - a4[0] * ctx->vol);
+        rep->it_photcons[k] = totalsrc > 0.0 ? (tion - tcol) / totalsrc : 0.0;
+    }
     // evolve.F90:277-279 calculate_photon_statistics(dt,xh,xh_av)
     if ((rc = c2r_photon_sums(c, 1, 2, after))) return rc;
     rep->h0_before = before[0] * ctx->vol; rep->h1_before = before[1] * ctx->vol;

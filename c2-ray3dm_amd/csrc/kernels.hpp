@@ -600,17 +600,9 @@ __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &
 
 // STREAM: the non-temporal cache policy above (the host turns it on for meshes whose n_HI array outgrows the L2s)
 template <bool DET, int LLS, bool STREAM>
-__global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
+__device__ __forceinline__ void sweep_tile(const KParams &p, const ShellArgs &sa, const FaceRect &fr, const v2f64 *ltab,
+                                           double *sm, const int face, const int tile, const int sl)
 {
-    __shared__ double sm[16];
-    __shared__ v2f64 s_log[kBlock];                      // kBlock/64 waves x 64 entries
-    const int face = blockIdx.y;
-    const int sl = blockIdx.z;
-    const int tile = blockIdx.x;
-    if (sl >= *sa.n_active) return;              // block-uniform: this source retired after the launch was sized
-    const FaceRect fr = sa.face[face];
-    if (tile >= fr.ntiles && !sa.has_boundary) return;   // block-uniform: nothing to do and no partial to write
-    const v2f64 *ltab = wave_log_table(p.logtab, s_log);
     double loss = 0.0;
     const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
     const unsigned bi = fr.magic ? __umulhi(t, fr.magic) : t;       // row-group index
@@ -629,6 +621,21 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
         if (threadIdx.x == 0)
             sa.loss_partial[((size_t)sl * 6 + face) * sa.tiles_max + tile] = tot;
     }
+}
+
+template <bool DET, int LLS, bool STREAM>
+__global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
+{
+    __shared__ double sm[16];
+    __shared__ v2f64 s_log[kBlock];                      // kBlock/64 waves x 64 entries
+    const int face = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int nact = *sa.n_active;
+    if ((int)blockIdx.z >= nact) return;         // block-uniform: this source retired after the launch was sized
+    const FaceRect fr = sa.face[face];
+    if (tile >= fr.ntiles && !sa.has_boundary) return;   // block-uniform: nothing to do and no partial to write
+    const v2f64 *ltab = wave_log_table(p.logtab, s_log);
+    sweep_tile<DET, LLS, STREAM>(p, sa, fr, ltab, sm, face, tile, (int)blockIdx.z);
 }
 
 // ==== tolerance ("fast") mode of the sweep =======================================================
@@ -830,18 +837,11 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
 #ifndef C2R_FAST_ATTR
 #define C2R_FAST_ATTR __launch_bounds__(kBlock)
 #endif
+// one (source, face, tile) block of work of k_sweep_shell_fast; sl = position in the active list
 template <bool DET, int LLS, bool STREAM>
-__global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
+__device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArgs &sa, const FaceRect &fr, const v2f64 *ltab,
+                                                double *sm, const int face, const int tile, const int sl)
 {
-    __shared__ double sm[16];
-    __shared__ v2f64 s_log[kBlock];                      // kBlock/64 waves x 64 entries
-    const int face = blockIdx.y;
-    const int sl = blockIdx.z;
-    const int tile = blockIdx.x;
-    if (sl >= *sa.n_active) return;
-    const FaceRect fr = sa.face[face];
-    if (tile >= fr.ntiles && !sa.has_boundary) return;
-    const v2f64 *ltab = wave_log_table(p.odtab, s_log);
     double loss = 0.0;
     const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
     const unsigned bi = fr.magic ? __umulhi(t, fr.magic) : t;
@@ -859,6 +859,21 @@ __global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
         if (threadIdx.x == 0)
             sa.loss_partial[((size_t)sl * 6 + face) * sa.tiles_max + tile] = tot;
     }
+}
+
+template <bool DET, int LLS, bool STREAM>
+__global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
+{
+    __shared__ double sm[16];
+    __shared__ v2f64 s_log[kBlock];                      // kBlock/64 waves x 64 entries
+    const int face = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int nact = *sa.n_active;
+    if ((int)blockIdx.z >= nact) return;
+    const FaceRect fr = sa.face[face];
+    if (tile >= fr.ntiles && !sa.has_boundary) return;
+    const v2f64 *ltab = wave_log_table(p.odtab, s_log);
+    sweep_tile_fast<DET, LLS, STREAM>(p, sa, fr, ltab, sm, face, tile, (int)blockIdx.z);
 }
 
 // ---- the first sub-boxes, fused: one workgroup per source, all shells of the sub-box in one launch -----
@@ -1038,8 +1053,11 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const int *active, const in
 __global__ __launch_bounds__(1024) void k_box_decide(const int *active_in, const int *n_in_dev, int *active_out,
                                                      int *n_out, int *n_out_host, const double *normflux, double S_star,
                                                      double loss_fraction, int can_grow, int nbox,
-                                                     double *loss_acc, double *final_loss, int *final_nbox)
+                                                     double *loss_acc, double *final_loss, int *final_nbox,
+                                                     const double *loss_partial, int bps)
 {
+    // loss_partial/bps: block partials of the sub-box's LAST shell launch (bps = 6 x tiles per source, 0: none) -- what
+    // k_loss_reduce would add, folded in here to save a launch; four interleaved partial sums, then in a fixed order
     __shared__ int scan[1024];
     __shared__ int base;
     const int n_in = *n_in_dev;
@@ -1051,7 +1069,16 @@ __global__ __launch_bounds__(1024) void k_box_decide(const int *active_in, const
         if (i < n_in) {
             s = active_in[i];
             const double flux = normflux[s] * S_star;
-            const double loss = loss_acc[s];
+            double loss = loss_acc[s];
+            if (bps > 0) {
+                const double *pp = loss_partial + (size_t)i * bps;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                int j = 0;
+                for (; j + 3 < bps; j += 4) { a0 += pp[j]; a1 += pp[j + 1]; a2 += pp[j + 2]; a3 += pp[j + 3]; }
+                for (; j < bps; ++j) a0 += pp[j];
+                loss = loss + ((a0 + a1) + (a2 + a3));
+                loss_acc[s] = loss;
+            }
             keep = (loss > loss_fraction * flux) && can_grow;
             if (keep) loss_acc[s] = 0.0;                      // evolve_source.F90:133
             else { final_loss[s] = loss; final_nbox[s] = nbox; }
