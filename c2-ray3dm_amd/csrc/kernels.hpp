@@ -689,7 +689,7 @@ __device__ __forceinline__ double tau_od(double tau, const KParams &p, const v2f
 __device__ __forceinline__ double table_at(const double *__restrict__ tab, double od)
 {
 #if defined(C2R_ABLATE) && (C2R_ABLATE & 8)
-    return 1.0e48 / od;
+    return 1.0e48 * (1.0 - 1.0e-4 * od);
 #endif
     typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
     const d2u v = *reinterpret_cast<const d2u *>(tab + (int)od);
@@ -704,6 +704,7 @@ __device__ __forceinline__ double table_at(const double *__restrict__ tab, doubl
 #endif
 template <bool DET, int LLS, bool STREAM, int NR>
 __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
+                                                  const double *__restrict__ thick,   // p.thick, or the block's LDS copy of it
                                                   const int face, const int s, const int a, const int b0, const int sgb,
                                                   const int nvalid)
 {
@@ -810,10 +811,10 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
             if (!stop && !(cd_in > p.max_coldensh) && nflux > 0.0) {
                 const double tau_in = cd_in * p.sigma, tau_out = cd_out * p.sigma;
                 const double od_in = tau_od(tau_in, p, ltab);
-                const double t_in = table_at(p.thick, od_in);
+                const double t_in = table_at(thick, od_in);
                 double dT, t_out;
                 if (fabs(tau_out - tau_in) > p.tau_limit) {
-                    t_out = table_at(p.thick, tau_od(tau_out, p, ltab));
+                    t_out = table_at(thick, tau_od(tau_out, p, ltab));
                     dT = t_in - t_out;
                 } else {
                     dT = (tau_out - tau_in) * table_at(p.thin, od_in);
@@ -840,7 +841,7 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
 // one (source, face, tile) block of work of k_sweep_shell_fast; sl = position in the active list
 template <bool DET, int LLS, bool STREAM>
 __device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArgs &sa, const FaceRect &fr, const v2f64 *ltab,
-                                                double *sm, const int face, const int tile, const int sl)
+                                                const double *thick, double *sm, const int face, const int tile, const int sl)
 {
     double loss = 0.0;
     const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
@@ -852,7 +853,7 @@ __device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArg
         const int sgb = pos ? 1 : -1;
         const int b0 = pos ? k0 : -1 - k0;
         const int left = pos ? (fr.b_lo + fr.wb - b0) : (b0 - fr.b_lo + 1);
-        loss = shell_rows_fast<DET, LLS, STREAM, kRows>(p, sa, ltab, face, sa.active[sl], a, b0, sgb, min(left, kRows));
+        loss = shell_rows_fast<DET, LLS, STREAM, kRows>(p, sa, ltab, thick, face, sa.active[sl], a, b0, sgb, min(left, kRows));
     }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
@@ -873,7 +874,7 @@ __global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
     const FaceRect fr = sa.face[face];
     if (tile >= fr.ntiles && !sa.has_boundary) return;
     const v2f64 *ltab = wave_log_table(p.odtab, s_log);
-    sweep_tile_fast<DET, LLS, STREAM>(p, sa, fr, ltab, sm, face, tile, (int)blockIdx.z);
+    sweep_tile_fast<DET, LLS, STREAM>(p, sa, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z);
 }
 
 // ---- the first sub-boxes, fused: one workgroup per source, all shells of the sub-box in one launch -----
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
             const unsigned bi = fr.magic ? __umulhi(lt, fr.magic) : lt;
             const int a = fr.a_lo + (int)(lt - __umul24(bi, (unsigned)fr.wa));
             const int b = fr.b_lo + (int)bi;
-            if (FAST) loss = loss + shell_rows_fast<DET, LLS, false, 1>(p, sa, ltab, f, s, a, b, b < 0 ? -1 : 1, 1);
+            if (FAST) loss = loss + shell_rows_fast<DET, LLS, false, 1>(p, sa, ltab, p.thick, f, s, a, b, b < 0 ? -1 : 1, 1);
             else loss = loss + shell_cell<DET, LLS, 0>(p, sa, ltab, f, s, a, b);
         }
         if (sa.has_boundary) {

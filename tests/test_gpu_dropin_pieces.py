@@ -20,7 +20,7 @@ from tests._util import GOLDEN, relerr
 sys.path.insert(0, GOLDEN)
 import inputs as gi      # noqa: E402  (tests/golden/inputs.py: seeded inputs + run-directory writer)
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("sweep_mode")]     # once per sweep mode (C2R_SWEEP_MODE reaches child processes too)
 
 
 def exe(n, variant=None):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 from tests._util import GOLDEN
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("sweep_mode")]     # once per sweep mode (C2R_SWEEP_MODE reaches child processes too)
 
 
 @pytest.mark.parametrize("case", ["refrun32_onesrc", "refrun32_std"])

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 from tests._util import F, load_case
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("sweep_mode")]     # once per sweep mode (C2R_SWEEP_MODE reaches child processes too)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
