@@ -257,7 +257,9 @@ def main():
                          "chem_kernel_ms_per_launch": prof["chem_ms"] / max(1, prof["chem_launches"]),
                          "chem_achieved_GBs": (CHEM_BYTES_PER_CELL * float(n) ** 3 * prof["chem_launches"] /
                                                (prof["chem_ms"] * 1e-3) / 1e9) if prof["chem_ms"] > 0 else 0.0,
-                         "note": "f64 VALU (divide/log10/sqrt) binds this kernel before HBM does; see DESIGN.md"},
+                         "note": "achieved = 28 algorithmic B per visited (cell, source) / launch time; the traffic actually leaving the L2s is ~38 B per visit "
+                                 "(shell planes make a round trip through HBM between launches) and the Gamma atomics cost the memory side a "
+                                 "read and a write each: ~47 B per visit at DRAM level, ~5.2 TB/s of the ~6.3 TB/s achievable; see DESIGN.md s5"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, srcpos, normflux, xh_state, nbox_first, pkg.box_cost, nd=nd)
