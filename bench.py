@@ -120,6 +120,10 @@ def main():
     ap.add_argument("--sweep-mode", choices=["exact", "fast"], default=os.environ.get("C2R_BENCH_SWEEP_MODE", "fast"),
                     help="c2r_params.sweep_mode: exact = the reference's f64 operation order (column densities bit-identical "
                          "to the Fortran), fast = re-associated arithmetic within the stated tolerance (include/c2ray_hip.h)")
+    ap.add_argument("--density-file", default=None,
+                    help="coarsened cubep3m density file (<z>n_all.dat: 3 x int32 + N^3 float32 stream, nbody_cubep3m.F90:87-107) "
+                         "instead of the synthetic field; scaled as scale_density does (density_unit grid, --n-box fine cells per side)")
+    ap.add_argument("--n-box", type=int, default=13824, help="fine N-body cells per side of the density file's simulation (nbody_cubep3m.F90:9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--balance", action="store_true",
                     help="cost-balanced source shares (by the previous pass) instead of the static stride")
@@ -155,6 +159,11 @@ def main():
     if args.density == "lognormal":
         rng = np.random.default_rng(20261003)
         nd = (nd * np.exp(rng.standard_normal(nd.size, dtype=np.float32) - 0.5)).astype(np.float32)
+    if args.density_file:
+        raw = pkg.fileio.read_density(args.density_file, mesh=n)               # density_module.F90:203-243
+        nd = pkg.fileio.scale_density(raw, s["zred"], n, args.n_box).ravel(order="F")
+        # cosmo_evol (cosmology.F90:186): the slice's comoving-at-z density is rescaled to the mid-step redshift -- here
+        # the file is taken to hold the slice of the step's own redshift
     srcpos, normflux = pkg.seeded_sources(n, S)
     thick, thin, _ = pkg.build_tables()          # rad_ini on the host (c2r_build_tables)
     b = pkg.HipBackend(n, thick, thin, device=local_rank, deterministic=args.deterministic, fast=args.sweep_mode == "fast")
@@ -239,7 +248,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d^3 mesh, %d sources (seeded), reference test problem at z=9 pre-ionised to "
                                    "x=%.3f, %s density, one evolve3D outer iteration per step (sweep all sources + "
-                                   "all-reduce + global chemistry pass)" % (n, S, args.x_init, args.density),
+                                   "all-reduce + global chemistry pass)" % (n, S, args.x_init, "cubep3m-file" if args.density_file else args.density),
                        "mesh": n, "sources": S, "sweep_mode": args.sweep_mode, "gamma_accumulation": "ordered" if args.deterministic else "atomic", "sources_per_gpu": len(pkg.static_source_share(S, 0, world)),
                        "parallelism": "sources sharded over %d GPU(s), RCCL all-reduce of Gamma" % world,
                        "visited_cell_sources_per_step": visited_all / args.steps,

@@ -131,6 +131,32 @@ def read_density(path, mesh=None, access="stream", header=True):
     return data.reshape(shape, order="F").copy()
 
 
+def cubep3m_density_name(dir_dens, redshift):
+    """nbody_cubep3m density file of a slice: <dir_dens><z, f6.3>n_all.dat (density_module.F90:159-163)."""
+    return os.path.join(dir_dens, "%6.3fn_all.dat" % redshift)
+
+
+def scale_density(raw, redshift, mesh, n_box, density_unit="grid", cosmological=True):
+    """scale_density (density_module.F90:246-287): file values -> comoving... proper gas number density (cm^-3, f32 as
+    the reference stores it).  density_unit "grid" (nbody_cubep3m.F90:115: the coarsened cubep3m density, in units of
+    the mean mass of a FINE N-body cell): convert = rho_crit_0 Omega_B/(mu m_p) (mesh/n_box)^3 (nbody_cubep3m.F90:127,
+    single-precision `real()` of the integers as there), times (1+z)^3 for cosmological runs; "particle" is 8 x that.
+    Cells that are empty or negative get 0.1 of a fine cell's mean (:281)."""
+    from .testproblem import RHO_CRIT_0, OMEGA_B, MU, M_P
+    m32, n32 = np.float32(mesh if np.isscalar(mesh) else mesh[0]), np.float32(n_box)
+    # rho_crit_0*Omega_B/(mu*m_p)*real(meshx)**3/(real(n_box)**3): the two cubes in single precision, then left to right
+    convert = RHO_CRIT_0 * OMEGA_B / (MU * M_P) * float(m32 * m32 * m32) / float(n32 * n32 * n32)
+    if density_unit == "particle":
+        convert = 8.0 * convert
+    elif density_unit != "grid":
+        raise ValueError("density_unit %r not restated (grid, particle)" % density_unit)
+    if cosmological:
+        convert = convert * (1.0 + redshift) ** 3
+    nd = (np.asarray(raw, dtype=np.float32).astype(np.float64) * convert).astype(np.float32)     # ndens is real(si)
+    nd[nd <= 0.0] = np.float32(0.1 * convert)
+    return nd
+
+
 def write_density(path, ndens, access="stream", header=True):
     a = np.asarray(ndens, dtype=np.float32)
     with open(path, "wb") as f:

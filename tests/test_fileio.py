@@ -112,3 +112,27 @@ def test_records_beyond_2GiB_are_gfortran_subrecords(tmp_path, monkeypatch):
     a = np.random.default_rng(3).random((9, 8, 7))
     fio.write_sm3d(str(tmp_path / "x.bin"), a)
     assert np.array_equal(fio.read_sm3d(str(tmp_path / "x.bin")), a)
+
+
+def test_cubep3m_density_scaling(tmp_path):
+    """scale_density (density_module.F90:246-287) for the coarsened cubep3m fields (density_unit "grid",
+    nbody_cubep3m.F90:115-127) and the slice file name (density_module.F90:159-163)."""
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    fio = pkg.fileio
+    assert os.path.basename(fio.cubep3m_density_name("/d/", 9.0)) == " 9.000n_all.dat"
+    assert os.path.basename(fio.cubep3m_density_name("/d/", 11.546)) == "11.546n_all.dat"
+    raw = np.array([[[0.0, 1.0], [2.5, -1.0]], [[100.0, 1e-3], [7.0, 3.0]]], dtype=np.float32)
+    nd = fio.scale_density(raw, 8.0, 300, 13824)
+    mean0 = 9.20346643016612840e-30 * 4.39999997615814209e-02 / (1.22200000286102295 * 1.67266100000000007e-24)
+    conv = mean0 * 300.0 ** 3 / 13824.0 ** 3 * 9.0 ** 3
+    assert nd.dtype == np.float32
+    assert np.allclose(nd[raw > 0], raw[raw > 0] * conv, rtol=2e-7)
+    assert np.allclose(nd[raw <= 0], 0.1 * conv, rtol=2e-7)          # empty cells: 0.1 particles
+    # a field whose mean is one coarse cell's share of the fine cells has the mean baryon density
+    coarse = np.full((4, 4, 4), (13824.0 / 300.0) ** 3, dtype=np.float32)
+    assert abs(float(fio.scale_density(coarse, 0.0, 300, 13824).mean()) / mean0 - 1) < 1e-6
+    # through the file format of the slice
+    p = str(tmp_path / fio.cubep3m_density_name("", 8.0).strip())
+    fio.write_density(p, raw)
+    assert np.array_equal(fio.read_density(p, mesh=2), raw)

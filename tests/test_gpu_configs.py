@@ -127,18 +127,27 @@ def test_bench_workload_256_x_1000(pkg, tables):
     b.close()
 
 
-def test_504_lognormal_two_sources_vs_oracle(pkg, tables):
-    """BASELINE configs[4]'s mesh (504^3, log-normal density sigma = 1, HBM-resident): two sources traced out to
-    q = 252 against the oracle; 24-bit index arithmetic, plane pitch 505, 1.0 GB grids."""
-    n = 504
-    tp = pkg.TestProblem(n)        # the 100 Mpc/h box: 0.028 of an LLS mean free path per cell, rays reach the limits
+def test_504_cubep3m_format_two_sources_vs_oracle(pkg, tables, tmp_path):
+    """BASELINE configs[4]'s mesh (504^3, HBM-resident) fed the way the reference feeds it: a coarsened cubep3m
+    density slice `<z>n_all.dat` (nbody_cubep3m.F90:87-107: 3 x int32 + N^3 float32 stream; log-normal, sigma = 1, in
+    units of a fine N-body cell's mean mass) -> read_density_file -> scale_density (density_module.F90:203-287).  Two
+    sources traced out to q = 252 against the oracle; 24-bit index arithmetic, plane pitch 505, 1.0 GB grids."""
+    n, n_box = 504, 10976                       # the 425 Mpc/h run's fine mesh (nbody_cubep3m.F90:17-18)
+    fio = pkg.fileio
+    tp = pkg.TestProblem(n)        # cell size of the 100 Mpc/h box: 0.028 of an LLS mean free path per cell, rays reach the limits
     s = tp.step(1)
-    nd, xh = tp.fields(1, 0.9995)
+    _, xh = tp.fields(1, 0.9995)
     rng = np.random.default_rng(20261003)
-    nd = (nd * np.exp(rng.standard_normal(nd.size, dtype=np.float32) - 0.5)).astype(np.float32)
+    raw = (np.exp(rng.standard_normal(n ** 3, dtype=np.float32) - 0.5) * np.float32((n_box / n) ** 3)).reshape((n, n, n), order="F")
+    raw[3, 4, 5] = 0.0                          # an empty cell: 0.1 particles (density_module.F90:281)
+    path = str(tmp_path / fio.cubep3m_density_name("", s["zred"]).strip())
+    fio.write_density(path, raw)
+    nd = fio.scale_density(fio.read_density(path, mesh=n), s["zred"], n, n_box).ravel(order="F")
+    assert abs(float(nd.mean(dtype=np.float64)) / s["ndens"] - 1) < 2e-3          # the mean IGM density of the test problem
+    del raw
     pos = np.array([[17, 480, 252], [300, 301, 302]], dtype=np.int32)
     nf = np.array([3e8, 1e9])
-    if "504" not in _cache:
+    if "504" not in _cache:                      # (the field is seeded: the same in both modes)
         _cache["504"] = oracle_pass(oracle_for(s, tables, n), nd, xh, pos, nf)
     oloss, onb, ovis, ophih, w = _cache["504"]
     b = backend(pkg, tables, s, n, nd, xh, pos, nf)
