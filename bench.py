@@ -195,7 +195,12 @@ def main():
     # GPUs the launches are 1/N as long and the per-launch barrier packets would cost ~3 %, so one event pair
     # per sub-box is used there (C2R_BENCH_PROFILE overrides: 0, 1, 2)
     xh_state = b.fetch("xh_av") if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None   # what the timed steps start from
-    prof_mode = int(os.environ.get("C2R_BENCH_PROFILE", "1" if world == 1 else "2"))
+    # ... and with few sources a launch is a few microseconds, the event pairs around each would cost more than the
+    # launches themselves (128^3 x 1 source: 0.73 ms per step with them, 0.46 without), and they keep the library from
+    # replaying the pass as a hipGraph: one pair per sub-box there
+    prof_mode = int(os.environ.get("C2R_BENCH_PROFILE", "1" if (world == 1 and S >= 64) else "2"))
+    if prof_mode == 2 and S < 64 and "C2R_BENCH_PROFILE" not in os.environ:
+        prof_mode = 0
     b.profile(prof_mode)
     visited_before = ev.visited
     ev.visited = 0
@@ -234,6 +239,8 @@ def main():
         # the timed launches are those of k_sweep_shell; the first two sub-boxes of every source (21^3 cells)
         # run in k_sweep_box_fused and are left out of both the bytes and the time
         vis_rank = max(0.0, vis_rank - fused_visited)
+        if prof_mode == 0:                         # no kernel timing (few sources): the sweep's share of the wall time bounds it
+            sweep_s, launches = dt_wall, 1
         achieved = SWEEP_BYTES_PER_VISIT * vis_rank / sweep_s / 1e9 if sweep_s > 0 else 0.0
         traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", "TRAFFIC.json")
@@ -261,7 +268,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": SWEEP_BYTES_PER_VISIT * vis_rank / launches,
                          "avg_launch_ms": prof["sweep_ms"] / launches, "launches": prof["sweep_launches"],
-                         "timing": {0: "off", 1: "HIP events around every k_sweep_shell launch",
+                         "timing": {0: "off (few sources: launches of a few microseconds); achieved = algorithmic bytes of the per-shell launches / whole step wall time", 1: "HIP events around every k_sweep_shell launch",
                                     2: "HIP events around every sub-box (5 launches + the small kernels between them)"}[prof_mode],
                          "chem_kernel_ms_per_launch": prof["chem_ms"] / max(1, prof["chem_launches"]),
                          "chem_achieved_GBs": (CHEM_BYTES_PER_CELL * float(n) ** 3 * prof["chem_launches"] /

@@ -47,6 +47,12 @@ struct Ctx {
     bool explicit_share = false; std::vector<int32_t> share;   // c2r_set_source_share: this rank's sources
     std::vector<int32_t> last_nbox;                              // final sub-box count per local source, last pass
     int box_hint = 0;                                            // largest of them: how far the next pass is expected to go
+    // hipGraph of a small batch's launch sequence up to box_hint (see sweep_batch); gen counts everything that
+    // the captured kernel arguments depend on (step scalars, tables, buffers, stream, scratch, physics switches)
+    struct BatchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long long gen = 0; int count = 0, n_active = 0, hint = 0; };
+    std::map<int, BatchGraph> graphs;
+    unsigned long long gen = 1;
+    bool use_graph = true;                                       // C2R_GRAPH=0: never (experiments)
     // cost-balanced distribution inside the library (c2r_set_balance): every rank learns every source's last
     // sub-box count through the all-reduce callback and computes the same LPT partition
     bool balance = false, auto_share = false;                    // auto_share: `share` was set by the balancer, not the caller
@@ -168,6 +174,7 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
     }
     ctx->batch_cap = cap;
     ctx->batch_want = want;
+    ++ctx->gen;                                   // every captured launch points into the old scratch
     return C2R_OK;
 }
 
@@ -277,8 +284,8 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
     }
     h_na[0] = n_active; h_na[1] = 0;
     hipStream_t st = ctx->stream;
-    // (the staging block is next written by the next sweep_batch, after this one's final synchronize)
-    HIP_TRY(hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st));
+    // (the staging block is next written by the next sweep_batch, after this one's final synchronize; it is uploaded
+    // below, by the graph's copy node or directly)
 
     KParams k = make_kparams(ctx);
     int cur = 0, last_bps = 0;     // last_bps: size of the last shell's loss partials per source (0: none), for k_box_decide
@@ -298,7 +305,9 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
     // outer iteration; with 1000 sources the same rule costs 5-20 % (stale large grids), hence the limit.
     constexpr int kFewSources = 32;
     const int hint = (ctx->sched_hint && n_active <= kFewSources) ? std::max(1, ctx->box_hint) : 1;
-    for (int nbox = 1; nbox <= ctx->nbox_max && bound > 0; ++nbox) {
+    // every launch of sub-box nbox for `bound` sources at most (no host wait, no event): shells or the fused box, loss
+    // reduction, the decision; flips `cur`
+    auto enqueue_box = [&](const int nbox, const int bound) -> int {
         int boxR[3], boxL[3];
         for (int d = 0; d < 3; ++d) {
             boxR[d] = std::min(p.subboxsize * nbox, ctx->hr[d]);
@@ -401,8 +410,51 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                            ctx->d_active[1 - cur], ctx->d_nactive + (1 - cur), ctx->d_hnactive + nbox, ctx->d_nflux_b,
                            p.S_star, p.loss_fraction, can_grow, nbox, ctx->d_loss_acc, ctx->d_final_loss, ctx->d_final_nbox,
                            (const double *)ctx->d_loss_partial, last_bps);
-        HIP_TRY(hipEventRecord(ctx->ev_box[nbox], st));
         cur = 1 - cur;
+        return C2R_OK;
+    };
+    int first_box = 1;
+    // A batch of few sources whose previous pass ended at sub-box `hint` replays that whole launch sequence (the batch
+    // upload, the source cells, sub-boxes 1..hint) as ONE hipGraph: the arguments of every launch are the same from
+    // outer iteration to outer iteration (the batch's data travel in the pinned staging block, read when the copy node
+    // runs), a replay costs one host call instead of ~8 us per launch, and dependent nodes follow each other in ~2 us.
+    const bool graph_ok = ctx->use_graph && ctx->sched_hint && n_active > 0 && n_active <= kFewSources && ctx->box_hint >= 1 &&
+                          !dbg && ctx->prof == 0;
+    bool uploaded = false;
+    if (graph_ok) {
+        Ctx::BatchGraph &bg = ctx->graphs[first];
+        if (!(bg.exec && bg.gen == ctx->gen && bg.count == count && bg.n_active == n_active && bg.hint == hint)) {
+            if (bg.exec) { hipGraphExecDestroy(bg.exec); bg.exec = nullptr; }
+            if (bg.graph) { hipGraphDestroy(bg.graph); bg.graph = nullptr; }
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                int rc = (int)hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st);
+                cur = 0;
+                for (int nbox = 1; nbox <= hint && nbox <= ctx->nbox_max && rc == C2R_OK; ++nbox) rc = enqueue_box(nbox, n_active);
+                const hipError_t e = hipStreamEndCapture(st, &bg.graph);
+                if (rc == C2R_OK && e == hipSuccess && hipGraphInstantiate(&bg.exec, bg.graph, nullptr, nullptr, 0) == hipSuccess) {
+                    bg.gen = ctx->gen; bg.count = count; bg.n_active = n_active; bg.hint = hint;
+                } else {
+                    if (bg.graph) { hipGraphDestroy(bg.graph); bg.graph = nullptr; }
+                    bg.exec = nullptr;
+                    (void)hipGetLastError();
+                    ctx->use_graph = false;            // this runtime / stream cannot capture: eager from now on
+                }
+            } else { (void)hipGetLastError(); ctx->use_graph = false; }
+        }
+        if (bg.exec) {
+            HIP_TRY(hipGraphLaunch(bg.exec, st));
+            uploaded = true;
+            const int done = std::min(hint, ctx->nbox_max);
+            cur = done & 1;
+            HIP_TRY(hipStreamSynchronize(st));
+            known = done; bound = ctx->h_nactive[done];
+            first_box = done + 1;
+        } else cur = 0;
+    }
+    if (!uploaded) HIP_TRY(hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st));
+    for (int nbox = first_box; nbox <= ctx->nbox_max && bound > 0; ++nbox) {
+        { const int rc = enqueue_box(nbox, bound); if (rc) return rc; }
+        HIP_TRY(hipEventRecord(ctx->ev_box[nbox], st));
         // counts that have already arrived (never blocks)
         while (known < nbox && hipEventQuery(ctx->ev_box[known + 1]) == hipSuccess) bound = ctx->h_nactive[++known];
         // blocking read-back: the box's own count where the previous pass ended, the previous box's beyond
@@ -573,6 +625,7 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     ctx->prm = *p;
     if (const char *e = getenv("C2R_FUSE_SMALL")) ctx->fuse_small = atoi(e) != 0;
     if (const char *e = getenv("C2R_SCHED_HINT")) ctx->sched_hint = atoi(e) != 0;
+    if (const char *e = getenv("C2R_GRAPH")) ctx->use_graph = atoi(e) != 0;
     if (p->sweep_mode != C2R_SWEEP_EXACT && p->sweep_mode != C2R_SWEEP_FAST) { delete ctx; return C2R_EINVAL; }
     ctx->fast = p->sweep_mode == C2R_SWEEP_FAST;
     if (const char *e = getenv("C2R_SWEEP_MODE")) ctx->fast = atoi(e) != 0;         // experiments, A/B runs
@@ -667,6 +720,7 @@ void c2r_destroy(c2r_ctx *c)
     if (!c) return;
     Ctx *ctx = C(c);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->graphs) { if (kv.second.exec) hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) hipGraphDestroy(kv.second.graph); }
     for (auto &kv : ctx->pinned) hipHostUnregister(const_cast<void *>(kv.first));
     free_sweep_scratch(ctx);
     for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
@@ -699,6 +753,7 @@ int c2r_set_stream(c2r_ctx *c, void *s)
         if (ctx->own_stream) { hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
         ctx->stream = (hipStream_t)s;
     }
+    ++ctx->gen;
     return C2R_OK;
 }
 
@@ -711,7 +766,7 @@ int c2r_set_tables(c2r_ctx *c, const double *thick, const double *thin, int32_t 
     HIP_TRY(hipMemcpy(ctx->d_thin, thin, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_thick + n, thick + n - 1, sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_thin + n, thin + n - 1, sizeof(double), hipMemcpyHostToDevice));
-    ctx->have_tables = true;
+    ctx->have_tables = true; ++ctx->gen;
     return C2R_OK;
 }
 
@@ -720,6 +775,7 @@ int c2r_set_step(c2r_ctx *c, const double dr[3], double vol, double lls, float c
     if (!c || !dr) return C2R_EINVAL;
     Ctx *ctx = C(c);
     if (!(dr[0] > 0) || !(dr[1] > 0) || !(dr[2] > 0) || !(vol > 0) || !(temper > 0)) FAIL(C2R_EINVAL, "dr, vol and temper must be positive");
+    if (ctx->dr[0] != dr[0] || ctx->dr[1] != dr[1] || ctx->dr[2] != dr[2] || ctx->vol != vol || ctx->lls != lls) ++ctx->gen;
     for (int d = 0; d < 3; ++d) ctx->dr[d] = dr[d];
     ctx->vol = vol; ctx->lls = lls; ctx->clumping = clumping; ctx->temper = temper;
     ctx->have_step = true;
@@ -744,7 +800,7 @@ int c2r_set_lls(c2r_ctx *c, int32_t type, const float *lls_grid, double R_max_LL
                            (const float *)ctx->d_lls, ctx->d_lls_T);
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
-    ctx->lls_type = type; ctx->R_max_LLS = R_max_LLS;
+    ctx->lls_type = type; ctx->R_max_LLS = R_max_LLS; ++ctx->gen;
     return C2R_OK;
 }
 
@@ -852,6 +908,7 @@ int c2r_bind_device_buffers(c2r_ctx *c, void *ndens, void *xh, void *xh_av, void
         if (ctx->own[w]) { hipFree(ctx->grid[w]); ctx->own[w] = false; }
         ctx->grid[w] = in[w];
     }
+    ++ctx->gen;
     return C2R_OK;
 }
 
