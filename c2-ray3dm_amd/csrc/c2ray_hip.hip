@@ -966,7 +966,6 @@ int c2r_pass_sources(c2r_ctx *c, double *photon_loss, int64_t *sum_nbox, int64_t
             rc = sweep_batch(ctx, first, count, first == 0, nullptr, &nb, nullptr);
             if (rc) return rc;
             for (int v : nb) { vis += visited_for_nbox(ctx, v); ctx->last_nbox.push_back(v); }
-            
         }
         if ((rc = sweep_finish(ctx))) return rc;
         ctx->box_hint = 0;
