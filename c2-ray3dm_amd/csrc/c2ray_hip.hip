@@ -85,7 +85,7 @@ struct Ctx {
     int *d_final_nbox = nullptr;
     double *d_photon_loss = nullptr; long long *d_sum_nbox = nullptr;
     // reductions
-    double *d_sum_partial = nullptr, *d_sum_out = nullptr;
+    double *d_sum_partial = nullptr, *d_sum_out = nullptr, *d_stat_partial = nullptr;
     unsigned long long *d_conv = nullptr; unsigned int *d_chemfail = nullptr;
     struct HostScalars { double sum; double photon_loss; long long sum_nbox; unsigned long long conv; unsigned int chemfail; double pair[2]; double four[4]; } *h_sc = nullptr,  // pinned
       *d_hsc = nullptr;                       // ... and its device alias: kernels store results there directly
@@ -684,6 +684,7 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipMalloc(&ctx->d_sum_nbox, sizeof(long long)));
     HIP_TRY(hipMalloc(&ctx->d_sum_partial, 4 * kSumBlocks * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_sum_out, 4 * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_stat_partial, 4 * kSumBlocks * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_conv, sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&ctx->d_chemfail, sizeof(unsigned int)));
     HIP_TRY(hipMalloc(&ctx->d_pair, 2 * sizeof(double)));
@@ -728,7 +729,7 @@ void c2r_destroy(c2r_ctx *c)
     hipFree(ctx->d_nhi); hipFree(ctx->d_nhi_T); hipFree(ctx->d_phih_T);
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
-    hipFree(ctx->d_photon_loss); hipFree(ctx->d_sum_nbox); hipFree(ctx->d_sum_partial); hipFree(ctx->d_sum_out);
+    hipFree(ctx->d_photon_loss); hipFree(ctx->d_sum_nbox); hipFree(ctx->d_sum_partial); hipFree(ctx->d_sum_out); hipFree(ctx->d_stat_partial);
     hipFree(ctx->d_conv); hipFree(ctx->d_chemfail); hipFree(ctx->d_dbg); hipFree(ctx->d_pair); hipFree(ctx->d_nbox_all);
     if (ctx->h_nbox_all) hipHostFree(ctx->h_nbox_all);
     if (ctx->h_sc) hipHostFree(ctx->h_sc);
@@ -1097,12 +1098,10 @@ int c2r_photon_sums(c2r_ctx *c, int32_t which_l, int32_t which_r, double out[4])
     return C2R_OK;
 }
 
-int c2r_global_pass(c2r_ctx *c, double dt, int64_t *conv_flag, double *sum_xh1)
+// global_pass (evolve.F90:499-573); stats_dst (device-visible, 4 doubles, or null): the photon-statistics sums of
+// (xh_intermed, xh_av) as the pass leaves them, from the same kernel
+static int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum_xh1, double *stats_dst)
 {
-    if (!c) return C2R_EINVAL;
-    Ctx *ctx = C(c);
-    int rc = check_ready(ctx);
-    if (rc) return rc;
     const c2r_params &p = ctx->prm;
     ChemParams cp{};
     cp.dt = dt; cp.eps = p.epsilon; cp.min_frac_change = p.minimum_fractional_change;
@@ -1113,20 +1112,39 @@ int c2r_global_pass(c2r_ctx *c, double dt, int64_t *conv_flag, double *sum_xh1)
     cp.brech0 = (double)ctx->clumping * p.bh00 * pow(ctx->temper / 1e4, p.albpow);
     cp.bh00 = p.bh00; cp.recpow = pow(ctx->temper / 1e4, p.albpow); cp.clump = ctx->d_clump;
     cp.acolh0 = p.colh0 * sqrt(ctx->temper) * exp(-p.temph0 / ctx->temper);
+    cp.clumping = (double)ctx->clumping; cp.colh0 = p.colh0; cp.sqrtt = sqrt(ctx->temper); cp.expt = exp(-p.temph0 / ctx->temper);
+    cp.stat_partial = ctx->d_stat_partial;
     prof_begin(ctx, ctx->ev_chem, ctx->ev_chem_used);
-    hipLaunchKernelGGL(k_global_pass, dim3(kSumBlocks), dim3(256), 0, ctx->stream, cp, ctx->ncell,
-                       (const float *)ctx->grid[0], (const double *)ctx->grid[1], (double *)ctx->grid[2],
-                       (double *)ctx->grid[3], (const double *)ctx->grid[4], ctx->d_sum_partial, ctx->d_conv,
-                       ctx->d_chemfail);
+    if (stats_dst)
+        hipLaunchKernelGGL(k_global_pass<true>, dim3(kSumBlocks), dim3(256), 0, ctx->stream, cp, ctx->ncell,
+                           (const float *)ctx->grid[0], (const double *)ctx->grid[1], (double *)ctx->grid[2],
+                           (double *)ctx->grid[3], (const double *)ctx->grid[4], ctx->d_sum_partial, ctx->d_conv,
+                           ctx->d_chemfail);
+    else
+        hipLaunchKernelGGL(k_global_pass<false>, dim3(kSumBlocks), dim3(256), 0, ctx->stream, cp, ctx->ncell,
+                           (const float *)ctx->grid[0], (const double *)ctx->grid[1], (double *)ctx->grid[2],
+                           (double *)ctx->grid[3], (const double *)ctx->grid[4], ctx->d_sum_partial, ctx->d_conv,
+                           ctx->d_chemfail);
     prof_end(ctx, ctx->ev_chem, ctx->ev_chem_used);
     hipLaunchKernelGGL(k_pass_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, ctx->d_conv,
                        ctx->d_chemfail, &ctx->d_hsc->sum, &ctx->d_hsc->conv, &ctx->d_hsc->chemfail);
+    if (stats_dst)
+        hipLaunchKernelGGL(k_sum_final, dim3(4), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_stat_partial, stats_dst);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
     if (conv_flag) *conv_flag = (int64_t)ctx->h_sc->conv;
     if (sum_xh1) *sum_xh1 = ctx->h_sc->sum;
     return C2R_OK;
+}
+
+int c2r_global_pass(c2r_ctx *c, double dt, int64_t *conv_flag, double *sum_xh1)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    return global_pass_impl(ctx, dt, conv_flag, sum_xh1, nullptr);
 }
 
 static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double restart_loss, c2r_report *rep)
@@ -1210,18 +1228,15 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
         }
         auto t1 = clk::now();
         rep->photon_loss_all = loss; rep->sum_nbox_all = nb; rep->visited += vis;
-        rc = c2r_global_pass(c, dt, &conv_flag, &sum1);                                // :269
+        // :269 global_pass; evolve.F90:570 calculate_photon_statistics(dt,xh_intermed,xh_av) + report (the conservation
+        // line): the sums come out of the same kernel into this iteration's pinned slot
+        rc = global_pass_impl(ctx, dt, &conv_flag, &sum1, niter <= C2R_MAX_ITER_LOG ? ctx->d_hit4 + 4 * (size_t)(niter - 1) : nullptr);
         if (rc) return rc;
         auto t2 = clk::now();
         rep->seconds_sweep += std::chrono::duration<double>(t1 - t0).count();
         rep->seconds_chem += std::chrono::duration<double>(t2 - t1).count();
         rep->chem_not_converged = (int32_t)ctx->h_sc->chemfail;
-        if (niter <= C2R_MAX_ITER_LOG) {
-            rep->it_conv_flag[niter - 1] = conv_flag; rep->it_sum_nbox[niter - 1] = nb;
-            // evolve.F90:570 calculate_photon_statistics(dt,xh_intermed,xh_av) + report: the conservation line.  The
-            // sums land in this iteration's pinned slot; nobody waits for them before the step ends.
-            if ((rc = photon_sums_launch(ctx, 3, 2, ctx->d_hit4 + 4 * (size_t)(niter - 1)))) return rc;
-        }
+        if (niter <= C2R_MAX_ITER_LOG) { rep->it_conv_flag[niter - 1] = conv_flag; rep->it_sum_nbox[niter - 1] = nb; }
         // evolve.F90:271-275: the place where the reference decides on an iteration dump
         if (ctx->iter_hook) {
             HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -1135,10 +1135,17 @@ struct ChemParams {
     double bh00, recpow;          // brech0 = clumping*bh00*recpow when clumping comes from a grid
     const float *clump;           // clumping_grid (clumping_module.F90:116) or null
     int max_iter;
+    // STATS variant: the four mesh sums of photonstatistics.F90 over (xh_intermed, xh_av) as this pass leaves them
+    double clumping, colh0, sqrtt, expt;
+    double *stat_partial;         // [4][gridDim.x]
 };
 
 // evolve0D_global (evolve_point.F90:305-406) + do_chemistry (:410-555) + doric (doric.f90:33-134).
 // Fixed grid, grid-stride: block partial sums of xh_intermed land in sum_partial[blockIdx.x].
+// STATS: also what k_photon_sums(xh_intermed, xh_av) would return after this pass -- the values are in registers here --
+// accumulated in the same order over the same grid, so the sums are bit-identical to the separate kernel's and the
+// 20 bytes per cell it reads are saved (evolve.F90:570 calculate_photon_statistics after every global pass).
+template <bool STATS>
 __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell, const float *__restrict__ ndens,
                                                      const double *__restrict__ xh, double *__restrict__ xh_av,
                                                      double *__restrict__ xh_intermed,
@@ -1147,6 +1154,7 @@ __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell,
 {
     __shared__ double sm[4];
     double lsum = 0.0;
+    double st_h0 = 0.0, st_h1 = 0.0, st_tr = 0.0, st_tc = 0.0;
     unsigned int nconv = 0, nfail = 0;
     for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < ncell; id += (size_t)gridDim.x * 256) {
         const double h_old1 = fmax(c.eps, xh[id]);
@@ -1185,9 +1193,26 @@ __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell,
         xh_intermed[id] = h1;
         xh_av[id] = hav1;
         lsum += h1;
+        if (STATS) {                                           // k_photon_sums with xl = xh_intermed, xr = xh_av, same expressions
+            st_h0 += nd * (1.0 - h1);
+            st_h1 += nd * h1;
+            const double y1 = hav1, y0 = 1.0 - y1;
+            const double de = nd * (y1 + c.abu_c);
+            const double cl = c.clump ? (double)c.clump[id] : c.clumping;
+            st_tr += nd * y1 * de * cl * c.bh00 * c.recpow;
+            st_tc += nd * y0 * de * c.colh0 * c.sqrtt * c.expt;
+        }
     }
     const double tot = block_sum_256(lsum, sm);
     if (threadIdx.x == 0) sum_partial[blockIdx.x] = tot;
+    if (STATS) {
+        double v[4] = {st_h0, st_h1, st_tr, st_tc};
+        for (int m = 0; m < 4; ++m) {
+            __syncthreads();
+            const double t4 = block_sum_256(v[m], sm);
+            if (threadIdx.x == 0) c.stat_partial[(size_t)m * gridDim.x + blockIdx.x] = t4;
+        }
+    }
     // integer counts: order-independent
     for (int off = 32; off > 0; off >>= 1) { nconv += __shfl_down(nconv, off, 64); nfail += __shfl_down(nfail, off, 64); }
     if ((threadIdx.x & 63) == 0) {

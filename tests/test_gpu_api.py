@@ -176,3 +176,25 @@ def test_host_array_pieces_do_source_and_global_pass(pkg, tables):
     assert conv.value == conv_o
     assert np.max(np.abs(xint - xint_o)) < 1e-12 and np.max(np.abs(xav - xav_o)) < 1e-12
     lib.c2r_destroy(ctx)
+
+
+def test_per_iteration_conservation_line_comes_out_of_the_global_pass(pkg, tables):
+    """c2r_report.it_photcons[k]: the conservation ratio the reference logs after every global pass
+    (evolve.F90:570 calculate_photon_statistics(dt,xh_intermed,xh_av) + report_photonstatistics).  Its four mesh sums
+    are accumulated inside k_global_pass, in the order of the separate kernel (c2r_photon_sums): the entry of the LAST
+    iteration must equal, bit for bit, what c2r_photon_sums(xh_intermed, xh_av) gives on the arrays the step leaves."""
+    m, a = load_case("evolve32_std_bubbles")
+    s, n = m["steps"]["step001"], m["n"]
+    b = pkg.HipBackend(n, *tables, device=0)
+    b.set_step((s["dr1"], s["dr2"], s["dr3"]), s["vol"], s["coldensh_LLS"], s["clumping"])
+    b.set_sources(s["srcpos"], s["normflux"]); b.set_rank(0, 1)
+    b.load(ndens=F(a["step001_ndens"]), xh=F(a["step001_xh_before"]))
+    rep = b.evolve3d_native(s["dt"])
+    after = b.photon_sums("xh_intermed", "xh_av")
+    vol, dt = s["vol"], s["dt"]
+    trec, tcol = after[2] * vol * dt, after[3] * vol * dt
+    tion = trec + (rep.h0_before - after[0] * vol)
+    expect = (tion - tcol) / rep.totalsrc
+    assert rep.it_photcons[rep.niter - 1] == expect
+    assert all(np.isfinite(rep.it_photcons[k]) and rep.it_photcons[k] != 0.0 for k in range(rep.niter))
+    b.close()
