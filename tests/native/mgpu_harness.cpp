@@ -65,7 +65,7 @@ static void *rank_main(void *p)
     const int rank = a->rank;
     c2r_ctx *ctx = nullptr;
     int ndev = 0;
-    hipGetDeviceCount(&ndev);
+    (void)hipGetDeviceCount(&ndev);
     const size_t ncell = (size_t)pb.mesh * pb.mesh * pb.mesh;
     // every rank owns its arrays, as every MPI process does (the library page-locks the arrays it is handed)
     std::vector<float> ndens = pb.ndens;
