@@ -39,7 +39,7 @@ static int host_allreduce(void *user, void *dev_buf, size_t count, void *stream)
     RankArg *a = static_cast<RankArg *>(user);
     Shared *sh = a->sh;
     if (sh->stage_cap[a->rank] < count) {                      // (re)allocate between collectives only: no one reads it now
-        if (sh->stage[a->rank]) hipHostFree(sh->stage[a->rank]);
+        if (sh->stage[a->rank]) (void)hipHostFree(sh->stage[a->rank]);
         if (hipHostMalloc((void **)&sh->stage[a->rank], 2 * count * sizeof(double)) != hipSuccess) return 1;   // [0,count) mine, [count,2count) sum
         sh->stage_cap[a->rank] = count;
     }
