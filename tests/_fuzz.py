@@ -2,7 +2,9 @@
 tests/fuzz_gpu.py (the long run by hand).  Random non-cubic meshes (every extent 3..44, odd and even), 1..12
 sources anywhere (also outside [1,N]), rates over 6 decades, density and ionization fields with structure,
 both fully and barely ionized gas, so that sub-boxes end anywhere between the first and the clipped last; the
-row-group tiling of k_sweep_shell (three rows per thread, groups per sign class) meets every remainder."""
+row-group tiling of k_sweep_shell (three rows per thread, groups per sign class) meets every remainder; one case in
+two also draws a non-default switch: type_of_LLS 2 or 3, source-ordered (deterministic) Gamma accumulation, one
+source per batch."""
 import numpy as np
 
 
@@ -29,7 +31,15 @@ def make_case(seed, pkg):
         nf[rng.integers(0, nsrc)] = 0.0
     lls = s["coldensh_LLS"] * 10.0 ** rng.uniform(-1, 1)
     k = int(rng.integers(0, nsrc))          # the source whose column densities are compared
-    return dict(mesh=mesh, dr=dr, vol=dr[0] * dr[1] * dr[2], nd=nd, xh=xh, pos=pos, nf=nf, lls=lls, k=k)
+    # the switches beside the shipped configuration (drawn last: the fields above are those of the earlier runs):
+    # type_of_LLS 2 (per-cell column) / 3 (hard barrier), source-ordered Gamma accumulation, several source batches
+    lls_type = int(rng.choice([1, 1, 2, 3]))
+    lls_grid = (lls * 10.0 ** rng.uniform(-1.0, 1.0, ncell)).astype(np.float32) if lls_type == 2 else None
+    r_max = float(dr[0] * rng.uniform(2.0, 0.7 * max(mesh))) if lls_type == 3 else 0.0
+    deterministic = bool(rng.random() < 0.25)
+    scratch = int(rng.choice([0, 0, 1]))     # 1 byte: one source per batch
+    return dict(mesh=mesh, dr=dr, vol=dr[0] * dr[1] * dr[2], nd=nd, xh=xh, pos=pos, nf=nf, lls=lls, k=k,
+                lls_type=lls_type, lls_grid=lls_grid, r_max=r_max, deterministic=deterministic, scratch=scratch)
 
 
 def run_case(seed, pkg, tables, fast):
@@ -38,13 +48,15 @@ def run_case(seed, pkg, tables, fast):
     from oracle.oracle import Oracle
     c = make_case(seed, pkg)
     mesh, ncell = c["mesh"], c["nd"].size
-    o = Oracle(mesh, c["dr"], c["vol"], c["lls"], *tables)
+    o = Oracle(mesh, c["dr"], c["vol"], c["lls"], *tables, lls_type=c["lls_type"], R_max_LLS=c["r_max"], lls_grid=c["lls_grid"])
     w = o.enable_tolerance_weight()
     phih_o = np.zeros(ncell)
     oloss, onb, ovis = o.pass_sources(c["nd"], c["xh"], phih_o, c["pos"], c["nf"])
     w = w.copy()
-    b = pkg.HipBackend(mesh, *tables, device=0, fast=fast)
+    b = pkg.HipBackend(mesh, *tables, device=0, fast=fast, deterministic=c["deterministic"], scratch_bytes=c["scratch"])
     b.set_step(c["dr"], c["vol"], c["lls"], 1.0)
+    if c["lls_type"] != 1:
+        b.set_lls(c["lls_type"], c["lls_grid"], c["r_max"])
     b.set_sources(c["pos"], c["nf"]); b.set_rank(0, 1); b.load(ndens=c["nd"], xh=c["xh"])
     b.begin_step(); b.zero_rates()
     loss, nbox, vis = b.pass_sources()
@@ -59,7 +71,7 @@ def run_case(seed, pkg, tables, fast):
     assert np.array_equal(cd == 0, cdo == 0), (seed, mesh, k)
     d = np.abs(phih - phih_o)
     nz = phih_o != 0
-    return dict(mesh=mesh, nsrc=len(c["nf"]), nbox=nbox, visited=vis,
+    return dict(mesh=mesh, nsrc=len(c["nf"]), nbox=nbox, visited=vis, variant="lls%d%s%s" % (c["lls_type"], " det" if c["deterministic"] else "", " batches" if c["scratch"] else ""),
                 loss=abs(loss - oloss) / max(abs(oloss), 1e-300),
                 cd=float(np.max(np.abs(cd - cdo) / np.maximum(cdo, 1e-300))),
                 gamma_rel=float(np.max(d[nz] / phih_o[nz])) if nz.any() else 0.0,
