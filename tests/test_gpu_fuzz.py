@@ -1,7 +1,7 @@
 """A 25-case cut of the randomized GPU-vs-oracle run (tests/_fuzz.py; the long run by hand is tests/fuzz_gpu.py),
 once per sweep mode: non-cubic meshes of every remainder class, sources inside and outside the mesh, neutral and
 highly ionized gas.  Integers and zero patterns exact (asserted in run_case), column densities, photon loss and
-rates within the mode's stated tolerances (tests/_util.TOL)."""
+rates within the mode's stated tolerances (tests/_util.TOL).  Then 20 random WHOLE steps (tests/_fuzz_steps.py)."""
 import pytest
 from tests._util import tol, gamma_ok
 from tests._fuzz import run_case
@@ -23,3 +23,15 @@ def test_random_pass_vs_oracle(pkg, tables, sweep_mode, seed):
     if sweep_mode == "exact":
         assert r["cd"] == 0.0          # column densities bit for bit
     assert gamma_ok(r["dgamma"], r["gamma_ref"], r["w"], sweep_mode == "fast"), (seed, r["mesh"], r["gamma_rel"], r["gamma_w"])
+
+
+@pytest.mark.parametrize("seed", range(3000, 3020))
+def test_random_whole_step_vs_oracle(pkg, tables, sweep_mode, seed):
+    """Whole evolve3D steps to convergence on random small meshes (tests/_fuzz_steps.py: clumping grids, the three LLS
+    types, cold / structured / highly ionized starts): every integer of the step and the ionized fractions."""
+    from tests._fuzz_steps import run_step_case
+    r = run_step_case(seed, pkg, tables, sweep_mode == "fast")
+    assert r["niter"][0] == r["niter"][1] and r["converged"][0] == r["converged"][1], (seed, r)
+    assert r["conv"][0] == r["conv"][1], (seed, r["mesh"])
+    assert r["nbox"][0] == r["nbox"][1], (seed, r["mesh"])
+    assert r["dx"] < tol("x"), (seed, r["mesh"], r["dx"])
