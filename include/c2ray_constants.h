@@ -56,4 +56,31 @@
 /* doric.f90:119  deltht threshold 1.0e-8 (f32 literal) */
 #define C2R_DELTHT_SMALL              9.99999993922529029e-09
 
+
+/* ---- non-isothermal runs (c2ray_parameters.f90:28 isothermal=.false.; shipped: .true.) ---- */
+/* radiation_photoionrates.F90:333  tau_heat_limit=1.0e-4 (f32 literal) */
+#define C2R_TAU_HEAT_LIMIT            9.99999974737875164e-05
+/* cgsconstants.f90:30,34  hplanck, k_B */
+#define C2R_HPLANCK                   6.62607550000000009e-27
+#define C2R_K_B                       1.38099999999999991e-16
+/* cgsphotoconstants.f90  ion_freq_HI=ev2fr*eth0 */
+#define C2R_ION_FREQ_HI               3.28851300169676800e+15
+/* atomic.f90:23-25  gamma1 = 5.0_dp/3.0_dp - 1.0_dp */
+#define C2R_GAMMA1                    (5.0 / 3.0 - 1.0)
+/* c2ray_parameters.f90:108,110  minitemp=1.0, relative_denergy=0.1 (f32 literal) */
+#define C2R_MINITEMP                  1.0
+#define C2R_RELATIVE_DENERGY          1.00000001490116119e-01
+/* thermal.f90:117 floor of |cooling - heating| (1d-50); :160 exit tolerance 1e-6 (f32 literal); :163 sub-step cap */
+#define C2R_THERMAL_RATE_FLOOR        1.0e-50
+#define C2R_THERMAL_TIME_TOL          9.99999997475242708e-07
+#define C2R_THERMAL_MAX_STEPS         10000
+/* cooling.f90:26  temppoints */
+#define C2R_COOL_POINTS               61
+/* evolve_point.F90:387-388  temperature clause of the global convergence test */
+#define C2R_TEMP_CONV_REL             1.0e-1
+#define C2R_TEMP_CONV_ABS             100.0
+/* cosmoparms.f90:28-31 (WMAP5+): H0 = 100 h km/s/Mpc in s^-1, Omega0 (f32 literals widened) */
+#define C2R_H0                        2.26830837024227824e-18
+#define C2R_OMEGA0                    2.70000010728836060e-01
+
 #endif

@@ -43,6 +43,16 @@ typedef struct {
      * NormFlux/(vol_ph n_HI) is a difference of two table values whose own rounding error (log10 and the
      * table position, ~1e-16 od per unit of tau) does not shrink with the difference. */
     double *tolw;
+    /* Non-isothermal run (c2ray_parameters.f90:28 isothermal=.false.; heat_thick == NULL: the shipped isothermal run).
+     * Pinned against the reference rebuilt with that one parameter changed (oracle/ref_build.sh 32:thermal) and run with
+     * a SYNTHETIC tables/corocool.tab (tests/golden/inputs.py cooling_table: the reference repository lacks the file). */
+    const double *heat_thick; /* stellar_heat_thick_table(0:NumTau,1)  radiation_tables.F90:300 */
+    const double *heat_thin;  /* stellar_heat_thin_table(0:NumTau,1)                            */
+    const double *cie_cool;   /* cooling.f90:27 cie_cool(1:temppoints), linear (10**table)      */
+    double cool_mintemp, cool_dtemp;   /* cooling.f90:78-79                                     */
+    double zred;              /* cosmology.F90:42 zred at the middle of the step (cosmo_cool)   */
+    float  *temper_grid;      /* temperature_module.F90:35 temperature_grid: (current, average, intermed) f32 per cell */
+    double *phiheat;          /* evolve_data.F90:42 phiheat_grid                                */
 } oracle_cfg;
 
 static inline int pmod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
@@ -153,6 +163,78 @@ void oracle_photoion_rates(const double *thick, const double *thin, double cd_in
     out[0] = p_cell / vol; out[1] = p_in; out[2] = p_out;
 }
 
+/* radiation_photoionrates.F90:323-417 heat_lookuptable (stellar table, NumFreqBnd=1): phi%heat */
+double oracle_heat_rate(const double *hthick, const double *hthin, double cd_in, double cd_out,
+                        double vol, double normflux)
+{
+    if (!(normflux > 0.0)) return 0.0;                                         /* :157 */
+    const double tau_in = cd_in * C2R_SIGMA_HI, tau_out = cd_out * C2R_SIGMA_HI;
+    const double tau_cell = (cd_out - cd_in) * C2R_SIGMA_HI;                   /* :104, :146 */
+    const double h_in = normflux * table_lookup(hthick, tau_in);               /* :384 */
+    if (fabs(tau_out - tau_in) > C2R_TAU_HEAT_LIMIT) {                         /* :388 */
+        const double h_out = normflux * table_lookup(hthick, tau_out);
+        return (h_in - h_out) / vol;
+    }
+    return normflux * tau_cell * table_lookup(hthin, tau_in) / vol;            /* :396-400 */
+}
+
+/* cooling.f90:38-59 coolin (cie_cool is 1-based in the reference) */
+double oracle_coolin(const oracle_cfg *c, double nucldens, double eldens, double temp0)
+{
+    const double tpos = (log10(temp0) - c->cool_mintemp) / c->cool_dtemp + 1.0;
+    int itpos = (int)tpos;
+    if (itpos < 1) itpos = 1;
+    if (itpos > C2R_COOL_POINTS - 1) itpos = C2R_COOL_POINTS - 1;
+    const double dtpos = tpos - (double)(float)itpos;
+    const int itpos1 = itpos + 1 < C2R_COOL_POINTS ? itpos + 1 : C2R_COOL_POINTS;
+    return nucldens * eldens * (c->cie_cool[itpos - 1] + (c->cie_cool[itpos1 - 1] - c->cie_cool[itpos - 1]) * dtpos);
+}
+
+/* tped.f90:32-62 */
+static inline double temper2pressr(double temper, double ndens, double eldens) { return (ndens + eldens) * C2R_K_B * temper; }
+static inline double pressr2temper(double pressr, double ndens, double eldens) { return pressr / (C2R_K_B * (ndens + eldens)); }
+static inline double electrondens(double ndens, double x1) { return ndens * (x1 + C2R_ABU_C); }
+
+/* cosmology.F90:198-225 cosmo_cool */
+static inline double cosmo_cool(const oracle_cfg *c, double e_int)
+{
+    const double zp = 1.0 + c->zred;
+    const double dzdt = C2R_H0 * zp * sqrt(C2R_OMEGA0 * (zp * zp * zp) + 1.0 - C2R_OMEGA0);
+    return e_int * 2.0 / zp * dzdt;
+}
+
+/* thermal.f90:22-189.  Outputs are left untouched when T_initial <= minitemp (:83). */
+void oracle_thermal(const oracle_cfg *c, double dt, double t_initial, double *t_final, double *t_average,
+                    double ndens_electron, double ndens_atom, double h_old1, double h_av1, double h1, double heating)
+{
+    double e_int = temper2pressr(t_initial, ndens_atom, electrondens(ndens_atom, h_old1)) / C2R_GAMMA1;   /* :66 */
+    const double cosmo_cool_rate = cosmo_cool(c, e_int);                       /* :73-76 (cosmological=.true.) */
+    if (!(t_initial > C2R_MINITEMP)) return;
+    double cumulative = 0.0, avg = 0.0, t_int = t_initial;
+    int i_heating = 0;
+    for (;;) {
+        i_heating++;
+        const double cooling = oracle_coolin(c, ndens_atom, ndens_electron, t_int) + cosmo_cool_rate;   /* :104 */
+        const double rate = dmax(C2R_THERMAL_RATE_FLOOR, fabs(cooling - heating));
+        const double timescale = e_int / fabs(rate);
+        const double dt_thermal = C2R_RELATIVE_DENERGY * timescale;
+        const double dt_ode = dmin(dt_thermal, dt - cumulative);               /* :127 */
+        e_int = e_int + dt_ode * (heating - cooling);
+        avg = avg + 0.5 * t_int * dt_ode;
+        t_int = pressr2temper(e_int * C2R_GAMMA1, ndens_atom, electrondens(ndens_atom, h_av1));   /* :137 */
+        avg = avg + 0.5 * t_int * dt_ode;
+        if (t_int < C2R_MINITEMP) {                                            /* :147-153 (no division by gamma1 there) */
+            e_int = temper2pressr(C2R_MINITEMP, ndens_atom, electrondens(ndens_atom, h_av1));
+            t_int = C2R_MINITEMP;
+        }
+        cumulative = cumulative + dt_ode;
+        if (cumulative >= dt || fabs(cumulative - dt) < C2R_THERMAL_TIME_TOL * dt) break;   /* :160 */
+        if (i_heating > C2R_THERMAL_MAX_STEPS) break;                          /* :163 */
+    }
+    *t_average = dt > 0.0 ? avg / dt : t_initial;                              /* :168-172 */
+    *t_final = pressr2temper(e_int * C2R_GAMMA1, ndens_atom, electrondens(ndens_atom, h1));   /* :175 */
+}
+
 /* doric.f90:33-134.  xfh/xfh_av are (0:1) = {neutral, ionized}. */
 void oracle_doric(double dt, double temp0, double rhe, double clumping,
                   double xfh[2], double xfh_av[2], double phih)
@@ -227,13 +309,15 @@ static void evolve0d(sweep_t *s, const int rt[3])
     const int stop = stop_far || cd_in > C2R_MAX_COLDENSH;                     /* :201 */
     const double cd_out = cd_in + xav0 * nd * path;                            /* :247, doric.f90:153 */
     s->cdout[id] = cd_out;
-    double phi[3] = {0.0, 0.0, 0.0};
+    double phi[3] = {0.0, 0.0, 0.0}, heat = 0.0;
     if (!stop) {
         oracle_photoion_rates(c->thick, c->thin, cd_in, cd_out, vol_ph, s->normflux, phi);
+        if (c->heat_thick) heat = oracle_heat_rate(c->heat_thick, c->heat_thin, cd_in, cd_out, vol_ph, s->normflux);   /* radiation_photoionrates.F90:142-172 */
         phi[0] = phi[0] / (xav0 * nd);                                         /* :262 */
         if (c->tolw) c->tolw[id] += (1.0 + cd_in * C2R_SIGMA_HI) * phi[1] / (vol_ph * (xav0 * nd));
     }
     s->phih[id] = s->phih[id] + phi[0];                                        /* :283 */
+    if (c->heat_thick) c->phiheat[id] = c->phiheat[id] + heat;                 /* :285-286 */
     if (rt[0] == s->last_l[0] || rt[1] == s->last_l[1] || rt[2] == s->last_l[2] ||
         rt[0] == s->last_r[0] || rt[1] == s->last_r[1] || rt[2] == s->last_r[2])
         s->loss = s->loss + phi[2] * c->vol / vol_ph;                          /* :290-293 */
@@ -328,22 +412,41 @@ long oracle_global_pass(const oracle_cfg *c, double dt, const float *ndens, cons
         h_av[0] = 1.0 - h_av[1];
         const double nd = (double)ndens[id];
         const double gamma = phih[id];
+        const int thermal = c->heat_thick != NULL;
+        /* get_temperature_point, temperature_module.F90:133-151; temperature_end = temperature_start (:436) */
+        float *tg = thermal ? c->temper_grid + 3 * id : NULL;
+        const double t_start_cur = thermal ? (double)tg[0] : c->temper, t_start_avg = thermal ? (double)tg[1] : c->temper;
+        double t_end_avg = t_start_avg, t_end_int = thermal ? (double)tg[2] : c->temper;
+        const double heat = thermal ? c->phiheat[id] : 0.0;                    /* :364 */
         int nit = 0;
         for (;;) {                                                             /* :442 */
             nit++;
             const double yh0_av_old = h_av[0];
             h[0] = h_old[0]; h[1] = h_old[1];                                  /* :463 */
-            const double de = nd * (h_av[1] + C2R_ABU_C);                      /* tped.f90:81 */
-            oracle_doric(dt, c->temper, de, c->clump_grid ? (double)c->clump_grid[id] : c->clumping, h, h_av, gamma);   /* :443-445 clumping_point */
+            double de = nd * (h_av[1] + C2R_ABU_C);                            /* tped.f90:81 */
+            oracle_doric(dt, t_end_avg, de, c->clump_grid ? (double)c->clump_grid[id] : c->clumping, h, h_av, gamma);   /* :443-445 clumping_point, :515 */
+            de = nd * (h_av[1] + C2R_ABU_C);                                   /* :518 */
+            if (thermal)                                                       /* :521-527 */
+                oracle_thermal(c, dt, t_start_cur, &t_end_int, &t_end_avg, de, nd, h_old[1], h_av[1], h[1], heat);
+            /* :531-538: the temperature clause compares temperature_end%current with its copy of the iteration
+             * before; thermal never writes %current, so the clause is |0/T| < 1e-3: true for every finite T > 0 */
             if (fabs((h_av[0] - yh0_av_old) / h_av[0]) < C2R_MIN_FRACTIONAL_CHANGE ||
-                h_av[0] < C2R_MIN_FRACTION_OF_ATOMS) break;                    /* :531-538 */
+                h_av[0] < C2R_MIN_FRACTION_OF_ATOMS) break;
             if (nit > C2R_MAX_CHEM_ITER) break;                                /* :541 */
+        }
+        double t_new_avg = t_start_avg;
+        if (thermal) {                                                         /* :553 set_temperature_point: f32 stores */
+            tg[2] = (float)t_end_int;
+            tg[1] = (float)t_end_avg;
+            t_new_avg = (double)tg[1];                                         /* :381 get_temperature_point again */
         }
         const double yh1_av_old = dmax(C2R_EPSILON, xh_av[id]);                /* :378 */
         const double yh0_av_old = 1.0 - yh1_av_old;
-        if (fabs(h_av[0] - yh0_av_old) > C2R_MIN_FRACTIONAL_CHANGE &&
-            fabs((h_av[0] - yh0_av_old) / h_av[0]) > C2R_MIN_FRACTIONAL_CHANGE &&
-            h_av[0] > C2R_MIN_FRACTION_OF_ATOMS) conv_flag++;                  /* :384-391 */
+        if ((fabs(h_av[0] - yh0_av_old) > C2R_MIN_FRACTIONAL_CHANGE &&
+             fabs((h_av[0] - yh0_av_old) / h_av[0]) > C2R_MIN_FRACTIONAL_CHANGE &&
+             h_av[0] > C2R_MIN_FRACTION_OF_ATOMS) ||
+            (fabs((t_start_avg - t_new_avg) / t_new_avg) > C2R_TEMP_CONV_REL &&
+             fabs(t_start_avg - t_new_avg) > C2R_TEMP_CONV_ABS)) conv_flag++;  /* :384-391 (.or. binds looser than .and.) */
         xh_intermed[id] = h[1];
         xh_av[id] = h_av[1];
     }
@@ -376,6 +479,12 @@ void oracle_photon_sums(const oracle_cfg *c, const float *ndens, const double *x
         h1 = h1 + nd * xh_l[id];
         const double y1 = xh_r[id], y0 = 1.0 - xh_r[id];
         const double de = nd * (y1 + C2R_ABU_C);
+        if (c->heat_thick) {                                                   /* :167 get_temperature_point: %average */
+            const double t = (double)c->temper_grid[3 * id + 1];
+            totrec = totrec + nd * y1 * de * (c->clump_grid ? (double)c->clump_grid[id] : c->clumping) * C2R_BH00 * pow(t / 1e4, C2R_ALBPOW);
+            totcoll = totcoll + nd * y0 * de * C2R_COLH0 * sqrt(t) * exp(-C2R_TEMPH0 / t);
+            continue;
+        }
         totrec = totrec + nd * y1 * de * (c->clump_grid ? (double)c->clump_grid[id] : c->clumping) * C2R_BH00 * rec;   /* :163-168 */
         totcoll = totcoll + nd * y0 * de * C2R_COLH0 * sq * ex;                /* :169-172 */
     }
@@ -437,6 +546,8 @@ void oracle_evolve3d_x(const oracle_cfg *c, double dt, const float *ndens, doubl
         if (conv_flag < conv_criterion ||
             (rel1 < C2R_CONVERGENCE_FRACTION && rel0 < C2R_CONVERGENCE_FRACTION)) {   /* :212 */
             memcpy(xh, xh_intermed, ncell * sizeof(double));
+            if (c->heat_thick)                                                 /* :220 set_final_temperature_point */
+                for (size_t id = 0; id < ncell; ++id) c->temper_grid[3 * id] = c->temper_grid[3 * id + 2];
             rep->converged = 1;
             break;
         } else if (niter > C2R_MAX_OUTER_ITER) {                               /* :228 */
@@ -446,6 +557,7 @@ void oracle_evolve3d_x(const oracle_cfg *c, double dt, const float *ndens, doubl
         prev1 = sum1; prev0 = sum0;
         niter++;
         memset(phih, 0, ncell * sizeof(double));                               /* :243 */
+        if (c->heat_thick) memset(c->phiheat, 0, ncell * sizeof(double));      /* :435 */
         if (c->tolw) memset(c->tolw, 0, ncell * sizeof(double));               /* checker diagnostic: last pass only */
         double loss; long nb, vis;
         oracle_pass_sources(c, ndens, xh_av, phih, srcpos, normflux, nsrc, 0, 1, &loss, &nb, &vis);

@@ -23,7 +23,10 @@ class Cfg(C.Structure):
                 ("coldensh_LLS", C.c_double), ("clumping", C.c_double), ("temper", C.c_double),
                 ("S_star", C.c_double), ("thick", C.c_void_p), ("thin", C.c_void_p),
                 ("lls_type", C.c_int), ("R_max_LLS", C.c_double), ("lls_grid", C.c_void_p),
-                ("clump_grid", C.c_void_p), ("tolw", C.c_void_p)]
+                ("clump_grid", C.c_void_p), ("tolw", C.c_void_p),
+                ("heat_thick", C.c_void_p), ("heat_thin", C.c_void_p), ("cie_cool", C.c_void_p),
+                ("cool_mintemp", C.c_double), ("cool_dtemp", C.c_double), ("zred", C.c_double),
+                ("temper_grid", C.c_void_p), ("phiheat", C.c_void_p)]
 
 
 class Report(C.Structure):
@@ -46,6 +49,8 @@ def lib():
         _LIB.oracle_sum.restype = C.c_double
         _LIB.oracle_global_pass.restype = C.c_long
         _LIB.oracle_do_source.restype = C.c_int
+        _LIB.oracle_heat_rate.restype = C.c_double
+        _LIB.oracle_coolin.restype = C.c_double
     return _LIB
 
 
@@ -72,6 +77,44 @@ class Oracle:
         self.tolw = None
         self.n = n
         self.ncell = n[0] * n[1] * n[2]
+
+    def enable_thermal(self, heat_thick, heat_thin, cool_logT, cool_logL, zred, temper_grid=None):
+        """Non-isothermal run (isothermal=.false.): heating tables, the cooling table as setup_cool (cooling.f90:64-87)
+        holds it, the redshift of cosmo_cool, and the state arrays -- temper_grid (ncell x 3 f32: current, average,
+        intermed; updated in place) and phiheat (allocated here)."""
+        self.heat_thick = np.ascontiguousarray(heat_thick, dtype=np.float64)
+        self.heat_thin = np.ascontiguousarray(heat_thin, dtype=np.float64)
+        assert self.heat_thick.size == 2001 and self.heat_thin.size == 2001 and len(cool_logT) == 61
+        # cooling.f90:83  10.0d0**cie_cool: libm's pow (python floats), not numpy's vector pow, which differs in the last bit
+        self.cie_cool = np.array([10.0 ** float(v) for v in cool_logL], dtype=np.float64)
+        self.cfg.heat_thick, self.cfg.heat_thin = self.heat_thick.ctypes.data, self.heat_thin.ctypes.data
+        self.cfg.cie_cool = self.cie_cool.ctypes.data
+        self.cfg.cool_mintemp = float(cool_logT[0]); self.cfg.cool_dtemp = float(cool_logT[1]) - float(cool_logT[0])
+        self.cfg.zred = zred
+        self.phiheat = np.zeros(self.ncell, dtype=np.float64)
+        self.cfg.phiheat = self.phiheat.ctypes.data
+        if temper_grid is not None:
+            self.set_temperature(temper_grid)
+
+    def set_temperature(self, temper_grid):
+        assert temper_grid.dtype == np.float32 and temper_grid.size == 3 * self.ncell and temper_grid.flags.c_contiguous
+        self.temper_grid = temper_grid
+        self.cfg.temper_grid = temper_grid.ctypes.data
+
+    def heat_rate(self, cd_in, cd_out, vol, normflux):
+        return lib().oracle_heat_rate(_p(self.heat_thick), _p(self.heat_thin), C.c_double(cd_in), C.c_double(cd_out),
+                                      C.c_double(vol), C.c_double(normflux))
+
+    def coolin(self, nucldens, eldens, temp0):
+        return lib().oracle_coolin(C.byref(self.cfg), C.c_double(nucldens), C.c_double(eldens), C.c_double(temp0))
+
+    def thermal(self, dt, t_initial, ndens_electron, ndens_atom, h_old1, h_av1, h1, heat):
+        """thermal.f90:22; returns (final, average), -1 where the reference leaves its output untouched."""
+        tf, ta = C.c_double(-1.0), C.c_double(-1.0)
+        lib().oracle_thermal(C.byref(self.cfg), C.c_double(dt), C.c_double(t_initial), C.byref(tf), C.byref(ta),
+                             C.c_double(ndens_electron), C.c_double(ndens_atom), C.c_double(h_old1), C.c_double(h_av1),
+                             C.c_double(h1), C.c_double(heat))
+        return tf.value, ta.value
 
     def enable_tolerance_weight(self):
         """Checker diagnostic (see oracle_cfg.tolw): accumulate, from now on, W = sum_s (1+tau_in) photo_in /

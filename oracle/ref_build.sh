@@ -37,10 +37,12 @@ SRCS="precision.f90 mathconstants.f90 cgsconstants.f90 cgsastroconstants.f90 c2r
 #   lls2   type_of_LLS=2       position-dependent LLS column (LLS_grid)
 #   lls3   type_of_LLS=3       hard barrier at R_max_cMpc
 #   clump5 type_of_clumping=5  pre-computed clumping grid (clumping_grid)
+#   thermal isothermal=.false.  heating and cooling (thermal.f90); the run directory needs tables/corocool.tab
 params_for_variant () {   # $1 = variant, $2 = output file
   case "$1" in
     lls2)   sed 's|^\( *integer,parameter :: type_of_LLS=\)1|\12|' "$REF/c2ray_parameters.f90" > "$2"; grep -q "type_of_LLS=2" "$2" ;;
     lls3)   sed 's|^\( *integer,parameter :: type_of_LLS=\)1|\13|' "$REF/c2ray_parameters.f90" > "$2"; grep -q "type_of_LLS=3" "$2" ;;
+    thermal) sed 's|^\( *logical,parameter :: isothermal=\).true.|\1.false.|' "$REF/c2ray_parameters.f90" > "$2"; grep -q "isothermal=.false." "$2" ;;
     clump5) sed 's|^\( *integer,parameter :: type_of_clumping=\)1|\15|' "$REF/c2ray_parameters.f90" > "$2"; grep -q "type_of_clumping=5" "$2" ;;
     *) echo "unknown variant $1" >&2; exit 1 ;;
   esac

@@ -14,7 +14,7 @@
 !! (sourceprops.F90:248), the answers file (inputs/input_example_test format)
 !! and driver.nml:
 !!   &ctl mode='evolve'|'sweep'|'point'|'tables', nsteps=, x_init=, dens_file=,
-!!        x_file=, dump_first=, dump_last=, ns_dump=, nrep=, out_dir= /
+!!        x_file=, dump_first=, dump_last=, ns_dump=, nrep=, out_dir=, t_file= /
 !!   (mode 'sweep' also writes <tag>_nbox.txt: the sub-box count each source ended with)
 !! usage: ref_driver <answers-file>
 program ref_driver
@@ -22,12 +22,17 @@ program ref_driver
   use precision, only: dp
   use clocks, only: setup_clocks
   use file_admin, only: stdinput, logf, flag_for_file_input
-  use c2ray_parameters, only: cosmological, type_of_clumping, use_LLS, type_of_LLS
+  use c2ray_parameters, only: cosmological, type_of_clumping, use_LLS, type_of_LLS, isothermal
   use my_mpi
   use output_module, only: setup_output
   use sizes, only: mesh
   use grid, only: grid_ini, dr, vol
-  use radiation_tables, only: rad_ini, stellar_photo_thick_table, stellar_photo_thin_table
+  use radiation_tables, only: rad_ini, stellar_photo_thick_table, stellar_photo_thin_table, &
+       stellar_heat_thick_table, stellar_heat_thin_table
+  use radiative_cooling, only: setup_cool, coolin
+  use thermalevolution, only: thermal
+  use temperature_module, only: temperature_grid
+  use ionfractions_module, only: ionstates
   use radiation_sed_parameters, only: S_star
   use radiation_photoionrates, only: photoion_rates, photrates
   use nbody, only: nbody_ini, NumZred, zred_array
@@ -41,7 +46,7 @@ program ref_driver
   use sourceprops, only: source_properties_ini, source_properties, NumSrc, srcpos, &
        NormFlux_stellar
   use photonstatistics, only: photon_loss, totrec, totcollisions, dh0, total_ion
-  use evolve_data, only: evolve_ini, phih_grid, xh_av, xh_intermed, coldensh_out, &
+  use evolve_data, only: evolve_ini, phih_grid, phiheat_grid, xh_av, xh_intermed, coldensh_out, &
        photon_loss_all
   use evolve_source, only: do_source, sum_nbox, sum_nbox_all
   use evolve, only: evolve3D
@@ -54,9 +59,9 @@ program ref_driver
   integer            :: nsteps = 1, dump_first = 1, dump_last = 1, ns_dump = 1, nrep = 1
   real(kind=dp)      :: x_init = -1.0_dp
   character(len=512) :: dens_file = 'none', x_file = 'none', out_dir = './dump/'
-  character(len=512) :: lls_file = 'none', clump_file = 'none'
+  character(len=512) :: lls_file = 'none', clump_file = 'none', t_file = 'none'
   namelist /ctl/ mode, nsteps, x_init, dens_file, x_file, dump_first, dump_last, &
-       ns_dump, nrep, out_dir, lls_file, clump_file
+       ns_dump, nrep, out_dir, lls_file, clump_file, t_file
 
   character(len=512) :: answers
   integer :: restart = 0, nz0 = 1, ierror = 0, nz, u, istep, ns, irep
@@ -64,7 +69,7 @@ program ref_driver
   real(kind=dp) :: end_time, sim_time, output_time, dt, actual_dt
   real(kind=dp) :: t_sweep
   integer(kind=8) :: c0, c1, crate
-  real, allocatable :: factor(:,:,:)
+  real, allocatable :: factor(:,:,:), t_init(:,:,:)
   character(len=8) :: tag
 
   ! ---- start-up, in the order of C2Ray.F90:108-198 -------------------------
@@ -80,6 +85,7 @@ program ref_driver
   call setup_output()
   call grid_ini()
   call rad_ini()
+  if (.not.isothermal) call setup_cool()          ! C2Ray.F90:143 (reads ./tables/corocool.tab)
   call material_ini(restart, nz0, ierror)
   call nbody_ini(ierror)
   call source_properties_ini()
@@ -92,6 +98,10 @@ program ref_driver
   if (trim(mode) == 'tables') then
      call dump_r8_1d('thick_table', stellar_photo_thick_table(:,1), size(stellar_photo_thick_table,1))
      call dump_r8_1d('thin_table', stellar_photo_thin_table(:,1), size(stellar_photo_thin_table,1))
+     if (.not.isothermal) then
+        call dump_r8_1d('heat_thick_table', stellar_heat_thick_table(:,1), size(stellar_heat_thick_table,1))
+        call dump_r8_1d('heat_thin_table', stellar_heat_thin_table(:,1), size(stellar_heat_thin_table,1))
+     endif
      stop
   endif
 
@@ -148,6 +158,18 @@ program ref_driver
               read(u) xh
               close(u)
            endif
+           ! non-isothermal builds: an initial temperature field (K, f32) instead of the uniform
+           ! initial_temperature that temperature_array_init (temperature_module.F90:43) fills in
+           if (.not.isothermal .and. trim(t_file) /= 'none') then
+              allocate(t_init(mesh(1),mesh(2),mesh(3)))
+              open(newunit=u, file=trim(t_file), access='stream', form='unformatted', status='old')
+              read(u) t_init
+              close(u)
+              temperature_grid(:,:,:)%current = t_init
+              temperature_grid(:,:,:)%average = t_init
+              temperature_grid(:,:,:)%intermed = t_init
+              deallocate(t_init)
+           endif
         endif
 
         write(tag,'(A,I3.3)') 'step', istep
@@ -163,6 +185,7 @@ program ref_driver
               phih_grid = 0.0
               photon_loss = 0.0
               sum_nbox = 0
+              if (.not.isothermal) phiheat_grid = 0.0
               do ns = 1, NumSrc
                  nbox_before = sum_nbox
                  call do_source(actual_dt, ns, 1)
@@ -174,6 +197,7 @@ program ref_driver
            call system_clock(c1)
            t_sweep = real(c1-c0,dp)/real(crate,dp)/real(nrep,dp)
            call dump_r8(trim(tag)//'_phih_grid', phih_grid)
+           if (.not.isothermal) call dump_r8(trim(tag)//'_phiheat_grid', phiheat_grid)
            open(newunit=u, file=trim(out_dir)//trim(tag)//'_sweep.txt', status='replace')
            write(u,'(A,1X,ES26.17E3)') 'photon_loss', photon_loss(1)
            write(u,'(A,1X,I12)') 'sum_nbox', sum_nbox
@@ -191,7 +215,10 @@ program ref_driver
 
         ! mode 'evolve' (restart_flag=0) or 'restart' (restart_flag=3: the reference reads
         ! ./iterdump.bin through start_from_dump, evolve.F90:328, on the first step)
-        if (istep >= dump_first .and. istep <= dump_last) call dump_inputs(tag)
+        if (istep >= dump_first .and. istep <= dump_last) then
+           call dump_inputs(tag)
+           if (.not.isothermal) call dump_temper(trim(tag)//'_temper_before')
+        endif
         write(logf,*) 'REFDRIVER step ', istep
         if (trim(mode) == 'restart' .and. istep == 1) then
            call evolve3D(sim_time, actual_dt, 3)
@@ -203,6 +230,10 @@ program ref_driver
            call dump_r8(trim(tag)//'_xh_av', xh_av)
            call dump_r8(trim(tag)//'_xh_intermed', xh_intermed)
            call dump_r8(trim(tag)//'_phih_grid', phih_grid)
+           if (.not.isothermal) then
+              call dump_r8(trim(tag)//'_phiheat_grid', phiheat_grid)
+              call dump_temper(trim(tag)//'_temper_after')
+           endif
            open(newunit=u, file=trim(out_dir)//trim(tag)//'_out.txt', status='replace')
            write(u,'(A,1X,ES26.17E3)') 'photon_loss_all', photon_loss_all(1)
            write(u,'(A,1X,I12)') 'sum_nbox_all', sum_nbox_all
@@ -234,6 +265,16 @@ contains
     write(uu) a
     close(uu)
   end subroutine dump_r8
+
+  !> temperature_grid as it lies in memory: (current, average, intermed) f32 per cell
+  subroutine dump_temper(name)
+    character(len=*), intent(in) :: name
+    integer :: uu
+    open(newunit=uu, file=trim(out_dir)//trim(name)//'.f32', access='stream', &
+         form='unformatted', status='replace')
+    write(uu) temperature_grid
+    close(uu)
+  end subroutine dump_temper
 
   subroutine dump_r8_1d(name, a, n)
     character(len=*), intent(in) :: name
@@ -355,6 +396,74 @@ contains
          form='unformatted', status='replace')
     write(uu) res
     close(uu)
+    deallocate(args, res)
+
+    if (.not.isothermal) call point_tests_thermal()
   end subroutine point_tests
+
+  !> non-isothermal builds: photoion_rates' heating (radiation_photoionrates.F90:323-417), coolin
+  !! (cooling.f90:38) and thermal (thermal.f90:22) on tabulated arguments
+  subroutine point_tests_thermal()
+    integer :: uu, m, ii
+    real(kind=dp), allocatable :: args(:,:), res(:,:)
+    real(kind=dp) :: xf(0:1), t_final, t_avg
+    type(photrates) :: phi
+    type(ionstates) :: ion
+
+    ! --- heating: rows of (colum_in, colum_out, vol)
+    open(newunit=uu, file='point_photo.f64', access='stream', form='unformatted', status='old')
+    read(uu) m
+    allocate(args(3,m), res(1,m))
+    read(uu) args
+    close(uu)
+    do ii = 1, m
+       phi = photoion_rates(args(1,ii), args(2,ii), args(3,ii), 1, 0.5_dp)
+       res(1,ii) = phi%heat
+    enddo
+    open(newunit=uu, file=trim(out_dir)//'point_heat_out.f64', access='stream', &
+         form='unformatted', status='replace')
+    write(uu) res
+    close(uu)
+    deallocate(args, res)
+
+    ! --- coolin: rows of (nucldens, eldens, temp0)
+    open(newunit=uu, file='point_cool.f64', access='stream', form='unformatted', status='old')
+    read(uu) m
+    allocate(args(3,m), res(1,m))
+    read(uu) args
+    close(uu)
+    xf = (/ 0.5_dp, 0.5_dp /)
+    do ii = 1, m
+       res(1,ii) = coolin(args(1,ii), args(2,ii), xf, args(3,ii))
+    enddo
+    open(newunit=uu, file=trim(out_dir)//'point_cool_out.f64', access='stream', &
+         form='unformatted', status='replace')
+    write(uu) res
+    close(uu)
+    deallocate(args, res)
+
+    ! --- thermal: rows of (dt, T_initial, ndens_electron, ndens_atom, h_old(1), h_av(1), h(1), heat);
+    !     zred is the first slice's (set above); outputs (final, average); -1 marks "not set"
+    !     (thermal leaves its outputs untouched when T_initial <= minitemp, thermal.f90:83)
+    open(newunit=uu, file='point_thermal.f64', access='stream', form='unformatted', status='old')
+    read(uu) m
+    allocate(args(8,m), res(2,m))
+    read(uu) args
+    close(uu)
+    do ii = 1, m
+       ion%h_old(1) = args(5,ii); ion%h_old(0) = 1.0_dp - args(5,ii)
+       ion%h_av(1) = args(6,ii); ion%h_av(0) = 1.0_dp - args(6,ii)
+       ion%h(1) = args(7,ii); ion%h(0) = 1.0_dp - args(7,ii)
+       phi%heat = args(8,ii)
+       t_final = -1.0_dp; t_avg = -1.0_dp
+       call thermal(args(1,ii), args(2,ii), t_final, t_avg, args(3,ii), args(4,ii), ion, phi)
+       res(1,ii) = t_final; res(2,ii) = t_avg
+    enddo
+    open(newunit=uu, file=trim(out_dir)//'point_thermal_out.f64', access='stream', &
+         form='unformatted', status='replace')
+    write(uu) zred
+    write(uu) res
+    close(uu)
+  end subroutine point_tests_thermal
 
 end program ref_driver

@@ -34,6 +34,20 @@ def oracle_for(meta, tables, n=None, lls_grid=None, clump_grid=None):
                   clump_grid=None if clump_grid is None else F(clump_grid))
 
 
+def load_thermal_tables():
+    """Heating tables and the (synthetic) cooling table the non-isothermal fixtures were generated with."""
+    t = np.load(os.path.join(GOLDEN, "tables_thermal.npz"))
+    return {k: t[k].copy() for k in ("heat_thick", "heat_thin", "cool_logT", "cool_logL")}
+
+
+def thermal_oracle_for(meta, tables, temper_grid, n=None):
+    """Oracle of a non-isothermal step: temper_grid (ncell x 3 f32: current, average, intermed) is updated in place."""
+    o = oracle_for(meta, tables, n)
+    tt = load_thermal_tables()
+    o.enable_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"], meta["zred"], temper_grid)
+    return o
+
+
 def expand(a, n):
     """Fixtures store uniform fields as one value."""
     a = np.asarray(a)

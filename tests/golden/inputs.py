@@ -39,11 +39,37 @@ def bubble_xfield(n, centres, radius, x_in=0.9995, x_out=2e-4, seed=7):
     return np.clip(x, 1e-6, 1.0 - 1e-6)
 
 
+def cooling_table():
+    """A SYNTHETIC 61-point cooling curve in the format of the reference's tables/corocool.tab (cooling.f90:71-76:
+    rows of log10 T, log10 Lambda [erg cm^3 s^-1]).  The reference repository does not ship that file, so the
+    non-isothermal fixtures are generated with this one: hydrogen excitation + collisional ionization +
+    recombination + free-free cooling of a primordial gas (textbook fits), rounded to the 4 decimals written.
+    Returns (text of the file, log10 T values, log10 Lambda values as the Fortran list-directed read sees them)."""
+    lt = [float("%.2f" % (1.0 + 0.1 * i)) for i in range(61)]
+    T = 10.0 ** np.array(lt)
+    lam = (7.5e-19 * np.exp(-118348.0 / T) / (1.0 + np.sqrt(T / 1e5))
+           + 1.27e-21 * np.sqrt(T) * np.exp(-157809.1 / T) / (1.0 + np.sqrt(T / 1e5))
+           + 8.7e-27 * np.sqrt(T) * (T / 1e3) ** -0.2 / (1.0 + (T / 1e6) ** 0.7)
+           + 1.42e-27 * 1.3 * np.sqrt(T))
+    ll = [float("%.4f" % v) for v in np.log10(lam)]
+    text = "".join("%5.2f %9.4f\n" % (a, b) for a, b in zip(lt, ll))
+    return text, np.array(lt), np.array(ll)
+
+
+def temperature_field(n, seed, lo=2.0, hi=4.5):
+    """Initial temperature field (K, f32) for the non-isothermal fixtures: log-uniform, cell by cell."""
+    rng = np.random.default_rng(seed)
+    return (10.0 ** rng.uniform(lo, hi, (n, n, n))).astype(np.float32)
+
+
 def run_driver(n, sources, nml, dens=None, xfield=None, extra_files=None, omp=False, threads=1, variant=None,
-               hip=False, d="/tmp/c2ray_golden_run"):
+               hip=False, d="/tmp/c2ray_golden_run", tfield=None):
     shutil.rmtree(d, ignore_errors=True)
     os.makedirs(d + "/results")
     os.makedirs(d + "/dump")
+    if variant == "thermal":                   # setup_cool (cooling.f90:64) opens ./tables/corocool.tab
+        os.makedirs(d + "/tables")
+        open(d + "/tables/corocool.tab", "w").write(cooling_table()[0])
     with open(d + "/answers", "w") as f:
         f.write(ANSWERS)
     with open(d + "/test_sources.dat", "w") as f:
@@ -57,6 +83,9 @@ def run_driver(n, sources, nml, dens=None, xfield=None, extra_files=None, omp=Fa
     if xfield is not None:
         xfield.T.tofile(d + "/x.f64")
         nml["x_file"] = "'x.f64'"
+    if tfield is not None:
+        tfield.astype(np.float32).T.tofile(d + "/t.f32")
+        nml["t_file"] = "'t.f32'"
     for name, writer in (extra_files or {}).items():
         writer(os.path.join(d, name))
     with open(d + "/driver.nml", "w") as f:

@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = os.path.join(ROOT, "oracle", "_ref")
 sys.path.insert(0, HERE)
 from inputs import ANSWERS, SRC_ONE, SRC_STD, density_factor, bubble_xfield, run_driver, \
-    read_kv, rd, parse_log   # noqa: E402
+    read_kv, rd, parse_log, cooling_table, temperature_field   # noqa: E402
 
 
 def case_tables():
@@ -80,8 +80,58 @@ def case_point():
           (len(out["cinterp_out_a"]), len(out["cinterp_out_b"]), len(photo), len(dor)))
 
 
+def case_thermal_tables_and_points():
+    """Reference rebuilt with isothermal=.false. (ref_build.sh 32:thermal), run with the synthetic cooling table:
+    the heating tables (radiation_tables.F90:455-543), and heat_lookuptable / coolin / thermal on tabulated arguments."""
+    text, lt, ll = cooling_table()
+    d = run_driver(32, SRC_ONE, {"mode": "'tables'"}, variant="thermal")
+    out = {"thick": np.fromfile(d + "/dump/thick_table.f64"), "thin": np.fromfile(d + "/dump/thin_table.f64"),
+           "heat_thick": np.fromfile(d + "/dump/heat_thick_table.f64"), "heat_thin": np.fromfile(d + "/dump/heat_thin_table.f64"),
+           "cool_logT": lt, "cool_logL": ll}
+    iso = np.load(os.path.join(HERE, "tables.npz"))
+    assert np.array_equal(out["thick"], iso["thick"]) and np.array_equal(out["thin"], iso["thin"])
+    assert out["heat_thick"].size == 2001
+    np.savez_compressed(os.path.join(HERE, "tables_thermal.npz"), **out)
+    pt = np.load(os.path.join(HERE, "point.npz"))
+    photo = pt["photo_in"]
+    rng = np.random.default_rng(20261004)
+    cool = np.array([(10.0 ** rng.uniform(-5, -1), 10.0 ** rng.uniform(-6, -1), T)
+                     for T in list(10.0 ** rng.uniform(0.5, 7.5, 60)) + [10.0, 12.589254117941675, 1e7, 9.99, 1.0000001e7]])
+    rows = []
+    for T0 in (0.5, 1.0, 50.0, 1e3, 1e4, 3e4, 1e6):
+        for heat in (0.0, 1e-30, 1e-26, 1e-24):
+            for dt in (3.15576e13, 3.15576e9):
+                for x in (2e-4, 0.5, 0.9995):
+                    nh = 10.0 ** rng.uniform(-5, -2)
+                    xav = min(1.0, x * (1.0 + 0.2 * rng.uniform()))
+                    xnew = min(1.0, xav * (1.0 + 0.2 * rng.uniform()))
+                    rows.append((dt, T0, nh * (xav + 7.09999994796817191e-07), nh, x, xav, xnew, heat))
+    th = np.array(rows)
+    def w(arr):
+        def f(p):
+            with open(p, "wb") as fh:
+                np.int32(len(arr)).tofile(fh); arr.tofile(fh)
+        return f
+    cd = pt["coldens"]
+    dor = pt["doric_in"]
+    d = run_driver(32, SRC_ONE, {"mode": "'point'"}, variant="thermal",
+                   extra_files={"point_coldens.f64": lambda p: cd.T.tofile(p),
+                                "point_cinterp.txt": lambda p: open(p, "w").write("16 17 15 1\n"),
+                                "point_photo.f64": w(photo), "point_doric.f64": w(dor),
+                                "point_cool.f64": w(cool), "point_thermal.f64": w(th)})
+    ph = np.fromfile(d + "/dump/point_photo_out.f64")
+    assert np.array_equal(ph[1:].reshape(-1, 3), pt["photo_out"])        # the photo rates do not depend on the switch
+    tho = np.fromfile(d + "/dump/point_thermal_out.f64")
+    np.savez_compressed(os.path.join(HERE, "point_thermal.npz"), photo_in=photo, photo_normflux=ph[0],
+                        heat_out=np.fromfile(d + "/dump/point_heat_out.f64"),
+                        cool_in=cool, cool_out=np.fromfile(d + "/dump/point_cool_out.f64"),
+                        thermal_in=th, thermal_zred=tho[0], thermal_out=tho[1:].reshape(-1, 2))
+    print("thermal: heat_thick[0]=%.17g heat_thin[0]=%.17g, %d heat rows, %d cool rows, %d thermal rows (zred %.6f)" %
+          (out["heat_thick"][0], out["heat_thin"][0], len(photo), len(cool), len(th), tho[0]))
+
+
 def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, keep=("xh_after", "phih_grid", "xh_av"),
-                variant=None, lls_grid=None, clump_grid=None):
+                variant=None, lls_grid=None, clump_grid=None, tfield=None):
     dens = density_factor(n, dens_seed) if dens_seed is not None else None
     nml = {"mode": "'evolve'", "nsteps": nsteps, "dump_first": dump[0], "dump_last": dump[-1]}
     extra = {}
@@ -89,7 +139,7 @@ def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, kee
         extra["lls.f32"] = lambda p: lls_grid.astype(np.float32).T.tofile(p); nml["lls_file"] = "'lls.f32'"
     if clump_grid is not None:
         extra["clump.f32"] = lambda p: clump_grid.astype(np.float32).T.tofile(p); nml["clump_file"] = "'clump.f32'"
-    d = run_driver(n, sources, nml, dens=dens, xfield=xfield, variant=variant, extra_files=extra)
+    d = run_driver(n, sources, nml, dens=dens, xfield=xfield, variant=variant, extra_files=extra, tfield=tfield)
     log = parse_log(d + "/results/C2Ray.log")
     arrays, meta = {}, {"n": n, "steps": {}}
     for s in dump:
@@ -103,6 +153,10 @@ def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, kee
         arrays[tag + "_ndens"] = rd(d, tag + "_ndens.f32", n, np.float32)
         for k in keep:
             arrays[tag + "_" + k] = rd(d, "%s_%s.f64" % (tag, k), n)
+        if variant == "thermal":       # temperature_grid as it lies in memory: cell-major (current, average, intermed) f32
+            for k in ("temper_before", "temper_after"):
+                arrays[tag + "_" + k] = np.fromfile("%s/dump/%s_%s.f32" % (d, tag, k), dtype=np.float32).reshape(-1, 3)
+            arrays[tag + "_phiheat_grid"] = rd(d, tag + "_phiheat_grid.f64", n)
     if lls_grid is not None: arrays["lls_grid"] = lls_grid.astype(np.float32)
     if clump_grid is not None: arrays["clump_grid"] = clump_grid.astype(np.float32)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
@@ -110,12 +164,12 @@ def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, kee
     print(name, {t: m["niter"] for t, m in meta["steps"].items()})
 
 
-def case_sweep(name, n, sources, x_init=None, dens_seed=None, xfield=None, ns_dump=1, full=True):
+def case_sweep(name, n, sources, x_init=None, dens_seed=None, xfield=None, ns_dump=1, full=True, variant=None):
     dens = density_factor(n, dens_seed) if dens_seed is not None else None
     nml = {"mode": "'sweep'", "ns_dump": ns_dump}
     if x_init is not None:
         nml["x_init"] = "%.17g" % x_init
-    d = run_driver(n, sources, nml, dens=dens, xfield=xfield)
+    d = run_driver(n, sources, nml, dens=dens, xfield=xfield, variant=variant)
     tag = "step001"
     kv = read_kv("%s/dump/%s_in.txt" % (d, tag))
     kv.update(read_kv("%s/dump/%s_sweep.txt" % (d, tag)))
@@ -124,6 +178,8 @@ def case_sweep(name, n, sources, x_init=None, dens_seed=None, xfield=None, ns_du
     phih = rd(d, tag + "_phih_grid.f64", n)
     cdo = rd(d, tag + "_coldensh_out.f64", n)
     arrays = {"xh": rd(d, tag + "_xh_before.f64", n), "ndens": rd(d, tag + "_ndens.f32", n, np.float32)}
+    if variant == "thermal":
+        arrays["phiheat"] = rd(d, tag + "_phiheat_grid.f64", n)
     if full:
         arrays.update(phih=phih, coldensh_out=cdo)
     else:   # large grids: three orthogonal planes through source ns_dump + checksums
@@ -297,6 +353,14 @@ def main():
         case_evolve("evolve32_lls3", 32, SRC_STD, 1, [1], dens_seed=11, xfield=x, variant="lls3")
         clump = 1.0 + 9.0 * rng.random((32, 32, 32)) ** 3
         case_evolve("evolve32_clump5", 32, SRC_STD, 1, [1], dens_seed=11, xfield=x, variant="clump5", clump_grid=clump)
+    # non-isothermal run (isothermal=.false.), with the synthetic cooling table of inputs.cooling_table()
+    if want("thermal"):
+        case_thermal_tables_and_points()
+        x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 7.0)
+        case_sweep("sweep32_thermal", 32, SRC_STD, dens_seed=5, xfield=x, ns_dump=5, variant="thermal")
+        x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 6.0)
+        case_evolve("evolve32_thermal", 32, SRC_STD, 3, [1, 3], dens_seed=11, xfield=x, variant="thermal",
+                    tfield=temperature_field(32, 5))
     if want("sweep64"):
         x = bubble_xfield(64, [(50, 50, 50), (20, 10, 10), (6, 8, 50), (20, 10, 26)], 14.0)
         srcs = SRC_STD[:8] + [(72, 72, 50, 1e58), (20, 10, 90, 1e54)]

@@ -1,0 +1,86 @@
+"""The oracle's non-isothermal path (isothermal=.false.: heat_lookuptable, coolin, thermal, the temperature clause of the
+global convergence test, phiheat_grid, set_final_temperature_point) against fixtures from the reference REBUILT with
+that one parameter changed (oracle/ref_build.sh 32:thermal) and run with the synthetic cooling table of
+tests/golden/inputs.cooling_table (the reference repository does not ship tables/corocool.tab).  Equality, as in
+tests/test_oracle.py: the restatement follows the reference statement by statement."""
+import numpy as np
+from tests._util import F, load_case, load_tables, load_thermal_tables, thermal_oracle_for, oracle_for
+
+TAB = load_tables()
+
+
+def _point_oracle():
+    from oracle.oracle import Oracle
+    p = np.load("tests/golden/point_thermal.npz")
+    tt = load_thermal_tables()
+    o = Oracle(32, 1e24, 1e72, 7e16, *TAB)
+    o.enable_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"], float(p["thermal_zred"]))
+    return o, p
+
+
+def test_heat_lookuptable_rows():
+    o, p = _point_oracle()
+    nf = float(p["photo_normflux"])
+    got = np.array([o.heat_rate(a, b, v, nf) for a, b, v in p["photo_in"]])
+    assert np.array_equal(got, p["heat_out"])
+    assert np.count_nonzero(got) > 80 and got.max() > 0
+
+
+def test_coolin_rows():
+    o, p = _point_oracle()
+    got = np.array([o.coolin(a, b, t) for a, b, t in p["cool_in"]])
+    assert np.array_equal(got, p["cool_out"])
+
+
+def test_thermal_rows():
+    """168 rows: T_initial at and below minitemp (outputs untouched), heating on and off, two time steps."""
+    o, p = _point_oracle()
+    got = np.array([o.thermal(*r) for r in p["thermal_in"]])
+    assert np.array_equal(got, p["thermal_out"])
+    assert np.count_nonzero(got[:, 0] == -1.0) == 48          # T_initial = 0.5 and 1.0: thermal.f90:83 skips them
+
+
+def test_sweep_heating_rates_vs_reference():
+    m, a = load_case("sweep32_thermal")
+    n = m["n"]
+    tg = np.zeros((n ** 3, 3), dtype=np.float32)
+    o = thermal_oracle_for(m, TAB, tg, n)
+    nd, xh = F(a["ndens"]), F(a["xh"])
+    phih = np.zeros(n ** 3)
+    loss, nb, vis = o.pass_sources(nd, xh, phih, m["srcpos"], m["normflux"])
+    assert nb == m["sum_nbox"] and loss == m["photon_loss"]
+    assert np.array_equal(phih, F(a["phih"]))
+    assert np.array_equal(o.phiheat, F(a["phiheat"]))
+    assert np.count_nonzero(o.phiheat) == np.count_nonzero(phih) > 5000
+
+
+def test_evolve3d_nonisothermal_vs_reference():
+    """Whole steps 1 and 3 of a non-isothermal run: iteration history, xh, Gamma, heating rates and the three temperature
+    fields, all equal to the reference's."""
+    m, a = load_case("evolve32_thermal")
+    n = m["n"]
+    for tag, s in m["steps"].items():
+        tg = np.ascontiguousarray(a[tag + "_temper_before"]).copy()
+        o = thermal_oracle_for(s, TAB, tg, n)
+        xh = F(a[tag + "_xh_before"])
+        rep, xav, xint, phih = o.evolve3d(s["dt"], F(a[tag + "_ndens"]), xh, s["srcpos"], s["normflux"])
+        assert rep.converged and rep.niter == s["niter"]
+        assert list(rep.it_conv_flag[:rep.niter]) == s["log"]["nonconv"]
+        assert rep.sum_nbox_all == s["sum_nbox_all"]
+        assert np.array_equal(xh, F(a[tag + "_xh_after"]))
+        assert np.array_equal(phih, F(a[tag + "_phih_grid"]))
+        assert np.array_equal(o.phiheat, F(a[tag + "_phiheat_grid"]))
+        assert np.array_equal(tg, a[tag + "_temper_after"])
+        assert np.array_equal(tg[:, 0], tg[:, 2])              # set_final_temperature_point
+        assert np.max(np.abs(tg[:, 0] / a[tag + "_temper_before"][:, 0] - 1)) > 0.05       # the step did heat/cool cells
+        for k in ("totrec", "totcollisions"):
+            assert abs(getattr(rep, k) / s[k] - 1) < 1e-13
+
+
+def test_isothermal_oracle_untouched_by_the_switch():
+    """heat_thick == NULL keeps the shipped path: same results as before on an isothermal fixture."""
+    m, a = load_case("sweep32_bubbles")
+    o = oracle_for(m, TAB, m["n"])
+    phih = np.zeros(m["n"] ** 3)
+    o.pass_sources(F(a["ndens"]), F(a["xh"]), phih, m["srcpos"], m["normflux"])
+    assert np.array_equal(phih, F(a["phih"]))
