@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libc2ray_hip.so")
 MAX_ITER_LOG = 128
 
-GRID_NDENS, GRID_XH, GRID_XH_AV, GRID_XH_INTERMED, GRID_PHIH = range(5)
+GRID_NDENS, GRID_XH, GRID_XH_AV, GRID_XH_INTERMED, GRID_PHIH, GRID_PHIHEAT, GRID_TEMPER = range(7)
 
 
 class Params(C.Structure):
@@ -53,6 +53,17 @@ class SedParams(C.Structure):
                 ("numtau", C.c_int32), ("reserved0", C.c_int32)]
 
 
+class ThermalParams(C.Structure):
+    _fields_ = [("tau_heat_limit", C.c_double), ("k_B", C.c_double), ("gamma1", C.c_double),
+                ("minitemp", C.c_double), ("relative_denergy", C.c_double),
+                ("thermal_rate_floor", C.c_double), ("thermal_time_tol", C.c_double),
+                ("temp_conv_rel", C.c_double), ("temp_conv_abs", C.c_double),
+                ("H0", C.c_double), ("Omega0", C.c_double),
+                ("cool_mintemp", C.c_double), ("cool_dtemp", C.c_double),
+                ("cool_points", C.c_int32), ("thermal_max_steps", C.c_int32),
+                ("cosmological", C.c_int32), ("reserved0", C.c_int32)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 ITERATION_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_double)
 
@@ -68,6 +79,10 @@ SYMBOLS = [
     ("c2r_set_step", C.c_int, [_P, C.POINTER(_D * 3), _D, _D, C.c_float, _D]),
     ("c2r_set_lls", C.c_int, [_P, _I32, _P, _D]),
     ("c2r_set_clumping_grid", C.c_int, [_P, _P]),
+    ("c2r_default_thermal", C.c_int, [C.POINTER(ThermalParams)]),
+    ("c2r_set_thermal", C.c_int, [_P, C.POINTER(ThermalParams), _P, _P, _I32, _P]),
+    ("c2r_set_redshift", C.c_int, [_P, _D]),
+    ("c2r_set_final_temperature", C.c_int, [_P]),
     ("c2r_set_sources", C.c_int, [_P, _P, _P, _I32]),
     ("c2r_set_rank", C.c_int, [_P, _I32, _I32, ALLREDUCE_FN, _P]),
     ("c2r_set_source_share", C.c_int, [_P, _P, _I32]),
@@ -94,8 +109,10 @@ SYMBOLS = [
     ("c2r_evolve3d_dev", C.c_int, [_P, _D, C.POINTER(Report)]),
     ("c2r_evolve3d_restart_dev", C.c_int, [_P, _D, _I32, _D, C.POINTER(Report)]),
     ("c2r_evolve3d", C.c_int, [_P, _D, _P, _P, _P, _P, _P, C.POINTER(Report)]),
+    ("c2r_evolve3d_thermal", C.c_int, [_P, _D, _I32, _D, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Report)]),
     ("c2r_default_sed", C.c_int, [C.POINTER(SedParams)]),
     ("c2r_build_tables", C.c_int, [C.POINTER(SedParams), _P, _P, _I32, C.POINTER(_D)]),
+    ("c2r_build_heat_tables", C.c_int, [C.POINTER(SedParams), _D, _P, _P, _I32]),
     ("c2r_selftest", C.c_int, [_P, C.POINTER(_I64)]),
     ("c2r_profile", C.c_int, [_P, _I32]),
     ("c2r_profile_read", C.c_int, [_P, C.POINTER(_D), C.POINTER(_I64), C.POINTER(_D), C.POINTER(_I64)]),
@@ -159,3 +176,21 @@ def build_tables(sed=None):
     if rc:
         raise C2RayHipError("c2r_build_tables -> %d" % rc)
     return thick, thin, r.value
+
+
+ION_FREQ_HI = 3.28851300169676800e+15      # cgsphotoconstants.f90: ion_freq_HI = ev2fr * eth0
+
+
+def build_heat_tables(sed=None, ion_freq_HI=ION_FREQ_HI):
+    """The heating tables of a non-isothermal run (c2r_build_heat_tables): returns (heat_thick, heat_thin)."""
+    import numpy as np
+    lib = load_library()
+    if sed is None:
+        sed = SedParams()
+        lib.c2r_default_sed(C.byref(sed))
+    n = sed.numtau + 1
+    hk, hn = np.empty(n), np.empty(n)
+    rc = lib.c2r_build_heat_tables(C.byref(sed), ion_freq_HI, hk.ctypes.data, hn.ctypes.data, n)
+    if rc:
+        raise C2RayHipError("c2r_build_heat_tables -> %d" % rc)
+    return hk, hn

@@ -25,8 +25,13 @@ struct Ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     size_t ncell = 0;
-    // grids: 0 ndens(f32) 1 xh 2 xh_av 3 xh_intermed 4 phih_grid
-    void *grid[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // grids: 0 ndens(f32) 1 xh 2 xh_av 3 xh_intermed 4 phih_grid; non-isothermal runs: 5 phiheat_grid 6 temperature_grid (3 x f32 per cell)
+    void *grid[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // non-isothermal runs (c2r_set_thermal): heating tables, cooling curve, transposed heating accumulator
+    bool thermal = false;
+    c2r_thermal_params tprm{};
+    double *d_hthick = nullptr, *d_hthin = nullptr, *d_cool = nullptr, *d_heat_T = nullptr;
+    double zred = 0.0; bool have_zred = false;
     // per-pass inputs of the sweep (owned): n_HI per cell and its (x,y)-transposed replica for the +-x
     // faces, and the transposed Gamma accumulator of those faces
     double *d_nhi = nullptr, *d_nhi_T = nullptr, *d_phih_T = nullptr;
@@ -120,7 +125,7 @@ inline const Ctx *C(const c2r_ctx *c) { return reinterpret_cast<const Ctx *>(c);
 
 #define FAIL(code, msg) do { ctx->err = (msg); return (code); } while (0)
 
-size_t grid_bytes(const Ctx *ctx, int which) { return ctx->ncell * (which == 0 ? sizeof(float) : sizeof(double)); }
+size_t grid_bytes(const Ctx *ctx, int which) { return ctx->ncell * (which == 0 ? sizeof(float) : (which == 6 ? 3 * sizeof(float) : sizeof(double))); }
 
 void free_sweep_scratch(Ctx *ctx)
 {
@@ -224,6 +229,8 @@ KParams make_kparams(const Ctx *ctx)
     k.gbox = ctx->d_gbox;
     k.lls_type = ctx->lls_type; k.R_max2 = ctx->R_max_LLS * ctx->R_max_LLS; k.lls = ctx->d_lls; k.lls_T = ctx->d_lls_T;
     k.thick = ctx->d_thick; k.thin = ctx->d_thin; k.logtab = ctx->d_logtab;
+    k.hthick = ctx->d_hthick; k.hthin = ctx->d_hthin; k.heat = (double *)ctx->grid[5]; k.heat_T = ctx->d_heat_T;
+    k.tau_heat_limit = ctx->tprm.tau_heat_limit;
     k.odtab = ctx->d_odtab;
     k.od_per_e = (double)(0.301029995663981195213738894724493027L / (long double)p.dlogtau);
     k.od_per_ln = (double)(0.434294481903251827651128918916605082L / (long double)p.dlogtau);
@@ -314,9 +321,14 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             boxL[d] = std::min(p.subboxsize * nbox, ctx->hl[d]);
         }
         if (nbox == 1) {
-            hipLaunchKernelGGL(k_source_cells, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
-                               ctx->d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
-                               ctx->d_loss_acc, dbg);
+            if (ctx->thermal)
+                hipLaunchKernelGGL(k_source_cells<true>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
+                                   ctx->d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
+                                   ctx->d_loss_acc, dbg);
+            else
+                hipLaunchKernelGGL(k_source_cells<false>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
+                                   ctx->d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
+                                   ctx->d_loss_acc, dbg);
         }
         const int q0 = p.subboxsize * (nbox - 1) + 1, q1 = std::min(p.subboxsize * nbox, ctx->Qmax);
         const bool det = ctx->d_gbox != nullptr;
@@ -358,8 +370,9 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                 ba.active = ctx->d_active[cur]; ba.n_active = ctx->d_nactive + cur; ba.loss_acc = ctx->d_loss_acc;
                 const dim3 grid(bound), blk(most <= 256 ? 256 : (most <= 512 ? 512 : 1024));
                 // (not in the k_sweep_shell launch timing of c2r_profile: a different kernel, 21^3 cells per source)
-#define C2R_LAUNCH_FUSED(D, L) do { if (ctx->fast) hipLaunchKernelGGL((k_sweep_box_fused<D, L, true>), grid, blk, 0, st, k, ba); \
-                                    else hipLaunchKernelGGL((k_sweep_box_fused<D, L, false>), grid, blk, 0, st, k, ba); } while (0)
+#define C2R_LAUNCH_FUSED_H(D, L, H) do { if (ctx->fast) hipLaunchKernelGGL((k_sweep_box_fused<D, L, true, H>), grid, blk, 0, st, k, ba); \
+                                    else hipLaunchKernelGGL((k_sweep_box_fused<D, L, false, H>), grid, blk, 0, st, k, ba); } while (0)
+#define C2R_LAUNCH_FUSED(D, L) do { if (ctx->thermal) C2R_LAUNCH_FUSED_H(D, L, true); else C2R_LAUNCH_FUSED_H(D, L, false); } while (0)
                 switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
                     case 2: C2R_LAUNCH_FUSED(false, 1); break;
                     case 3: C2R_LAUNCH_FUSED(true, 1); break;
@@ -369,6 +382,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                     default: C2R_LAUNCH_FUSED(true, 3); break;
                 }
 #undef C2R_LAUNCH_FUSED
+#undef C2R_LAUNCH_FUSED_H
             }
         } else {
         int in_box = 0;                         // k_sweep_shell launches of this sub-box (coarse timing)
@@ -381,11 +395,12 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             if (ctx->prof == 1) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
             {
                 const dim3 grid(sa.tiles_max, 6, bound), blk(kBlock);
-#define C2R_LAUNCH_SWEEP(D, L) do { \
-    if (ctx->fast) { if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_shell_fast<D, L, true>), grid, blk, 0, st, k, sa); \
-                     else hipLaunchKernelGGL((k_sweep_shell_fast<D, L, false>), grid, blk, 0, st, k, sa); } \
-    else if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_shell<D, L, true>), grid, blk, 0, st, k, sa); \
-    else hipLaunchKernelGGL((k_sweep_shell<D, L, false>), grid, blk, 0, st, k, sa); } while (0)
+#define C2R_LAUNCH_SWEEP_H(D, L, H) do { \
+    if (ctx->fast) { if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_shell_fast<D, L, true, H>), grid, blk, 0, st, k, sa); \
+                     else hipLaunchKernelGGL((k_sweep_shell_fast<D, L, false, H>), grid, blk, 0, st, k, sa); } \
+    else if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_shell<D, L, true, H>), grid, blk, 0, st, k, sa); \
+    else hipLaunchKernelGGL((k_sweep_shell<D, L, false, H>), grid, blk, 0, st, k, sa); } while (0)
+#define C2R_LAUNCH_SWEEP(D, L) do { if (ctx->thermal) C2R_LAUNCH_SWEEP_H(D, L, true); else C2R_LAUNCH_SWEEP_H(D, L, false); } while (0)
                 switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
                     case 2: C2R_LAUNCH_SWEEP(false, 1); break;
                     case 3: C2R_LAUNCH_SWEEP(true, 1); break;
@@ -395,6 +410,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                     default: C2R_LAUNCH_SWEEP(true, 3); break;
                 }
 #undef C2R_LAUNCH_SWEEP
+#undef C2R_LAUNCH_SWEEP_H
             }
             if (ctx->prof == 1) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(1); }
             // the partials of the sub-box's last shell are summed by k_box_decide itself
@@ -490,6 +506,7 @@ int sweep_prepare(Ctx *ctx)
     hipLaunchKernelGGL(k_prepare_nhi, g, dim3(256), 0, ctx->stream, p.mesh[0], p.mesh[1], p.mesh[2], p.epsilon,
                        (const float *)ctx->grid[0], (const double *)ctx->grid[2], ctx->d_nhi, ctx->d_nhi_T);
     HIP_TRY(hipMemsetAsync(ctx->d_phih_T, 0, grid_bytes(ctx, 4), ctx->stream));
+    if (ctx->thermal) HIP_TRY(hipMemsetAsync(ctx->d_heat_T, 0, grid_bytes(ctx, 5), ctx->stream));
     return C2R_OK;
 }
 
@@ -500,6 +517,9 @@ int sweep_finish(Ctx *ctx)
     const dim3 g((p.mesh[1] + 31) / 32, (p.mesh[0] + 31) / 32, p.mesh[2]);
     hipLaunchKernelGGL((k_transpose_xy<double, true>), g, dim3(256), 0, ctx->stream, p.mesh[1], p.mesh[0], p.mesh[2],
                        (const double *)ctx->d_phih_T, (double *)ctx->grid[4]);
+    if (ctx->thermal)
+        hipLaunchKernelGGL((k_transpose_xy<double, true>), g, dim3(256), 0, ctx->stream, p.mesh[1], p.mesh[0], p.mesh[2],
+                           (const double *)ctx->d_heat_T, (double *)ctx->grid[5]);
     HIP_TRY(hipGetLastError());
     return C2R_OK;
 }
@@ -521,6 +541,7 @@ int check_ready(Ctx *ctx)
     HIP_TRY(hipSetDevice(ctx->prm.device));
     if (!ctx->have_tables) FAIL(C2R_ESTATE, "c2r_set_tables has not been called");
     if (!ctx->have_step) FAIL(C2R_ESTATE, "c2r_set_step has not been called");
+    if (ctx->thermal && !ctx->have_zred && ctx->tprm.cosmological) FAIL(C2R_ESTATE, "non-isothermal run: c2r_set_redshift has not been called");
     return C2R_OK;
 }
 
@@ -725,6 +746,7 @@ void c2r_destroy(c2r_ctx *c)
     for (auto &kv : ctx->pinned) hipHostUnregister(const_cast<void *>(kv.first));
     free_sweep_scratch(ctx);
     for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
+    hipFree(ctx->grid[5]); hipFree(ctx->grid[6]); hipFree(ctx->d_hthick); hipFree(ctx->d_hthin); hipFree(ctx->d_cool); hipFree(ctx->d_heat_T);
     hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_logtab); hipFree(ctx->d_odtab);
     hipFree(ctx->d_nhi); hipFree(ctx->d_nhi_T); hipFree(ctx->d_phih_T);
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
@@ -814,6 +836,75 @@ int c2r_set_clumping_grid(c2r_ctx *c, const float *clump_grid)
     if (!clump_grid) { hipFree(ctx->d_clump); ctx->d_clump = nullptr; return C2R_OK; }
     if (!ctx->d_clump) HIP_TRY(hipMalloc(&ctx->d_clump, grid_bytes(ctx, 0)));
     HIP_TRY(hipMemcpy(ctx->d_clump, clump_grid, grid_bytes(ctx, 0), hipMemcpyHostToDevice));
+    return C2R_OK;
+}
+
+int c2r_default_thermal(c2r_thermal_params *t)
+{
+    if (!t) return C2R_EINVAL;
+    memset(t, 0, sizeof *t);
+    t->tau_heat_limit = C2R_TAU_HEAT_LIMIT;
+    t->k_B = C2R_K_B; t->gamma1 = C2R_GAMMA1; t->minitemp = C2R_MINITEMP; t->relative_denergy = C2R_RELATIVE_DENERGY;
+    t->thermal_rate_floor = C2R_THERMAL_RATE_FLOOR; t->thermal_time_tol = C2R_THERMAL_TIME_TOL;
+    t->temp_conv_rel = C2R_TEMP_CONV_REL; t->temp_conv_abs = C2R_TEMP_CONV_ABS;
+    t->H0 = C2R_H0; t->Omega0 = C2R_OMEGA0;
+    t->cool_mintemp = 0.0; t->cool_dtemp = 0.0;          // from the cooling table file: temp(1), temp(2)-temp(1) (cooling.f90:78-79)
+    t->cool_points = C2R_COOL_POINTS; t->thermal_max_steps = C2R_THERMAL_MAX_STEPS; t->cosmological = 1;
+    return C2R_OK;
+}
+
+int c2r_set_thermal(c2r_ctx *c, const c2r_thermal_params *t, const double *heat_thick, const double *heat_thin, int32_t n,
+                    const double *cie_cool)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    HIP_TRY(hipSetDevice(ctx->prm.device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ++ctx->gen;
+    if (!t) { ctx->thermal = false; return C2R_OK; }     // back to the isothermal path (the arrays stay allocated)
+    if (!heat_thick || !heat_thin || !cie_cool) FAIL(C2R_EINVAL, "non-isothermal run needs the heating tables and the cooling curve");
+    if (n != ctx->prm.numtau + 1) FAIL(C2R_EINVAL, "table length must be numtau+1");
+    if (t->cool_points < 2 || !(t->cool_dtemp > 0.0) || !(t->gamma1 > 0.0) || !(t->k_B > 0.0) || t->thermal_max_steps < 1)
+        FAIL(C2R_EINVAL, "c2r_thermal_params: cool_points >= 2, cool_dtemp > 0, gamma1 > 0, k_B > 0, thermal_max_steps >= 1");
+    ctx->tprm = *t;
+    if (!ctx->d_hthick) {
+        HIP_TRY(hipMalloc(&ctx->d_hthick, (size_t)(n + 1) * sizeof(double)));
+        HIP_TRY(hipMalloc(&ctx->d_hthin, (size_t)(n + 1) * sizeof(double)));
+        HIP_TRY(hipMalloc(&ctx->grid[5], grid_bytes(ctx, 5)));
+        HIP_TRY(hipMalloc(&ctx->grid[6], grid_bytes(ctx, 6)));
+        HIP_TRY(hipMalloc(&ctx->d_heat_T, grid_bytes(ctx, 5)));
+        HIP_TRY(hipMemset(ctx->grid[5], 0, grid_bytes(ctx, 5)));          // evolve_data.F90:78 phiheat_grid=0.0
+        HIP_TRY(hipMemset(ctx->grid[6], 0, grid_bytes(ctx, 6)));
+    }
+    hipFree(ctx->d_cool); ctx->d_cool = nullptr;
+    HIP_TRY(hipMalloc(&ctx->d_cool, (size_t)t->cool_points * sizeof(double)));
+    HIP_TRY(hipMemcpy(ctx->d_cool, cie_cool, (size_t)t->cool_points * sizeof(double), hipMemcpyHostToDevice));
+    // padded like the photo tables: tab[numtau+1] = tab[numtau]
+    HIP_TRY(hipMemcpy(ctx->d_hthick, heat_thick, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_hthin, heat_thin, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_hthick + n, heat_thick + n - 1, sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_hthin + n, heat_thin + n - 1, sizeof(double), hipMemcpyHostToDevice));
+    ctx->thermal = true;
+    return C2R_OK;
+}
+
+int c2r_set_redshift(c2r_ctx *c, double zred)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (!(zred > -1.0)) FAIL(C2R_EINVAL, "zred must be > -1");
+    ctx->zred = zred; ctx->have_zred = true;
+    return C2R_OK;
+}
+
+int c2r_set_final_temperature(c2r_ctx *c)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (!ctx->thermal) return C2R_OK;                     // temperature_module.F90:181: nothing to do when isothermal
+    HIP_TRY(hipSetDevice(ctx->prm.device));
+    hipLaunchKernelGGL(k_final_temperature, dim3(kSumBlocks), dim3(256), 0, ctx->stream, ctx->ncell, (float *)ctx->grid[6]);
+    HIP_TRY(hipGetLastError());
     return C2R_OK;
 }
 
@@ -915,15 +1006,17 @@ int c2r_bind_device_buffers(c2r_ctx *c, void *ndens, void *xh, void *xh_av, void
 
 int c2r_device_ptr(c2r_ctx *c, int32_t which, void **ptr)
 {
-    if (!c || !ptr || which < 0 || which > 4) return C2R_EINVAL;
+    if (!c || !ptr || which < 0 || which > 6) return C2R_EINVAL;
+    if (which > 4 && !C(c)->thermal) return C2R_ESTATE;
     *ptr = C(c)->grid[which];
     return C2R_OK;
 }
 
 int c2r_upload(c2r_ctx *c, int32_t which, const void *host)
 {
-    if (!c || !host || which < 0 || which > 4) return C2R_EINVAL;
+    if (!c || !host || which < 0 || which > 6) return C2R_EINVAL;
     Ctx *ctx = C(c);
+    if (which > 4 && !ctx->thermal) FAIL(C2R_ESTATE, "arrays 5 and 6 exist in non-isothermal runs only (c2r_set_thermal)");
     HIP_TRY(hipMemcpyAsync(ctx->grid[which], host, grid_bytes(ctx, which), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return C2R_OK;
@@ -931,8 +1024,9 @@ int c2r_upload(c2r_ctx *c, int32_t which, const void *host)
 
 int c2r_download(c2r_ctx *c, int32_t which, void *host)
 {
-    if (!c || !host || which < 0 || which > 4) return C2R_EINVAL;
+    if (!c || !host || which < 0 || which > 6) return C2R_EINVAL;
     Ctx *ctx = C(c);
+    if (which > 4 && !ctx->thermal) FAIL(C2R_ESTATE, "arrays 5 and 6 exist in non-isothermal runs only (c2r_set_thermal)");
     HIP_TRY(hipMemcpyAsync(host, ctx->grid[which], grid_bytes(ctx, which), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return C2R_OK;
@@ -943,6 +1037,7 @@ int c2r_zero_rates(c2r_ctx *c)
     if (!c) return C2R_EINVAL;
     Ctx *ctx = C(c);
     HIP_TRY(hipMemsetAsync(ctx->grid[4], 0, grid_bytes(ctx, 4), ctx->stream));
+    if (ctx->thermal) HIP_TRY(hipMemsetAsync(ctx->grid[5], 0, grid_bytes(ctx, 5), ctx->stream));     // evolve.F90:435
     return C2R_OK;
 }
 
@@ -987,6 +1082,8 @@ int c2r_allreduce_rates(c2r_ctx *c)
     Ctx *ctx = C(c);
     if (ctx->nranks <= 1 || !ctx->ar) return C2R_OK;
     if (ctx->ar(ctx->ar_user, ctx->grid[4], ctx->ncell, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-reduce callback failed");
+    if (ctx->thermal && ctx->ar(ctx->ar_user, ctx->grid[5], ctx->ncell, (void *)ctx->stream) != 0)     // evolve.F90:604-609
+        FAIL(C2R_ECALLBACK, "all-reduce callback failed");
     return C2R_OK;
 }
 
@@ -1080,7 +1177,8 @@ static int photon_sums_launch(Ctx *ctx, int which_l, int which_r, double *dst)
                        (const float *)ctx->grid[0], (const double *)ctx->grid[which_l],
                        (const double *)ctx->grid[which_r], p.abu_c, (double)ctx->clumping, (const float *)ctx->d_clump,
                        p.bh00, pow(ctx->temper / 1e4, p.albpow), p.colh0, sqrt(ctx->temper),
-                       exp(-p.temph0 / ctx->temper), ctx->d_sum_partial);
+                       exp(-p.temph0 / ctx->temper), ctx->d_sum_partial, ctx->thermal ? (const float *)ctx->grid[6] : nullptr,
+                       p.albpow, p.temph0);
     hipLaunchKernelGGL(k_sum_final, dim3(4), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, dst);
     HIP_TRY(hipGetLastError());
     return C2R_OK;
@@ -1114,17 +1212,27 @@ static int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum
     cp.acolh0 = p.colh0 * sqrt(ctx->temper) * exp(-p.temph0 / ctx->temper);
     cp.clumping = (double)ctx->clumping; cp.colh0 = p.colh0; cp.sqrtt = sqrt(ctx->temper); cp.expt = exp(-p.temph0 / ctx->temper);
     cp.stat_partial = ctx->d_stat_partial;
+    if (ctx->thermal) {
+        const c2r_thermal_params &t = ctx->tprm;
+        cp.temper = (float *)ctx->grid[6]; cp.phiheat = (const double *)ctx->grid[5]; cp.cool = ctx->d_cool;
+        cp.cool_mintemp = t.cool_mintemp; cp.cool_dtemp = t.cool_dtemp; cp.cool_points = t.cool_points;
+        cp.thermal_max_steps = t.thermal_max_steps;
+        cp.k_B = t.k_B; cp.gamma1 = t.gamma1; cp.minitemp = t.minitemp; cp.rel_denergy = t.relative_denergy;
+        cp.rate_floor = t.thermal_rate_floor; cp.time_tol = t.thermal_time_tol;
+        // cosmology.F90:220: dzdt = H0*(1.+zred)*sqrt(Omega0*(1.+zred)**3+1.-Omega0)
+        cp.zp = 1.0 + ctx->zred;
+        cp.dzdt = t.cosmological ? t.H0 * cp.zp * sqrt(t.Omega0 * (cp.zp * cp.zp * cp.zp) + 1.0 - t.Omega0) : 0.0;
+        cp.temph0 = p.temph0; cp.albpow = p.albpow;
+        cp.tconv_rel = t.temp_conv_rel; cp.tconv_abs = t.temp_conv_abs;
+    }
     prof_begin(ctx, ctx->ev_chem, ctx->ev_chem_used);
-    if (stats_dst)
-        hipLaunchKernelGGL(k_global_pass<true>, dim3(kSumBlocks), dim3(256), 0, ctx->stream, cp, ctx->ncell,
-                           (const float *)ctx->grid[0], (const double *)ctx->grid[1], (double *)ctx->grid[2],
-                           (double *)ctx->grid[3], (const double *)ctx->grid[4], ctx->d_sum_partial, ctx->d_conv,
-                           ctx->d_chemfail);
-    else
-        hipLaunchKernelGGL(k_global_pass<false>, dim3(kSumBlocks), dim3(256), 0, ctx->stream, cp, ctx->ncell,
-                           (const float *)ctx->grid[0], (const double *)ctx->grid[1], (double *)ctx->grid[2],
-                           (double *)ctx->grid[3], (const double *)ctx->grid[4], ctx->d_sum_partial, ctx->d_conv,
-                           ctx->d_chemfail);
+#define C2R_LAUNCH_GLOBAL(S, T) hipLaunchKernelGGL((k_global_pass<S, T>), dim3(kSumBlocks), dim3(256), 0, ctx->stream, cp, ctx->ncell, \
+                           (const float *)ctx->grid[0], (const double *)ctx->grid[1], (double *)ctx->grid[2], \
+                           (double *)ctx->grid[3], (const double *)ctx->grid[4], ctx->d_sum_partial, ctx->d_conv, \
+                           ctx->d_chemfail)
+    if (stats_dst) { if (ctx->thermal) C2R_LAUNCH_GLOBAL(true, true); else C2R_LAUNCH_GLOBAL(true, false); }
+    else { if (ctx->thermal) C2R_LAUNCH_GLOBAL(false, true); else C2R_LAUNCH_GLOBAL(false, false); }
+#undef C2R_LAUNCH_GLOBAL
     prof_end(ctx, ctx->ev_chem, ctx->ev_chem_used);
     hipLaunchKernelGGL(k_pass_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, ctx->d_conv,
                        ctx->d_chemfail, &ctx->d_hsc->sum, &ctx->d_hsc->conv, &ctx->d_hsc->chemfail);
@@ -1200,6 +1308,8 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
         }
         if (conv_flag < conv_criterion || (rel1 < p.convergence_fraction && rel0 < p.convergence_fraction)) {   // :212
             HIP_TRY(hipMemcpyAsync(ctx->grid[1], ctx->grid[3], grid_bytes(ctx, 1), hipMemcpyDeviceToDevice, ctx->stream));   // :218
+            if (ctx->thermal)                                                          // :220 set_final_temperature_point
+                hipLaunchKernelGGL(k_final_temperature, dim3(kSumBlocks), dim3(256), 0, ctx->stream, ctx->ncell, (float *)ctx->grid[6]);
             rep->converged = 1;
             break;
         } else if (niter > p.max_outer_iter) {                                         // :228
@@ -1328,6 +1438,38 @@ int c2r_evolve3d_restart(c2r_ctx *c, double dt, int32_t niter, double photon_los
     if ((rc = c2r_download(c, 2, xh_av))) return rc;
     if ((rc = c2r_download(c, 3, xh_int))) return rc;
     return c2r_download(c, 4, phih);
+}
+
+int c2r_evolve3d_thermal(c2r_ctx *c, double dt, int32_t restart_niter, double photon_loss_all, const float *ndens,
+                         double *xh, double *xh_av, double *xh_int, double *phih, double *phiheat, float *temperature_grid,
+                         c2r_report *rep)
+{
+    if (!c || !ndens || !xh || !temperature_grid) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (!ctx->thermal) FAIL(C2R_ESTATE, "c2r_set_thermal has not been called");
+    const bool restart = restart_niter >= 0;
+    if (restart && (!xh_av || !xh_int || !phih || !phiheat)) return C2R_EINVAL;
+    int rc;
+    pin_host_array(ctx, ndens, grid_bytes(ctx, 0)); pin_host_array(ctx, xh, grid_bytes(ctx, 1));
+    pin_host_array(ctx, xh_av, grid_bytes(ctx, 2)); pin_host_array(ctx, xh_int, grid_bytes(ctx, 3));
+    pin_host_array(ctx, phih, grid_bytes(ctx, 4)); pin_host_array(ctx, phiheat, grid_bytes(ctx, 5));
+    pin_host_array(ctx, temperature_grid, grid_bytes(ctx, 6));
+    if ((rc = c2r_upload(c, 0, ndens))) return rc;
+    if ((rc = c2r_upload(c, 1, xh))) return rc;
+    if ((rc = c2r_upload(c, 6, temperature_grid))) return rc;
+    if (restart) {       // start_from_dump (evolve.F90:328-426) read these, phiheat_grid and temperature_grid (:372-375)
+        if ((rc = c2r_upload(c, 2, xh_av))) return rc;
+        if ((rc = c2r_upload(c, 3, xh_int))) return rc;
+        if ((rc = c2r_upload(c, 4, phih))) return rc;
+        if ((rc = c2r_upload(c, 5, phiheat))) return rc;
+    }
+    if ((rc = evolve3d_worker(c, dt, restart ? restart_niter : -1, photon_loss_all, rep))) return rc;
+    if ((rc = c2r_download(c, 1, xh))) return rc;
+    if (xh_av && (rc = c2r_download(c, 2, xh_av))) return rc;
+    if (xh_int && (rc = c2r_download(c, 3, xh_int))) return rc;
+    if (phih && (rc = c2r_download(c, 4, phih))) return rc;
+    if (phiheat && (rc = c2r_download(c, 5, phiheat))) return rc;
+    return c2r_download(c, 6, temperature_grid);
 }
 
 int c2r_selftest(c2r_ctx *c, int64_t *mismatches)

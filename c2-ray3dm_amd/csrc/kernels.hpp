@@ -51,6 +51,11 @@ struct KParams {
     double *gbox;              // deterministic mode: [S_batch][2][ncell] per-source Gamma ([0] x-fastest cells of
                                // z/y faces, [1] y-fastest cells of x faces); null: atomics into phih/phih_T
     const double *thick, *thin;
+    // non-isothermal runs (c2ray_parameters.f90:28 isothermal=.false.; HEAT kernels only): heating tables
+    // stellar_heat_thick/thin_table (padded like thick/thin), phiheat_grid and its transposed accumulator
+    const double *hthick, *hthin;
+    double *heat, *heat_T;
+    double tau_heat_limit;    // radiation_photoionrates.F90:333
     const v2f64 *logtab;      // [kLogTab] {r_i, -log10 r_i} for log10_tab
     // tolerance ("fast") mode of the sweep (c2r_params.sweep_mode = 1, k_sweep_shell_fast)
     const v2f64 *odtab;       // [kLogTab] {r_i, 1 + (-log10 r_i - minlogtau)/dlogtau}: table position of tau = 1/r_i
@@ -241,19 +246,34 @@ __device__ __forceinline__ double read_table(const double *__restrict__ tab, con
 
 // radiation_photoionrates.F90:71-179, :233-317 for NumFreqBnd=1, stellar table.
 // Returns photo_cell_HI (already divided by vol_ph); out = photo_out.
+// HEAT: also phi%heat of heat_lookuptable (:323-417) from the same two table positions.
+template <bool HEAT = false>
 __device__ __forceinline__ double photoion(const KParams &p, const v2f64 *__restrict__ ltab, double cd_in, double cd_out,
-                                           double vol_ph, double nflux, double &p_out)
+                                           double vol_ph, double nflux, double &p_out, double *heat = nullptr)
 {
     const double tau_in = cd_in * p.sigma, tau_out = cd_out * p.sigma;
     const TauPos pin = tau_pos(tau_in, p, ltab);
     const double p_in = nflux * read_table(p.thick, pin);
     double p_cell;
-    if (fabs(tau_out - tau_in) > p.tau_limit) {
-        p_out = nflux * read_table(p.thick, tau_pos(tau_out, p, ltab));
+    TauPos pout = pin;
+    const bool thick_cell = fabs(tau_out - tau_in) > p.tau_limit;
+    if (thick_cell) {
+        pout = tau_pos(tau_out, p, ltab);
+        p_out = nflux * read_table(p.thick, pout);
         p_cell = p_in - p_out;
     } else {
         p_cell = nflux * (tau_out - tau_in) * read_table(p.thin, pin);
         p_out = p_in - p_cell;
+    }
+    if (HEAT) {
+        const double h_in = nflux * read_table(p.hthick, pin);                         // :384
+        if (fabs(tau_out - tau_in) > p.tau_heat_limit) {                               // :388
+            if (!thick_cell) pout = tau_pos(tau_out, p, ltab);                         // (only if tau_heat_limit < tau_photo_limit)
+            *heat = fdiv(h_in - nflux * read_table(p.hthick, pout), vol_ph);
+        } else {
+            const double tau_cell = (cd_out - cd_in) * p.sigma;                        // :104, :146
+            *heat = fdiv(nflux * tau_cell * read_table(p.hthin, pin), vol_ph);         // :396-400
+        }
     }
     return fdiv(p_cell, vol_ph);
 }
@@ -273,6 +293,7 @@ __device__ __forceinline__ double block_sum_256(double v, double *sm /* >= 4 dou
 
 // ---- source cells (q = 0) ------------------------------------------------------------------
 // evolve_point.F90:151-160 (source cell) + the common tail of evolve0D.  One thread per source.
+template <bool HEAT>
 __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0, int boxR1, int boxR2,
                                int boxL0, int boxL1, int boxL2, double *loss_acc, double *dbg_cdout)
 {
@@ -297,8 +318,10 @@ __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0
     const double nflux = p.normflux[s];
     double p_out = 0.0, gamma = 0.0;
     if (nflux > 0.0) {      // cd_in = 0 is never above max_coldensh
-        gamma = photoion(p, ltab, cd_in, cd_out, vol_ph, nflux, p_out) / nhi;
+        double heat = 0.0;
+        gamma = photoion<HEAT>(p, ltab, cd_in, cd_out, vol_ph, nflux, p_out, &heat) / nhi;
         if (!p.gbox) atomicAdd(&p.phih[id], gamma);
+        if (HEAT && heat != 0.0) atomicAdd(&p.heat[id], heat);       // evolve_point.F90:285-286 (always by atomics)
     }
     if (p.gbox) p.gbox[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = gamma;
     // degenerate meshes only: the source cell itself sits on the sub-box surface
@@ -468,7 +491,7 @@ __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArg
 }
 
 // Returns the cell's photon-loss contribution (0 unless it lies on the sub-box surface).
-template <bool DET, int LLS, bool STREAM>
+template <bool DET, int LLS, bool STREAM, bool HEAT>
 __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                               const int face, const int s, const int a, const int b, const CellState &cs)
 {
@@ -503,9 +526,10 @@ __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs 
     const double nflux = p.normflux[s];
     double gamma = 0.0;
     if (!cs.stop_far && !(cs.cd_in > p.max_coldensh) && nflux > 0.0) {
-        double p_out;
-        gamma = fdiv(photoion(p, ltab, cs.cd_in, cd_out, cs.vol_ph, nflux, p_out), cs.nhi);
+        double p_out, heat = 0.0;
+        gamma = fdiv(photoion<HEAT>(p, ltab, cs.cd_in, cd_out, cs.vol_ph, nflux, p_out, &heat), cs.nhi);
         if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[cs.id], gamma);
+        if (HEAT && heat != 0.0) atomicAdd(&(xf ? p.heat_T : p.heat)[cs.id], heat);      // evolve_point.F90:285-286
         if (sa.has_boundary) {
             const bool bnd = dl.d0 == sa.boxR[0] || dl.d1 == sa.boxR[1] || dl.d2 == sa.boxR[2] ||
                              dl.d0 == -sa.boxL[0] || dl.d1 == -sa.boxL[1] || dl.d2 == -sa.boxL[2];
@@ -521,7 +545,7 @@ __device__ __forceinline__ double weight_rcp(const KParams &p, double c) { retur
 
 // One cell (a,b): four upstream corners of plane q-1 (zero weight and value outside |.| <= q-1: an
 // out-of-range offset reads 0), state, commit.  Used by the fused first-sub-box kernel.
-template <bool DET, int LLS, int GLC>
+template <bool DET, int LLS, int GLC, bool HEAT>
 __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                              const int face, const int s, const int a, const int b)
 {
@@ -540,7 +564,7 @@ __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &
     const double c4v = buf_load_f64<GLC>(r_prev, (ina && inb) ? o8 : kOOB);
     const CellState cs = cell_state<LLS, false>(p, sa, face, s, a, b, c1v, c2v, c3v, c4v, weight_rcp(p, c1v), weight_rcp(p, c2v),
                                          weight_rcp(p, c3v), weight_rcp(p, c4v));
-    return cell_commit<DET, LLS, false>(p, sa, ltab, face, s, a, b, cs);
+    return cell_commit<DET, LLS, false, HEAT>(p, sa, ltab, face, s, a, b, cs);
 }
 
 // kRows cells of one column: (a,b0), (a,b0+sgb), ... with sgb the sign class of all their rows (rows are
@@ -554,7 +578,7 @@ __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &
 #define C2R_ROWS 3
 #endif
 constexpr int kRows = C2R_ROWS;
-template <bool DET, int LLS, bool STREAM>
+template <bool DET, int LLS, bool STREAM, bool HEAT>
 __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                              const int face, const int s, const int a, const int b0, const int sgb,
                                              const int nvalid)
@@ -587,19 +611,19 @@ __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &
 #if C2R_ROWS >= 4
     const CellState c3 = cell_state<LLS, STREAM>(p, sa, face, s, a, b0 + 3 * sgb, vm[3], va[3], vm[4], va[4], rm[3], ra[3], rm[4], ra[4]);
 #endif
-    double loss = cell_commit<DET, LLS, STREAM>(p, sa, ltab, face, s, a, b0, c0);
-    if (nvalid > 1) loss = loss + cell_commit<DET, LLS, STREAM>(p, sa, ltab, face, s, a, b0 + sgb, c1);
+    double loss = cell_commit<DET, LLS, STREAM, HEAT>(p, sa, ltab, face, s, a, b0, c0);
+    if (nvalid > 1) loss = loss + cell_commit<DET, LLS, STREAM, HEAT>(p, sa, ltab, face, s, a, b0 + sgb, c1);
 #if C2R_ROWS >= 3
-    if (nvalid > 2) loss = loss + cell_commit<DET, LLS, STREAM>(p, sa, ltab, face, s, a, b0 + 2 * sgb, c2);
+    if (nvalid > 2) loss = loss + cell_commit<DET, LLS, STREAM, HEAT>(p, sa, ltab, face, s, a, b0 + 2 * sgb, c2);
 #endif
 #if C2R_ROWS >= 4
-    if (nvalid > 3) loss = loss + cell_commit<DET, LLS, STREAM>(p, sa, ltab, face, s, a, b0 + 3 * sgb, c3);
+    if (nvalid > 3) loss = loss + cell_commit<DET, LLS, STREAM, HEAT>(p, sa, ltab, face, s, a, b0 + 3 * sgb, c3);
 #endif
     return loss;
 }
 
 // STREAM: the non-temporal cache policy above (the host turns it on for meshes whose n_HI array outgrows the L2s)
-template <bool DET, int LLS, bool STREAM>
+template <bool DET, int LLS, bool STREAM, bool HEAT>
 __device__ __forceinline__ void sweep_tile(const KParams &p, const ShellArgs &sa, const FaceRect &fr, const v2f64 *ltab,
                                            double *sm, const int face, const int tile, const int sl)
 {
@@ -614,7 +638,7 @@ __device__ __forceinline__ void sweep_tile(const KParams &p, const ShellArgs &sa
         const int sgb = pos ? 1 : -1;
         const int b0 = pos ? k0 : -1 - k0;
         const int left = pos ? (fr.b_lo + fr.wb - b0) : (b0 - fr.b_lo + 1);     // rows from b0 to the end of the class
-        loss = shell_rows<DET, LLS, STREAM>(p, sa, ltab, face, sa.active[sl], a, b0, sgb, min(left, kRows));
+        loss = shell_rows<DET, LLS, STREAM, HEAT>(p, sa, ltab, face, sa.active[sl], a, b0, sgb, min(left, kRows));
     }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
@@ -623,7 +647,7 @@ __device__ __forceinline__ void sweep_tile(const KParams &p, const ShellArgs &sa
     }
 }
 
-template <bool DET, int LLS, bool STREAM>
+template <bool DET, int LLS, bool STREAM, bool HEAT>
 __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
 {
     __shared__ double sm[16];
@@ -635,7 +659,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
     const FaceRect fr = sa.face[face];
     if (tile >= fr.ntiles && !sa.has_boundary) return;   // block-uniform: nothing to do and no partial to write
     const v2f64 *ltab = wave_log_table(p.logtab, s_log);
-    sweep_tile<DET, LLS, STREAM>(p, sa, fr, ltab, sm, face, tile, (int)blockIdx.z);
+    sweep_tile<DET, LLS, STREAM, HEAT>(p, sa, fr, ltab, sm, face, tile, (int)blockIdx.z);
 }
 
 // ==== tolerance ("fast") mode of the sweep =======================================================
@@ -702,7 +726,7 @@ __device__ __forceinline__ double table_at(const double *__restrict__ tab, doubl
 #ifndef C2R_ABLATE
 #define C2R_ABLATE 0
 #endif
-template <bool DET, int LLS, bool STREAM, int NR>
+template <bool DET, int LLS, bool STREAM, int NR, bool HEAT>
 __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                                   const double *__restrict__ thick,   // p.thick, or the block's LDS copy of it
                                                   const int face, const int s, const int a, const int b0, const int sgb,
@@ -812,9 +836,11 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
                 const double tau_in = cd_in * p.sigma, tau_out = cd_out * p.sigma;
                 const double od_in = tau_od(tau_in, p, ltab);
                 const double t_in = table_at(thick, od_in);
-                double dT, t_out;
-                if (fabs(tau_out - tau_in) > p.tau_limit) {
-                    t_out = table_at(thick, tau_od(tau_out, p, ltab));
+                double dT, t_out, od_out = od_in;
+                const bool thick_cell = fabs(tau_out - tau_in) > p.tau_limit;
+                if (thick_cell) {
+                    od_out = tau_od(tau_out, p, ltab);
+                    t_out = table_at(thick, od_out);
                     dT = t_in - t_out;
                 } else {
                     dT = (tau_out - tau_in) * table_at(p.thin, od_in);
@@ -825,6 +851,16 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
                 if (C2R_ABLATE & 1) { if (gamma == 1.2345e-300) atomicAdd(&p.phih[id[k]], gamma); }
                 else
                 if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id[k]], gamma);
+                if (HEAT) {       // heat_lookuptable (radiation_photoionrates.F90:323-417) at the same table positions
+                    const double h_in = table_at(p.hthick, od_in);
+                    double dH;
+                    if (fabs(tau_out - tau_in) > p.tau_heat_limit) {
+                        if (!thick_cell) od_out = tau_od(tau_out, p, ltab);
+                        dH = h_in - table_at(p.hthick, od_out);
+                    } else dH = ((cd_out - cd_in) * p.sigma) * table_at(p.hthin, od_in);
+                    const double heat = (nflux * dH) * rcp1(area * path);          // phi%heat = .../vol_ph
+                    if (heat != 0.0) atomicAdd(&(xf ? p.heat_T : p.heat)[id[k]], heat);
+                }
                 if (sa.has_boundary && (bnd_col || b == sa.boxR[va] || b == -sa.boxL[va]))
                     loss = loss + fdiv((nflux * t_out) * p.vol, area * path);
             }
@@ -839,7 +875,7 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
 #define C2R_FAST_ATTR __launch_bounds__(kBlock)
 #endif
 // one (source, face, tile) block of work of k_sweep_shell_fast; sl = position in the active list
-template <bool DET, int LLS, bool STREAM>
+template <bool DET, int LLS, bool STREAM, bool HEAT>
 __device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArgs &sa, const FaceRect &fr, const v2f64 *ltab,
                                                 const double *thick, double *sm, const int face, const int tile, const int sl)
 {
@@ -853,7 +889,7 @@ __device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArg
         const int sgb = pos ? 1 : -1;
         const int b0 = pos ? k0 : -1 - k0;
         const int left = pos ? (fr.b_lo + fr.wb - b0) : (b0 - fr.b_lo + 1);
-        loss = shell_rows_fast<DET, LLS, STREAM, kRows>(p, sa, ltab, thick, face, sa.active[sl], a, b0, sgb, min(left, kRows));
+        loss = shell_rows_fast<DET, LLS, STREAM, kRows, HEAT>(p, sa, ltab, thick, face, sa.active[sl], a, b0, sgb, min(left, kRows));
     }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
@@ -862,7 +898,7 @@ __device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArg
     }
 }
 
-template <bool DET, int LLS, bool STREAM>
+template <bool DET, int LLS, bool STREAM, bool HEAT>
 __global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
 {
     __shared__ double sm[16];
@@ -874,7 +910,7 @@ __global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
     const FaceRect fr = sa.face[face];
     if (tile >= fr.ntiles && !sa.has_boundary) return;
     const v2f64 *ltab = wave_log_table(p.odtab, s_log);
-    sweep_tile_fast<DET, LLS, STREAM>(p, sa, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z);
+    sweep_tile_fast<DET, LLS, STREAM, HEAT>(p, sa, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z);
 }
 
 // ---- the first sub-boxes, fused: one workgroup per source, all shells of the sub-box in one launch -----
@@ -894,7 +930,7 @@ struct BoxArgs {
     double *loss_acc;
 };
 
-template <bool DET, int LLS, bool FAST>
+template <bool DET, int LLS, bool FAST, bool HEAT>
 __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
 {
     __shared__ double sm[16];
@@ -915,8 +951,8 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
             const unsigned bi = fr.magic ? __umulhi(lt, fr.magic) : lt;
             const int a = fr.a_lo + (int)(lt - __umul24(bi, (unsigned)fr.wa));
             const int b = fr.b_lo + (int)bi;
-            if (FAST) loss = loss + shell_rows_fast<DET, LLS, false, 1>(p, sa, ltab, p.thick, f, s, a, b, b < 0 ? -1 : 1, 1);
-            else loss = loss + shell_cell<DET, LLS, 0>(p, sa, ltab, f, s, a, b);
+            if (FAST) loss = loss + shell_rows_fast<DET, LLS, false, 1, HEAT>(p, sa, ltab, p.thick, f, s, a, b, b < 0 ? -1 : 1, 1);
+            else loss = loss + shell_cell<DET, LLS, 0, HEAT>(p, sa, ltab, f, s, a, b);
         }
         if (sa.has_boundary) {
             const double tot = block_sum_256(loss, sm);       // contains a barrier
@@ -1138,14 +1174,72 @@ struct ChemParams {
     // STATS variant: the four mesh sums of photonstatistics.F90 over (xh_intermed, xh_av) as this pass leaves them
     double clumping, colh0, sqrtt, expt;
     double *stat_partial;         // [4][gridDim.x]
+    // THERMAL variant (c2ray_parameters.f90:28 isothermal=.false.): temperature_grid, phiheat_grid, the cooling curve
+    float *temper;                // temperature_module.F90:35: (current, average, intermed) f32 per cell
+    const double *phiheat;        // evolve_data.F90:42
+    const double *cool;           // cooling.f90:27 cie_cool(1:cool_points), linear
+    double cool_mintemp, cool_dtemp;
+    int cool_points, thermal_max_steps;
+    double k_B, gamma1, minitemp, rel_denergy, rate_floor, time_tol;   // tped.f90, atomic.f90:25, c2ray_parameters.f90:108-110, thermal.f90:117,160
+    double zp, dzdt;              // cosmology.F90:198-225 cosmo_cool = e*2/(1+zred)*dzdt (dzdt = 0: not cosmological)
+    double temph0, albpow;        // doric.f90:73-78 at the cell's own temperature
+    double tconv_rel, tconv_abs;  // evolve_point.F90:387-388
 };
+
+// cooling.f90:38-59 coolin
+__device__ __forceinline__ double coolin_dev(const ChemParams &c, double nucldens, double eldens, double temp0)
+{
+    const double tpos = (log10(temp0) - c.cool_mintemp) / c.cool_dtemp + 1.0;
+    const int itpos = min(c.cool_points - 1, max(1, (int)tpos));
+    const double dtpos = tpos - (double)itpos;
+    const int itpos1 = min(c.cool_points, itpos + 1);
+    const double c0 = c.cool[itpos - 1], c1 = c.cool[itpos1 - 1];
+    return nucldens * eldens * (c0 + (c1 - c0) * dtpos);
+}
+
+// thermal.f90:22-189: explicit sub-stepping of the internal energy, each sub-step limited to rel_denergy of the
+// thermal time scale.  t_final / t_average are left untouched when t_initial <= minitemp (:83).
+__device__ __forceinline__ void thermal_dev(const ChemParams &c, double t_initial, double &t_final, double &t_average,
+                                            double ndens_electron, double nd, double h_old1, double h_av1, double h1, double heating)
+{
+    const double ne_old = nd * (h_old1 + c.abu_c), ne_av = nd * (h_av1 + c.abu_c), ne_new = nd * (h1 + c.abu_c);   // tped.f90:81
+    double e_int = (nd + ne_old) * c.k_B * t_initial / c.gamma1;                    // :66 temper2pressr/(gamma1)
+    const double cosmo_cool_rate = e_int * 2.0 / c.zp * c.dzdt;                     // :73-76, cosmology.F90:223
+    if (!(t_initial > c.minitemp)) return;
+    double cumulative = 0.0, avg = 0.0, t_int = t_initial;
+    int i_heating = 0;
+    for (;;) {
+        i_heating++;
+        const double cooling = coolin_dev(c, nd, ndens_electron, t_int) + cosmo_cool_rate;        // :104
+        const double rate = fmax(c.rate_floor, fabs(cooling - heating));
+        const double timescale = e_int / fabs(rate);
+        const double dt_thermal = c.rel_denergy * timescale;
+        const double dt_ode = fmin(dt_thermal, c.dt - cumulative);                  // :127
+        e_int = e_int + dt_ode * (heating - cooling);
+        avg = avg + 0.5 * t_int * dt_ode;
+        t_int = e_int * c.gamma1 / (c.k_B * (nd + ne_av));                          // :137 pressr2temper
+        avg = avg + 0.5 * t_int * dt_ode;
+        if (t_int < c.minitemp) {                                                   // :147-153
+            e_int = (nd + ne_av) * c.k_B * c.minitemp;
+            t_int = c.minitemp;
+        }
+        cumulative = cumulative + dt_ode;
+        if (cumulative >= c.dt || fabs(cumulative - c.dt) < c.time_tol * c.dt) break;   // :160
+        if (i_heating > c.thermal_max_steps) break;                                 // :163
+    }
+    t_average = c.dt > 0.0 ? avg / c.dt : t_initial;                                // :168-172
+    t_final = e_int * c.gamma1 / (c.k_B * (nd + ne_new));                           // :175
+}
 
 // evolve0D_global (evolve_point.F90:305-406) + do_chemistry (:410-555) + doric (doric.f90:33-134).
 // Fixed grid, grid-stride: block partial sums of xh_intermed land in sum_partial[blockIdx.x].
 // STATS: also what k_photon_sums(xh_intermed, xh_av) would return after this pass -- the values are in registers here --
 // accumulated in the same order over the same grid, so the sums are bit-identical to the separate kernel's and the
 // 20 bytes per cell it reads are saved (evolve.F90:570 calculate_photon_statistics after every global pass).
-template <bool STATS>
+// THERMAL: the non-isothermal do_chemistry -- doric at the cell's own (time-averaged) temperature, thermal after every
+// doric call (evolve_point.F90:515-527), the temperature clause of the global convergence test (:387-388) and
+// set_temperature_point (:553; f32 stores of %intermed and %average).
+template <bool STATS, bool THERMAL>
 __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell, const float *__restrict__ ndens,
                                                      const double *__restrict__ xh, double *__restrict__ xh_av,
                                                      double *__restrict__ xh_intermed,
@@ -1164,14 +1258,27 @@ __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell,
         double hav0 = 1.0 - hav1;
         const double nd = (double)ndens[id];
         const double gamma = phih[id];
-        const double brech0 = c.clump ? (double)c.clump[id] * c.bh00 * c.recpow : c.brech0;   // evolve_point.F90:443-445
+        double brech0 = c.clump ? (double)c.clump[id] * c.bh00 * c.recpow : c.brech0;   // evolve_point.F90:443-445
+        double acolh0 = c.acolh0;
+        // get_temperature_point (temperature_module.F90:133-151); temperature_end = temperature_start (:436)
+        double t_start_cur = 0.0, t_start_avg = 0.0, t_end_avg = 0.0, t_end_int = 0.0, heat = 0.0;
+        if (THERMAL) {
+            t_start_cur = (double)c.temper[3 * id]; t_start_avg = (double)c.temper[3 * id + 1]; t_end_int = (double)c.temper[3 * id + 2];
+            t_end_avg = t_start_avg;
+            heat = c.phiheat[id];                                    // evolve_point.F90:364
+        }
         double h1 = h_old1, h0 = h_old0;
         int nit = 0;
         for (;;) {
             nit++;
             const double yh0_av_old = hav0;
             const double de = nd * (hav1 + c.abu_c);                 // tped.f90:81
-            const double aih0 = gamma + de * c.acolh0;
+            if (THERMAL) {                                           // doric.f90:73-78 at temperature_end%average
+                const double cl = c.clump ? (double)c.clump[id] : c.clumping;
+                brech0 = cl * c.bh00 * pow(t_end_avg / 1e4, c.albpow);
+                acolh0 = c.colh0 * sqrt(t_end_avg) * exp(-c.temph0 / t_end_avg);
+            }
+            const double aih0 = gamma + de * acolh0;
             const double delth = aih0 + de * brech0;
             const double eq1 = aih0 / delth;
             const double eq0 = de * brech0 / delth;
@@ -1184,12 +1291,24 @@ __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell,
             hav1 = eq1 + (h_old1 - eq1) * avg;
             hav0 = 1.0 - hav1;
             if (hav0 < c.eps) hav0 = c.eps;
+            if (THERMAL)                                             // :518-527 (de from the new average)
+                thermal_dev(c, t_start_cur, t_end_int, t_end_avg, nd * (hav1 + c.abu_c), nd, h_old1, hav1, h1, heat);
+            // :531-538: the temperature clause compares temperature_end%current with its copy from the iteration
+            // before; thermal never writes %current, so it is |0/T| < 1e-3: true for every finite T > 0
             if (fabs((hav0 - yh0_av_old) / hav0) < c.min_frac_change || hav0 < c.min_frac_atoms) break;
             if (nit > c.max_iter) { nfail++; break; }
         }
         const double yh0_old = 1.0 - fmax(c.eps, xav_in);           // evolve_point.F90:378-379
-        if (fabs(hav0 - yh0_old) > c.min_frac_change && fabs((hav0 - yh0_old) / hav0) > c.min_frac_change &&
-            hav0 > c.min_frac_atoms) nconv++;
+        bool notconv = fabs(hav0 - yh0_old) > c.min_frac_change && fabs((hav0 - yh0_old) / hav0) > c.min_frac_change &&
+                       hav0 > c.min_frac_atoms;
+        double t_stat = 0.0;
+        if (THERMAL) {
+            const float f_int = (float)t_end_int, f_avg = (float)t_end_avg;       // set_temperature_point, :553
+            c.temper[3 * id + 2] = f_int; c.temper[3 * id + 1] = f_avg;
+            t_stat = (double)f_avg;                                                // :381 get_temperature_point again
+            notconv = notconv || (fabs((t_start_avg - t_stat) / t_stat) > c.tconv_rel && fabs(t_start_avg - t_stat) > c.tconv_abs);
+        }
+        if (notconv) nconv++;
         xh_intermed[id] = h1;
         xh_av[id] = hav1;
         lsum += h1;
@@ -1199,8 +1318,13 @@ __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell,
             const double y1 = hav1, y0 = 1.0 - y1;
             const double de = nd * (y1 + c.abu_c);
             const double cl = c.clump ? (double)c.clump[id] : c.clumping;
+            if (THERMAL) {                                         // photonstatistics.F90:167-177 at temperature%average
+                st_tr += nd * y1 * de * cl * c.bh00 * pow(t_stat / 1e4, c.albpow);
+                st_tc += nd * y0 * de * c.colh0 * sqrt(t_stat) * exp(-c.temph0 / t_stat);
+            } else {
             st_tr += nd * y1 * de * cl * c.bh00 * c.recpow;
             st_tc += nd * y0 * de * c.colh0 * c.sqrtt * c.expt;
+            }
         }
     }
     const double tot = block_sum_256(lsum, sm);
@@ -1228,8 +1352,9 @@ __global__ __launch_bounds__(256) void k_photon_sums(size_t ncell, const float *
                                                      const double *__restrict__ xl, const double *__restrict__ xr,
                                                      double abu_c, double clumping, const float *__restrict__ clump,
                                                      double bh00, double recpow, double colh0, double sqrtt, double expt,
-                                                     double *partial)
-{
+                                                     double *partial, const float *__restrict__ temper, double albpow,
+                                                     double temph0)
+{   // temper != null: non-isothermal run, the rate coefficients at every cell's temperature%average (:167)
     __shared__ double sm[4];
     double h0 = 0.0, h1 = 0.0, tr = 0.0, tc = 0.0;
     for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < ncell; id += (size_t)gridDim.x * 256) {
@@ -1240,6 +1365,12 @@ __global__ __launch_bounds__(256) void k_photon_sums(size_t ncell, const float *
         const double y1 = xr[id], y0 = 1.0 - y1;
         const double de = nd * (y1 + abu_c);
         const double cl = clump ? (double)clump[id] : clumping;
+        if (temper) {
+            const double t = (double)temper[3 * id + 1];
+            tr += nd * y1 * de * cl * bh00 * pow(t / 1e4, albpow);
+            tc += nd * y0 * de * colh0 * sqrt(t) * exp(-temph0 / t);
+            continue;
+        }
         tr += nd * y1 * de * cl * bh00 * recpow;              // photonstatistics.F90:166-168, left to right
         tc += nd * y0 * de * colh0 * sqrtt * expt;            // :169-172
     }
@@ -1249,6 +1380,13 @@ __global__ __launch_bounds__(256) void k_photon_sums(size_t ncell, const float *
         if (threadIdx.x == 0) partial[(size_t)m * gridDim.x + blockIdx.x] = tot;
         __syncthreads();
     }
+}
+
+// set_final_temperature_point (temperature_module.F90:172-183): %current = %intermed on convergence (evolve.F90:220)
+__global__ __launch_bounds__(256) void k_final_temperature(size_t ncell, float *temper)
+{
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < ncell; id += (size_t)gridDim.x * 256)
+        temper[3 * id] = temper[3 * id + 2];
 }
 
 __global__ __launch_bounds__(256) void k_sum_partial(size_t n, const double *__restrict__ a, double *partial)

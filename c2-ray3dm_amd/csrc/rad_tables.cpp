@@ -67,9 +67,11 @@ int c2r_default_sed(c2r_sed_params *p)
     return C2R_OK;
 }
 
-int c2r_build_tables(const c2r_sed_params *sp, double *thick, double *thin, int32_t n, double *R_star_out)
+// rad_ini for the black-body source; hthick/hthin (optional): the heating tables of a non-isothermal run
+static int build_all(const c2r_sed_params *sp, double ion_freq_HI, double *thick, double *thin, double *hthick, double *hthin,
+                     int32_t n, double *R_star_out)
 {
-    if (!sp || !thick || !thin || n != sp->numtau + 1 || sp->numtau < 1) return C2R_EINVAL;
+    if (!sp || n != sp->numtau + 1 || sp->numtau < 1) return C2R_EINVAL;
     const int NF = kNumFreq, NT = sp->numtau;
     // radiation_sed_parameters.F90:82-163  spectrum_parms (black body)
     const double T_eff = std::fmax(std::fmin(sp->T_eff, (double)1e6f), (double)2000.f);
@@ -114,7 +116,7 @@ int c2r_build_tables(const c2r_sed_params *sp, double *thick, double *thin, int3
                      : 0.0;
     }
     for (int it = 0; it <= NT; ++it) {
-        double sum_thick = 0.0, sum_thin = 0.0;
+        double sum_thick = 0.0, sum_thin = 0.0, sum_hthick = 0.0, sum_hthin = 0.0;
         for (int i = 0; i <= NF; ++i) {
             double fk = 0.0, fn = 0.0;
             if (tau[it] * cs[i] < 700.0) {                                           // :390
@@ -123,11 +125,29 @@ int c2r_build_tables(const c2r_sed_params *sp, double *thick, double *thin, int3
             }
             sum_thick = sum_thick + fk * delta_freq * romw[i];                      // romberg.f90:182-184
             sum_thin = sum_thin + fn * delta_freq * romw[i];
+            if (hthick) {                                                            // :455-475 fill_heating_integrands_HI
+                const double hk = sp->hplanck * (freq[i] - ion_freq_HI) * fk;
+                const double hn = sp->hplanck * (freq[i] - ion_freq_HI) * fn;
+                sum_hthick = sum_hthick + hk * delta_freq * romw[i];                 // :521-530 make_heat_tables_HI
+                sum_hthin = sum_hthin + hn * delta_freq * romw[i];
+            }
         }
-        thick[it] = sum_thick;
-        thin[it] = sum_thin;
+        if (thick) { thick[it] = sum_thick; thin[it] = sum_thin; }
+        if (hthick) { hthick[it] = sum_hthick; hthin[it] = sum_hthin; }
     }
     return C2R_OK;
+}
+
+int c2r_build_tables(const c2r_sed_params *sp, double *thick, double *thin, int32_t n, double *R_star_out)
+{
+    if (!thick || !thin) return C2R_EINVAL;
+    return build_all(sp, 0.0, thick, thin, nullptr, nullptr, n, R_star_out);
+}
+
+int c2r_build_heat_tables(const c2r_sed_params *sp, double ion_freq_HI, double *heat_thick, double *heat_thin, int32_t n)
+{
+    if (!heat_thick || !heat_thin) return C2R_EINVAL;
+    return build_all(sp, ion_freq_HI, nullptr, nullptr, heat_thick, heat_thin, n, nullptr);
 }
 
 }  // extern "C"

@@ -129,6 +129,30 @@ class HipBackend:
         self._check(self.lib.c2r_set_step(self.ctx, (C.c_double * 3)(*dr), vol, coldensh_LLS, clumping, temper),
                     "c2r_set_step")
 
+    def set_thermal(self, heat_thick, heat_thin, cool_logT, cool_logL, cosmological=True):
+        """Non-isothermal run (c2ray_parameters.f90:28 isothermal=.false.; c2r_set_thermal): the heating tables
+        (build_heat_tables / radiation_tables.F90:521-543) and the cooling table as the rows of tables/corocool.tab
+        (log10 T, log10 Lambda; fileio.read_cooling_table).  The context then owns phiheat_grid and temperature_grid
+        (load / fetch by those names; temperature_grid is (ncell, 3) f32: current, average, intermed)."""
+        t = _capi.ThermalParams()
+        self._check(self.lib.c2r_default_thermal(C.byref(t)), "c2r_default_thermal")
+        t.cool_mintemp = float(cool_logT[0]); t.cool_dtemp = float(cool_logT[1]) - float(cool_logT[0])   # cooling.f90:78-79
+        t.cool_points = len(cool_logL)
+        t.cosmological = 1 if cosmological else 0
+        hk = np.ascontiguousarray(heat_thick, dtype=np.float64); hn = np.ascontiguousarray(heat_thin, dtype=np.float64)
+        cie = np.array([10.0 ** float(v) for v in cool_logL], dtype=np.float64)      # cooling.f90:83, libm pow as the reference
+        self._check(self.lib.c2r_set_thermal(self.ctx, C.byref(t), hk.ctypes.data, hn.ctypes.data, hk.size, cie.ctypes.data),
+                    "c2r_set_thermal")
+        self.thermal = True
+
+    def set_isothermal(self):
+        self._check(self.lib.c2r_set_thermal(self.ctx, None, None, None, 0, None), "c2r_set_thermal")
+        self.thermal = False
+
+    def set_redshift(self, zred):
+        """cosmology.F90:42 zred at the middle of the step (cosmo_cool); per step, non-isothermal runs."""
+        self._check(self.lib.c2r_set_redshift(self.ctx, zred), "c2r_set_redshift")
+
     def set_lls(self, type_of_LLS=1, lls_grid=None, R_max_LLS=0.0):
         g = None if lls_grid is None else _flat(lls_grid, np.float32)
         self._check(self.lib.c2r_set_lls(self.ctx, type_of_LLS, None if g is None else g.ctypes.data, R_max_LLS),
@@ -205,9 +229,19 @@ class HipBackend:
             self._cb = _capi.ALLREDUCE_FN(0)
         self._check(self.lib.c2r_set_rank(self.ctx, rank, npr, self._cb, None), "c2r_set_rank")
 
-    def load(self, ndens=None, xh=None, xh_av=None, xh_intermed=None, phih_grid=None):
-        """Host (numpy, Fortran-order flat or (N,N,N) with i fastest when ravelled 'F') -> HBM."""
+    def load(self, ndens=None, xh=None, xh_av=None, xh_intermed=None, phih_grid=None, phiheat_grid=None, temperature_grid=None):
+        """Host (numpy, Fortran-order flat or (N,N,N) with i fastest when ravelled 'F') -> HBM.
+        temperature_grid: (ncell, 3) f32 as temperature_module.F90:35 lays it out, or one field (K) for all three."""
         torch = self.torch
+        if phiheat_grid is not None:
+            a = _flat(phiheat_grid, np.float64)
+            self._check(self.lib.c2r_upload(self.ctx, _capi.GRID_PHIHEAT, a.ctypes.data), "c2r_upload")
+        if temperature_grid is not None:
+            t = np.asarray(temperature_grid)
+            if t.size == self.ncell:
+                t = np.repeat(_flat(t, np.float32)[:, None], 3, axis=1)
+            t = np.ascontiguousarray(t.reshape(self.ncell, 3), dtype=np.float32)
+            self._check(self.lib.c2r_upload(self.ctx, _capi.GRID_TEMPER, t.ctypes.data), "c2r_upload")
         if ndens is not None:
             self.ndens.copy_(torch.from_numpy(_flat(ndens, np.float32)))
         for name, a in (("xh", xh), ("xh_av", xh_av), ("xh_intermed", xh_intermed), ("phih_grid", phih_grid)):
@@ -215,6 +249,14 @@ class HipBackend:
                 getattr(self, name).copy_(torch.from_numpy(_flat(a, np.float64)))
 
     def fetch(self, name):
+        if name == "phiheat_grid":
+            a = np.empty(self.ncell, dtype=np.float64)
+            self._check(self.lib.c2r_download(self.ctx, _capi.GRID_PHIHEAT, a.ctypes.data), "c2r_download")
+            return a
+        if name == "temperature_grid":
+            a = np.empty((self.ncell, 3), dtype=np.float32)
+            self._check(self.lib.c2r_download(self.ctx, _capi.GRID_TEMPER, a.ctypes.data), "c2r_download")
+            return a
         return getattr(self, name).cpu().numpy()
 
     # -- backend interface used by Evolve ---------------------------------------------------------
@@ -224,6 +266,7 @@ class HipBackend:
 
     def accept(self):
         self.xh.copy_(self.xh_intermed)           # evolve.F90:218
+        self._check(self.lib.c2r_set_final_temperature(self.ctx), "c2r_set_final_temperature")     # :220 (no-op when isothermal)
 
     def sum_xh_intermed(self):
         s = C.c_double()
@@ -260,6 +303,14 @@ class HipBackend:
 
     def rates_tensor(self):
         return self.phih_grid
+
+    def heat_tensor(self):
+        """phiheat_grid (context-owned) as a torch tensor sharing the device memory, or None when isothermal."""
+        if not getattr(self, "thermal", False):
+            return None
+        ptr = C.c_void_p()
+        self._check(self.lib.c2r_device_ptr(self.ctx, _capi.GRID_PHIHEAT, C.byref(ptr)), "c2r_device_ptr")
+        return self.torch.as_tensor(_DevView(ptr.value, self.ncell), device=self.device)
 
     def scalars_tensor(self, values):
         return self.torch.tensor(values, dtype=self.torch.float64, device=self.device)
@@ -404,6 +455,9 @@ class Evolve:
     def mpi_accumulate_grid_quantities(self):
         if self.npr > 1:
             self.comm.all_reduce(self.b.rates_tensor())                        # :599 phih_grid
+            heat = self.b.heat_tensor() if hasattr(self.b, "heat_tensor") else None
+            if heat is not None:
+                self.comm.all_reduce(heat)                                     # :604-609 phiheat_grid
             t = self.b.scalars_tensor([self.photon_loss, float(self.sum_nbox)])  # :587, :612
             self.comm.all_reduce(t)
             vals = t.tolist()
@@ -427,15 +481,21 @@ class Evolve:
         self._ndump += 1
         name = "iterdump2.bin" if self._ndump % 2 == 0 else "iterdump1.bin"
         b = self.b
+        th = getattr(b, "thermal", False)
         fileio.write_iteration_dump(os.path.join(self.dump_dir, name), niter, self.photon_loss_all,
-                                    b.fetch("phih_grid"), b.fetch("xh_av"), b.fetch("xh_intermed"), mesh=b.mesh)
+                                    b.fetch("phih_grid"), b.fetch("xh_av"), b.fetch("xh_intermed"), mesh=b.mesh,
+                                    phiheat_grid=b.fetch("phiheat_grid") if th else None,
+                                    temperature_grid=b.fetch("temperature_grid") if th else None)
 
     # evolve.F90:328-426
     def start_from_dump(self, restart):
         from . import fileio
         name = {1: "iterdump1.bin", 2: "iterdump2.bin", 3: "iterdump.bin"}[restart]
-        niter, loss, phih, xav, xint = fileio.read_iteration_dump(os.path.join(self.dump_dir, name), self.b.mesh)
+        th = getattr(self.b, "thermal", False)
+        niter, loss, phih, xav, xint, *rest = fileio.read_iteration_dump(os.path.join(self.dump_dir, name), self.b.mesh, thermal=th)
         self.b.load(xh_av=xav, xh_intermed=xint, phih_grid=phih)      # every rank reads the same file (:393-416)
+        if th:
+            self.b.load(phiheat_grid=rest[0], temperature_grid=rest[1])
         self.photon_loss_all = loss
         return niter
 

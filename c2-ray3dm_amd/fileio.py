@@ -96,6 +96,47 @@ def write_IonRates3D(results_dir, zred, phih_grid, mesh=None):
     return path
 
 
+def write_Temper3D(results_dir, zred, temperature_grid, mesh):
+    """output.F90:314-329 (non-isothermal runs): temperature_grid%current, f32.  temperature_grid is (ncell, 3)."""
+    path = os.path.join(results_dir, "Temper3D_%s.bin" % zred_str(zred))
+    write_sm3d(path, _as3d(np.asarray(temperature_grid, dtype=np.float32).reshape(-1, 3)[:, 0], mesh, np.float32))
+    return path
+
+
+def read_Temper3D(path, mesh):
+    """temperature_restart_init (temperature_module.F90:79-130): the file's field into all three components."""
+    t = read_sm3d(path, np.float32)
+    want = (mesh,) * 3 if np.isscalar(mesh) else tuple(mesh)
+    if t.shape != want:
+        raise ValueError("file with temperatures unusable: mesh found in file %r, expected %r" % (t.shape, want))
+    return np.repeat(t.ravel(order="F")[:, None], 3, axis=1)
+
+
+def write_HeatRates3D(results_dir, zred, phiheat_grid, mesh=None):
+    """output.F90:367-378 (non-isothermal runs): real(phiheat_grid, kind=si)."""
+    path = os.path.join(results_dir, "HeatRates3D_%s.bin" % zred_str(zred))
+    write_sm3d(path, _as3d(phiheat_grid, mesh, np.float64).astype(np.float32))
+    return path
+
+
+def read_cooling_table(path):
+    """setup_cool (cooling.f90:64-87): rows of (log10 T, log10 Lambda), list-directed.  Returns the two columns;
+    the caller derives mintemp = logT[0], dtemp = logT[1] - logT[0] and cie_cool = 10**logL as the reference does."""
+    lt, ll = [], []
+    for line in open(path):
+        cols = line.replace(",", " ").split()
+        if len(cols) >= 2:
+            lt.append(float(cols[0].replace("d", "e").replace("D", "e")))
+            ll.append(float(cols[1].replace("d", "e").replace("D", "e")))
+    return np.asarray(lt), np.asarray(ll)
+
+
+def write_cooling_table(path, logT, logL):
+    with open(path, "w") as f:
+        for a, b in zip(logT, logL):
+            f.write("%5.2f %9.4f\n" % (a, b))
+
+
 def _as3d(a, mesh, dtype):
     a = np.asarray(a, dtype=dtype)
     if a.ndim == 1:
@@ -192,19 +233,25 @@ def write_sources(path, srcpos, normflux, S_star=S_STAR):
             f.write("%d %d %d %.17e 0.0\n" % (i, j, k, nf * S_star))
 
 
-def write_iteration_dump(path, niter, photon_loss_all, phih_grid, xh_av, xh_intermed, mesh=None):
+def write_iteration_dump(path, niter, photon_loss_all, phih_grid, xh_av, xh_intermed, mesh=None, phiheat_grid=None,
+                         temperature_grid=None):
     """write_iteration_dump (evolve.F90:285-324): Fortran sequential records
-    niter (int32) | photon_loss_all(NumFreqBnd=1) f64 | phih_grid | xh_av | xh_intermed (N^3 f64 each)."""
+    niter (int32) | photon_loss_all(NumFreqBnd=1) f64 | phih_grid | xh_av | xh_intermed (N^3 f64 each); non-isothermal
+    runs (:314-317) add phiheat_grid (f64) and temperature_grid (N^3 x (current, average, intermed) f32)."""
     with open(path, "wb") as f:
         _rec(f, np.int32(niter).tobytes())
         _rec(f, np.asarray([photon_loss_all], dtype=np.float64).tobytes())
         for a in (phih_grid, xh_av, xh_intermed):
             _rec(f, np.asfortranarray(_as3d(a, mesh, np.float64)).tobytes(order="F"))
+        if temperature_grid is not None:
+            _rec(f, np.asfortranarray(_as3d(phiheat_grid, mesh, np.float64)).tobytes(order="F"))
+            _rec(f, np.ascontiguousarray(np.asarray(temperature_grid, dtype=np.float32).reshape(-1, 3)).tobytes())
 
 
-def read_iteration_dump(path, mesh):
+def read_iteration_dump(path, mesh, thermal=False):
     """start_from_dump (evolve.F90:328-426).  Returns (niter, photon_loss_all, phih, xh_av, xh_intermed)
-    with the arrays flat in Fortran order."""
+    with the arrays flat in Fortran order; thermal=True (non-isothermal dumps, :372-375) appends phiheat_grid and
+    temperature_grid ((ncell, 3) f32)."""
     raw = open(path, "rb").read()
     body, off = _read_rec(raw, 0)
     niter = int(np.frombuffer(body, dtype=np.int32)[0])
@@ -218,6 +265,14 @@ def read_iteration_dump(path, mesh):
         if a.size != mesh[0] * mesh[1] * mesh[2]:
             raise ValueError("iteration dump does not match the mesh")
         arrs.append(a.copy())
+    if thermal:
+        body, off = _read_rec(raw, off)
+        arrs.append(np.frombuffer(body, dtype=np.float64).copy())
+        body, off = _read_rec(raw, off)
+        t = np.frombuffer(body, dtype=np.float32)
+        if arrs[-1].size != mesh[0] * mesh[1] * mesh[2] or t.size != 3 * mesh[0] * mesh[1] * mesh[2]:
+            raise ValueError("iteration dump does not match the mesh")
+        arrs.append(t.reshape(-1, 3).copy())
     return (niter, loss) + tuple(arrs)
 
 

@@ -141,6 +141,42 @@ int  c2r_set_lls(c2r_ctx *ctx, int32_t type_of_LLS, const float *lls_grid, doubl
  * clumping_module.F90:106-118) used by doric and the photon statistics; NULL returns to the scalar
  * clumping of c2r_set_step. */
 int  c2r_set_clumping_grid(c2r_ctx *ctx, const float *clump_grid);
+/* ---- non-isothermal runs (c2ray_parameters.f90:28 isothermal=.false.; the shipped value is .true.) ----------
+ * Parameters of the heating/cooling path: `parameter`s of c2ray_parameters.f90:105-110, thermal.f90, tped.f90,
+ * atomic.f90:23-25, cosmoparms.f90:28-41, radiation_photoionrates.F90:333, evolve_point.F90:387-388.
+ * c2r_default_thermal fills the shipped values; cool_mintemp / cool_dtemp come from the cooling table file
+ * (setup_cool, cooling.f90:64-87: temp(1) and temp(2)-temp(1) of tables/corocool.tab). */
+typedef struct c2r_thermal_params {
+    double tau_heat_limit;           /* radiation_photoionrates.F90:333 */
+    double k_B, gamma1;              /* cgsconstants.f90:34, atomic.f90:25 */
+    double minitemp, relative_denergy;        /* c2ray_parameters.f90:108,110 */
+    double thermal_rate_floor, thermal_time_tol;   /* thermal.f90:117 (1d-50), :160 (1e-6) */
+    double temp_conv_rel, temp_conv_abs;      /* evolve_point.F90:387-388 (0.1, 100 K) */
+    double H0, Omega0;               /* cosmoparms.f90:30,41 (cosmo_cool, cosmology.F90:198-225) */
+    double cool_mintemp, cool_dtemp; /* cooling.f90:78-79: log10 T of the first table row, row spacing */
+    int32_t cool_points;             /* cooling.f90:26 temppoints */
+    int32_t thermal_max_steps;       /* thermal.f90:163 */
+    int32_t cosmological;            /* c2ray_parameters.f90:105 */
+    int32_t reserved0;
+} c2r_thermal_params;
+int  c2r_default_thermal(c2r_thermal_params *t);
+/* Switches the context to the non-isothermal path (t = NULL: back to isothermal): heat_thick / heat_thin =
+ * stellar_heat_thick_table / _thin_table(0:NumTau,1) (radiation_tables.F90:521-543; n = numtau+1), cie_cool = the
+ * cooling curve as setup_cool holds it (cooling.f90:83: 10**table, cool_points values).  From then on the sweep also
+ * accumulates phi%heat into phiheat_grid (array 5; evolve_point.F90:285-286, heat_lookuptable
+ * radiation_photoionrates.F90:323-417), the all-reduce covers it (evolve.F90:604-609), and the global pass runs
+ * doric at every cell's own temperature followed by thermal (thermal.f90:22; evolve_point.F90:515-527) on
+ * temperature_grid (array 6: temperature_module.F90:35, (current, average, intermed) f32 per cell), with the
+ * temperature clause of the convergence test (:387-388) and set_final_temperature_point on convergence (evolve.F90:220).
+ * With deterministic_rates the heating rates are still accumulated with atomics. */
+int  c2r_set_thermal(c2r_ctx *ctx, const c2r_thermal_params *t, const double *heat_thick, const double *heat_thin,
+                     int32_t n, const double *cie_cool);
+/* cosmology.F90:42 zred at the time the driver calls evolve3D (redshift_evol of the middle of the step,
+ * C2Ray.F90:368): cosmo_cool's redshift.  Per time step, non-isothermal runs only. */
+int  c2r_set_redshift(c2r_ctx *ctx, double zred);
+/* set_final_temperature_point (temperature_module.F90:172-183) for hosts that drive the loop piecewise. */
+int  c2r_set_final_temperature(c2r_ctx *ctx);
+
 /* srcpos(3,NumSrc) (1-based, may lie outside the mesh: wrapped at use) and
  * NormFlux_stellar(1:NumSrc) (sourceprops.F90:121-123,167-168). */
 int  c2r_set_sources(c2r_ctx *ctx, const int32_t *srcpos, const double *normflux, int32_t nsrc);
@@ -175,7 +211,8 @@ int  c2r_get_device(const c2r_ctx *ctx, int32_t *device);
  * context's own.  Any pointer may be NULL to keep the context's buffer. */
 int  c2r_bind_device_buffers(c2r_ctx *ctx, void *ndens, void *xh, void *xh_av,
                              void *xh_intermed, void *phih_grid);
-/* which: 0 ndens, 1 xh, 2 xh_av, 3 xh_intermed, 4 phih_grid */
+/* which: 0 ndens, 1 xh, 2 xh_av, 3 xh_intermed, 4 phih_grid; non-isothermal runs (context-owned, C2R_ESTATE otherwise):
+ * 5 phiheat_grid (f64), 6 temperature_grid (3 x f32 per cell: current, average, intermed) */
 int  c2r_device_ptr(c2r_ctx *ctx, int32_t which, void **ptr);
 int  c2r_upload(c2r_ctx *ctx, int32_t which, const void *host);
 int  c2r_download(c2r_ctx *ctx, int32_t which, void *host);
@@ -234,6 +271,12 @@ int  c2r_evolve3d(c2r_ctx *ctx, double dt, const float *ndens, double *xh, doubl
 int  c2r_evolve3d_restart(c2r_ctx *ctx, double dt, int32_t niter, double photon_loss_all,
                           const float *ndens, double *xh, double *xh_av, double *xh_intermed,
                           double *phih_grid, c2r_report *rep);
+/* evolve3D of a non-isothermal run on the driver's host arrays (restart_niter < 0: restart=0; otherwise the shim's
+ * start_from_dump has read niter, photon_loss_all and ALL of the arrays below from the dump, evolve.F90:364-375):
+ * additionally uploads temperature_grid, downloads phiheat_grid and temperature_grid. */
+int  c2r_evolve3d_thermal(c2r_ctx *ctx, double dt, int32_t restart_niter, double photon_loss_all, const float *ndens,
+                          double *xh, double *xh_av, double *xh_intermed, double *phih_grid, double *phiheat_grid,
+                          float *temperature_grid, c2r_report *rep);
 /* Called after every outer iteration (global pass done, stream idle) at the point where the
  * reference checks the wall clock and writes an iteration dump (evolve.F90:271-275); the hook may
  * c2r_download() arrays 2,3,4 (xh_av, xh_intermed, phih_grid).  Non-zero return aborts (C2R_ECALLBACK). */
@@ -256,6 +299,9 @@ int  c2r_default_sed(c2r_sed_params *p);
  * NumFreqBnd=1.  Fills stellar_photo_thick_table / _thin_table(0:numtau); n = numtau+1.
  * R_star (optional) returns the rescaled black-body radius the reference logs. */
 int  c2r_build_tables(const c2r_sed_params *sed, double *thick, double *thin, int32_t n, double *R_star);
+/* The heating tables of a non-isothermal run (fill_heating_integrands_HI + make_heat_tables_HI,
+ * radiation_tables.F90:455-543): the photo integrands times hplanck*(nu - ion_freq_HI). */
+int  c2r_build_heat_tables(const c2r_sed_params *sed, double ion_freq_HI, double *heat_thick, double *heat_thin, int32_t n);
 
 /* Device self-test: the kernels' division helpers (bare Newton-Raphson core, reciprocal-multiply
  * for launch-invariant divisors) against the compiler's IEEE division on 4x2^22 pseudo-random

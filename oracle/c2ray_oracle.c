@@ -53,6 +53,7 @@ typedef struct {
     double zred;              /* cosmology.F90:42 zred at the middle of the step (cosmo_cool)   */
     float  *temper_grid;      /* temperature_module.F90:35 temperature_grid: (current, average, intermed) f32 per cell */
     double *phiheat;          /* evolve_data.F90:42 phiheat_grid                                */
+    double *tolw_heat;        /* checker diagnostic like tolw, for the heating rate: sum_s (1+tau_in) heat_in / vol_ph */
 } oracle_cfg;
 
 static inline int pmod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
@@ -313,6 +314,8 @@ static void evolve0d(sweep_t *s, const int rt[3])
     if (!stop) {
         oracle_photoion_rates(c->thick, c->thin, cd_in, cd_out, vol_ph, s->normflux, phi);
         if (c->heat_thick) heat = oracle_heat_rate(c->heat_thick, c->heat_thin, cd_in, cd_out, vol_ph, s->normflux);   /* radiation_photoionrates.F90:142-172 */
+        if (c->heat_thick && c->tolw_heat && s->normflux > 0.0)
+            c->tolw_heat[id] += (1.0 + cd_in * C2R_SIGMA_HI) * s->normflux * table_lookup(c->heat_thick, cd_in * C2R_SIGMA_HI) / vol_ph;
         phi[0] = phi[0] / (xav0 * nd);                                         /* :262 */
         if (c->tolw) c->tolw[id] += (1.0 + cd_in * C2R_SIGMA_HI) * phi[1] / (vol_ph * (xav0 * nd));
     }
@@ -559,6 +562,7 @@ void oracle_evolve3d_x(const oracle_cfg *c, double dt, const float *ndens, doubl
         memset(phih, 0, ncell * sizeof(double));                               /* :243 */
         if (c->heat_thick) memset(c->phiheat, 0, ncell * sizeof(double));      /* :435 */
         if (c->tolw) memset(c->tolw, 0, ncell * sizeof(double));               /* checker diagnostic: last pass only */
+        if (c->tolw_heat) memset(c->tolw_heat, 0, ncell * sizeof(double));
         double loss; long nb, vis;
         oracle_pass_sources(c, ndens, xh_av, phih, srcpos, normflux, nsrc, 0, 1, &loss, &nb, &vis);
         rep->photon_loss_all = loss; rep->sum_nbox_all = nb; rep->visited += vis;

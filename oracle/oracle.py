@@ -26,7 +26,7 @@ class Cfg(C.Structure):
                 ("clump_grid", C.c_void_p), ("tolw", C.c_void_p),
                 ("heat_thick", C.c_void_p), ("heat_thin", C.c_void_p), ("cie_cool", C.c_void_p),
                 ("cool_mintemp", C.c_double), ("cool_dtemp", C.c_double), ("zred", C.c_double),
-                ("temper_grid", C.c_void_p), ("phiheat", C.c_void_p)]
+                ("temper_grid", C.c_void_p), ("phiheat", C.c_void_p), ("tolw_heat", C.c_void_p)]
 
 
 class Report(C.Structure):
@@ -122,6 +122,12 @@ class Oracle:
         self.tolw = np.zeros(self.ncell, dtype=np.float64)
         self.cfg.tolw = self.tolw.ctypes.data
         return self.tolw
+
+    def enable_heat_tolerance_weight(self):
+        """As enable_tolerance_weight, for the heating rate: W_heat = sum_s (1+tau_in) heat_in / vol_ph per cell."""
+        self.tolw_heat = np.zeros(self.ncell, dtype=np.float64)
+        self.cfg.tolw_heat = self.tolw_heat.ctypes.data
+        return self.tolw_heat
 
     # -- point functions ------------------------------------------------------------------
     def cinterp(self, cdout, pos, src):

@@ -136,3 +136,38 @@ def test_cubep3m_density_scaling(tmp_path):
     p = str(tmp_path / fio.cubep3m_density_name("", 8.0).strip())
     fio.write_density(p, raw)
     assert np.array_equal(fio.read_density(p, mesh=2), raw)
+
+
+def test_nonisothermal_dump_cooling_table_and_temperature_files(tmp_path):
+    """The two extra records of a non-isothermal iteration dump (evolve.F90:314-317, :372-375), tables/corocool.tab
+    (cooling.f90:64-87) and Temper3D / HeatRates3D (output.F90:314-329, :367-378; temperature_restart_init)."""
+    import __graft_entry__ as g
+    fio = g.load_package().fileio
+    from tests.golden.inputs import cooling_table
+    n = 6
+    rng = np.random.default_rng(3)
+    ph, xa, xi, he = (rng.random(n ** 3) for _ in range(4))
+    tg = (1e4 * rng.random((n ** 3, 3))).astype(np.float32)
+    p = str(tmp_path / "iterdump1.bin")
+    fio.write_iteration_dump(p, 7, 1.5e50, ph, xa, xi, mesh=n, phiheat_grid=he, temperature_grid=tg)
+    niter, loss, ph2, xa2, xi2, he2, tg2 = fio.read_iteration_dump(p, n, thermal=True)
+    assert (niter, loss) == (7, 1.5e50)
+    for a, b in ((ph, ph2), (xa, xa2), (xi, xi2), (he, he2), (tg, tg2)):
+        assert np.array_equal(a, b)
+    # record sizes: 4 | 8 | 3 x 8 N^3 | 8 N^3 | 12 N^3, each framed by two int32 markers
+    assert len(open(p, "rb").read()) == 4 + 8 + 4 * 8 * n ** 3 + 12 * n ** 3 + 7 * 8
+    assert len(fio.read_iteration_dump(p, n)) == 5                     # an isothermal reader stops after xh_intermed
+    text, lt, ll = cooling_table()
+    tab = str(tmp_path / "corocool.tab")
+    fio.write_cooling_table(tab, lt, ll)
+    assert open(tab).read() == text
+    lt2, ll2 = fio.read_cooling_table(tab)
+    assert np.array_equal(lt, lt2) and np.array_equal(ll, ll2) and len(lt) == 61
+    t3 = fio.write_Temper3D(str(tmp_path), 8.515, tg, n)
+    assert t3.endswith("Temper3D_8.515.bin")
+    back = fio.read_Temper3D(t3, n)
+    assert np.array_equal(back[:, 0], tg[:, 0]) and np.array_equal(back[:, 1], tg[:, 0]) and np.array_equal(back[:, 2], tg[:, 0])
+    h3 = fio.write_HeatRates3D(str(tmp_path), 8.515, he, n)
+    assert np.array_equal(fio.read_sm3d(h3).ravel(order="F"), he.astype(np.float32))
+    with pytest.raises(ValueError):
+        fio.read_Temper3D(t3, n + 1)

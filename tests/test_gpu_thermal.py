@@ -1,0 +1,216 @@
+"""GPU parity tests of the non-isothermal path (c2ray_parameters.f90:28 isothermal=.false.: heating rates in the sweep,
+doric at every cell's temperature, thermal.f90, the temperature clause of the convergence test), once per sweep mode,
+against fixtures from the reference rebuilt with that one parameter changed and against the oracle (itself equal to
+those fixtures bit for bit, tests/test_oracle_thermal.py).  The cooling table is the synthetic one of
+tests/golden/inputs.cooling_table (the reference repository does not ship tables/corocool.tab).
+
+Stated tolerances: integers (sub-boxes, outer iterations, non-converged-cell sequence) exact; xh tests/_util.TOL["x"];
+heating rates like Gamma, |d heat| <= rtol heat + wtol W_heat with W_heat = sum_s (1+tau_in) heat_in / vol_ph (the
+heating rate is the same difference of two table values); temperatures 1.5e-7 relative = one unit in the last place
+of the f32 temperature_grid (the f64 values agree to ~1e-15, a stored value can round the other way)."""
+import ctypes as C
+import numpy as np
+import pytest
+from tests._util import F, load_case, load_thermal_tables, thermal_oracle_for, tol, assert_gamma, TOL, sweep_mode, STATE_RTOL
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("sweep_mode")]
+T_RTOL = 1.5e-7
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+def backend(pkg, tables, m, n):
+    tt = load_thermal_tables()
+    b = pkg.HipBackend(n, *tables, device=0)
+    b.set_step((m["dr1"], m["dr2"], m["dr3"]), m["vol"], m["coldensh_LLS"], m["clumping"])
+    b.set_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"])
+    b.set_redshift(m["zred"])
+    b.set_sources(m["srcpos"], m["normflux"])
+    b.set_rank(0, 1)
+    return b
+
+
+def assert_heat(got, ref, w, what="", state_rtol=0.0):
+    t = TOL[sweep_mode()]
+    assert np.array_equal(got == 0, ref == 0), what
+    excess = np.abs(got - ref) - ((t["gamma_rtol"] + state_rtol) * np.abs(ref) + t["gamma_wtol"] * w)
+    assert excess.max() <= 0, "%s heating rate out of tolerance: worst excess %.3g at %d (ref %.6g, W %.3g)" % (
+        what, excess.max(), int(np.argmax(excess)), ref.flat[int(np.argmax(excess))], w.flat[int(np.argmax(excess))])
+
+
+def assert_temper(got, ref, what=""):
+    rel = np.abs(got.astype(np.float64) / ref.astype(np.float64) - 1)
+    assert rel.max() <= T_RTOL, (what, rel.max())
+    assert np.count_nonzero(got != ref) <= 1e-3 * got.size, (what, np.count_nonzero(got != ref))
+
+
+def test_sweep_heating_rates_vs_reference(pkg, tables):
+    m, a = load_case("sweep32_thermal")
+    n = m["n"]
+    nd, xh = F(a["ndens"]), F(a["xh"])
+    o = thermal_oracle_for(m, tables, np.zeros((n ** 3, 3), dtype=np.float32), n)
+    w, wh = o.enable_tolerance_weight(), o.enable_heat_tolerance_weight()
+    ophih = np.zeros(n ** 3)
+    o.pass_sources(nd, xh, ophih, m["srcpos"], m["normflux"])
+    b = backend(pkg, tables, m, n)
+    b.load(ndens=nd, xh=xh, temperature_grid=np.full(n ** 3, 1e4, dtype=np.float32))
+    b.begin_step(); b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    assert nbox == m["sum_nbox"]
+    assert abs(loss - m["photon_loss"]) <= tol("loss") * abs(m["photon_loss"])
+    assert_gamma(b.fetch("phih_grid"), F(a["phih"]), w, "Gamma vs the Fortran")
+    heat = b.fetch("phiheat_grid")
+    assert_heat(heat, F(a["phiheat"]), wh, "vs the Fortran")
+    assert np.count_nonzero(heat) > 5000
+    # a second pass accumulates on top (evolve_point.F90:285), zero_rates clears (evolve.F90:435)
+    b.pass_sources()
+    assert np.max(np.abs(b.fetch("phiheat_grid") / np.where(heat > 0, 2 * heat, 1) - (heat > 0))) < 1e-12
+    b.zero_rates()
+    assert not b.fetch("phiheat_grid").any()
+    b.close()
+
+
+@pytest.mark.parametrize("tag", ["step001", "step003"])
+def test_evolve3d_nonisothermal_vs_reference(pkg, tables, tag):
+    m, a = load_case("evolve32_thermal")
+    n, s = m["n"], m["steps"][tag]
+    b = backend(pkg, tables, s, n)
+    nd, xh0, t0 = F(a[tag + "_ndens"]), F(a[tag + "_xh_before"]), a[tag + "_temper_before"]
+    b.load(ndens=nd, xh=xh0, temperature_grid=t0)
+    rep = b.evolve3d_native(s["dt"])
+    assert rep.converged and rep.niter == s["niter"]
+    assert list(rep.it_conv_flag[:rep.niter]) == s["log"]["nonconv"]
+    assert rep.sum_nbox_all == s["sum_nbox_all"]
+    assert np.max(np.abs(b.fetch("xh") - F(a[tag + "_xh_after"]))) < tol("x")
+    tg = b.fetch("temperature_grid")
+    assert_temper(tg, a[tag + "_temper_after"], tag)
+    assert np.array_equal(tg[:, 0], tg[:, 2])                       # set_final_temperature_point
+    # rates of the last pass: the oracle's whole step gives the tolerance weights
+    tgo = np.ascontiguousarray(t0).copy()
+    o = thermal_oracle_for(s, tables, tgo, n)
+    w, wh = o.enable_tolerance_weight(), o.enable_heat_tolerance_weight()
+    xo = xh0.copy()
+    o.evolve3d(s["dt"], nd, xo, s["srcpos"], s["normflux"])
+    assert_gamma(b.fetch("phih_grid"), F(a[tag + "_phih_grid"]), w, tag, state_rtol=STATE_RTOL)
+    assert_heat(b.fetch("phiheat_grid"), F(a[tag + "_phiheat_grid"]), wh, tag, state_rtol=STATE_RTOL)
+    for k in ("totrec", "totcollisions"):
+        assert abs(getattr(rep, k) / s[k] - 1) < 1e-9
+    b.close()
+
+
+def test_python_loop_and_host_entry_equal_native(pkg, tables):
+    """The Python mirror of the loop (piecewise calls + c2r_set_final_temperature) and c2r_evolve3d_thermal on host arrays
+    (what the Fortran shim calls) give the native device-resident step."""
+    m, a = load_case("evolve32_thermal")
+    n, tag = m["n"], "step001"
+    s = m["steps"][tag]
+    nd, xh0, t0 = F(a[tag + "_ndens"]), F(a[tag + "_xh_before"]), np.ascontiguousarray(a[tag + "_temper_before"])
+    out = []
+    for how in ("native", "python", "host"):
+        b = backend(pkg, tables, s, n)
+        if how == "host":
+            xh, xav, xint, ph, he, tg = xh0.copy(), np.empty(n ** 3), np.empty(n ** 3), np.empty(n ** 3), np.empty(n ** 3), t0.copy()
+            rep = pkg._capi.Report()
+            p = lambda v: v.ctypes.data_as(C.c_void_p)
+            b._check(b.lib.c2r_evolve3d_thermal(b.ctx, s["dt"], -1, 0.0, p(nd), p(xh), p(xav), p(xint), p(ph), p(he), p(tg),
+                                                C.byref(rep)), "c2r_evolve3d_thermal")
+            out.append((rep.niter, xh, tg, he))
+        else:
+            b.load(ndens=nd, xh=xh0, temperature_grid=t0)
+            if how == "native":
+                niter = b.evolve3d_native(s["dt"]).niter
+            else:
+                niter = pkg.Evolve(b).evolve3D(0.0, s["dt"], 0)["niter"]
+            out.append((niter, b.fetch("xh"), b.fetch("temperature_grid"), b.fetch("phiheat_grid")))
+        b.close()
+    for k in (1, 2):
+        assert out[k][0] == out[0][0] == s["niter"]
+        assert np.max(np.abs(out[k][1] - out[0][1])) < 1e-12
+        assert_temper(out[k][2], out[0][2])
+        assert np.max(np.abs(out[k][3] - out[0][3])) <= 1e-12 * out[0][3].max()
+
+
+def test_restart_from_nonisothermal_iteration_dump(pkg, tables, tmp_path):
+    """An iteration dump with the two extra records of a non-isothermal run (evolve.F90:314-317), written from the
+    iteration hook after outer iteration 2, restarts the step in a new context as the reference's restart does."""
+    fio = pkg.fileio
+    m, a = load_case("evolve32_thermal")
+    n, tag = m["n"], "step001"
+    s = m["steps"][tag]
+    nd, xh0, t0 = F(a[tag + "_ndens"]), F(a[tag + "_xh_before"]), a[tag + "_temper_before"]
+    b = backend(pkg, tables, s, n)
+    b.load(ndens=nd, xh=xh0, temperature_grid=t0)
+    path = str(tmp_path / "iterdump.bin")
+
+    def hook(niter, loss):
+        if niter == 2:
+            fio.write_iteration_dump(path, niter, loss, b.fetch("phih_grid"), b.fetch("xh_av"), b.fetch("xh_intermed"), mesh=n,
+                                     phiheat_grid=b.fetch("phiheat_grid"), temperature_grid=b.fetch("temperature_grid"))
+    b.set_iteration_hook(hook)
+    rep = b.evolve3d_native(s["dt"])
+    b.set_iteration_hook(None)
+    end = (b.fetch("xh"), b.fetch("temperature_grid"))
+    b.close()
+    niter, loss, phih, xav, xint, heat, tg = fio.read_iteration_dump(path, n, thermal=True)
+    assert niter == 2 and tg.shape == (n ** 3, 3) and heat.any()
+    b = backend(pkg, tables, s, n)
+    b.load(ndens=nd, xh=xh0, xh_av=xav, xh_intermed=xint, phih_grid=phih, phiheat_grid=heat, temperature_grid=tg)
+    rep2 = b.evolve3d_native(s["dt"], restart_niter=niter, restart_photon_loss=loss)
+    # evolve3D(restart/=0) repeats the global pass on the dumped state and tests convergence with the saved sums of a
+    # fresh process (evolve.F90:153-157, :67-74): not the uninterrupted history -- the oracle's restart is the reference
+    tgo = tg.copy()
+    o = thermal_oracle_for(s, tables, tgo, n)
+    o.phiheat[:] = heat
+    xo, xavo, xinto, pho = xh0.copy(), xav.copy(), xint.copy(), phih.copy()
+    orep = o.evolve3d_restart(s["dt"], nd, xo, xavo, xinto, pho, s["srcpos"], s["normflux"], niter)
+    assert (rep2.converged, rep2.niter) == (orep.converged, orep.niter)
+    assert list(rep2.it_conv_flag[niter - 1:rep2.niter]) == list(orep.it_conv_flag[niter - 1:orep.niter])
+    assert np.max(np.abs(b.fetch("xh") - xo)) < tol("x")
+    assert_temper(b.fetch("temperature_grid"), tgo)
+    assert rep.niter == s["niter"] and end[0].shape == xo.shape
+    b.close()
+
+
+def test_isothermal_path_untouched_and_switchable(pkg, tables):
+    """The thermal arrays do not exist in an isothermal context (C2R_ESTATE), and c2r_set_thermal(NULL) returns a
+    context to the isothermal kernels: same rates as a context that never left them."""
+    m, a = load_case("sweep32_bubbles")
+    n = m["n"]
+    nd, xh = F(a["ndens"]), F(a["xh"])
+    res = []
+    for switch in (False, True):
+        b = pkg.HipBackend(n, *tables, device=0)
+        b.set_step((m["dr1"], m["dr2"], m["dr3"]), m["vol"], m["coldensh_LLS"], m["clumping"])
+        if switch:
+            tt = load_thermal_tables()
+            b.set_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"])
+            b.set_isothermal()
+        else:
+            with pytest.raises(pkg.C2RayHipError):
+                b.fetch("phiheat_grid")
+        b.set_sources(m["srcpos"], m["normflux"]); b.set_rank(0, 1)
+        b.load(ndens=nd, xh=xh)
+        b.begin_step(); b.zero_rates()
+        r = b.pass_sources()
+        conv, _ = b.global_pass(m["dt"])
+        res.append((r[1:], conv, b.fetch("phih_grid"), b.fetch("xh_intermed")))
+        b.close()
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+    assert np.max(np.abs(res[0][2] - res[1][2])) <= 1e-12 * res[0][2].max()
+    assert np.array_equal(res[0][3], res[1][3]) or np.max(np.abs(res[0][3] - res[1][3])) < 1e-13
+
+
+def test_nonisothermal_context_needs_the_redshift(pkg, tables):
+    m, a = load_case("sweep32_thermal")
+    tt = load_thermal_tables()
+    b = pkg.HipBackend(m["n"], *tables, device=0)
+    b.set_step((m["dr1"], m["dr2"], m["dr3"]), m["vol"], m["coldensh_LLS"], m["clumping"])
+    b.set_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"])
+    b.set_sources(m["srcpos"], m["normflux"]); b.set_rank(0, 1)
+    with pytest.raises(pkg.C2RayHipError, match="c2r_set_redshift"):
+        b.pass_sources()
+    b.close()

@@ -49,12 +49,26 @@ def test_rccl_binding_exports_its_header(pkg):
 
 def test_struct_layout_matches_header(pkg):
     """sizeof() of the two ABI structs as the C compiler sees them."""
-    src = '#include <stdio.h>\n#include "c2ray_hip.h"\nint main(){printf("%zu %zu\\n",sizeof(c2r_params),sizeof(c2r_report));return 0;}\n'
+    src = ('#include <stdio.h>\n#include "c2ray_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n",sizeof(c2r_params),sizeof(c2r_report),'
+           'sizeof(c2r_thermal_params),sizeof(c2r_sed_params));return 0;}\n')
     exe = "/tmp/c2r_sizeof"
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
-    a, b = map(int, subprocess.check_output([exe]).split())
+    a, b, c, d = map(int, subprocess.check_output([exe]).split())
     import ctypes as C
     assert C.sizeof(pkg.Params) == a and C.sizeof(pkg.Report) == b
+    assert C.sizeof(pkg._capi.ThermalParams) == c and C.sizeof(pkg.SedParams) == d
+
+
+def test_default_thermal_params_are_the_reference_constants(pkg):
+    """c2ray_parameters.f90:105-110, atomic.f90:23-25, radiation_photoionrates.F90:333, evolve_point.F90:387-388."""
+    import ctypes as C
+    t = pkg._capi.ThermalParams()
+    assert pkg.load_library().c2r_default_thermal(C.byref(t)) == 0
+    assert t.minitemp == 1.0 and t.relative_denergy == float(np.float32(0.1)) and t.thermal_max_steps == 10000
+    assert t.gamma1 == 5.0 / 3.0 - 1.0 and t.tau_heat_limit == float(np.float32(1.0e-4))
+    assert t.temp_conv_rel == 0.1 and t.temp_conv_abs == 100.0 and t.cool_points == 61 and t.cosmological == 1
+    assert t.thermal_time_tol == float(np.float32(1e-6)) and t.thermal_rate_floor == 1e-50
+    assert t.Omega0 == float(np.float32(0.27)) and abs(t.H0 / (float(np.float32(0.7)) * 100.0 * 1e5 / 3.08600011031262003e+24) - 1) < 1e-15
 
 
 def test_default_params_are_the_reference_constants(pkg):

@@ -47,3 +47,19 @@ def test_other_sed_parameters(pkg):
     bad = pkg.SedParams()
     pkg.load_library().c2r_default_sed(C.byref(bad))
     assert pkg.load_library().c2r_build_tables(C.byref(bad), thick.ctypes.data, thin.ctypes.data, 17, None) != 0
+
+
+def test_heating_tables_equal_reference_bit_for_bit(pkg):
+    """c2r_build_heat_tables against the tables of the reference rebuilt with isothermal=.false.
+    (radiation_tables.F90:455-543), and the two values that build logs (:222-226)."""
+    from tests._util import load_thermal_tables
+    tt = load_thermal_tables()
+    hk, hn = pkg._capi.build_heat_tables()
+    assert np.array_equal(hk, tt["heat_thick"]) and np.array_equal(hn, tt["heat_thin"])
+    assert abs(hk[0] / 1.0706414469369616e37 - 1) < 1e-15 and abs(hn[0] / 2.621026881130597e36 - 1) < 1e-15
+    # mean photon excess energy of the unattenuated spectrum: between 0 and a few ionization energies
+    thick = pkg.build_tables()[0]
+    assert 0.1 < hk[0] / thick[0] / (6.62607550000000009e-27 * pkg._capi.ION_FREQ_HI) < 2.0
+    assert np.all(np.diff(hk[1:]) <= 0)
+    lib = pkg.load_library()
+    assert lib.c2r_build_heat_tables(None, 0.0, hk.ctypes.data, hn.ctypes.data, 2001) != 0
