@@ -541,7 +541,6 @@ int check_ready(Ctx *ctx)
     HIP_TRY(hipSetDevice(ctx->prm.device));
     if (!ctx->have_tables) FAIL(C2R_ESTATE, "c2r_set_tables has not been called");
     if (!ctx->have_step) FAIL(C2R_ESTATE, "c2r_set_step has not been called");
-    if (ctx->thermal && !ctx->have_zred && ctx->tprm.cosmological) FAIL(C2R_ESTATE, "non-isothermal run: c2r_set_redshift has not been called");
     return C2R_OK;
 }
 
@@ -1214,6 +1213,7 @@ static int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum
     cp.stat_partial = ctx->d_stat_partial;
     if (ctx->thermal) {
         const c2r_thermal_params &t = ctx->tprm;
+        if (t.cosmological && !ctx->have_zred) FAIL(C2R_ESTATE, "non-isothermal run: c2r_set_redshift has not been called (cosmo_cool needs zred)");
         cp.temper = (float *)ctx->grid[6]; cp.phiheat = (const double *)ctx->grid[5]; cp.cool = ctx->d_cool;
         cp.cool_mintemp = t.cool_mintemp; cp.cool_dtemp = t.cool_dtemp; cp.cool_points = t.cool_points;
         cp.thermal_max_steps = t.thermal_max_steps;

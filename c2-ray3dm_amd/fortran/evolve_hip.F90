@@ -21,20 +21,24 @@ module c2ray_hip
   use file_admin, only: logf
   use sizes, only: mesh
   use grid, only: dr, vol
-  use temperature_module, only: temper_val
+  use temperature_module, only: temper_val, temperature_grid
   use clumping_module, only: clumping, clumping_grid
   use lls_module, only: coldensh_LLS, LLS_grid, R_max_LLS
   use sourceprops, only: NumSrc, srcpos, NormFlux_stellar
   use radiation_sizes, only: NumTau
-  use radiation_tables, only: stellar_photo_thick_table, stellar_photo_thin_table, minlogtau, dlogtau
+  use radiation_tables, only: stellar_photo_thick_table, stellar_photo_thin_table, minlogtau, dlogtau, &
+       stellar_heat_thick_table, stellar_heat_thin_table
   use radiation_sed_parameters, only: S_star
   use cgsphotoconstants, only: sigma_HI_at_ion_freq
-  use cgsconstants, only: bh00, albpow, colh0, temph0
+  use cgsconstants, only: bh00, albpow, colh0, temph0, k_B
+  use atomic, only: gamma1
+  use cosmology_parameters, only: H0, Omega0
+  use cosmology, only: zred
   use mathconstants, only: pi
   use abundances, only: abu_c
   use c2ray_parameters, only: epsilon, convergence_fraction, minimum_fractional_change, &
        minimum_fraction_of_atoms, loss_fraction, subboxsize, max_subbox, use_LLS, type_of_LLS, &
-       type_of_clumping
+       type_of_clumping, isothermal, cosmological, minitemp, relative_denergy
 #ifdef MPI
   ! -DMPI builds of the driver (mpi.F90:83-160): one rank per GPU; sources are distributed over the ranks inside the
   ! library (master_slave.F90:74-96 / :124-330) and Gamma is summed with RCCL over xGMI (evolve.F90:577-616)
@@ -75,7 +79,42 @@ module c2ray_hip
           total_ion, totalsrc, photcons, it_photcons(C2R_MAX_ITER_LOG)
   end type c2r_report
 
+  !> mirror of struct c2r_thermal_params (non-isothermal builds of the driver: c2ray_parameters.f90:28)
+  type, bind(C) :: c2r_thermal_params
+     real(c_double) :: tau_heat_limit, k_B, gamma1, minitemp, relative_denergy, thermal_rate_floor, &
+          thermal_time_tol, temp_conv_rel, temp_conv_abs, H0, Omega0, cool_mintemp, cool_dtemp
+     integer(c_int32_t) :: cool_points, thermal_max_steps, cosmological, reserved0
+  end type c2r_thermal_params
+
   interface
+     integer(c_int) function c2r_default_thermal(t) bind(C, name="c2r_default_thermal")
+       import :: c_int, c2r_thermal_params
+       type(c2r_thermal_params), intent(out) :: t
+     end function c2r_default_thermal
+     integer(c_int) function c2r_set_thermal(ctx, t, heat_thick, heat_thin, n, cie_cool) bind(C, name="c2r_set_thermal")
+       import :: c_int, c_ptr, c_double, c_int32_t, c2r_thermal_params
+       type(c_ptr), value :: ctx
+       type(c2r_thermal_params), intent(in) :: t
+       real(c_double), intent(in) :: heat_thick(*), heat_thin(*), cie_cool(*)
+       integer(c_int32_t), value :: n
+     end function c2r_set_thermal
+     integer(c_int) function c2r_set_redshift(ctx, zred) bind(C, name="c2r_set_redshift")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: zred
+     end function c2r_set_redshift
+     !> temperature_grid is an array of type(temperature_states): three default reals per cell, passed by address
+     integer(c_int) function c2r_evolve3d_thermal(ctx, dt, restart_niter, photon_loss_all, ndens, xh, xh_av, &
+          xh_intermed, phih_grid, phiheat_grid, temperature_grid, rep) bind(C, name="c2r_evolve3d_thermal")
+       import :: c_int, c_ptr, c_double, c_float, c_int32_t, c2r_report
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt, photon_loss_all
+       integer(c_int32_t), value :: restart_niter
+       real(c_float), intent(in) :: ndens(*)
+       real(c_double), intent(inout) :: xh(*), xh_av(*), xh_intermed(*), phih_grid(*), phiheat_grid(*)
+       type(*), dimension(*), intent(inout) :: temperature_grid
+       type(c2r_report), intent(out) :: rep
+     end function c2r_evolve3d_thermal
      integer(c_int) function c2r_default_params(p) bind(C, name="c2r_default_params")
        import :: c_int, c2r_params
        type(c2r_params), intent(out) :: p
@@ -204,7 +243,7 @@ module c2ray_hip
        import :: c_int, c_ptr, c_double, c_int32_t
        type(c_ptr), value :: ctx
        integer(c_int32_t), value :: which
-       real(c_double), intent(out) :: host(*)
+       type(*), dimension(*), intent(inout) :: host       ! f64 N^3 (arrays 1-5) or temperature_grid (array 6)
      end function c2r_download
   end interface
 
@@ -265,6 +304,7 @@ contains
          int(NumTau+1, c_int32_t)), "c2r_set_tables")
     call check(c2r_get_device(ctx, dev), "c2r_get_device")
     write(logf,*) "c2ray_hip: evolve hot path on HIP device ", dev
+    if (.not.isothermal) call thermal_hip_ini()
 #ifdef MPI
     ! Join the RCCL communicator: rank 0 makes the 128-byte token, one broadcast next to those of mpi.F90 hands it
     ! out, every rank attaches on its own device.  From here on c2r_evolve3d sweeps this rank's share of the sources
@@ -279,6 +319,32 @@ contains
     endif
 #endif
   end subroutine evolve_hip_ini
+
+  !> Non-isothermal builds (c2ray_parameters.f90:28): hand the heating tables (rad_ini filled them,
+  !! radiation_tables.F90:521-543), the cooling curve and the thermal parameters to the library.  The cooling curve is
+  !! private to radiative_cooling, so the table file is read here exactly as setup_cool reads it (cooling.f90:64-87).
+  subroutine thermal_hip_ini()
+    integer, parameter :: temppoints = 61                              ! cooling.f90:26
+    real(kind=dp) :: temp(temppoints), cie_cool(temppoints)
+    type(c2r_thermal_params) :: t
+    integer :: itemp
+    open(unit=22, file='tables/corocool.tab', status='old')
+    do itemp = 1, temppoints
+       read(22,*) temp(itemp), cie_cool(itemp)
+    enddo
+    close(22)
+    do itemp = 1, temppoints
+       cie_cool(itemp) = 10.0d0**cie_cool(itemp)
+    enddo
+    call check(c2r_default_thermal(t), "c2r_default_thermal")
+    t%k_B = k_B; t%gamma1 = gamma1; t%minitemp = minitemp; t%relative_denergy = relative_denergy
+    t%H0 = H0; t%Omega0 = Omega0
+    t%cool_mintemp = temp(1); t%cool_dtemp = temp(2) - temp(1); t%cool_points = temppoints
+    t%cosmological = merge(1_c_int32_t, 0_c_int32_t, cosmological)
+    call check(c2r_set_thermal(ctx, t, stellar_heat_thick_table(:,1), stellar_heat_thin_table(:,1), &
+         int(NumTau+1, c_int32_t), cie_cool), "c2r_set_thermal")
+    write(logf,*) "c2ray_hip: heating and cooling on the device (thermal.f90)"
+  end subroutine thermal_hip_ini
 
   subroutine evolve_hip_end()
     integer(c_int) :: rc
@@ -310,6 +376,7 @@ contains
     endif
     call check(c2r_set_sources(ctx, srcpos, NormFlux_stellar(1:NumSrc), int(NumSrc, c_int32_t)), &
          "c2r_set_sources")
+    if (.not.isothermal) call check(c2r_set_redshift(ctx, zred), "c2r_set_redshift")   ! cosmo_cool, cosmology.F90:198
   end subroutine hip_step_state
 
   function grid_address(g) result(p)
@@ -331,8 +398,9 @@ module evolve_source
   use precision, only: dp
   use density_module, only: ndens
   use photonstatistics, only: photon_loss
-  use evolve_data, only: phih_grid, xh_av, coldensh_out
-  use c2ray_hip, only: ctx, check, hip_step_state, c2r_do_source_host
+  use evolve_data, only: phih_grid, phiheat_grid, xh_av, coldensh_out
+  use c2ray_parameters, only: isothermal
+  use c2ray_hip, only: ctx, check, hip_step_state, c2r_do_source_host, c2r_download
 
   implicit none
 
@@ -358,10 +426,17 @@ contains
 
     real(c_double) :: photon_loss_src
     integer(c_int32_t) :: nbox
+    real(kind=dp), allocatable, save :: heat_src(:,:,:)
 
     call hip_step_state()
     call check(c2r_do_source_host(ctx, int(ns1, c_int32_t), ndens, xh_av, phih_grid, coldensh_out, &
          photon_loss_src, nbox), "c2r_do_source_host")
+    if (.not.isothermal) then
+       ! the source's heating rates (evolve_point.F90:285-286) are on the device after the call: add them on the host
+       if (.not.allocated(heat_src)) allocate(heat_src(size(phiheat_grid,1), size(phiheat_grid,2), size(phiheat_grid,3)))
+       call check(c2r_download(ctx, 5_c_int32_t, heat_src), "c2r_download")
+       phiheat_grid = phiheat_grid + heat_src
+    endif
     photon_loss(1) = photon_loss(1) + photon_loss_src                 ! evolve_source.F90:216
     sum_nbox = sum_nbox + nbox                                        ! evolve_source.F90:219
 
@@ -383,9 +458,10 @@ module evolve
   use ionfractions_module, only: xh
   use sourceprops, only: NumSrc
   use c2ray_parameters, only: convergence_fraction
+  use temperature_module, only: temperature_grid
   use photonstatistics, only: photon_loss, LLS_loss, state_before, calculate_photon_statistics, &
        report_photonstatistics, update_grandtotal_photonstatistics
-  use evolve_data, only: phih_grid, xh_av, xh_intermed, photon_loss_all
+  use evolve_data, only: phih_grid, phiheat_grid, xh_av, xh_intermed, photon_loss_all
   use evolve_source, only: sum_nbox, sum_nbox_all
   use c2ray_hip
 
@@ -422,7 +498,13 @@ contains
     if (rank == 0) write(timefile,"(A,F8.1)") "Time before starting iteration: ", timestamp_wallclock ()
 
     niter0 = 0
-    if (restart == 0) then
+    if (.not.isothermal) then
+       ! heating and cooling: also phiheat_grid and temperature_grid (evolve_point.F90:285, :553; evolve.F90:220)
+       if (restart /= 0) call start_from_dump(restart, niter0)
+       call check(c2r_evolve3d_thermal(ctx, dt, int(merge(niter0, -1, restart /= 0), c_int32_t), photon_loss_all(1), &
+            ndens, xh, xh_av, xh_intermed, phih_grid, phiheat_grid, temperature_grid, last_report), &
+            "c2r_evolve3d_thermal")
+    elseif (restart == 0) then
        call check(c2r_evolve3d(ctx, dt, ndens, xh, xh_av, xh_intermed, phih_grid, last_report), &
             "c2r_evolve3d")
     else
@@ -483,6 +565,10 @@ contains
        rc = c2r_download(ctx, 4_c_int32_t, phih_grid)
        if (rc == 0) rc = c2r_download(ctx, 2_c_int32_t, xh_av)
        if (rc == 0) rc = c2r_download(ctx, 3_c_int32_t, xh_intermed)
+       if (.not.isothermal) then
+          if (rc == 0) rc = c2r_download(ctx, 5_c_int32_t, phiheat_grid)
+          if (rc == 0) rc = c2r_download(ctx, 6_c_int32_t, temperature_grid)
+       endif
        if (rc == 0) call write_iteration_dump(int(niter))
     endif
   end function iteration_hook
@@ -499,9 +585,9 @@ contains
     path = trim(adjustl(dump_dir))//trim(leaf)
   end function dump_path
 
-  !> One pass over the five unformatted records of an iteration dump, in the reference's order
-  !! (evolve.F90:303-311 write, :358-416 read; isothermal runs have no temperature record):
-  !! niter | photon_loss_all | phih_grid | xh_av | xh_intermed.
+  !> One pass over the unformatted records of an iteration dump, in the reference's order
+  !! (evolve.F90:303-317 write, :358-375 read): niter | photon_loss_all | phih_grid | xh_av | xh_intermed, and in
+  !! non-isothermal builds | phiheat_grid | temperature_grid.
   subroutine dump_records (path, writing, niter)
     character(len=*), intent(in) :: path
     logical, intent(in) :: writing
@@ -513,6 +599,10 @@ contains
        write(iterdump) phih_grid
        write(iterdump) xh_av
        write(iterdump) xh_intermed
+       if (.not.isothermal) then
+          write(iterdump) phiheat_grid
+          write(iterdump) temperature_grid
+       endif
     else
        open(unit=iterdump, file=trim(path), form="unformatted", status="old")
        read(iterdump) niter
@@ -520,6 +610,10 @@ contains
        read(iterdump) phih_grid
        read(iterdump) xh_av
        read(iterdump) xh_intermed
+       if (.not.isothermal) then
+          read(iterdump) phiheat_grid
+          read(iterdump) temperature_grid
+       endif
     endif
     close(iterdump)
   end subroutine dump_records

@@ -34,6 +34,29 @@ def main():
             niter, nbox, loss, conv = rep.niter, rep.sum_nbox_all, rep.photon_loss_all, list(rep.it_conv_flag[:rep.niter])
         out[mode] = dict(niter=niter, nbox=nbox, loss=loss, conv=np.array(conv), xh=b.fetch("xh"), phih=b.fetch("phih_grid"))
         b.close()
+    # non-isothermal step (isothermal=.false.): the heating rates are sharded and all-reduced like Gamma
+    # (evolve.F90:604-609), the temperature evolution is replicated with the global pass
+    from tests._util import load_thermal_tables
+    tt = load_thermal_tables()
+    mt, at = load_case("evolve32_thermal")
+    st = mt["steps"]["step001"]
+    for mode in ("thermal_python", "thermal_native"):
+        b = pkg.HipBackend(mt["n"], *tables, device=0)
+        b.set_step((st["dr1"], st["dr2"], st["dr3"]), st["vol"], st["coldensh_LLS"], st["clumping"])
+        b.set_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"])
+        b.set_redshift(st["zred"])
+        b.set_sources(st["srcpos"], st["normflux"])
+        b.load(ndens=F(at["step001_ndens"]), xh=F(at["step001_xh_before"]), temperature_grid=at["step001_temper_before"])
+        ev = pkg.Evolve(b, comm=dist)
+        if mode == "thermal_python":
+            r = ev.evolve3D(0.0, st["dt"], 0)
+            niter, conv = r["niter"], [e["conv_flag"] for e in r["log"]]
+        else:
+            rep = b.evolve3d_native(st["dt"])
+            niter, conv = rep.niter, list(rep.it_conv_flag[:rep.niter])
+        out[mode] = dict(niter=niter, conv=np.array(conv), xh=b.fetch("xh"), heat=b.fetch("phiheat_grid"),
+                         temper=b.fetch("temperature_grid"))
+        b.close()
     if dist.get_rank() == 0:
         flat = {"%s_%s" % (k, kk): v for k, d in out.items() for kk, v in d.items()}
         np.savez(sys.argv[1], **flat)

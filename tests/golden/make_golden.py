@@ -209,18 +209,22 @@ def read_sm3d(path, dtype):
     return data.reshape(tuple(int(v) for v in n), order="F")
 
 
-def case_refrun(name, n, sources):
+def case_refrun(name, n, sources, variant=None):
     """The reference's OWN program (C2Ray.F90, all 14 slices x 10 steps) on its test problem:
-    the outputs a user of the reference sees.  Used by the drop-in integration test."""
+    the outputs a user of the reference sees.  Used by the drop-in integration test.
+    variant "thermal": the non-isothermal build, with the synthetic cooling table in ./tables/."""
     d = "/tmp/c2ray_golden_refrun"
     shutil.rmtree(d, ignore_errors=True)
     os.makedirs(d + "/results")
+    if variant == "thermal":
+        os.makedirs(d + "/tables")
+        open(d + "/tables/corocool.tab", "w").write(cooling_table()[0])
     open(d + "/answers", "w").write(ANSWERS)
     with open(d + "/test_sources.dat", "w") as f:
         f.write("%d\n" % len(sources))
         for (i, j, k, flux) in sources:
             f.write("%d %d %d %.17e 0.0\n" % (i, j, k, flux))
-    exe = os.path.join(REF, "N%d" % n, "serial", "c2ray_test")
+    exe = os.path.join(REF, "N%d%s" % (n, "_" + variant if variant else ""), "serial", "c2ray_test")
     subprocess.check_call([exe, "answers"], cwd=d, stdout=subprocess.DEVNULL)
     outs = sorted(f for f in os.listdir(d + "/results") if f.startswith("xfrac3D_"))
     nonconv = [int(l.split(":")[1]) for l in open(d + "/results/C2Ray.log") if "Number of non-converged points:" in l]
@@ -228,6 +232,11 @@ def case_refrun(name, n, sources):
     arrays = {"xfrac_" + f[len("xfrac3D_"):-4]: read_sm3d(d + "/results/" + f, np.float64) for f in keep}
     arrays.update({"ionrates_" + f[len("xfrac3D_"):-4]:
                    read_sm3d(d + "/results/IonRates3D_" + f[len("xfrac3D_"):], np.float32) for f in keep[:1]})
+    if variant == "thermal":
+        arrays.update({"temper_" + f[len("xfrac3D_"):-4]:
+                       read_sm3d(d + "/results/Temper3D_" + f[len("xfrac3D_"):], np.float32) for f in keep})
+        arrays.update({"heatrates_" + f[len("xfrac3D_"):-4]:
+                       read_sm3d(d + "/results/HeatRates3D_" + f[len("xfrac3D_"):], np.float32) for f in keep[:1]})
     import hashlib
     sha = {f: hashlib.sha256(open(d + "/results/" + f, "rb").read()).hexdigest()
            for f in keep + ["IonRates3D_" + keep[0][len("xfrac3D_"):]]}
@@ -361,6 +370,8 @@ def main():
         x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 6.0)
         case_evolve("evolve32_thermal", 32, SRC_STD, 3, [1, 3], dens_seed=11, xfield=x, variant="thermal",
                     tfield=temperature_field(32, 5))
+    if want("refrun32thermal"):
+        case_refrun("refrun32_thermal", 32, SRC_STD, variant="thermal")
     if want("sweep64"):
         x = bubble_xfield(64, [(50, 50, 50), (20, 10, 10), (6, 8, 50), (20, 10, 26)], 14.0)
         srcs = SRC_STD[:8] + [(72, 72, 50, 1e58), (20, 10, 90, 1e54)]

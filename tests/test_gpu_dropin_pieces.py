@@ -110,3 +110,55 @@ def test_fortran_evolve3d_restart_from_iteration_dump(rundir, name, sources, den
     assert log["nonconv"] == m["log"]["nonconv"]
     assert np.max(np.abs(gi.rd(d, "step001_xh_after.f64", 32) - a["xh_after"])) < 1e-9
     assert relerr(gi.rd(d, "step001_phih_grid.f64", 32), a["phih_grid"]) < 1e-9
+
+
+# ---- non-isothermal build of the driver (isothermal=.false.; oracle/ref_build.sh 32:thermal) ----------------------
+# The shim reads tables/corocool.tab as setup_cool does, hands the heating tables rad_ini built to the library, and
+# passes phiheat_grid / temperature_grid (an array of type(temperature_states)) through c2r_evolve3d_thermal.
+T_RTOL = 1.5e-7        # one unit in the last place of the f32 temperature_grid (see tests/test_gpu_thermal.py)
+
+
+def test_fortran_nonisothermal_evolve3d_three_steps(rundir):
+    need(32, "thermal")
+    m = json.load(open(os.path.join(GOLDEN, "evolve32_thermal.json")))["steps"]
+    a = np.load(os.path.join(GOLDEN, "evolve32_thermal.npz"))
+    d = gi.run_driver(32, gi.SRC_STD, {"mode": "'evolve'", "nsteps": 3, "dump_first": 1, "dump_last": 3},
+                      dens=gi.density_factor(32, 11), xfield=gi.bubble_xfield(32, BUBBLES, 6.0), variant="thermal",
+                      tfield=gi.temperature_field(32, 5), hip=True, d=rundir)
+    assert "heating and cooling on the device" in open(d + "/results/C2Ray.log").read()
+    log = gi.parse_log(d + "/results/C2Ray.log")
+    for k, tag in ((0, "step001"), (2, "step003")):
+        s = m[tag]
+        assert log[k]["nonconv"] == s["log"]["nonconv"], tag                     # same iteration history
+        kv = gi.read_kv("%s/dump/%s_out.txt" % (d, tag))
+        assert kv["sum_nbox_all"] == s["sum_nbox_all"]
+        assert np.max(np.abs(gi.rd(d, tag + "_xh_after.f64", 32) - a[tag + "_xh_after"])) < 1e-9
+        tg = np.fromfile("%s/dump/%s_temper_after.f32" % (d, tag), dtype=np.float32).reshape(-1, 3)
+        ref = a[tag + "_temper_after"]
+        assert np.max(np.abs(tg.astype(np.float64) / ref - 1)) <= T_RTOL, tag
+        assert np.count_nonzero(tg != ref) <= 1e-3 * tg.size
+        assert np.array_equal(tg[:, 0], tg[:, 2])                                # set_final_temperature_point
+        heat, rheat = gi.rd(d, tag + "_phiheat_grid.f64", 32), a[tag + "_phiheat_grid"]
+        assert np.array_equal(heat == 0, rheat == 0)
+        assert relerr(heat, rheat) < 1e-8
+        for q in ("totrec", "totcollisions"):
+            assert abs(kv[q] / s[q] - 1) < 1e-9
+    if True:    # the temperatures the second step started from are the first step's results
+        t1 = np.fromfile(d + "/dump/step001_temper_after.f32", dtype=np.float32)
+        t2 = np.fromfile(d + "/dump/step002_temper_before.f32", dtype=np.float32)
+        assert np.array_equal(t1, t2)
+
+
+def test_fortran_do_source_nonisothermal_sweep(rundir):
+    """do_source of the shim in a non-isothermal build: the source's heating rates are added to the host phiheat_grid."""
+    need(32, "thermal")
+    m = json.load(open(os.path.join(GOLDEN, "sweep32_thermal.json")))
+    a = np.load(os.path.join(GOLDEN, "sweep32_thermal.npz"))
+    d = gi.run_driver(32, gi.SRC_STD, {"mode": "'sweep'", "ns_dump": m["ns_dump"]}, dens=gi.density_factor(32, 5),
+                      xfield=gi.bubble_xfield(32, BUBBLES, 7.0), variant="thermal", hip=True, d=rundir)
+    kv = gi.read_kv(d + "/dump/step001_sweep.txt")
+    assert kv["sum_nbox"] == m["sum_nbox"]
+    assert relerr(gi.rd(d, "step001_phih_grid.f64", 32), a["phih"]) < 1e-8
+    heat = gi.rd(d, "step001_phiheat_grid.f64", 32)
+    assert np.array_equal(heat == 0, a["phiheat"] == 0) and heat.any()
+    assert relerr(heat, a["phiheat"]) < 1e-8

@@ -42,3 +42,39 @@ def test_test_problem_run_matches_the_reference_outputs(tmp_path, case):
             # the photon-loss fraction (column 7 of PhotonCounts) is a tiny tail quantity of the last iteration
             tol = 5e-2 if (name == "PhotonCounts" and j == 7) else 2e-3
             assert np.all(np.abs(got[:, j] - ref[:, j]) <= tol * np.abs(ref[:, j]) + 1e-12), (name, j)
+
+
+def test_nonisothermal_test_problem_run_matches_the_reference_outputs(tmp_path):
+    """The same 140 steps with heating and cooling (isothermal=.false., the synthetic cooling table): the reference's
+    non-isothermal build of its own program against the harness on the GPU -- xfrac3D, Temper3D and HeatRates3D files."""
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    from c2ray3dm_amd.harness import run_test_problem
+    from tests.golden.inputs import cooling_table
+    m = json.load(open(os.path.join(GOLDEN, "refrun32_thermal.json")))
+    a = np.load(os.path.join(GOLDEN, "refrun32_thermal.npz"))
+    src = str(tmp_path / "test_sources.dat")
+    with open(src, "w") as f:
+        f.write("%d\n" % len(m["sources"]))
+        for (i, j, k, flux) in m["sources"]:
+            f.write("%d %d %d %.17e 0.0\n" % (i, j, k, flux))
+    tab = str(tmp_path / "corocool.tab")
+    open(tab, "w").write(cooling_table()[0])
+    res = str(tmp_path / "results")
+    reports = run_test_problem(m["n"], src, res, cooling_table=tab)
+    assert sorted(f for f in os.listdir(res) if f.startswith("xfrac3D_")) == m["outputs"]
+    assert sorted(f[len("Temper3D_"):] for f in os.listdir(res) if f.startswith("Temper3D_")) == [f[len("xfrac3D_"):] for f in m["outputs"]]
+    assert all(r["converged"] for r in reports)
+    niter = sum(r["niter"] for r in reports)
+    assert abs(niter - m["total_outer_iterations"]) <= 0.01 * m["total_outer_iterations"]
+    for f in m["kept"]:
+        z = f[len("xfrac3D_"):-4]
+        x = pkg.fileio.read_sm3d(os.path.join(res, f))
+        assert np.max(np.abs(x - a["xfrac_" + z])) < 1e-6, f
+        t = pkg.fileio.read_sm3d(os.path.join(res, "Temper3D_%s.bin" % z))
+        assert np.max(np.abs(t / a["temper_" + z] - 1)) < 1e-5, f          # (harness scalars agree to ~1e-9, see the module docstring)
+    z = m["kept"][0][len("xfrac3D_"):-4]
+    h = pkg.fileio.read_sm3d(os.path.join(res, "HeatRates3D_%s.bin" % z))
+    ref = a["heatrates_" + z]
+    assert np.array_equal(h == 0, ref == 0) and np.max(np.abs(h - ref)) <= 1e-4 * ref.max()
+    assert a["temper_" + z].min() < 8000 < 15000 < a["temper_" + z].max()   # cells cooled adiabatically and were photo-heated

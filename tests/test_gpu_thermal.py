@@ -211,6 +211,9 @@ def test_nonisothermal_context_needs_the_redshift(pkg, tables):
     b.set_step((m["dr1"], m["dr2"], m["dr3"]), m["vol"], m["coldensh_LLS"], m["clumping"])
     b.set_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"])
     b.set_sources(m["srcpos"], m["normflux"]); b.set_rank(0, 1)
+    b.load(ndens=F(a["ndens"]), xh=F(a["xh"]), temperature_grid=np.full(m["n"] ** 3, 1e4, dtype=np.float32))
+    b.begin_step(); b.zero_rates()
+    b.pass_sources()                                  # the sweep does not need it
     with pytest.raises(pkg.C2RayHipError, match="c2r_set_redshift"):
-        b.pass_sources()
+        b.global_pass(m["dt"])                        # cosmo_cool does
     b.close()

@@ -30,3 +30,14 @@ def test_two_ranks_on_one_gpu_match_reference(tmp_path):
         assert np.max(np.abs(got[mode + "_xh"] - F(a["step001_xh_after"]))) < 1e-9
         ref = F(a["step001_phih_grid"])
         assert np.max(np.abs(got[mode + "_phih"] - ref) / np.maximum(ref, 1e-60)) < 1e-8
+    # the non-isothermal step on two ranks (heating rates sharded + all-reduced, evolve.F90:604-609)
+    mt, at = load_case("evolve32_thermal")
+    st = mt["steps"]["step001"]
+    for mode in ("thermal_python", "thermal_native"):
+        assert int(got[mode + "_niter"]) == st["niter"]
+        assert list(got[mode + "_conv"]) == st["log"]["nonconv"]
+        assert np.max(np.abs(got[mode + "_xh"] - F(at["step001_xh_after"]))) < 1e-9
+        ref = F(at["step001_phiheat_grid"])
+        assert np.array_equal(got[mode + "_heat"] == 0, ref == 0)
+        assert np.max(np.abs(got[mode + "_heat"] - ref) / np.maximum(ref, 1e-60)) < 1e-8
+        assert np.max(np.abs(got[mode + "_temper"].astype(np.float64) / at["step001_temper_after"] - 1)) <= 1.5e-7
