@@ -28,10 +28,14 @@ def test_random_pass_vs_oracle(pkg, tables, sweep_mode, seed):
 @pytest.mark.parametrize("seed", range(3000, 3020))
 def test_random_whole_step_vs_oracle(pkg, tables, sweep_mode, seed):
     """Whole evolve3D steps to convergence on random small meshes (tests/_fuzz_steps.py: clumping grids, the three LLS
-    types, cold / structured / highly ionized starts): every integer of the step and the ionized fractions."""
+    types, cold / structured / highly ionized starts, one in three non-isothermal): every integer of the step, the
+    ionized fractions and the temperatures."""
     from tests._fuzz_steps import run_step_case
     r = run_step_case(seed, pkg, tables, sweep_mode == "fast")
     assert r["niter"][0] == r["niter"][1] and r["converged"][0] == r["converged"][1], (seed, r)
     assert r["conv"][0] == r["conv"][1], (seed, r["mesh"])
     assert r["nbox"][0] == r["nbox"][1], (seed, r["mesh"])
     assert r["dx"] < tol("x"), (seed, r["mesh"], r["dx"])
+    # a few units in the last place of the f32 temperature_grid: one per global pass at most, and a step that does not
+    # converge repeats the pass 101 times (worst of 51 non-isothermal cases in 150: 2.1e-7, such a step)
+    assert r["dtemp"] <= 5e-7, (seed, r["mesh"], r["dtemp"])
