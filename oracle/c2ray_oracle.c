@@ -9,7 +9,9 @@
  * Parity status: PINNED.  Every function here is checked in tests/test_oracle.py
  * against fixtures under tests/golden/ that were produced by the UNMODIFIED
  * reference compiled with amdflang (oracle/ref_build.sh, oracle/ref_driver.F90,
- * tests/golden/make_golden.py).
+ * tests/golden/make_golden.py).  The non-isothermal branches (heat_thick != NULL) are pinned the same way against the
+ * reference rebuilt with isothermal=.false.; the cooling table that build reads is synthetic (the reference
+ * repository lacks tables/corocool.tab) -- tests/test_oracle_thermal.py, DESIGN.md s8a.
  *
  * Each function cites the reference file:line it restates.  Operation order and
  * operand widths follow the reference statement by statement, because the
