@@ -129,6 +129,9 @@ def main():
                     help="cost-balanced source shares (by the previous pass) instead of the static stride")
     ap.add_argument("--deterministic", action="store_true",
                     help="per-source Gamma grids reduced in source order instead of f64 atomics")
+    ap.add_argument("--thermal", action="store_true",
+                    help="time the non-isothermal variant (isothermal=.false.: heating rates in the sweep, thermal.f90 in the "
+                         "global pass; synthetic cooling table, T = 1e4 K start).  Not the headline configuration; no CPU baseline")
     args = ap.parse_args()
 
     import torch
@@ -170,6 +173,15 @@ def main():
     b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], s["clumping"], s["temper"])
     b.set_sources(srcpos, normflux)
     b.load(ndens=nd, xh=xh)
+    if args.thermal:
+        from tests.golden.inputs import cooling_table
+        hk, hn = pkg._capi.build_heat_tables()
+        _, lt, ll = cooling_table()
+        b.set_thermal(hk, hn, lt, ll)
+        b.set_redshift(s["zred"])
+        b.load(temperature_grid=np.full(n ** 3, 1e4, dtype=np.float32))
+        args.no_cpu_baseline = True
+    bytes_per_visit = SWEEP_BYTES_PER_VISIT + (16 if args.thermal else 0)      # + phiheat_grid read-modify-write
     ev = pkg.Evolve(b, comm=dist if world > 1 else None, balance=args.balance)
     b.begin_step()
 
@@ -241,7 +253,7 @@ def main():
         vis_rank = max(0.0, vis_rank - fused_visited)
         if prof_mode == 0:                         # no kernel timing (few sources): the sweep's share of the wall time bounds it
             sweep_s, launches = dt_wall, 1
-        achieved = SWEEP_BYTES_PER_VISIT * vis_rank / sweep_s / 1e9 if sweep_s > 0 else 0.0
+        achieved = bytes_per_visit * vis_rank / sweep_s / 1e9 if sweep_s > 0 else 0.0
         traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", "TRAFFIC.json")
         if os.path.exists(tpath):      # PMC counters of the same command, from the latest committed profile
@@ -256,7 +268,7 @@ def main():
             "config": {"workload": "%d^3 mesh, %d sources (seeded), reference test problem at z=9 pre-ionised to "
                                    "x=%.3f, %s density, one evolve3D outer iteration per step (sweep all sources + "
                                    "all-reduce + global chemistry pass)" % (n, S, args.x_init, "cubep3m-file" if args.density_file else args.density),
-                       "mesh": n, "sources": S, "sweep_mode": args.sweep_mode, "gamma_accumulation": "ordered" if args.deterministic else "atomic", "sources_per_gpu": len(pkg.static_source_share(S, 0, world)),
+                       "mesh": n, "sources": S, "sweep_mode": args.sweep_mode, "isothermal": not args.thermal, "gamma_accumulation": "ordered" if args.deterministic else "atomic", "sources_per_gpu": len(pkg.static_source_share(S, 0, world)),
                        "parallelism": "sources sharded over %d GPU(s), RCCL all-reduce of Gamma" % world,
                        "visited_cell_sources_per_step": visited_all / args.steps,
                        "visited_per_s": visited_all / dt_wall,
@@ -266,7 +278,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_sweep_shell_fast" if args.sweep_mode == "fast" else "k_sweep_shell", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note,
-                         "algorithmic_bytes_per_launch": SWEEP_BYTES_PER_VISIT * vis_rank / launches,
+                         "algorithmic_bytes_per_launch": bytes_per_visit * vis_rank / launches, "algorithmic_bytes_per_visit": bytes_per_visit,
                          "avg_launch_ms": prof["sweep_ms"] / launches, "launches": prof["sweep_launches"],
                          "timing": {0: "off (few sources: launches of a few microseconds); achieved = algorithmic bytes of the per-shell launches / whole step wall time", 1: "HIP events around every k_sweep_shell launch",
                                     2: "HIP events around every sub-box (5 launches + the small kernels between them)"}[prof_mode],
