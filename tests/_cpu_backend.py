@@ -39,12 +39,25 @@ class OracleBackend:
 
     def accept(self):
         self.xh[:] = self.xh_intermed
+        if self.thermal:                                    # set_final_temperature_point, evolve.F90:220
+            self.o.temper_grid[:, 0] = self.o.temper_grid[:, 2]
 
     def sum_xh_intermed(self):
         return self.o.sum(self.xh_intermed)
 
     def zero_rates(self):
         self.phih_grid[:] = 0.0
+        if self.thermal:
+            self.o.phiheat[:] = 0.0                         # evolve.F90:435
+
+    @property
+    def thermal(self):
+        """Non-isothermal oracle (Oracle.enable_thermal): phiheat and temper_grid live in the oracle object."""
+        return getattr(self.o, "heat_thick", None) is not None
+
+    def heat_tensor(self):
+        import torch
+        return torch.from_numpy(self.o.phiheat) if self.thermal else None
 
     def set_source_share(self, indices=None):
         self.share = None if indices is None else np.asarray(indices, dtype=np.int64)

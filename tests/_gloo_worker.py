@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch.distributed as dist   # noqa: E402
 import __graft_entry__ as g        # noqa: E402
-from tests._util import F, load_case, oracle_for, load_tables   # noqa: E402
+from tests._util import F, load_case, oracle_for, load_tables, thermal_oracle_for   # noqa: E402
 from tests._cpu_backend import OracleBackend                   # noqa: E402
 
 
@@ -20,6 +20,14 @@ def main():
     b = OracleBackend(oracle_for(s, tables, m["n"]), F(a["step001_ndens"]), F(a["step001_xh_before"]),
                       s["srcpos"], s["normflux"])
     balance = len(sys.argv) > 2 and sys.argv[2] == "balance"
+    extra = {}
+    if len(sys.argv) > 2 and sys.argv[2] == "thermal":      # non-isothermal step: the heating rates are all-reduced too
+        m, a = load_case("evolve32_thermal")
+        s = m["steps"]["step001"]
+        tg = np.ascontiguousarray(a["step001_temper_before"]).copy()
+        b = OracleBackend(thermal_oracle_for(s, tables, tg, m["n"]), F(a["step001_ndens"]), F(a["step001_xh_before"]),
+                          s["srcpos"], s["normflux"])
+        extra = dict(temper=tg, heat=b.o.phiheat)
     r = pkg.Evolve(b, comm=dist, balance=balance).evolve3D(0.0, s["dt"], 0)
     import torch
     mine = torch.from_numpy(b.xh.copy())
@@ -28,7 +36,7 @@ def main():
     if dist.get_rank() == 0:
         np.savez(sys.argv[1], niter=r["niter"], sum_nbox_all=r["sum_nbox_all"],
                  photon_loss_all=r["photon_loss_all"], xh=b.xh, phih=b.phih_grid,
-                 xh_rank1=gathered[1].numpy())
+                 xh_rank1=gathered[1].numpy(), conv=np.array([e["conv_flag"] for e in r["log"]]), **extra)
     dist.barrier()
     dist.destroy_process_group()
 

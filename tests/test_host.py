@@ -241,3 +241,27 @@ def test_two_ranks_gloo_equals_one_rank(pkg, tmp_path, mode):
     # the 1e-16 re-association noise of the rank-wise sum grows to ~1e-10 over the iterations
     assert relerr(got["phih"], b.phih_grid, floor=1e-60) < 1e-8
     assert np.array_equal(got["xh_rank1"], got["xh"])       # ranks agree bit for bit
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_gloo_nonisothermal_step(pkg, tmp_path):
+    """The non-isothermal step on two ranks over gloo (CPU test double): the heating rates are sharded with the sources and
+    all-reduced next to Gamma (evolve.F90:604-609), the temperature evolution is replicated with the global pass, and
+    Evolve.accept finalises the temperatures -- against the reference's fixture."""
+    script = os.path.join(ROOT, "tests", "_gloo_worker.py")
+    out = tmp_path / "out.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29733", script, str(out), "thermal"],
+                          env=env, cwd=ROOT, timeout=280)
+    got = np.load(out)
+    m, a = load_case("evolve32_thermal")
+    s = m["steps"]["step001"]
+    assert int(got["niter"]) == s["niter"] and list(got["conv"]) == s["log"]["nonconv"]
+    assert int(got["sum_nbox_all"]) == s["sum_nbox_all"]
+    assert np.max(np.abs(got["xh"] - F(a["step001_xh_after"]))) < 1e-12
+    assert np.max(np.abs(got["temper"].astype(np.float64) / a["step001_temper_after"] - 1)) <= 1.5e-7
+    assert np.array_equal(got["temper"][:, 0], got["temper"][:, 2])
+    ref = F(a["step001_phiheat_grid"])
+    assert np.array_equal(got["heat"] == 0, ref == 0) and relerr(got["heat"], ref, floor=1e-60) < 1e-8
+    assert np.array_equal(got["xh_rank1"], got["xh"])
