@@ -249,7 +249,9 @@ int  c2r_sum(c2r_ctx *ctx, int32_t which, double *sum);
  * ns = 1..NumSrc as in c2r_do_source. */
 int  c2r_do_source_host(c2r_ctx *ctx, int32_t ns, const float *ndens, const double *xh_av,
                         double *phih_grid, double *coldensh_out, double *photon_loss_src, int32_t *nbox);
-/* global_pass(conv_flag,dt) (evolve.F90:499): evolve0D_global over the mesh with the host arrays. */
+/* global_pass(conv_flag,dt) (evolve.F90:499): evolve0D_global over the mesh with the host arrays.  In a non-isothermal
+ * context phiheat_grid and temperature_grid are used as they lie on the device (c2r_upload arrays 5 and 6 first, c2r_download
+ * array 6 afterwards). */
 int  c2r_global_pass_host(c2r_ctx *ctx, double dt, const float *ndens, const double *xh, double *xh_av,
                           double *xh_intermed, const double *phih_grid, int64_t *conv_flag);
 
@@ -279,7 +281,8 @@ int  c2r_evolve3d_thermal(c2r_ctx *ctx, double dt, int32_t restart_niter, double
                           float *temperature_grid, c2r_report *rep);
 /* Called after every outer iteration (global pass done, stream idle) at the point where the
  * reference checks the wall clock and writes an iteration dump (evolve.F90:271-275); the hook may
- * c2r_download() arrays 2,3,4 (xh_av, xh_intermed, phih_grid).  Non-zero return aborts (C2R_ECALLBACK). */
+ * c2r_download() arrays 2,3,4 (xh_av, xh_intermed, phih_grid) and, in a non-isothermal run, 5 and 6 (phiheat_grid,
+ * temperature_grid: the two extra records of such a dump, evolve.F90:314-317).  Non-zero return aborts (C2R_ECALLBACK). */
 typedef int (*c2r_iteration_fn)(void *user, int32_t niter, double photon_loss_all);
 int  c2r_set_iteration_hook(c2r_ctx *ctx, c2r_iteration_fn fn, void *user);
 
