@@ -217,3 +217,45 @@ def test_nonisothermal_context_needs_the_redshift(pkg, tables):
     with pytest.raises(pkg.C2RayHipError, match="c2r_set_redshift"):
         b.global_pass(m["dt"])                        # cosmo_cool does
     b.close()
+
+
+def test_pass_and_global_pass_at_128_vs_oracle(pkg, tables):
+    """BASELINE's 128^3 mesh, structured density and ionization, temperatures 100 K .. 1e5 K, six sources: one sweep
+    (Gamma, heating rates) and one non-isothermal global pass against the oracle, cell by cell."""
+    from tests.test_gpu_fullsize import field_case
+    from tests._util import oracle_for
+    n, nsrc, seed = 128, 6, 61
+    s, nd, xh = field_case(pkg, n, seed, "bubbles")
+    s = dict(s)
+    pos, nf = pkg.seeded_sources(n, nsrc, seed=seed)
+    rng = np.random.default_rng(seed)
+    t0 = np.ascontiguousarray(np.repeat((10.0 ** rng.uniform(2.0, 5.0, n ** 3)).astype(np.float32)[:, None], 3, axis=1))
+    tgo = t0.copy()
+    tt = load_thermal_tables()
+    o = oracle_for(s, tables, n)
+    o.enable_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"], s["zred"], tgo)
+    w, wh = o.enable_tolerance_weight(), o.enable_heat_tolerance_weight()
+    ophih = np.zeros(n ** 3)
+    oloss, onb, ovis = o.pass_sources(nd, xh, ophih, pos, nf)
+    xav, xint = xh.copy(), xh.copy()
+    oconv = o.global_pass(s["dt"], nd, xh, xav, xint, ophih)
+    b = pkg.HipBackend(n, *tables, device=0)
+    b.set_step((s["dr1"], s["dr2"], s["dr3"]), s["vol"], s["coldensh_LLS"], s["clumping"])
+    b.set_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"])
+    b.set_redshift(s["zred"])
+    b.set_sources(pos, nf); b.set_rank(0, 1)
+    b.load(ndens=nd, xh=xh, temperature_grid=t0)
+    b.begin_step(); b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    assert (nbox, vis) == (onb, ovis)
+    assert abs(loss - oloss) <= tol("loss") * abs(oloss) + 1e-300
+    assert_gamma(b.fetch("phih_grid"), ophih, w, "128^3")
+    assert_heat(b.fetch("phiheat_grid"), o.phiheat, wh, "128^3")
+    conv, _ = b.global_pass(s["dt"])
+    assert conv == oconv
+    assert np.max(np.abs(b.fetch("xh_intermed") - xint)) < tol("x")
+    tg = b.fetch("temperature_grid")
+    assert_temper(tg, tgo, "128^3")
+    assert np.array_equal(tg[:, 0], t0[:, 0])                         # %current is only set on convergence
+    assert np.max(np.abs(tg[:, 2].astype(np.float64) / t0[:, 0] - 1)) > 0.5          # some cells heated or cooled a lot
+    b.close()
