@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 def main():
     ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-    fast = len(sys.argv) > 3 and sys.argv[3] == "fast"
+    fast = (len(sys.argv) > 3 and sys.argv[3] == "fast") or (len(sys.argv) <= 3 and os.environ.get("C2R_SWEEP_MODE") == "1")
     import __graft_entry__ as g
     from tests._util import load_tables, gamma_ok
     from tests._fuzz import run_case
