@@ -18,6 +18,7 @@ using namespace c2r;
 namespace {
 
 constexpr int kSumBlocks = 1024;      // fixed grid of every deterministic reduction
+constexpr int kFoldLossMax = 64;      // up to this many active sources k_box_decide also sums the last shell's loss partials
 constexpr int kFusedQmax = 10;        // sub-boxes ending at q <= this run in k_sweep_box_fused (one launch per sub-box)
 
 struct Ctx {
@@ -413,11 +414,14 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
 #undef C2R_LAUNCH_SWEEP_H
             }
             if (ctx->prof == 1) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(1); }
-            // the partials of the sub-box's last shell are summed by k_box_decide itself
-            if (sa.has_boundary && q < q1)
+            // the partials of the sub-box's last shell are summed by k_box_decide itself when few sources are active (one
+            // launch less where launches are all there is); with many, its single workgroup would read 6 x tiles partials
+            // for every source (2.5 MB through one CU: 89 us per sub-box, 1.6 % of the bench step) -- one block per source then
+            const bool fold = bound <= kFoldLossMax;
+            if (sa.has_boundary && (q < q1 || !fold))
                 hipLaunchKernelGGL(k_loss_reduce, dim3(bound), dim3(256), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
                                    ctx->d_loss_partial, 6 * sa.tiles_max, ctx->d_loss_acc);
-            if (q == q1 && sa.has_boundary) last_bps = 6 * sa.tiles_max;
+            if (q == q1 && sa.has_boundary && fold) last_bps = 6 * sa.tiles_max;
         }
         if (ctx->prof == 2) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(in_box); }
         }
