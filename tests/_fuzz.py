@@ -4,7 +4,8 @@ sources anywhere (also outside [1,N]), rates over 6 decades, density and ionizat
 both fully and barely ionized gas, so that sub-boxes end anywhere between the first and the clipped last; the
 row-group tiling of k_sweep_shell (three rows per thread, groups per sign class) meets every remainder; one case in
 two also draws a non-default switch: type_of_LLS 2 or 3, source-ordered (deterministic) Gamma accumulation, one
-source per batch."""
+source per batch; three in ten run in a non-isothermal context and compare the heating rates too (asserted here, within
+the Gamma tolerance with the heating weight W_heat)."""
 import numpy as np
 
 
@@ -38,7 +39,8 @@ def make_case(seed, pkg):
     r_max = float(dr[0] * rng.uniform(2.0, 0.7 * max(mesh))) if lls_type == 3 else 0.0
     deterministic = bool(rng.random() < 0.25)
     scratch = int(rng.choice([0, 0, 1]))     # 1 byte: one source per batch
-    return dict(mesh=mesh, dr=dr, vol=dr[0] * dr[1] * dr[2], nd=nd, xh=xh, pos=pos, nf=nf, lls=lls, k=k,
+    heating = bool(rng.random() < 0.3)       # a non-isothermal context: the sweep also accumulates the heating rates
+    return dict(heating=heating, mesh=mesh, dr=dr, vol=dr[0] * dr[1] * dr[2], nd=nd, xh=xh, pos=pos, nf=nf, lls=lls, k=k,
                 lls_type=lls_type, lls_grid=lls_grid, r_max=r_max, deterministic=deterministic, scratch=scratch)
 
 
@@ -50,17 +52,37 @@ def run_case(seed, pkg, tables, fast):
     mesh, ncell = c["mesh"], c["nd"].size
     o = Oracle(mesh, c["dr"], c["vol"], c["lls"], *tables, lls_type=c["lls_type"], R_max_LLS=c["r_max"], lls_grid=c["lls_grid"])
     w = o.enable_tolerance_weight()
+    wh = None
+    if c["heating"]:
+        from tests._util import load_thermal_tables
+        tt = load_thermal_tables()
+        o.enable_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"], 9.0, np.zeros((ncell, 3), dtype=np.float32))
+        wh = o.enable_heat_tolerance_weight()
     phih_o = np.zeros(ncell)
     oloss, onb, ovis = o.pass_sources(c["nd"], c["xh"], phih_o, c["pos"], c["nf"])
     w = w.copy()
+    heat_o = o.phiheat.copy() if c["heating"] else None
+    wh = wh.copy() if c["heating"] else None
     b = pkg.HipBackend(mesh, *tables, device=0, fast=fast, deterministic=c["deterministic"], scratch_bytes=c["scratch"])
     b.set_step(c["dr"], c["vol"], c["lls"], 1.0)
     if c["lls_type"] != 1:
         b.set_lls(c["lls_type"], c["lls_grid"], c["r_max"])
     b.set_sources(c["pos"], c["nf"]); b.set_rank(0, 1); b.load(ndens=c["nd"], xh=c["xh"])
+    if c["heating"]:
+        b.set_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"])
     b.begin_step(); b.zero_rates()
     loss, nbox, vis = b.pass_sources()
     phih = b.fetch("phih_grid")
+    heat_w = 0.0
+    if c["heating"]:
+        heat = b.fetch("phiheat_grid")
+        assert np.array_equal(heat == 0, heat_o == 0), (seed, mesh)
+        hz = heat_o != 0
+        from tests._util import TOL
+        t = TOL["fast" if fast else "exact"]
+        excess = np.abs(heat - heat_o) - (t["gamma_rtol"] * heat_o + t["gamma_wtol"] * wh)
+        assert excess.max() <= 0, (seed, mesh, "heating rate out of tolerance", float(excess.max()))
+        heat_w = float(np.max(np.abs(heat - heat_o)[hz] / wh[hz])) if hz.any() else 0.0
     assert (nbox, vis) == (onb, ovis), (seed, mesh, nbox, onb, vis, ovis)
     assert np.array_equal(phih == 0, phih_o == 0), (seed, mesh)
     k = c["k"]
@@ -71,7 +93,7 @@ def run_case(seed, pkg, tables, fast):
     assert np.array_equal(cd == 0, cdo == 0), (seed, mesh, k)
     d = np.abs(phih - phih_o)
     nz = phih_o != 0
-    return dict(mesh=mesh, nsrc=len(c["nf"]), nbox=nbox, visited=vis, variant="lls%d%s%s" % (c["lls_type"], " det" if c["deterministic"] else "", " batches" if c["scratch"] else ""),
+    return dict(mesh=mesh, nsrc=len(c["nf"]), nbox=nbox, visited=vis, variant="lls%d%s%s%s" % (c["lls_type"], " det" if c["deterministic"] else "", " batches" if c["scratch"] else "", " heat" if c["heating"] else ""), heat_w=heat_w,
                 loss=abs(loss - oloss) / max(abs(oloss), 1e-300),
                 cd=float(np.max(np.abs(cd - cdo) / np.maximum(cdo, 1e-300))),
                 gamma_rel=float(np.max(d[nz] / phih_o[nz])) if nz.any() else 0.0,

@@ -19,7 +19,7 @@ def main():
     from tests._fuzz import run_case
     pkg = g.load_package()
     tables = load_tables()
-    worst = {"gamma_rel": 0.0, "gamma_w": 0.0, "cd": 0.0, "loss": 0.0}
+    worst = {"gamma_rel": 0.0, "gamma_w": 0.0, "cd": 0.0, "loss": 0.0, "heat_w": 0.0}      # heat_w: |d heat| / W_heat in the cases with heating
     for case in range(ncase):
         r = run_case(seed0 + case, pkg, tables, fast)
         if os.environ.get("C2R_FUZZ_CALIBRATE") != "1":        # calibration runs only print
