@@ -80,6 +80,7 @@ struct Ctx {
     double *d_planes = nullptr;
     int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr;
     double *d_gbox = nullptr;   // deterministic mode: [batch_cap][2][ncell]
+    double *d_gbox_h = nullptr; // ... and the per-source heating rates of a non-isothermal run
     // one device block + one pinned staging block hold the small per-batch arrays below (one copy per batch)
     char *d_batch = nullptr, *h_batch = nullptr; size_t batch_bytes = 0;
     int *d_active[2] = {nullptr, nullptr};
@@ -130,10 +131,10 @@ size_t grid_bytes(const Ctx *ctx, int which) { return ctx->ncell * (which == 0 ?
 
 void free_sweep_scratch(Ctx *ctx)
 {
-    hipFree(ctx->d_planes); hipFree(ctx->d_gbox); hipFree(ctx->d_batch); hipFree(ctx->d_loss_partial);
+    hipFree(ctx->d_planes); hipFree(ctx->d_gbox); hipFree(ctx->d_gbox_h); hipFree(ctx->d_batch); hipFree(ctx->d_loss_partial);
     if (ctx->h_batch) hipHostFree(ctx->h_batch);
     ctx->d_batch = ctx->h_batch = nullptr; ctx->d_nactive = nullptr;
-    ctx->d_planes = nullptr; ctx->d_gbox = nullptr; ctx->d_srcpos_b = nullptr; ctx->d_srcw_b = nullptr; ctx->d_nflux_b = nullptr;
+    ctx->d_planes = nullptr; ctx->d_gbox = nullptr; ctx->d_gbox_h = nullptr; ctx->d_srcpos_b = nullptr; ctx->d_srcw_b = nullptr; ctx->d_nflux_b = nullptr;
     ctx->d_active[0] = ctx->d_active[1] = nullptr;
     ctx->d_loss_partial = ctx->d_loss_acc = ctx->d_final_loss = nullptr; ctx->d_final_nbox = nullptr;
     ctx->batch_cap = 0; ctx->batch_want = 0;
@@ -153,7 +154,7 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
     if (want <= ctx->batch_cap || want <= ctx->batch_want) return C2R_OK;
     free_sweep_scratch(ctx);
     const size_t per_src = 2 * 6 * ctx->PP * sizeof(double) + (size_t)6 * ctx->tiles_cap * sizeof(double) + 64 +
-                           (ctx->prm.deterministic_rates ? 2 * ctx->ncell * sizeof(double) : 0);
+                           (ctx->prm.deterministic_rates ? (ctx->thermal ? 4 : 2) * ctx->ncell * sizeof(double) : 0);
     size_t budget = ctx->prm.scratch_bytes;
     if (budget == 0) {
         size_t fr = 0, tot = 0;
@@ -165,6 +166,7 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
     cap = std::min(cap, 65535);                 // grid.z of k_sweep_shell
     HIP_TRY(hipMalloc(&ctx->d_planes, (size_t)cap * 2 * 6 * ctx->PP * sizeof(double)));
     if (ctx->prm.deterministic_rates) HIP_TRY(hipMalloc(&ctx->d_gbox, (size_t)cap * 2 * ctx->ncell * sizeof(double)));
+    if (ctx->prm.deterministic_rates && ctx->thermal) HIP_TRY(hipMalloc(&ctx->d_gbox_h, (size_t)cap * 2 * ctx->ncell * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_loss_partial, (size_t)cap * 6 * ctx->tiles_cap * sizeof(double)));
     // small per-batch arrays: doubles first, then ints
     //   nflux[cap] final_loss[cap] loss_acc[cap] | srcpos[3cap] srcw[3cap] active0[cap] active1[cap] final_nbox[cap] nactive[2]
@@ -227,7 +229,7 @@ KParams make_kparams(const Ctx *ctx)
     k.exact_udiv = udiv_ok(p.dlogtau) && udiv_ok(ctx->dr[0]);
     k.R = ctx->R; k.P = ctx->P; k.PP = ctx->PP;
     k.nhi = ctx->d_nhi; k.nhi_T = ctx->d_nhi_T; k.phih = (double *)ctx->grid[4]; k.phih_T = ctx->d_phih_T;
-    k.gbox = ctx->d_gbox;
+    k.gbox = ctx->d_gbox; k.gbox_h = ctx->thermal ? ctx->d_gbox_h : nullptr;
     k.lls_type = ctx->lls_type; k.R_max2 = ctx->R_max_LLS * ctx->R_max_LLS; k.lls = ctx->d_lls; k.lls_T = ctx->d_lls_T;
     k.thick = ctx->d_thick; k.thin = ctx->d_thin; k.logtab = ctx->d_logtab;
     k.hthick = ctx->d_hthick; k.hthin = ctx->d_hthin; k.heat = (double *)ctx->grid[5]; k.heat_T = ctx->d_heat_T;
@@ -486,7 +488,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
     }
     if (ctx->d_gbox)
         hipLaunchKernelGGL(k_gamma_reduce, dim3((p.mesh[0] + 255) / 256, p.mesh[1], p.mesh[2]), dim3(256), 0, st, k, count,
-                           ctx->d_final_nbox, p.subboxsize, (double *)ctx->grid[4]);
+                           ctx->d_final_nbox, p.subboxsize, (double *)ctx->grid[4], ctx->thermal ? (double *)ctx->grid[5] : nullptr);
     hipLaunchKernelGGL(k_batch_totals, dim3(1), dim3(1024), 0, st, count, ctx->d_final_loss, ctx->d_final_nbox,
                        ctx->d_photon_loss, ctx->d_sum_nbox, first_of_pass ? 1 : 0, &ctx->d_hsc->photon_loss,
                        &ctx->d_hsc->sum_nbox);
@@ -864,6 +866,7 @@ int c2r_set_thermal(c2r_ctx *c, const c2r_thermal_params *t, const double *heat_
     HIP_TRY(hipSetDevice(ctx->prm.device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ++ctx->gen;
+    if (ctx->prm.deterministic_rates && (t != nullptr) != ctx->thermal) free_sweep_scratch(ctx);   // per-source heating grids come and go
     if (!t) { ctx->thermal = false; return C2R_OK; }     // back to the isothermal path (the arrays stay allocated)
     if (!heat_thick || !heat_thin || !cie_cool) FAIL(C2R_EINVAL, "non-isothermal run needs the heating tables and the cooling curve");
     if (n != ctx->prm.numtau + 1) FAIL(C2R_EINVAL, "table length must be numtau+1");

@@ -48,6 +48,7 @@ struct KParams {
     int lls_type;              // 1 homogeneous, 2 per-cell grid, 3 hard barrier
     double R_max2;             // R_max_LLS^2 (type 3)
     const float *lls, *lls_T;  // LLS_grid and its (x,y)-transposed replica (type 2)
+    double *gbox_h;            // ... and per-source heating rates of a non-isothermal run, same layout (null: isothermal)
     double *gbox;              // deterministic mode: [S_batch][2][ncell] per-source Gamma ([0] x-fastest cells of
                                // z/y faces, [1] y-fastest cells of x faces); null: atomics into phih/phih_T
     const double *thick, *thin;
@@ -321,8 +322,9 @@ __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0
         double heat = 0.0;
         gamma = photoion<HEAT>(p, ltab, cd_in, cd_out, vol_ph, nflux, p_out, &heat) / nhi;
         if (!p.gbox) atomicAdd(&p.phih[id], gamma);
-        if (HEAT && heat != 0.0) atomicAdd(&p.heat[id], heat);       // evolve_point.F90:285-286 (always by atomics)
-    }
+        if (HEAT && !p.gbox && heat != 0.0) atomicAdd(&p.heat[id], heat);       // evolve_point.F90:285-286
+        if (HEAT && p.gbox) p.gbox_h[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = heat;
+    } else if (HEAT && p.gbox) p.gbox_h[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = 0.0;
     if (p.gbox) p.gbox[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = gamma;
     // degenerate meshes only: the source cell itself sits on the sub-box surface
     if (boxR0 == 0 || boxR1 == 0 || boxR2 == 0 || boxL0 == 0 || boxL1 == 0 || boxL2 == 0)
@@ -524,12 +526,12 @@ __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs 
     }
 
     const double nflux = p.normflux[s];
-    double gamma = 0.0;
+    double gamma = 0.0, heat = 0.0;
     if (!cs.stop_far && !(cs.cd_in > p.max_coldensh) && nflux > 0.0) {
-        double p_out, heat = 0.0;
+        double p_out;
         gamma = fdiv(photoion<HEAT>(p, ltab, cs.cd_in, cd_out, cs.vol_ph, nflux, p_out, &heat), cs.nhi);
         if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[cs.id], gamma);
-        if (HEAT && heat != 0.0) atomicAdd(&(xf ? p.heat_T : p.heat)[cs.id], heat);      // evolve_point.F90:285-286
+        if (HEAT && !DET && heat != 0.0) atomicAdd(&(xf ? p.heat_T : p.heat)[cs.id], heat);      // evolve_point.F90:285-286
         if (sa.has_boundary) {
             const bool bnd = dl.d0 == sa.boxR[0] || dl.d1 == sa.boxR[1] || dl.d2 == sa.boxR[2] ||
                              dl.d0 == -sa.boxL[0] || dl.d1 == -sa.boxL[1] || dl.d2 == -sa.boxL[2];
@@ -538,6 +540,7 @@ __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs 
     }
     // deterministic mode: every visited cell records its rate (zero included) for k_gamma_reduce
     if (DET) p.gbox[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + cs.id] = gamma;
+    if (DET && HEAT) p.gbox_h[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + cs.id] = heat;
     return loss;
 }
 
@@ -831,7 +834,7 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
                                c2 = wrap_pos(p.srcw[3 * s + 2], p.n[2], dl.d2);
                 sa.dbg_cdout[c0 + (unsigned)p.n[0] * (c1 + (unsigned)p.n[1] * c2)] = cd_out;
             }
-            double gamma = 0.0;
+            double gamma = 0.0, heat = 0.0;
             if (!stop && !(cd_in > p.max_coldensh) && nflux > 0.0) {
                 const double tau_in = cd_in * p.sigma, tau_out = cd_out * p.sigma;
                 const double od_in = tau_od(tau_in, p, ltab);
@@ -858,13 +861,14 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
                         if (!thick_cell) od_out = tau_od(tau_out, p, ltab);
                         dH = h_in - table_at(p.hthick, od_out);
                     } else dH = ((cd_out - cd_in) * p.sigma) * table_at(p.hthin, od_in);
-                    const double heat = (nflux * dH) * rcp1(area * path);          // phi%heat = .../vol_ph
-                    if (heat != 0.0) atomicAdd(&(xf ? p.heat_T : p.heat)[id[k]], heat);
+                    heat = (nflux * dH) * rcp1(area * path);                       // phi%heat = .../vol_ph
+                    if (!DET && heat != 0.0) atomicAdd(&(xf ? p.heat_T : p.heat)[id[k]], heat);
                 }
                 if (sa.has_boundary && (bnd_col || b == sa.boxR[va] || b == -sa.boxL[va]))
                     loss = loss + fdiv((nflux * t_out) * p.vol, area * path);
             }
             if (DET) p.gbox[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + id[k]] = gamma;
+            if (DET && HEAT) p.gbox_h[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + id[k]] = heat;
         }
         o8 += db8;
     }
@@ -966,7 +970,7 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
 // of the serial reference, evolve_point.F90:283 inside master_slave.F90:85's loop).  One thread per
 // cell; a source contributes where the cell lies inside its final sub-box (evolve_source.F90:135-136).
 __global__ __launch_bounds__(256) void k_gamma_reduce(KParams p, int nsrc, const int *final_nbox, int subbox,
-                                                      double *phih)
+                                                      double *phih, double *heat /* phiheat_grid, or null */)
 {
     // block = 256 cells along x of one (y,z) row: the y and z parts of the box test are block-uniform
     const int c0 = blockIdx.x * 256 + threadIdx.x, c1 = blockIdx.y, c2 = blockIdx.z;
@@ -975,6 +979,7 @@ __global__ __launch_bounds__(256) void k_gamma_reduce(KParams p, int nsrc, const
     const unsigned id = (unsigned)c0 + (unsigned)p.n[0] * ((unsigned)c1 + (unsigned)p.n[1] * (unsigned)c2);
     const unsigned id_t = (unsigned)c1 + (unsigned)p.n[1] * ((unsigned)c0 + (unsigned)p.n[0] * (unsigned)c2);
     double acc = live ? phih[id] : 0.0;
+    double acc_h = (live && heat) ? heat[id] : 0.0;
     for (int s = 0; s < nsrc; ++s) {
         const int nb = final_nbox[s];                 // uniform
         if (nb <= 0) continue;
@@ -991,9 +996,11 @@ __global__ __launch_bounds__(256) void k_gamma_reduce(KParams p, int nsrc, const
             const bool xf = abs(d0) > m12;            // cinterp branch priority z > y > x
             const double *g = p.gbox + ((size_t)s * 2 + (xf ? 1 : 0)) * ncell;
             acc = acc + g[xf ? id_t : id];
+            if (heat) acc_h = acc_h + (p.gbox_h + ((size_t)s * 2 + (xf ? 1 : 0)) * ncell)[xf ? id_t : id];
         }
     }
     if (live) phih[id] = acc;
+    if (live && heat) heat[id] = acc_h;
 }
 
 // nhi[i,j,k] = max(1-max(xh_av,eps),eps) * ndens (ion%h_av(0)*ndens_p of evolve0D) and its (x,y)-transposed

@@ -168,7 +168,7 @@ int  c2r_default_thermal(c2r_thermal_params *t);
  * doric at every cell's own temperature followed by thermal (thermal.f90:22; evolve_point.F90:515-527) on
  * temperature_grid (array 6: temperature_module.F90:35, (current, average, intermed) f32 per cell), with the
  * temperature clause of the convergence test (:387-388) and set_final_temperature_point on convergence (evolve.F90:220).
- * With deterministic_rates the heating rates are still accumulated with atomics. */
+ * With deterministic_rates the heating rates are reduced in source order like Gamma (twice the per-source scratch). */
 int  c2r_set_thermal(c2r_ctx *ctx, const c2r_thermal_params *t, const double *heat_thick, const double *heat_thin,
                      int32_t n, const double *cie_cool);
 /* cosmology.F90:42 zred at the time the driver calls evolve3D (redshift_evol of the middle of the step,
