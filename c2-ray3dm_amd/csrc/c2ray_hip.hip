@@ -873,13 +873,16 @@ int c2r_set_thermal(c2r_ctx *c, const c2r_thermal_params *t, const double *heat_
     if (t->cool_points < 2 || !(t->cool_dtemp > 0.0) || !(t->gamma1 > 0.0) || !(t->k_B > 0.0) || t->thermal_max_steps < 1)
         FAIL(C2R_EINVAL, "c2r_thermal_params: cool_points >= 2, cool_dtemp > 0, gamma1 > 0, k_B > 0, thermal_max_steps >= 1");
     ctx->tprm = *t;
-    if (!ctx->d_hthick) {
-        HIP_TRY(hipMalloc(&ctx->d_hthick, (size_t)(n + 1) * sizeof(double)));
-        HIP_TRY(hipMalloc(&ctx->d_hthin, (size_t)(n + 1) * sizeof(double)));
+    // (each allocation on its own: a call that failed half-way is completed by the next one)
+    if (!ctx->d_hthick) HIP_TRY(hipMalloc(&ctx->d_hthick, (size_t)(n + 1) * sizeof(double)));
+    if (!ctx->d_hthin) HIP_TRY(hipMalloc(&ctx->d_hthin, (size_t)(n + 1) * sizeof(double)));
+    if (!ctx->d_heat_T) HIP_TRY(hipMalloc(&ctx->d_heat_T, grid_bytes(ctx, 5)));
+    if (!ctx->grid[5]) {
         HIP_TRY(hipMalloc(&ctx->grid[5], grid_bytes(ctx, 5)));
-        HIP_TRY(hipMalloc(&ctx->grid[6], grid_bytes(ctx, 6)));
-        HIP_TRY(hipMalloc(&ctx->d_heat_T, grid_bytes(ctx, 5)));
         HIP_TRY(hipMemset(ctx->grid[5], 0, grid_bytes(ctx, 5)));          // evolve_data.F90:78 phiheat_grid=0.0
+    }
+    if (!ctx->grid[6]) {
+        HIP_TRY(hipMalloc(&ctx->grid[6], grid_bytes(ctx, 6)));
         HIP_TRY(hipMemset(ctx->grid[6], 0, grid_bytes(ctx, 6)));
     }
     hipFree(ctx->d_cool); ctx->d_cool = nullptr;
