@@ -1,0 +1,82 @@
+// What the MEMORY SYSTEM alone allows for the per-shell sweep's traffic mix, with no arithmetic: every "visit" of the
+// shipped kernel moves  (A) one n_HI double from a 134 MB grid (a wave reads 64 consecutive cells of a pseudo-random
+// row),  (B) the shell plane of the previous shell: two rows of 8-byte values per three cells, streamed once
+// (non-temporal),  (C) one 8-byte plane store (non-temporal),  (D) one f64 atomic add into a second 134 MB grid at the
+// n_HI position.  This kernel issues exactly those accesses for 3 "cells" per thread like k_sweep_shell_fast and
+// nothing else; each stream can be switched off.  Result: visits per second of the mix = the no-compute ceiling of
+// the DESIGN (not of the chip: a design that keeps the planes on chip would drop B and C).
+//   hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics trafficmix.hip -o trafficmix
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#define CK(e) do { hipError_t r = (e); if (r != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(r), __LINE__); return 1; } } while (0)
+
+template <int MASK>      // 1: n_HI loads  2: plane loads  4: plane stores  8: atomics
+__global__ __launch_bounds__(256) void k_mix(const double *__restrict__ nhi, double *__restrict__ gam, const double *__restrict__ pin,
+                                              double *__restrict__ pout, unsigned nrows, size_t plane_elems, unsigned seed)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned wave = (unsigned)(t >> 6), lane = threadIdx.x & 63;
+    unsigned x = seed + wave * 2654435761u;
+    double acc = 0.0;
+    // the plane streams: thread t owns elements [3t, 3t+3) of the output and reads 4 rows x 2 columns of the input
+    // (the column neighbour is the adjacent lane's element: an L1 hit, as in the kernel)
+    const size_t o = (t * 3) % (plane_elems - 8);
+    if (MASK & 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc += __builtin_nontemporal_load(pin + (o + r) % plane_elems);
+            acc += __builtin_nontemporal_load(pin + (o + r + 1) % plane_elems);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        x = x * 1664525u + 1013904223u;
+        const size_t id = (size_t)((x >> 8) % nrows) * 64 + lane;
+        double v = 1.0;
+        if (MASK & 1) v = __builtin_nontemporal_load(nhi + id);
+        if (MASK & 4) __builtin_nontemporal_store(v + acc, pout + o + c);
+        if (MASK & 8) atomicAdd(gam + id, v * 1e-30);
+        acc += v;
+    }
+    if (acc == -1.0) pout[0] = acc;
+}
+
+template <int MASK>
+double run(const double *nhi, double *gam, const double *pin, double *pout, unsigned nrows, size_t plane_elems, size_t nthreads)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const int blocks = (int)(nthreads / 256);
+    hipLaunchKernelGGL((k_mix<MASK>), dim3(blocks), dim3(256), 0, 0, nhi, gam, pin, pout, nrows, plane_elems, 1u);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k_mix<MASK>), dim3(blocks), dim3(256), 0, 0, nhi, gam, pin, pout, nrows, plane_elems, 7u + rep);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    return (double)nthreads * 3 / (best * 1e-3);      // visits per second
+}
+
+int main()
+{
+    const size_t n = (size_t)256 * 256 * 256;                 // the 256^3 mesh
+    const size_t nthreads = (size_t)1 << 27;                  // 4.0e8 visits per launch (a q = 100 shell of 1000 sources is 2.4e8)
+    const size_t plane_elems = nthreads * 3 + 64;             // 3.2 GB per plane stream: far beyond L2 and MALL, like 1000 sources' planes
+    double *nhi, *gam, *pin, *pout;
+    CK(hipMalloc(&nhi, n * 8)); CK(hipMalloc(&gam, n * 8)); CK(hipMalloc(&pin, plane_elems * 8)); CK(hipMalloc(&pout, plane_elems * 8));
+    CK(hipMemset(nhi, 0, n * 8)); CK(hipMemset(gam, 0, n * 8)); CK(hipMemset(pin, 0, plane_elems * 8)); CK(hipMemset(pout, 0, plane_elems * 8));
+    const unsigned nrows = (unsigned)(n / 64);
+#define RUN(M, what) printf("%-58s %.3e visits/s\n", what, run<M>(nhi, gam, pin, pout, nrows, plane_elems, nthreads))
+    RUN(15, "all four streams (the shipped design's mix)");
+    RUN(7,  "without the Gamma atomics");
+    RUN(13, "without the plane loads");
+    RUN(11, "without the plane stores");
+    RUN(9,  "n_HI loads + atomics only (planes on chip)");
+    RUN(1,  "n_HI loads only");
+    RUN(8,  "atomics only");
+    RUN(6,  "plane loads + stores only");
+    return 0;
+}
