@@ -254,12 +254,13 @@ def main():
         if prof_mode == 0:                         # no kernel timing (few sources): the sweep's share of the wall time bounds it
             sweep_s, launches = dt_wall, 1
         achieved = bytes_per_visit * vis_rank / sweep_s / 1e9 if sweep_s > 0 else 0.0
-        traffic, traffic_note = None, None
+        traffic, traffic_note, mix_ceiling = None, None, None
         tpath = os.path.join(ROOT, "profiles", "TRAFFIC.json")
         if os.path.exists(tpath):      # PMC counters of the same command, from the latest committed profile
             tj = json.load(open(tpath))
             traffic = (tj["fetch_corrected_bytes_per_visit"] + tj["write_bytes_per_visit"]) * vis_rank / launches
             traffic_note = tj["source"]
+            mix_ceiling = tj.get("mix_ceiling_visits_per_s")
         out = {
             "metric": "cells-traced/sec (grid^3 x sources / wallclock) on 256^3",
             "value": value, "unit": "cells-traced/s", "n_gpus": world, "steps": args.steps,
@@ -278,6 +279,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_sweep_shell_fast" if args.sweep_mode == "fast" else "k_sweep_shell", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note,
+                         # informational: the kernel's visits/s against what the memory system sustains for the same four
+                         # streams with no arithmetic at all (profiles/micro/trafficmix.hip, a committed measurement)
+                         "frac_of_memory_only_mix": (vis_rank / sweep_s / mix_ceiling) if (mix_ceiling and sweep_s > 0 and not args.thermal) else None,
                          "algorithmic_bytes_per_launch": bytes_per_visit * vis_rank / launches, "algorithmic_bytes_per_visit": bytes_per_visit,
                          "avg_launch_ms": prof["sweep_ms"] / launches, "launches": prof["sweep_launches"],
                          "timing": {0: "off (few sources: launches of a few microseconds); achieved = algorithmic bytes of the per-shell launches / whole step wall time", 1: "HIP events around every k_sweep_shell launch",
