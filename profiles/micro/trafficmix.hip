@@ -42,6 +42,57 @@ __global__ __launch_bounds__(256) void k_mix(const double *__restrict__ nhi, dou
     if (acc == -1.0) pout[0] = acc;
 }
 
+// The cell-major ("gather") alternative: a thread owns 3 mesh cells and loops over G sources whose face lies in the cells'
+// plane: one n_HI load and ONE atomic per cell, the plane streams per (cell, source) as before.  G*3 visits per thread.
+template <int G>
+__global__ __launch_bounds__(256) void k_gather(const double *__restrict__ nhi, double *__restrict__ gam, const double *__restrict__ pin,
+                                                 double *__restrict__ pout, unsigned nrows, size_t plane_elems, unsigned seed)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned wave = (unsigned)(t >> 6), lane = threadIdx.x & 63;
+    unsigned x = seed + wave * 2654435761u;
+    double acc[3] = {0.0, 0.0, 0.0};
+    size_t id[3];
+    double v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        x = x * 1664525u + 1013904223u;
+        id[c] = (size_t)((x >> 8) % nrows) * 64 + lane;
+        v[c] = __builtin_nontemporal_load(nhi + id[c]);
+    }
+    for (int g = 0; g < G; ++g) {
+        const size_t o = (((size_t)g * gridDim.x * 256 + t) * 3) % (plane_elems - 8);     // every source's plane is its own coalesced stream
+        double a = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a += __builtin_nontemporal_load(pin + (o + r) % plane_elems);
+            a += __builtin_nontemporal_load(pin + (o + r + 1) % plane_elems);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { __builtin_nontemporal_store(v[c] + a, pout + o + c); acc[c] += v[c] + a; }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) atomicAdd(gam + id[c], acc[c] * 1e-30);
+}
+
+template <int G>
+double run_gather(const double *nhi, double *gam, const double *pin, double *pout, unsigned nrows, size_t plane_elems, size_t nthreads)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const int blocks = (int)(nthreads / G / 256);
+    hipLaunchKernelGGL((k_gather<G>), dim3(blocks), dim3(256), 0, 0, nhi, gam, pin, pout, nrows, plane_elems, 1u);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k_gather<G>), dim3(blocks), dim3(256), 0, 0, nhi, gam, pin, pout, nrows, plane_elems, 7u + rep);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    return (double)blocks * 256 * 3 * G / (best * 1e-3);
+}
+
 template <int MASK>
 double run(const double *nhi, double *gam, const double *pin, double *pout, unsigned nrows, size_t plane_elems, size_t nthreads)
 {
@@ -78,5 +129,8 @@ int main()
     RUN(1,  "n_HI loads only");
     RUN(8,  "atomics only");
     RUN(6,  "plane loads + stores only");
+    printf("%-58s %.3e visits/s\n", "cell-major, 2 sources per cell (1 n_HI load + 1 atomic per cell)", run_gather<2>(nhi, gam, pin, pout, nrows, plane_elems, nthreads));
+    printf("%-58s %.3e visits/s\n", "cell-major, 4 sources per cell", run_gather<4>(nhi, gam, pin, pout, nrows, plane_elems, nthreads));
+    printf("%-58s %.3e visits/s\n", "cell-major, 8 sources per cell", run_gather<8>(nhi, gam, pin, pout, nrows, plane_elems, nthreads));
     return 0;
 }
