@@ -107,6 +107,28 @@ def cpu_baseline(mesh, srcpos, normflux, xfield, gpu_nbox, box_cost, nd=None):
                       "relaxed xh_av field the timed GPU steps start from" % (nsamp, mesh)}
 
 
+def self_launch(ngpus):
+    """Start `ngpus` ranks of this script under torch.distributed.run as a child process and relay its output."""
+    import socket
+    with socket.socket() as sk:                 # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    out = proc.stdout.splitlines()
+    lines = [l for l in out if l.startswith("{")]
+    for l in out:                               # anything else the ranks printed
+        if not l.startswith("{"):
+            print(l)
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write("bench.py: the %d-rank child run failed (exit code %d)\n" % (ngpus, proc.returncode))
+        return proc.returncode or 1
+    print(lines[-1])                            # ONE JSON line, rank 0's
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +156,12 @@ def main():
                          "global pass; synthetic cooling table, T = 1e4 K start).  Not the headline configuration; no CPU baseline")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  Nothing here has touched
+        # the GPU (no torch import, no HIP call), the ranks are CHILD processes (torch.distributed.run, one per GPU,
+        # rendezvous on 127.0.0.1), rank 0's JSON line is relayed, and a failing rank fails the run.
+        sys.exit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     import __graft_entry__ as g
@@ -141,9 +169,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if world != args.gpus:                     # started by a launcher with another rank count: the launcher wins
         args.gpus = world
     one_gpu_test = os.environ.get("C2R_BENCH_TEST_ONE_GPU") == "1"    # CI only: every rank on cuda:0, gloo
     if world > 1:
@@ -251,12 +277,13 @@ def main():
         # the timed launches are those of k_sweep_shell; the first two sub-boxes of every source (21^3 cells)
         # run in k_sweep_box_fused and are left out of both the bytes and the time
         vis_rank = max(0.0, vis_rank - fused_visited)
-        if prof_mode == 0:                         # no kernel timing (few sources): the sweep's share of the wall time bounds it
-            sweep_s, launches = dt_wall, 1
-        achieved = bytes_per_visit * vis_rank / sweep_s / 1e9 if sweep_s > 0 else 0.0
+        # prof_mode 0 (few sources: launches of a few microseconds, replayed as a hipGraph): no kernel was timed, so the
+        # roofline object carries nulls instead of numbers derived from the whole step's wall time
+        timed = prof_mode != 0 and sweep_s > 0
+        achieved = bytes_per_visit * vis_rank / sweep_s / 1e9 if timed else None
         traffic, traffic_note, mix_ceiling = None, None, None
         tpath = os.path.join(ROOT, "profiles", "TRAFFIC.json")
-        if os.path.exists(tpath):      # PMC counters of the same command, from the latest committed profile
+        if os.path.exists(tpath) and timed:      # PMC counters of the same command, from the latest committed profile
             tj = json.load(open(tpath))
             traffic = (tj["fetch_corrected_bytes_per_visit"] + tj["write_bytes_per_visit"]) * vis_rank / launches
             traffic_note = tj["source"]
@@ -271,20 +298,22 @@ def main():
                                    "all-reduce + global chemistry pass)" % (n, S, args.x_init, "cubep3m-file" if args.density_file else args.density),
                        "mesh": n, "sources": S, "sweep_mode": args.sweep_mode, "isothermal": not args.thermal, "gamma_accumulation": "ordered" if args.deterministic else "atomic", "sources_per_gpu": len(pkg.static_source_share(S, 0, world)),
                        "parallelism": "sources sharded over %d GPU(s), RCCL all-reduce of Gamma" % world,
+                       "ranks": dist.get_world_size() if world > 1 else 1,
+                       "collective": None if world == 1 else ("gloo (C2R_BENCH_TEST_ONE_GPU)" if one_gpu_test else "nccl (RCCL)"),
                        "visited_cell_sources_per_step": visited_all / args.steps,
                        "visited_per_s": visited_all / dt_wall,
                        "visited_cell_sources_whole_run_rank0": float(ev.visited + visited_before),
                        "mean_subboxes_per_source": [x / S for x in nbox_hist]},
             "check": check,
             "roofline": {"bound": "hbm", "kernel": "k_sweep_shell_fast" if args.sweep_mode == "fast" else "k_sweep_shell", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if timed else None,
                          "traffic": traffic, "traffic_source": traffic_note,
                          # informational: the kernel's visits/s against what the memory system sustains for the same four
                          # streams with no arithmetic at all (profiles/micro/trafficmix.hip, a committed measurement)
-                         "frac_of_memory_only_mix": (vis_rank / sweep_s / mix_ceiling) if (mix_ceiling and sweep_s > 0 and not args.thermal) else None,
-                         "algorithmic_bytes_per_launch": bytes_per_visit * vis_rank / launches, "algorithmic_bytes_per_visit": bytes_per_visit,
-                         "avg_launch_ms": prof["sweep_ms"] / launches, "launches": prof["sweep_launches"],
-                         "timing": {0: "off (few sources: launches of a few microseconds); achieved = algorithmic bytes of the per-shell launches / whole step wall time", 1: "HIP events around every k_sweep_shell launch",
+                         "frac_of_memory_only_mix": (vis_rank / sweep_s / mix_ceiling) if (mix_ceiling and timed and not args.thermal) else None,
+                         "algorithmic_bytes_per_launch": bytes_per_visit * vis_rank / launches if timed else None, "algorithmic_bytes_per_visit": bytes_per_visit,
+                         "avg_launch_ms": prof["sweep_ms"] / launches if timed else None, "launches": prof["sweep_launches"],
+                         "timing": {0: "off (few sources: launches of a few microseconds inside a hipGraph): no kernel timing, roofline fields are null", 1: "HIP events around every k_sweep_shell launch",
                                     2: "HIP events around every sub-box (5 launches + the small kernels between them)"}[prof_mode],
                          "chem_kernel_ms_per_launch": prof["chem_ms"] / max(1, prof["chem_launches"]),
                          "chem_achieved_GBs": (CHEM_BYTES_PER_CELL * float(n) ** 3 * prof["chem_launches"] /

@@ -74,6 +74,7 @@ SYMBOLS = [
     ("c2r_create", C.c_int, [C.POINTER(_P), C.POINTER(Params)]),
     ("c2r_destroy", None, [_P]),
     ("c2r_last_error", C.c_char_p, [_P]),
+    ("c2r_info", C.c_char_p, [_P]),
     ("c2r_set_stream", C.c_int, [_P, _P]),
     ("c2r_set_tables", C.c_int, [_P, _P, _P, _I32]),
     ("c2r_set_step", C.c_int, [_P, C.POINTER(_D * 3), _D, _D, C.c_float, _D]),

@@ -108,6 +108,8 @@ struct Ctx {
     // the whole run: evolve_data.F90:75-90), so the per-step transfers run at DMA speed
     std::map<const void *, size_t> pinned;
     std::string err;
+    // c2r_info: how the device was chosen, the sweep mode, warnings (e.g. C2R_DEVICE_AUTO without a local-rank variable)
+    bool device_auto = false; std::string device_var, info_device, info_warn, info;
 };
 
 inline Ctx *C(c2r_ctx *c) { return reinterpret_cast<Ctx *>(c); }
@@ -314,7 +316,8 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
     // box's own count (normally zero: done).  Measured (profiles/r02_launch_bound/): 128^3 x 1 source 0.80 -> 0.73 ms per
     // outer iteration; with 1000 sources the same rule costs 5-20 % (stale large grids), hence the limit.
     constexpr int kFewSources = 32;
-    const int hint = (ctx->sched_hint && n_active <= kFewSources) ? std::max(1, ctx->box_hint) : 1;
+    const bool few = ctx->sched_hint && n_active <= kFewSources;
+    const int hint = few ? std::max(1, ctx->box_hint) : 1;
     // every launch of sub-box nbox for `bound` sources at most (no host wait, no event): shells or the fused box, loss
     // reduction, the decision; flips `cur`
     auto enqueue_box = [&](const int nbox, const int bound) -> int {
@@ -419,7 +422,9 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             // the partials of the sub-box's last shell are summed by k_box_decide itself when few sources are active (one
             // launch less where launches are all there is); with many, its single workgroup would read 6 x tiles partials
             // for every source (2.5 MB through one CU: 89 us per sub-box, 1.6 % of the bench step) -- one block per source then
-            const bool fold = bound <= kFoldLossMax;
+            // (decided by the batch's INITIAL active count: `bound` depends on when the host happens to see a count arrive,
+            // and the two paths round differently -- the photon loss, which feeds the keep/retire decision, must not)
+            const bool fold = n_active <= kFoldLossMax;
             if (sa.has_boundary && (q < q1 || !fold))
                 hipLaunchKernelGGL(k_loss_reduce, dim3(bound), dim3(256), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
                                    ctx->d_loss_partial, 6 * sa.tiles_max, ctx->d_loss_acc);
@@ -480,7 +485,8 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
         // counts that have already arrived (never blocks)
         while (known < nbox && hipEventQuery(ctx->ev_box[known + 1]) == hipSuccess) bound = ctx->h_nactive[++known];
         // blocking read-back: the box's own count where the previous pass ended, the previous box's beyond
-        const int need = nbox == hint ? nbox : (nbox > hint ? nbox - 1 : 0);
+        // (many sources: always the previous box's -- one sub-box stays in flight from the first box on)
+        const int need = !few ? nbox - 1 : (nbox == hint ? nbox : (nbox > hint ? nbox - 1 : 0));
         if (need > known) {
             HIP_TRY(hipEventSynchronize(ctx->ev_box[need]));
             known = need; bound = ctx->h_nactive[need];
@@ -653,8 +659,7 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     if (const char *e = getenv("C2R_SCHED_HINT")) ctx->sched_hint = atoi(e) != 0;
     if (const char *e = getenv("C2R_GRAPH")) ctx->use_graph = atoi(e) != 0;
     if (p->sweep_mode != C2R_SWEEP_EXACT && p->sweep_mode != C2R_SWEEP_FAST) { delete ctx; return C2R_EINVAL; }
-    ctx->fast = p->sweep_mode == C2R_SWEEP_FAST;
-    if (const char *e = getenv("C2R_SWEEP_MODE")) ctx->fast = atoi(e) != 0;         // experiments, A/B runs
+    ctx->fast = p->sweep_mode == C2R_SWEEP_FAST;          // the caller's choice only: no environment override
     *out = reinterpret_cast<c2r_ctx *>(ctx);     // returned even on failure so c2r_last_error works
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -665,10 +670,17 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
         static const char *const names[] = {"C2R_DEVICE", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK",
                                             "MPI_LOCALRANKID", "PMI_LOCAL_RANK", "SLURM_LOCALID"};
         int dev = 0;
+        const char *used = nullptr;
         for (const char *nm : names)
-            if (const char *e = getenv(nm)) { dev = atoi(e); break; }
+            if (const char *e = getenv(nm)) { dev = atoi(e); used = nm; break; }
         ctx->prm.device = ((dev % ndev) + ndev) % ndev;
+        ctx->device_auto = true; ctx->device_var = used ? used : "";
+        char b[256];
+        if (used) snprintf(b, sizeof b, "device %d of %d visible (C2R_DEVICE_AUTO: %s=%d)", ctx->prm.device, ndev, used, dev);
+        else snprintf(b, sizeof b, "device 0 of %d visible (C2R_DEVICE_AUTO: no local-rank variable is set)", ndev);
+        ctx->info_device = b;
     } else if (p->device >= ndev) FAIL(C2R_EINVAL, "device ordinal beyond the visible HIP devices");
+    else { char b[96]; snprintf(b, sizeof b, "device %d of %d visible (explicit)", p->device, ndev); ctx->info_device = b; }
     HIP_TRY(hipSetDevice(ctx->prm.device));
     HIP_TRY(hipStreamCreate(&ctx->stream));
     ctx->own_stream = true;
@@ -769,6 +781,17 @@ void c2r_destroy(c2r_ctx *c)
 }
 
 const char *c2r_last_error(const c2r_ctx *c) { return c ? C(c)->err.c_str() : "null context"; }
+
+const char *c2r_info(c2r_ctx *c)
+{
+    if (!c) return "null context";
+    Ctx *ctx = C(c);
+    ctx->info = ctx->info_device + "; sweep_mode " + (ctx->fast ? "fast (C2R_SWEEP_FAST)" : "exact (C2R_SWEEP_EXACT)") +
+                "; rates " + (ctx->prm.deterministic_rates ? "ordered per-source sums" : "f64 atomics") +
+                "; rank " + std::to_string(ctx->rank) + " of " + std::to_string(ctx->nranks);
+    if (!ctx->info_warn.empty()) ctx->info += "; " + ctx->info_warn;
+    return ctx->info.c_str();
+}
 
 int c2r_set_stream(c2r_ctx *c, void *s)
 {
@@ -935,6 +958,14 @@ int c2r_set_rank(c2r_ctx *c, int32_t rank, int32_t nranks, c2r_allreduce_fn fn, 
     if (nranks < 1 || rank < 0 || rank >= nranks) FAIL(C2R_EINVAL, "need 0 <= rank < nranks");
     if (nranks > 1 && !fn) FAIL(C2R_EINVAL, "nranks > 1 needs an all-reduce callback");
     ctx->rank = rank; ctx->nranks = nranks; ctx->ar = fn; ctx->ar_user = user;
+    if (nranks > 1 && ctx->device_auto && ctx->device_var.empty() && ctx->info_warn.empty()) {
+        // several ranks, one process per GPU, and nothing told this process which GPU is its own: every rank of the
+        // node would share device 0.  Not an error (tests run several ranks on one GPU on purpose), but never silent.
+        ctx->info_warn = "WARNING: C2R_DEVICE_AUTO with nranks > 1 and no local-rank variable (C2R_DEVICE, LOCAL_RANK, "
+                         "OMPI_COMM_WORLD_LOCAL_RANK, MV2_COMM_WORLD_LOCAL_RANK, MPI_LOCALRANKID, PMI_LOCAL_RANK, SLURM_LOCALID): "
+                         "every rank of this node runs on device 0";
+        fprintf(stderr, "c2ray_hip: %s\n", ctx->info_warn.c_str());
+    }
     if (ctx->auto_share) { ctx->explicit_share = false; ctx->auto_share = false; ctx->share.clear(); }
     ctx->nbox_all.clear();
     return C2R_OK;

@@ -74,7 +74,11 @@ class HipBackend:
         p = _capi.default_params(self.mesh, device)
         p.scratch_bytes = scratch_bytes
         p.deterministic_rates = 1 if deterministic else 0
-        # fast=None: the library default (C2R_SWEEP_EXACT unless the C2R_SWEEP_MODE experiment switch is set)
+        # fast=None: this HOST's switch -- the environment variable C2R_SWEEP_MODE (0/1; how the GPU tests run every case
+        # in both modes), else the library default C2R_SWEEP_EXACT.  The library itself reads no environment variable:
+        # an explicit fast=True/False is what the context gets.
+        if fast is None and os.environ.get("C2R_SWEEP_MODE") is not None:
+            fast = os.environ["C2R_SWEEP_MODE"] not in ("0", "")
         if fast is not None:
             p.sweep_mode = 1 if fast else 0
         self.params = p
@@ -110,6 +114,10 @@ class HipBackend:
         if rc != 0:
             msg = self.lib.c2r_last_error(self.ctx) if self.ctx else b""
             raise C2RayHipError("%s failed (%d): %s" % (what, rc, (msg or b"").decode()))
+
+    def info(self):
+        """c2r_info: device (and how C2R_DEVICE_AUTO resolved it), sweep mode, rate accumulation, rank."""
+        return (self.lib.c2r_info(self.ctx) or b"").decode()
 
     def close(self):
         if getattr(self, "ctx", None):

@@ -277,6 +277,8 @@ contains
   subroutine evolve_hip_ini()
     type(c2r_params) :: p
     integer(c_int32_t) :: dev
+    character(len=16) :: envval
+    integer :: envstat
 #ifdef MPI
     character(kind=c_char) :: uid(128)
     integer :: mympierror
@@ -299,11 +301,17 @@ contains
     p%pi = pi; p%abu_c = abu_c
     p%bh00 = bh00; p%albpow = albpow; p%colh0 = colh0; p%temph0 = temph0
     p%S_star = S_star
+    ! Sweep arithmetic: the reference has no such parameter, so this drop-in takes it from its own run-time switch, the
+    ! environment variable C2R_SWEEP_MODE (unset or 0: C2R_SWEEP_EXACT, column densities bit-identical to the Fortran;
+    ! 1: C2R_SWEEP_FAST).  The library reads no environment: what is set here is what runs, and it is logged below.
+    call get_environment_variable("C2R_SWEEP_MODE", envval, status=envstat)
+    if (envstat == 0 .and. len_trim(envval) > 0 .and. trim(envval) /= "0") p%sweep_mode = 1_c_int32_t
     call check(c2r_create(ctx, p), "c2r_create")
     call check(c2r_set_tables(ctx, stellar_photo_thick_table(:,1), stellar_photo_thin_table(:,1), &
          int(NumTau+1, c_int32_t)), "c2r_set_tables")
     call check(c2r_get_device(ctx, dev), "c2r_get_device")
     write(logf,*) "c2ray_hip: evolve hot path on HIP device ", dev
+    write(logf,*) "c2ray_hip: sweep mode ", merge("fast (C2R_SWEEP_FAST) ", "exact (C2R_SWEEP_EXACT)", p%sweep_mode == 1)
     if (.not.isothermal) call thermal_hip_ini()
 #ifdef MPI
     ! Join the RCCL communicator: rank 0 makes the 128-byte token, one broadcast next to those of mpi.F90 hands it

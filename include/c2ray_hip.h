@@ -63,8 +63,13 @@ typedef struct c2r_params {
                                       *    bit-identical to the Fortran;
                                       * C2R_SWEEP_FAST (1): algebraically re-associated arithmetic (factored
                                       *    interpolation weights, 2^-48 reciprocals, fused table position): same
-                                      *    integer results, column densities and rates within ~1e-13 of the exact mode
-                                      *    (tolerances stated in tests/test_gpu_fast.py), ~1.5x the throughput */
+                                      *    integer results, column densities within 1e-11 and rates within
+                                      *    |dGamma| <= 1e-12 Gamma + 2e-14 W of the oracle (W = sum_s (1+tau_in) photo_in /
+                                      *    (vol_ph n_HI): the rate that passes THROUGH the cell; worst plain relative error
+                                      *    measured 7.6e-8, in cells whose own rate is ~1e-7 of W; exact mode 1e-13 / 1.8e-8):
+                                      *    the tolerances the GPU tests apply live in tests/_util.py (TOL); ~1.3x the
+                                      *    throughput.  Only this field selects the mode: the library reads no environment
+                                      *    variable for it (the Fortran shim and the Python host have their own switches) */
     int32_t reserved1;
     double  epsilon;                 /* c2ray_parameters.f90:31 */
     double  convergence_fraction;    /* :25 */
@@ -120,6 +125,10 @@ int  c2r_default_params(c2r_params *p);
 int  c2r_create(c2r_ctx **ctx, const c2r_params *p);
 void c2r_destroy(c2r_ctx *ctx);
 const char *c2r_last_error(const c2r_ctx *ctx);
+/* One line describing how the context runs: the device and how C2R_DEVICE_AUTO resolved it (which launcher variable),
+ * the sweep mode, the rate accumulation, rank/nranks, and a WARNING when C2R_DEVICE_AUTO found no local-rank variable
+ * although nranks > 1 (also printed to stderr by c2r_set_rank).  Valid until the next call on the context. */
+const char *c2r_info(c2r_ctx *ctx);
 /* Run on a caller-provided hipStream_t (NULL = the context's own stream). */
 int  c2r_set_stream(c2r_ctx *ctx, void *hip_stream);
 

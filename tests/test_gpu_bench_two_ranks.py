@@ -36,3 +36,23 @@ def test_bench_two_ranks_equal_one_rank(balance):
     for k in ("phih_grid_sum", "xh_intermed_sum", "xh_av_sum"):
         assert abs(a["check"][k] / b["check"][k] - 1) < 1e-11, k
     assert b["config"]["sources_per_gpu"] == 32
+
+
+def test_bench_plain_form_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher and no WORLD_SIZE -- the shape of the driver's N = 1 command -- must
+    work: the parent starts the two ranks itself (before it touches the GPU) and relays rank 0's single line."""
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + ARGS, capture_output=True,
+                         text=True, timeout=900, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["C2R_BENCH_TEST_ONE_GPU"] = "1"
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + ARGS, capture_output=True,
+                         text=True, timeout=900, cwd=ROOT, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    json_lines = [l for l in two.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(json_lines) == 1
+    a, b = line(one.stdout), json.loads(json_lines[0])
+    assert (a["n_gpus"], b["n_gpus"]) == (1, 2) and b["config"]["ranks"] == 2 and b["config"]["collective"] == "gloo (C2R_BENCH_TEST_ONE_GPU)"
+    assert a["check"]["sum_nbox_last_step"] == b["check"]["sum_nbox_last_step"]
+    for k in ("phih_grid_sum", "xh_intermed_sum", "xh_av_sum"):
+        assert abs(a["check"][k] / b["check"][k] - 1) < 1e-11, k

@@ -265,3 +265,18 @@ def test_two_ranks_gloo_nonisothermal_step(pkg, tmp_path):
     ref = F(a["step001_phiheat_grid"])
     assert np.array_equal(got["heat"] == 0, ref == 0) and relerr(got["heat"], ref, floor=1e-60) < 1e-8
     assert np.array_equal(got["xh_rank1"], got["xh"])
+
+
+def test_bench_plain_multi_gpu_form_is_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts its ranks as child processes (torch.distributed.run) instead of
+    refusing; here, without a GPU, both ranks fail loudly (no CPU fallback) and the parent reports that with a non-zero
+    exit code and no JSON line -- and it got there without importing torch itself."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mesh", "16", "--sources", "2",
+                        "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                       cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert "2-rank child run failed" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "No HIP GPUs are available" in r.stderr or "no GPU visible" in r.stderr or "no HIP device" in r.stderr
