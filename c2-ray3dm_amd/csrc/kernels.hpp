@@ -22,6 +22,7 @@ constexpr int kBlock = C2R_BLOCK;   // threads per block of the sweep; a face's 
 
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 constexpr int kLogTab = 64;              // intervals of the log10 table (log10_tab)
+constexpr int kMaxFusedShells = 5;       // most shells one launch walks (a sub-box: c2ray_parameters.f90:54 subboxsize)
 
 struct KParams {
     int n[3];
@@ -917,13 +918,401 @@ __global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
     sweep_tile_fast<DET, LLS, STREAM, HEAT>(p, sa, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z);
 }
 
+// ==== a whole sub-box per launch, the shells handed from one to the next through LDS (fast mode) ==================
+// k_sweep_shell_fast round-trips a source's shell planes through HBM between launches: 8 B stored and >= 8 B loaded per
+// visited (cell, source) on top of the 28 algorithmic bytes.  k_sweep_octant_fast walks the shells q0..q0+n-1 of an
+// unclipped sub-box in ONE launch with the column densities in LDS:
+//  * a workgroup owns one OCTANT of one source's cube (sign classes of x, y, z): the quadrant (a, b sign classes) of
+//    the z face, then of the y face, then of the x face.  cinterp's upstream corners are |a|-1, |a| and |b|-1, |b| of
+//    the same face, so a quadrant depends on nothing outside itself except (i) the axis column a = 0 / row b = 0, which
+//    the classes a <= 0 / b <= 0 recompute for themselves (column density only: the classes a, b >= 0 own those cells;
+//    bit-identical values, 1/q of the cells), and (ii) the cube's edge cells, which the face of higher cinterp
+//    priority owns -- and that is the same octant's z (then y) quadrant, done earlier by the same workgroup.
+//  * a quadrant is marched in STRIPS of 3 x groups rows, low |b| first.  A strip's cells of all n shells live in one LDS
+//    plane that is updated IN PLACE: the cells of a shell are walked in DESCENDING (row group, |a|) order, 256 at a time;
+//    a trip reads its upstream corners (old values), passes one LDS-only barrier, computes and writes its own cells.
+//    Every reader of an old value sits in the same or an earlier trip, so one barrier per trip and one per shell suffice,
+//    and they wait for LDS traffic only (n_HI loads and Gamma atomics stay in flight across them).
+//  * the row just below a strip comes from the strip before it: its top row of every shell is kept in a ring of six
+//    LDS rows (slot arithmetic at bnd_slot).  No halo is recomputed, nothing is read twice.
+//  * at the start of a strip its plane is filled from HBM: shell q0-1 where it exists, the edge cells of shells
+//    q0..q0+n-2 that a face of higher priority stored into this face's planes (they sit beyond this face's own cells
+//    until the shell that reads them), 0.0 elsewhere -- exactly what the per-shell kernel's out-of-range read returns.
+//    The last shell's cells go to this face's plane: the input of the next sub-box, whichever kernel runs it.
+//  * per-cell arithmetic is shell_rows_fast's, expression for expression; both table positions and all three table
+//    reads of a cell are issued unconditionally (selects instead of branches) so that the three cells of a thread
+//    stay interleaved, and the next trip's n_HI loads are issued before this trip's atomics (vmcnt retires in order).
+//  Column densities, rates and sub-box counts are bit-identical to the per-shell launches; the photon loss differs by
+//  the order of its block sums.
+struct OctArgs {
+    int q0, nshell;              // shells q0 .. q0+nshell-1: one whole, unclipped sub-box beyond the fused ones (q0 > 10)
+    int groups;                  // row groups (kRows rows each) per strip
+    int pitch;                   // LDS row pitch in doubles (>= q0 + nshell + 1)
+    unsigned magic[2][kMaxFusedShells];   // division by the column count of shell j: [0] z and y faces (q+1), [1] x faces (q)
+    double inv_q[kMaxFusedShells], path_scale[kMaxFusedShells], lls_scale[kMaxFusedShells];
+    double d2axis[3][kMaxFusedShells];    // (dr_axis q)^2
+    const int *active, *n_active;
+    double *loss_partial;        // [n_active][8]
+    // edge cells of the shells q0..q0+nshell-2, private to an octant (the last shell's go to the planes, for the next
+    // sub-box): [source][octant][3 kinds][kMaxFusedShells-1][pitch] -- kind 0: z face -> y face (row |b| = q of the y plane, by
+    // |a|), 1: z face -> x face (row |b| = q of the x plane, by |a|), 2: y face -> x face (column |a| = q of the x plane, by |b|).
+    // A workgroup writes and reads only its own part: no other octant's stores can land between (shared planes would
+    // race on the axis cells, which two octants hold)
+    double *edges;
+};
+
+__device__ __forceinline__ void lds_barrier()
+{
+    // workgroup barrier that orders LDS accesses only: no s_waitcnt vmcnt(0), global loads and atomics stay in flight
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Register discipline of k_sweep_octant_fast.  Its three nested loops (strips, shells, trips) would keep ~150 launch-uniform
+// values alive in SGPRs -- the per-cell constants of KParams, three buffer descriptors, the per-shell scalars -- and the
+// 102 a wave has overflow into VGPR lanes: 320 v_readlane / v_writelane in a trip of ~700 vector instructions, measured.
+// So every piece of work inside the loops (fill, trip) reads the kernel arguments afresh through a pointer to the kernarg
+// segment that the optimiser cannot see through (an empty asm redefines it): the scalar loads and the descriptor arithmetic
+// then sit inside the piece, run on the scalar unit beside the vector work, and nothing but a dozen integers is live across it.
+#define C2R_AS4 __attribute__((address_space(4)))
+typedef const C2R_AS4 char *kargp_t;
+__device__ __forceinline__ kargp_t fresh_kernarg()
+{
+    kargp_t k = (kargp_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
+}
+
+// what a quadrant pass keeps in SGPRs across its loops
+struct OctPass {
+    int axis;                    // 2 z face, 1 y face, 0 x face
+    int s, oct;                  // source (batch-local), octant
+    int aneg, bneg, fneg;        // sign classes of the plane coordinates a, b and of the face (0: >= 0, 1: <= 0)
+    int sw_a, sw_b, sw_p;        // the source cell, wrapped (KParams.srcw), along the plane coordinates a, b and the face axis
+    double nflux;
+};
+// a strip of a quadrant: rows |b| = w_lo .. w_lo+rows-1; base = ring position of "the row below, shell q0-1"
+struct OctStrip { int w_lo, base; };
+
+// one trip's cell assignment: thread -> column |a| = u, rows |b| = w0 .. w0+nvalid-1 of the strip starting at w_lo
+struct TripMap { bool live; int u, g, w0, nvalid; };
+__device__ __forceinline__ TripMap trip_map(unsigned t, int items, int ncol, unsigned magic, int ng, int w_lo, int qb)
+{
+    TripMap m;
+    m.live = t < (unsigned)items;
+    t = min(t, (unsigned)max(items - 1, 0));                 // idle lanes shadow the last item, side effects masked
+    const unsigned gi = magic ? __umulhi(t, magic) : t;
+    m.u = ncol - 1 - (int)(t - __umul24(gi, (unsigned)ncol));
+    m.g = ng - 1 - (int)gi;
+    m.w0 = w_lo + kRows * m.g;
+    m.nvalid = min(kRows, qb - m.w0 + 1);
+    return m;
+}
+
+// launch constants of shell j of the pass, from the (fresh) kernel arguments
+struct OctShell { int q, pd, qb, ncol, ng, items; unsigned magic; };
+__device__ __forceinline__ OctShell oct_shell(const C2R_AS4 OctArgs &o, const OctPass &ps, const int w_lo, const int j)
+{
+    OctShell h;
+    h.q = o.q0 + j;
+    h.pd = ps.fneg ? -h.q : h.q;
+    h.qb = ps.axis == 2 ? h.q : h.q - 1;                     // rows / columns this face owns in shell q
+    h.ncol = (ps.axis == 0 ? h.q - 1 : h.q) + 1;
+    h.ng = h.qb >= w_lo ? min(o.groups, (h.qb - w_lo) / kRows + 1) : 0;
+    h.items = h.ng * h.ncol;
+    h.magic = o.magic[ps.axis == 0 ? 1 : 0][j];
+    return h;
+}
+// n_HI of the cells a thread handles in trip t0 of shell j: ids and loads (out of range where it has no cell)
+template <bool STREAM>
+__device__ __forceinline__ void oct_fetch_nhi(const kargp_t kp, const OctPass &ps, const int w_lo, const int j, const int t0,
+                                              unsigned (&id)[kRows], double (&nhi)[kRows])
+{
+    const C2R_AS4 KParams &p = *reinterpret_cast<const C2R_AS4 KParams *>(kp);
+    const C2R_AS4 OctArgs &o = *reinterpret_cast<const C2R_AS4 OctArgs *>(kp + sizeof(KParams));
+    const OctShell h = oct_shell(o, ps, w_lo, j);
+    const TripMap m = trip_map((unsigned)(t0 + (int)threadIdx.x), h.items, h.ncol, h.magic, h.ng, w_lo, h.qb);
+    const bool xf = ps.axis == 0;
+    const int ua = xf ? 1 : 0, va = ps.axis == 2 ? 1 : 2;
+    const unsigned na = (unsigned)p.n[ua], nmid = xf ? (unsigned)p.n[0] : (unsigned)p.n[1];
+    const unsigned stride_b = ps.axis == 2 ? na : na * nmid;
+    const unsigned cp = wrap_pos(ps.sw_p, p.n[ps.axis], h.pd);
+    const unsigned base_p = ps.axis == 2 ? na * nmid * cp : na * cp;
+    const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(xf ? p.nhi_T : p.nhi, ncell * 8u);
+    const unsigned ca = wrap_pos(ps.sw_a, p.n[ua], (ps.aneg ? -1 : 1) * m.u);
+#pragma unroll
+    for (int c = 0; c < kRows; ++c) {
+        id[c] = ca + base_p + __umul24(stride_b, wrap_pos(ps.sw_b, p.n[va], (ps.bneg ? -1 : 1) * (m.w0 + c)));
+        nhi[c] = buf_load_f64<STREAM ? C2R_NHI_AUX : 0>(r_x, (m.live && c < m.nvalid) ? id[c] * 8u : kOOB);
+    }
+}
+
+// Fill a strip's LDS plane from HBM: shell q0-1 where it exists, the edge cells of shells q0..q0+n-2 that a face of
+// higher priority left in the octant's scratch, 0.0 elsewhere; the row below the strip (shell q0-1) into the ring.
+template <bool STREAM>
+__device__ __forceinline__ void oct_fill(const kargp_t kp, double *s_pl, const OctPass &ps, const OctStrip &st)
+{
+    const C2R_AS4 KParams &p = *reinterpret_cast<const C2R_AS4 KParams *>(kp);
+    const C2R_AS4 OctArgs &o = *reinterpret_cast<const C2R_AS4 OctArgs *>(kp + sizeof(KParams));
+    const int tid = threadIdx.x;
+    const int pitch = o.pitch, rows = kRows * o.groups, q0 = o.q0, qm = q0 - 1, q1 = q0 + o.nshell - 1;
+    const int sga = ps.aneg ? -1 : 1, sgb = ps.bneg ? -1 : 1;
+    const unsigned plane_bytes = (unsigned)p.PP * 8u;
+    const unsigned in_off = (unsigned)((qm & 1) * 6 + 2 * (2 - ps.axis) + ps.fneg) * plane_bytes;
+    const unsigned edge_bytes = (unsigned)((kMaxFusedShells - 1) * pitch) * 8u;                           // one kind
+    const __amdgpu_buffer_rsrc_t r_pl = make_rsrc(p.planes + (size_t)ps.s * 12 * p.PP, 12u * plane_bytes);      // both parities
+    const __amdgpu_buffer_rsrc_t r_ed = make_rsrc(o.edges + ((size_t)ps.s * 8 + ps.oct) * 3 * (kMaxFusedShells - 1) * pitch, 3u * edge_bytes);
+    const int R = p.R, P = p.P;
+    const bool xf = ps.axis == 0;
+    double *s_bnd = s_pl + rows * pitch;
+    const int lw = pitch <= 64 ? 6 : (pitch <= 128 ? 7 : 8);
+    const int u0 = tid & ((1 << lw) - 1), rr = tid >> lw, rstep = kBlock >> lw;
+    for (int r = rr; r <= rows; r += rstep) {             // r == rows: the row below the strip, into the ring
+        const int w = r < rows ? st.w_lo + r : st.w_lo - 1;
+        double *dst = r < rows ? s_pl + r * pitch : s_bnd + st.base * pitch;
+        for (int u = u0; u < pitch; u += 1 << lw) {
+            const int m = max(w, u);
+            const bool in = m <= qm && w >= 0;                                          // shell q0-1
+            const double v = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_pl, in ? in_off + (unsigned)((sgb * w + R) * P + (sga * u + R)) * 8u : kOOB);
+            double e = 0.0;
+            if (ps.axis != 2) {                                                         // another face's edge cells of shell m
+                const bool ed = r < rows && m >= q0 && m < q1 && (xf || w == m);
+                const unsigned kind = ps.axis == 1 ? 0u : (w == m ? 1u : 2u);
+                e = buf_load_f64<0>(r_ed, ed ? kind * edge_bytes + (unsigned)((m - q0) * pitch + (w == m ? u : w)) * 8u : kOOB);
+            }
+            dst[u] = v + e;                                                             // at most one of them is not 0.0
+        }
+    }
+}
+
+// One trip: up to 256 (column, row group) items of shell j of the strip.  id / nhi: this trip's cells on entry, the
+// next trip's on exit.
+template <int LLS, bool STREAM>
+__device__ __forceinline__ void oct_trip(const kargp_t kp, const v2f64 *__restrict__ ltab, double *s_pl, const OctPass &ps,
+                                         const OctStrip &st, const int j, const int t0, unsigned (&id_nx)[kRows],
+                                         double (&nhi_nx)[kRows], double &loss)
+{
+    constexpr int NR = kRows;
+    const C2R_AS4 KParams &p = *reinterpret_cast<const C2R_AS4 KParams *>(kp);
+    const C2R_AS4 OctArgs &o = *reinterpret_cast<const C2R_AS4 OctArgs *>(kp + sizeof(KParams));
+    const int axis = ps.axis;
+    const bool xf = axis == 0;
+    const int ua = xf ? 1 : 0, va = axis == 2 ? 1 : 2;            // mesh axes of the plane coordinates (a, b)
+    const int pitch = o.pitch, rows = NR * o.groups, nshell = o.nshell;
+    const int w_lo = st.w_lo, w_hi = w_lo + rows - 1;
+    double *s_bnd = s_pl + rows * pitch;                          // ring of 6 rows
+    const OctShell h = oct_shell(o, ps, w_lo, j);
+    const int q = h.q, pd = h.pd, ncol = h.ncol;
+    const bool last = j == nshell - 1;
+    const int slot_old = (st.base + j) % 6;                       // row w_lo-1 as shell q-1 left it
+    const int slot_new = (st.base + j + 5) % 6;                   // row w_hi of this shell, for the next strip
+    const TripMap mp = trip_map((unsigned)(t0 + (int)threadIdx.x), h.items, ncol, h.magic, h.ng, w_lo, h.qb);
+    const int u = mp.u, w0 = mp.w0;
+    unsigned id[NR];
+    double nhi[NR];
+#pragma unroll
+    for (int c = 0; c < NR; ++c) { id[c] = id_nx[c]; nhi[c] = nhi_nx[c]; }
+    // upstream corners: columns |a|-1, |a|, rows w0-1 .. w0+NR-1 (|a| = 0, w0 = 0: weight 0, any finite value)
+    double vm[NR + 1], va_[NR + 1];
+    {
+        const int um = max(u - 1, 0);
+        const int r0 = w0 - w_lo;
+        const double *below = mp.g == 0 ? s_bnd + slot_old * pitch : s_pl + (r0 - 1) * pitch;
+        vm[0] = below[um]; va_[0] = below[u];
+#pragma unroll
+        for (int r = 1; r <= NR; ++r) {
+            const double *row = s_pl + min(r0 + r - 1, rows - 1) * pitch;
+            vm[r] = row[um]; va_[r] = row[u];
+        }
+    }
+    lds_barrier();
+    const int sga = ps.aneg ? -1 : 1, sgb = ps.bneg ? -1 : 1;
+    const int a = sga * u;
+    const bool own_col = !(ps.aneg && u == 0);
+    const double sigma = p.sigma, wfloor = p.wfloor;
+    const double inv_q = o.inv_q[j], path_scale = o.path_scale[j], lls_scale = o.lls_scale[j], d2ax = o.d2axis[axis][j];
+    const double omu = (double)u * inv_q, ddu = 1.0 - omu;
+    const int a2 = u * u;
+    const double du2 = p.dr2[ua] * (double)a2, dr2v = p.dr2[va];
+    double R[NR + 1], T[NR + 1];
+#pragma unroll
+    for (int r = 0; r <= NR; ++r) {
+        const double rm = rcp1(fmax(wfloor, vm[r] * sigma)), ra = rcp1(fmax(wfloor, va_[r] * sigma));
+        R[r] = __builtin_fma(omu, rm, ddu * ra);
+        T[r] = __builtin_fma(omu, vm[r] * rm, ddu * (va_[r] * ra));
+    }
+    const unsigned plane_bytes = (unsigned)p.PP * 8u;
+    const unsigned cur_off = (unsigned)(q & 1) * 6u * plane_bytes;
+    const unsigned face_off = (unsigned)(2 * (2 - axis) + ps.fneg) * plane_bytes;
+    const unsigned edge_bytes = (unsigned)((kMaxFusedShells - 1) * pitch) * 8u;
+    const int PR = p.R, PP_ = p.P;
+    const double nflux = ps.nflux, numtau_d = p.numtau_d, od_per_e = p.od_per_e, od_per_ln = p.od_per_ln;
+    // the table position of tau (tau_od), with the kernel arguments already in registers
+    auto od_of = [&](double tau) {
+        const double x = fmax(1.0e-20, tau);
+        const double m = __builtin_amdgcn_frexp_mant(x);
+        const int e = __builtin_amdgcn_frexp_exp(x);
+        const v2f64 rt = ltab[((unsigned)__double2hiint(m) >> 14) & 63u];
+        const double z = __builtin_fma(m, rt.x, -1.0);
+        double P = __builtin_fma(z, 1.0 / 7.0, -1.0 / 6.0);
+        P = __builtin_fma(z, P, 0.2);
+        P = __builtin_fma(z, P, -0.25);
+        P = __builtin_fma(z, P, 1.0 / 3.0);
+        P = __builtin_fma(z, P, -0.5);
+        const double l1p = __builtin_fma(z * z, P, z);
+        return fmin(numtau_d, __builtin_fma((double)e, od_per_e, __builtin_fma(l1p, od_per_ln, rt.y)));
+    };
+    // ---- the three cells, one after the other; the atomics wait for the end of the trip so that no table read queues
+    // behind one (vmcnt retires in order)
+    double gam[NR];
+    bool rate[NR];
+#pragma unroll
+    for (int c = 0; c < NR; ++c) {
+        const int w = w0 + c, b = sgb * w;
+        const bool valid = mp.live && c < mp.nvalid;
+        const bool own = valid && own_col && !(ps.bneg && w == 0);
+        const double omv = (double)w * inv_q, ddv = 1.0 - omv;
+        const double den = __builtin_fma(omv, R[c], ddv * R[c + 1]);
+        const double num = __builtin_fma(omv, T[c], ddv * T[c + 1]);
+        const double cdi = num * rcp1(den);                               // (q > 10 here: no sqrt2 / sqrt3 factors)
+        const double pq = sqrt_pos((double)(q * q + a2 + w * w));
+        const double path = pq * path_scale;
+        const double dist2 = __builtin_fma(dr2v, (double)(w * w), du2 + d2ax);
+        bool stop = false;
+        double cd_in;
+        if (LLS == 3) { stop = dist2 > p.R_max2; cd_in = cdi; }
+        else if (LLS == 2) cd_in = __builtin_fma((double)(xf ? p.lls_T : p.lls)[valid ? id[c] : 0u] * inv_q, pq, cdi);
+        else cd_in = __builtin_fma(lls_scale, pq, cdi);
+        const double np = nhi[c] * path;
+        const double cd_out = cd_in + np;
+        if (valid) {
+            s_pl[(w - w_lo) * pitch + u] = cd_out;
+            if (w == w_hi) {
+                s_bnd[slot_new * pitch + u] = cd_out;
+                // x face: the strip above also reads the y face's edge cell of this row (column |a| = q), which no
+                // thread computes: it sits in the plane since the fill
+                if (xf && u == ncol - 1) s_bnd[slot_new * pitch + u + 1] = s_pl[(w - w_lo) * pitch + u + 1];
+            }
+        }
+        if (last) {
+            // this face's plane, and the edge cells also into the planes of the faces that read them (as the per-shell
+            // kernel; a recomputed axis cell stores the same bits as its owner): the input of the next sub-box
+            const __amdgpu_buffer_rsrc_t r_pl = make_rsrc(p.planes + (size_t)ps.s * 12 * p.PP, 12u * plane_bytes);
+            constexpr int SA = STREAM ? C2R_STORE_AUX : 0;
+            buf_store_f64<SA>(r_pl, own ? cur_off + face_off + (unsigned)((b + PR) * PP_ + (a + PR)) * 8u : kOOB, cd_out);
+            if (axis == 2) {
+                if (valid && u == q)
+                    buf_store_f64<SA>(r_pl, cur_off + (ps.aneg ? 5u : 4u) * plane_bytes + (unsigned)((pd + PR) * PP_ + (b + PR)) * 8u, cd_out);
+                if (valid && w == q)
+                    buf_store_f64<SA>(r_pl, cur_off + (ps.bneg ? 3u : 2u) * plane_bytes + (unsigned)((pd + PR) * PP_ + (a + PR)) * 8u, cd_out);
+            } else if (axis == 1) {
+                if (valid && u == q)
+                    buf_store_f64<SA>(r_pl, cur_off + (ps.aneg ? 5u : 4u) * plane_bytes + (unsigned)((b + PR) * PP_ + (pd + PR)) * 8u, cd_out);
+            }
+        } else if (axis != 0 && valid && (u == q || w == q)) {
+            // earlier shells: edge cells into the octant's private scratch, recomputed axis cells included -- this
+            // octant's later quadrants read them
+            const __amdgpu_buffer_rsrc_t r_ed = make_rsrc(o.edges + ((size_t)ps.s * 8 + ps.oct) * 3 * (kMaxFusedShells - 1) * pitch, 3u * edge_bytes);
+            if (axis == 2) {
+                if (u == q) buf_store_f64<0>(r_ed, 1u * edge_bytes + (unsigned)(j * pitch + w) * 8u, cd_out);
+                if (w == q) buf_store_f64<0>(r_ed, 0u * edge_bytes + (unsigned)(j * pitch + u) * 8u, cd_out);
+            } else {
+                if (u == q) buf_store_f64<0>(r_ed, 2u * edge_bytes + (unsigned)(j * pitch + w) * 8u, cd_out);
+            }
+        }
+        rate[c] = own && !stop && !(cd_in > p.max_coldensh) && nflux > 0.0;
+        gam[c] = 0.0;
+        if (rate[c]) {
+            const double tau_in = cd_in * sigma, tau_out = cd_out * sigma;
+            const double od_in = od_of(tau_in);
+            const double t_in = table_at(p.thick, od_in);
+            double dT, t_out;
+            if (fabs(tau_out - tau_in) > p.tau_limit) {
+                t_out = table_at(p.thick, od_of(tau_out));
+                dT = t_in - t_out;
+            } else {
+                dT = (tau_out - tau_in) * table_at(p.thin, od_in);
+                t_out = t_in - dT;
+            }
+            const double area = p.fourpi * dist2;
+            gam[c] = (nflux * dT) * rcp1(area * np);
+            if (last) loss = loss + fdiv((nflux * t_out) * p.vol, area * path);   // the whole last shell lies on the box surface
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- the next trip's n_HI, issued ahead of this trip's atomics
+    {
+        int jn = j, tn = t0 + kBlock;
+        if (tn >= h.items) { jn = j + 1; tn = 0; }
+        if (jn < nshell) oct_fetch_nhi<STREAM>(kp, ps, w_lo, jn, tn, id_nx, nhi_nx);
+    }
+    asm volatile("" ::: "memory");
+    double *const phih = xf ? p.phih_T : p.phih;
+#pragma unroll
+    for (int c = 0; c < NR; ++c)
+        if (rate[c] && gam[c] != 0.0) atomicAdd(&phih[id[c]], gam[c]);
+}
+
+template <int LLS, bool STREAM>
+__global__ __launch_bounds__(kBlock) void k_sweep_octant_fast(KParams p, OctArgs oa)
+{
+    extern __shared__ double s_dyn[];                    // [3 groups + 6][pitch]
+    __shared__ double sm[16];
+    __shared__ v2f64 s_log[kBlock];
+    const int sl = blockIdx.y;
+    if (sl >= *oa.n_active) return;                      // block-uniform
+    OctPass ps;
+    ps.s = oa.active[sl];
+    ps.oct = blockIdx.x & 7;
+    const v2f64 *ltab = wave_log_table(p.odtab, s_log);
+    const int sx = ps.oct & 1, sy = (ps.oct >> 1) & 1, sz = (ps.oct >> 2) & 1;      // sign classes: 0: >= 0, 1: <= 0
+    const int sw0 = p.srcw[3 * ps.s + 0], sw1 = p.srcw[3 * ps.s + 1], sw2 = p.srcw[3 * ps.s + 2];
+    ps.nflux = p.normflux[ps.s];
+    const int rows = kRows * oa.groups, nshell = oa.nshell, q0 = oa.q0;
+    for (int i = threadIdx.x; i < 6 * oa.pitch; i += kBlock) s_dyn[rows * oa.pitch + i] = 0.0;
+    lds_barrier();
+    double loss = 0.0;
+    for (int axis = 2; axis >= 0; --axis) {              // z, y, x: the order of the edge hand-offs
+        ps.axis = axis;
+        ps.aneg = axis == 0 ? sy : sx; ps.bneg = axis == 2 ? sy : sz; ps.fneg = axis == 2 ? sz : (axis == 1 ? sy : sx);
+        ps.sw_a = axis == 0 ? sw1 : sw0; ps.sw_b = axis == 2 ? sw1 : sw2; ps.sw_p = axis == 2 ? sw2 : (axis == 1 ? sw1 : sw0);
+        const int qb1 = (axis == 2) ? q0 + nshell - 1 : q0 + nshell - 2;       // rows |b| = 0..qb1 in the last shell
+        const int nstrips = (qb1 + rows) / rows;
+        OctStrip st;
+        st.base = 0;
+        for (int k = 0; k < nstrips; ++k) {
+            st.w_lo = k * rows;
+            oct_fill<STREAM>(fresh_kernarg(), s_dyn, ps, st);
+            lds_barrier();
+            int j = 0;
+            while (j < nshell && ((axis == 2) ? q0 + j : q0 + j - 1) < st.w_lo) ++j;       // shells in which the strip has no cell yet
+            unsigned id_nx[kRows];
+            double nhi_nx[kRows];
+            if (j < nshell) oct_fetch_nhi<STREAM>(fresh_kernarg(), ps, st.w_lo, j, 0, id_nx, nhi_nx);
+            for (; j < nshell; ++j) {
+                const int qb = (axis == 2) ? q0 + j : q0 + j - 1;
+                const int items = min(oa.groups, (qb - st.w_lo) / kRows + 1) * ((axis == 0 ? q0 + j - 1 : q0 + j) + 1);
+                for (int t0 = 0; t0 < items; t0 += kBlock)
+                    oct_trip<LLS, STREAM>(fresh_kernarg(), ltab, s_dyn, ps, st, j, t0, id_nx, nhi_nx, loss);
+                lds_barrier();
+            }
+            st.base = (st.base + 4) % 6;
+        }
+        __syncthreads();                                 // this quadrant's edge cells are visible to the octant's next quadrants
+    }
+    const double tot = block_sum_256(loss, sm);
+    if (threadIdx.x == 0) oa.loss_partial[(size_t)sl * 8 + ps.oct] = tot;
+}
+
 // ---- the first sub-boxes, fused: one workgroup per source, all shells of the sub-box in one launch -----
 // Near the source a shell has few cells (24q^2+2: 26 ... 602 for q = 1..5) and a launch per shell is
 // nothing but latency, with the six faces' 256-thread tiles mostly empty.  Here the cells of a shell are
 // packed over the six faces (face_off = prefix sums of the owned rectangles) and a source's workgroup walks
 // the shells itself, a barrier between them; its photon loss through the box surface is summed in a fixed
 // order and added to loss_acc[source] (no k_loss_reduce).  Same per-cell code as k_sweep_shell.
-constexpr int kMaxFused = 5;
+constexpr int kMaxFused = kMaxFusedShells;
 struct BoxArgs {
     int nshell;
     int ncell[kMaxFused];            // packed cells of each shell
@@ -1086,7 +1475,7 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const int *active, const in
     const int sl = blockIdx.x;
     if (sl >= *n_active) return;
     double v = 0.0;
-    for (int i = threadIdx.x; i < bps; i += 256) v += loss_partial[(size_t)sl * bps + i];   // bps = 6*tiles_max
+    for (int i = threadIdx.x; i < bps; i += 256) v += loss_partial[(size_t)sl * bps + i];   // bps = 6*tiles_max (shells), 8 (octants)
     const double tot = block_sum_256(v, sm);
     if (threadIdx.x == 0) loss_acc[active[sl]] += tot;
 }
