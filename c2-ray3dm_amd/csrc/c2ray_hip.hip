@@ -374,11 +374,11 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             OctArgs oa{};
             oa.q0 = q0; oa.nshell = q1 - q0 + 1;
             oa.pitch = q1 + 2;
-            // row groups per strip: the one that fills the 256-thread trips best over the sub-box's shells and faces, within
-            // 32 KB of LDS (ties: the larger -- fewer strips to fill)
+            // segments (of kOctRows rows) per strip: the count that fills the 256-thread rounds best over the sub-box's shells
+            // and faces, within 48 KB of LDS (two planes + the ring); ties: the larger -- fewer strips to fill
             int best_g = 1; double best_eff = -1.0;
             for (int g = 1; g <= 16; ++g) {
-                if ((size_t)(kRows * g + 6) * oa.pitch * sizeof(double) > (32u << 10) && g > 1) break;
+                if ((size_t)(2 * kOctRows * g + 6) * oa.pitch * sizeof(double) > (48u << 10) && g > 1) break;
                 long long work = 0, slots = 0;
                 for (int j = 0; j < oa.nshell; ++j)
                     for (int ax = 0; ax < 3; ++ax) {
@@ -400,7 +400,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             oa.active = ctx->d_active[cur]; oa.n_active = ctx->d_nactive + cur;
             oa.loss_partial = ctx->d_loss_oct; oa.edges = ctx->d_edges;
             const dim3 grid(8, bound), blk(kBlock);
-            const size_t lds = (size_t)(kRows * oa.groups + 6) * oa.pitch * sizeof(double);
+            const size_t lds = (size_t)(2 * kOctRows * oa.groups + 6) * oa.pitch * sizeof(double);
             if (ctx->prof) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
 #define C2R_LAUNCH_OCT(L) do { if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_octant_fast<L, true>), grid, blk, lds, st, k, oa); \
                                else hipLaunchKernelGGL((k_sweep_octant_fast<L, false>), grid, blk, lds, st, k, oa); } while (0)

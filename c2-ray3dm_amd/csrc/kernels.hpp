@@ -367,6 +367,15 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned
 #ifndef C2R_PLANE_AUX
 #define C2R_PLANE_AUX 2
 #endif
+// buffer_atomic_add_f64 (no return): hipcc has no builtin for the f64 form, the LLVM intrinsic is declared by name.  An
+// offset beyond the buffer drops the lane's add, so a predicated-off atomic needs no branch -- and an unconditional
+// instruction is one the compiler can count when it sizes the s_waitcnt vmcnt(N) of the loads around it.
+__device__ double c2r_raw_buffer_atomic_fadd_f64(double v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.atomic.fadd.f64");
+__device__ __forceinline__ void buf_atomic_add_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double v)
+{
+    (void)c2r_raw_buffer_atomic_fadd_f64(v, r, (int)byte_off, 0, 0);
+}
 template <int AUX = 0>
 __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double v)
 {
@@ -582,6 +591,9 @@ __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &
 #define C2R_ROWS 3
 #endif
 constexpr int kRows = C2R_ROWS;
+#ifndef C2R_OCT_ROWS
+#define C2R_OCT_ROWS 6
+#endif
 template <bool DET, int LLS, bool STREAM, bool HEAT>
 __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                              const int face, const int s, const int a, const int b0, const int sgb,
@@ -995,23 +1007,10 @@ struct OctPass {
 // a strip of a quadrant: rows |b| = w_lo .. w_lo+rows-1; base = ring position of "the row below, shell q0-1"
 struct OctStrip { int w_lo, base; };
 
-// one trip's cell assignment: thread -> column |a| = u, rows |b| = w0 .. w0+nvalid-1 of the strip starting at w_lo
-struct TripMap { bool live; int u, g, w0, nvalid; };
-__device__ __forceinline__ TripMap trip_map(unsigned t, int items, int ncol, unsigned magic, int ng, int w_lo, int qb)
-{
-    TripMap m;
-    m.live = t < (unsigned)items;
-    t = min(t, (unsigned)max(items - 1, 0));                 // idle lanes shadow the last item, side effects masked
-    const unsigned gi = magic ? __umulhi(t, magic) : t;
-    m.u = ncol - 1 - (int)(t - __umul24(gi, (unsigned)ncol));
-    m.g = ng - 1 - (int)gi;
-    m.w0 = w_lo + kRows * m.g;
-    m.nvalid = min(kRows, qb - m.w0 + 1);
-    return m;
-}
+constexpr int kOctRows = C2R_OCT_ROWS;       // rows |b| a thread walks in one go (a "segment"); a strip is groups x kOctRows rows
 
 // launch constants of shell j of the pass, from the (fresh) kernel arguments
-struct OctShell { int q, pd, qb, ncol, ng, items; unsigned magic; };
+struct OctShell { int q, pd, qb, ncol, nseg, items; unsigned magic; };
 __device__ __forceinline__ OctShell oct_shell(const C2R_AS4 OctArgs &o, const OctPass &ps, const int w_lo, const int j)
 {
     OctShell h;
@@ -1019,45 +1018,23 @@ __device__ __forceinline__ OctShell oct_shell(const C2R_AS4 OctArgs &o, const Oc
     h.pd = ps.fneg ? -h.q : h.q;
     h.qb = ps.axis == 2 ? h.q : h.q - 1;                     // rows / columns this face owns in shell q
     h.ncol = (ps.axis == 0 ? h.q - 1 : h.q) + 1;
-    h.ng = h.qb >= w_lo ? min(o.groups, (h.qb - w_lo) / kRows + 1) : 0;
-    h.items = h.ng * h.ncol;
+    h.nseg = h.qb >= w_lo ? min(o.groups, (h.qb - w_lo) / kOctRows + 1) : 0;
+    h.items = h.nseg * h.ncol;
     h.magic = o.magic[ps.axis == 0 ? 1 : 0][j];
     return h;
 }
-// n_HI of the cells a thread handles in trip t0 of shell j: ids and loads (out of range where it has no cell)
-template <bool STREAM>
-__device__ __forceinline__ void oct_fetch_nhi(const kargp_t kp, const OctPass &ps, const int w_lo, const int j, const int t0,
-                                              unsigned (&id)[kRows], double (&nhi)[kRows])
-{
-    const C2R_AS4 KParams &p = *reinterpret_cast<const C2R_AS4 KParams *>(kp);
-    const C2R_AS4 OctArgs &o = *reinterpret_cast<const C2R_AS4 OctArgs *>(kp + sizeof(KParams));
-    const OctShell h = oct_shell(o, ps, w_lo, j);
-    const TripMap m = trip_map((unsigned)(t0 + (int)threadIdx.x), h.items, h.ncol, h.magic, h.ng, w_lo, h.qb);
-    const bool xf = ps.axis == 0;
-    const int ua = xf ? 1 : 0, va = ps.axis == 2 ? 1 : 2;
-    const unsigned na = (unsigned)p.n[ua], nmid = xf ? (unsigned)p.n[0] : (unsigned)p.n[1];
-    const unsigned stride_b = ps.axis == 2 ? na : na * nmid;
-    const unsigned cp = wrap_pos(ps.sw_p, p.n[ps.axis], h.pd);
-    const unsigned base_p = ps.axis == 2 ? na * nmid * cp : na * cp;
-    const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
-    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(xf ? p.nhi_T : p.nhi, ncell * 8u);
-    const unsigned ca = wrap_pos(ps.sw_a, p.n[ua], (ps.aneg ? -1 : 1) * m.u);
-#pragma unroll
-    for (int c = 0; c < kRows; ++c) {
-        id[c] = ca + base_p + __umul24(stride_b, wrap_pos(ps.sw_b, p.n[va], (ps.bneg ? -1 : 1) * (m.w0 + c)));
-        nhi[c] = buf_load_f64<STREAM ? C2R_NHI_AUX : 0>(r_x, (m.live && c < m.nvalid) ? id[c] * 8u : kOOB);
-    }
-}
 
-// Fill a strip's LDS plane from HBM: shell q0-1 where it exists, the edge cells of shells q0..q0+n-2 that a face of
-// higher priority left in the octant's scratch, 0.0 elsewhere; the row below the strip (shell q0-1) into the ring.
+// Fill a strip's two LDS planes from HBM.  Plane (j+1)&1 holds shell q0+j while it is current: plane 0 receives shell
+// q0-1 where it exists, both planes the edge cells that a face of higher priority left in the octant's scratch (those of
+// shell q0+j into plane (j+1)&1, beyond this face's own cells of that shell), 0.0 elsewhere -- what the per-shell kernel's
+// out-of-range read returns; the row below the strip (shell q0-1) goes into the ring.
 template <bool STREAM>
 __device__ __forceinline__ void oct_fill(const kargp_t kp, double *s_pl, const OctPass &ps, const OctStrip &st)
 {
     const C2R_AS4 KParams &p = *reinterpret_cast<const C2R_AS4 KParams *>(kp);
     const C2R_AS4 OctArgs &o = *reinterpret_cast<const C2R_AS4 OctArgs *>(kp + sizeof(KParams));
     const int tid = threadIdx.x;
-    const int pitch = o.pitch, rows = kRows * o.groups, q0 = o.q0, qm = q0 - 1, q1 = q0 + o.nshell - 1;
+    const int pitch = o.pitch, rows = kOctRows * o.groups, q0 = o.q0, qm = q0 - 1, q1 = q0 + o.nshell - 1;
     const int sga = ps.aneg ? -1 : 1, sgb = ps.bneg ? -1 : 1;
     const unsigned plane_bytes = (unsigned)p.PP * 8u;
     const unsigned in_off = (unsigned)((qm & 1) * 6 + 2 * (2 - ps.axis) + ps.fneg) * plane_bytes;
@@ -1066,89 +1043,73 @@ __device__ __forceinline__ void oct_fill(const kargp_t kp, double *s_pl, const O
     const __amdgpu_buffer_rsrc_t r_ed = make_rsrc(o.edges + ((size_t)ps.s * 8 + ps.oct) * 3 * (kMaxFusedShells - 1) * pitch, 3u * edge_bytes);
     const int R = p.R, P = p.P;
     const bool xf = ps.axis == 0;
-    double *s_bnd = s_pl + rows * pitch;
+    double *s_bnd = s_pl + 2 * rows * pitch;
     const int lw = pitch <= 64 ? 6 : (pitch <= 128 ? 7 : 8);
     const int u0 = tid & ((1 << lw) - 1), rr = tid >> lw, rstep = kBlock >> lw;
     for (int r = rr; r <= rows; r += rstep) {             // r == rows: the row below the strip, into the ring
         const int w = r < rows ? st.w_lo + r : st.w_lo - 1;
-        double *dst = r < rows ? s_pl + r * pitch : s_bnd + st.base * pitch;
         for (int u = u0; u < pitch; u += 1 << lw) {
             const int m = max(w, u);
             const bool in = m <= qm && w >= 0;                                          // shell q0-1
             const double v = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_pl, in ? in_off + (unsigned)((sgb * w + R) * P + (sga * u + R)) * 8u : kOOB);
+            if (r == rows) { s_bnd[st.base * pitch + u] = v; continue; }
             double e = 0.0;
-            if (ps.axis != 2) {                                                         // another face's edge cells of shell m
-                const bool ed = r < rows && m >= q0 && m < q1 && (xf || w == m);
+            const bool ed = ps.axis != 2 && m >= q0 && m < q1 && (xf || w == m);         // another face's edge cell of shell m
+            if (ps.axis != 2) {
                 const unsigned kind = ps.axis == 1 ? 0u : (w == m ? 1u : 2u);
                 e = buf_load_f64<0>(r_ed, ed ? kind * edge_bytes + (unsigned)((m - q0) * pitch + (w == m ? u : w)) * 8u : kOOB);
             }
-            dst[u] = v + e;                                                             // at most one of them is not 0.0
+            const int eb = (m - q0 + 1) & 1;                                            // the plane of shell m
+            s_pl[r * pitch + u] = (ed && eb == 0) ? e : v;
+            s_pl[(rows + r) * pitch + u] = (ed && eb == 1) ? e : 0.0;
         }
     }
 }
 
-// One trip: up to 256 (column, row group) items of shell j of the strip.  id / nhi: this trip's cells on entry, the
-// next trip's on exit.
+// Shell j of a strip: every thread takes (column |a| = u, segment of kOctRows rows) items and walks the rows of each
+// upward, carrying the row sums of the interpolation from row to row; reads the plane of shell j-1, writes the plane of
+// shell j (no ordering inside a shell: one barrier per shell, by the caller).
 template <int LLS, bool STREAM>
-__device__ __forceinline__ void oct_trip(const kargp_t kp, const v2f64 *__restrict__ ltab, double *s_pl, const OctPass &ps,
-                                         const OctStrip &st, const int j, const int t0, unsigned (&id_nx)[kRows],
-                                         double (&nhi_nx)[kRows], double &loss)
+__device__ __forceinline__ void oct_shell_items(const kargp_t kp, const v2f64 *__restrict__ ltab, double *s_pl, const OctPass &ps,
+                                                const OctStrip &st, const int j, double &loss)
 {
-    constexpr int NR = kRows;
+    constexpr int L = kOctRows;
     const C2R_AS4 KParams &p = *reinterpret_cast<const C2R_AS4 KParams *>(kp);
     const C2R_AS4 OctArgs &o = *reinterpret_cast<const C2R_AS4 OctArgs *>(kp + sizeof(KParams));
     const int axis = ps.axis;
     const bool xf = axis == 0;
     const int ua = xf ? 1 : 0, va = axis == 2 ? 1 : 2;            // mesh axes of the plane coordinates (a, b)
-    const int pitch = o.pitch, rows = NR * o.groups, nshell = o.nshell;
+    const int pitch = o.pitch, rows = L * o.groups;
     const int w_lo = st.w_lo, w_hi = w_lo + rows - 1;
-    double *s_bnd = s_pl + rows * pitch;                          // ring of 6 rows
+    double *const cur = s_pl + ((j + 1) & 1) * rows * pitch;      // shell j, written
+    const double *const prv = s_pl + (j & 1) * rows * pitch;      // shell j-1, read
+    double *const s_bnd = s_pl + 2 * rows * pitch;                // ring of 6 rows
     const OctShell h = oct_shell(o, ps, w_lo, j);
     const int q = h.q, pd = h.pd, ncol = h.ncol;
-    const bool last = j == nshell - 1;
-    const int slot_old = (st.base + j) % 6;                       // row w_lo-1 as shell q-1 left it
-    const int slot_new = (st.base + j + 5) % 6;                   // row w_hi of this shell, for the next strip
-    const TripMap mp = trip_map((unsigned)(t0 + (int)threadIdx.x), h.items, ncol, h.magic, h.ng, w_lo, h.qb);
-    const int u = mp.u, w0 = mp.w0;
-    unsigned id[NR];
-    double nhi[NR];
-#pragma unroll
-    for (int c = 0; c < NR; ++c) { id[c] = id_nx[c]; nhi[c] = nhi_nx[c]; }
-    // upstream corners: columns |a|-1, |a|, rows w0-1 .. w0+NR-1 (|a| = 0, w0 = 0: weight 0, any finite value)
-    double vm[NR + 1], va_[NR + 1];
-    {
-        const int um = max(u - 1, 0);
-        const int r0 = w0 - w_lo;
-        const double *below = mp.g == 0 ? s_bnd + slot_old * pitch : s_pl + (r0 - 1) * pitch;
-        vm[0] = below[um]; va_[0] = below[u];
-#pragma unroll
-        for (int r = 1; r <= NR; ++r) {
-            const double *row = s_pl + min(r0 + r - 1, rows - 1) * pitch;
-            vm[r] = row[um]; va_[r] = row[u];
-        }
-    }
-    lds_barrier();
+    const bool last = j == o.nshell - 1;
+    const double *const ring_old = s_bnd + ((st.base + j) % 6) * pitch;       // row w_lo-1 as shell q-1 left it
+    double *const ring_new = s_bnd + ((st.base + j + 5) % 6) * pitch;         // row w_hi of this shell, for the next strip
     const int sga = ps.aneg ? -1 : 1, sgb = ps.bneg ? -1 : 1;
-    const int a = sga * u;
-    const bool own_col = !(ps.aneg && u == 0);
     const double sigma = p.sigma, wfloor = p.wfloor;
     const double inv_q = o.inv_q[j], path_scale = o.path_scale[j], lls_scale = o.lls_scale[j], d2ax = o.d2axis[axis][j];
-    const double omu = (double)u * inv_q, ddu = 1.0 - omu;
-    const int a2 = u * u;
-    const double du2 = p.dr2[ua] * (double)a2, dr2v = p.dr2[va];
-    double R[NR + 1], T[NR + 1];
-#pragma unroll
-    for (int r = 0; r <= NR; ++r) {
-        const double rm = rcp1(fmax(wfloor, vm[r] * sigma)), ra = rcp1(fmax(wfloor, va_[r] * sigma));
-        R[r] = __builtin_fma(omu, rm, ddu * ra);
-        T[r] = __builtin_fma(omu, vm[r] * rm, ddu * (va_[r] * ra));
-    }
+    const double dr2u = p.dr2[ua], dr2v = p.dr2[va];
     const unsigned plane_bytes = (unsigned)p.PP * 8u;
     const unsigned cur_off = (unsigned)(q & 1) * 6u * plane_bytes;
     const unsigned face_off = (unsigned)(2 * (2 - axis) + ps.fneg) * plane_bytes;
     const unsigned edge_bytes = (unsigned)((kMaxFusedShells - 1) * pitch) * 8u;
     const int PR = p.R, PP_ = p.P;
     const double nflux = ps.nflux, numtau_d = p.numtau_d, od_per_e = p.od_per_e, od_per_ln = p.od_per_ln;
+    const double tau_limit = p.tau_limit, fourpi = p.fourpi, max_cd = p.max_coldensh;
+    const double *const thick = p.thick;
+    const unsigned na = (unsigned)p.n[ua], nmid = xf ? (unsigned)p.n[0] : (unsigned)p.n[1];
+    const unsigned stride_b = axis == 2 ? na : na * nmid;
+    const unsigned cp = wrap_pos(ps.sw_p, p.n[axis], pd);
+    const unsigned base_p = axis == 2 ? na * nmid * cp : na * cp;
+    const int n_a = p.n[ua], n_b = p.n[va];
+    const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(xf ? p.nhi_T : p.nhi, ncell * 8u);
+    const __amdgpu_buffer_rsrc_t r_ph = make_rsrc(xf ? p.phih_T : p.phih, ncell * 8u);
+    constexpr int NA = STREAM ? C2R_NHI_AUX : 0;
     // the table position of tau (tau_od), with the kernel arguments already in registers
     auto od_of = [&](double tau) {
         const double x = fmax(1.0e-20, tau);
@@ -1164,101 +1125,130 @@ __device__ __forceinline__ void oct_trip(const kargp_t kp, const v2f64 *__restri
         const double l1p = __builtin_fma(z * z, P, z);
         return fmin(numtau_d, __builtin_fma((double)e, od_per_e, __builtin_fma(l1p, od_per_ln, rt.y)));
     };
-    // ---- the three cells, one after the other; the atomics wait for the end of the trip so that no table read queues
-    // behind one (vmcnt retires in order)
-    double gam[NR];
-    bool rate[NR];
-#pragma unroll
-    for (int c = 0; c < NR; ++c) {
-        const int w = w0 + c, b = sgb * w;
-        const bool valid = mp.live && c < mp.nvalid;
-        const bool own = valid && own_col && !(ps.bneg && w == 0);
-        const double omv = (double)w * inv_q, ddv = 1.0 - omv;
-        const double den = __builtin_fma(omv, R[c], ddv * R[c + 1]);
-        const double num = __builtin_fma(omv, T[c], ddv * T[c + 1]);
-        const double cdi = num * rcp1(den);                               // (q > 10 here: no sqrt2 / sqrt3 factors)
-        const double pq = sqrt_pos((double)(q * q + a2 + w * w));
-        const double path = pq * path_scale;
-        const double dist2 = __builtin_fma(dr2v, (double)(w * w), du2 + d2ax);
-        bool stop = false;
-        double cd_in;
-        if (LLS == 3) { stop = dist2 > p.R_max2; cd_in = cdi; }
-        else if (LLS == 2) cd_in = __builtin_fma((double)(xf ? p.lls_T : p.lls)[valid ? id[c] : 0u] * inv_q, pq, cdi);
-        else cd_in = __builtin_fma(lls_scale, pq, cdi);
-        const double np = nhi[c] * path;
-        const double cd_out = cd_in + np;
-        if (valid) {
-            s_pl[(w - w_lo) * pitch + u] = cd_out;
+    for (unsigned t = threadIdx.x; t < (unsigned)h.items; t += kBlock) {
+        const unsigned seg = h.magic ? __umulhi(t, h.magic) : t;
+        const int u = (int)(t - __umul24(seg, (unsigned)ncol));
+        const int w0 = w_lo + L * (int)seg;
+        const int nvalid = min(L, h.qb - w0 + 1);
+        const int a = sga * u, um = max(u - 1, 0);
+        const bool own_col = !(ps.aneg && u == 0);
+        const double omu = (double)u * inv_q, ddu = 1.0 - omu;
+        const int a2 = u * u;
+        const double du2 = dr2u * (double)a2;
+        const unsigned id_col = wrap_pos(ps.sw_a, n_a, a) + base_p;
+        // the row below the segment: columns |a|-1, |a| (|a| = 0, |b| = 0: weight 0, any finite value)
+        double Rp, Tp;
+        {
+            const double *below = seg == 0 ? ring_old : prv + (w0 - w_lo - 1) * pitch;
+            const double vm = below[um], va_ = below[u];
+            const double rm = rcp1(fmax(wfloor, vm * sigma)), ra = rcp1(fmax(wfloor, va_ * sigma));
+            Rp = __builtin_fma(omu, rm, ddu * ra);
+            Tp = __builtin_fma(omu, vm * rm, ddu * (va_ * ra));
+        }
+        // n_HI two rows ahead; the atomic of a row is issued one row late, after the next row's table reads (vmcnt retires
+        // in order: no read then waits behind an atomic that was issued less than a row ago)
+        // (two register sets, rows alternate between them: a rotating copy would need the data a row early)
+        unsigned idA = id_col + __umul24(stride_b, wrap_pos(ps.sw_b, n_b, sgb * w0));
+        unsigned idB = id_col + __umul24(stride_b, wrap_pos(ps.sw_b, n_b, sgb * (w0 + 1)));
+        double nhA = buf_load_f64<NA>(r_x, idA * 8u);
+        double nhB = buf_load_f64<NA>(r_x, nvalid > 1 ? idB * 8u : kOOB);
+        double g_prev = 0.0;
+        unsigned id_prev = 0;
+        // one row: the cell (u, w0 + r) with its n_HI and index in (nhi, id); reloads them for row r + 2
+        auto row_step = [&](const int r, double &nhi_io, unsigned &id_io) {
+            const double nhi = nhi_io;
+            const unsigned id = id_io;
+            const int w = w0 + r, b = sgb * w;
+            const double *row = prv + (w - w_lo) * pitch;
+            const double vm = row[um], va_ = row[u];
+            const double rm = rcp1(fmax(wfloor, vm * sigma)), ra = rcp1(fmax(wfloor, va_ * sigma));
+            const double Rc = __builtin_fma(omu, rm, ddu * ra);
+            const double Tc = __builtin_fma(omu, vm * rm, ddu * (va_ * ra));
+            const double omv = (double)w * inv_q, ddv = 1.0 - omv;
+            const double den = __builtin_fma(omv, Rp, ddv * Rc);
+            const double num = __builtin_fma(omv, Tp, ddv * Tc);
+            Rp = Rc; Tp = Tc;
+            const double cdi = num * rcp1(den);                               // (q > 10 here: no sqrt2 / sqrt3 factors)
+            const double pq = sqrt_pos((double)(q * q + a2 + w * w));
+            const double path = pq * path_scale;
+            const double dist2 = __builtin_fma(dr2v, (double)(w * w), du2 + d2ax);
+            bool stop = false;
+            double cd_in;
+            if (LLS == 3) { stop = dist2 > p.R_max2; cd_in = cdi; }
+            else if (LLS == 2) cd_in = __builtin_fma((double)(xf ? p.lls_T : p.lls)[id] * inv_q, pq, cdi);
+            else cd_in = __builtin_fma(lls_scale, pq, cdi);
+            const double np = nhi * path;
+            const double cd_out = cd_in + np;
+            cur[(w - w_lo) * pitch + u] = cd_out;
             if (w == w_hi) {
-                s_bnd[slot_new * pitch + u] = cd_out;
+                ring_new[u] = cd_out;
                 // x face: the strip above also reads the y face's edge cell of this row (column |a| = q), which no
-                // thread computes: it sits in the plane since the fill
-                if (xf && u == ncol - 1) s_bnd[slot_new * pitch + u + 1] = s_pl[(w - w_lo) * pitch + u + 1];
+                // thread computes: it sits in this shell's plane since the fill
+                if (xf && u == ncol - 1) ring_new[u + 1] = cur[(w - w_lo) * pitch + u + 1];
             }
-        }
-        if (last) {
-            // this face's plane, and the edge cells also into the planes of the faces that read them (as the per-shell
-            // kernel; a recomputed axis cell stores the same bits as its owner): the input of the next sub-box
-            const __amdgpu_buffer_rsrc_t r_pl = make_rsrc(p.planes + (size_t)ps.s * 12 * p.PP, 12u * plane_bytes);
-            constexpr int SA = STREAM ? C2R_STORE_AUX : 0;
-            buf_store_f64<SA>(r_pl, own ? cur_off + face_off + (unsigned)((b + PR) * PP_ + (a + PR)) * 8u : kOOB, cd_out);
-            if (axis == 2) {
-                if (valid && u == q)
-                    buf_store_f64<SA>(r_pl, cur_off + (ps.aneg ? 5u : 4u) * plane_bytes + (unsigned)((pd + PR) * PP_ + (b + PR)) * 8u, cd_out);
-                if (valid && w == q)
-                    buf_store_f64<SA>(r_pl, cur_off + (ps.bneg ? 3u : 2u) * plane_bytes + (unsigned)((pd + PR) * PP_ + (a + PR)) * 8u, cd_out);
-            } else if (axis == 1) {
-                if (valid && u == q)
-                    buf_store_f64<SA>(r_pl, cur_off + (ps.aneg ? 5u : 4u) * plane_bytes + (unsigned)((b + PR) * PP_ + (pd + PR)) * 8u, cd_out);
+            const bool own = own_col && !(ps.bneg && w == 0);
+            if (last) {
+                // this face's plane, and the edge cells also into the planes of the faces that read them (as the per-shell
+                // kernel; a recomputed axis cell stores the same bits as its owner): the input of the next sub-box
+                const __amdgpu_buffer_rsrc_t r_pl = make_rsrc(p.planes + (size_t)ps.s * 12 * p.PP, 12u * plane_bytes);
+                constexpr int SA = STREAM ? C2R_STORE_AUX : 0;
+                buf_store_f64<SA>(r_pl, own ? cur_off + face_off + (unsigned)((b + PR) * PP_ + (a + PR)) * 8u : kOOB, cd_out);
+                if (axis == 2) {
+                    if (u == q)
+                        buf_store_f64<SA>(r_pl, cur_off + (ps.aneg ? 5u : 4u) * plane_bytes + (unsigned)((pd + PR) * PP_ + (b + PR)) * 8u, cd_out);
+                    if (w == q)
+                        buf_store_f64<SA>(r_pl, cur_off + (ps.bneg ? 3u : 2u) * plane_bytes + (unsigned)((pd + PR) * PP_ + (a + PR)) * 8u, cd_out);
+                } else if (axis == 1) {
+                    if (u == q)
+                        buf_store_f64<SA>(r_pl, cur_off + (ps.aneg ? 5u : 4u) * plane_bytes + (unsigned)((b + PR) * PP_ + (pd + PR)) * 8u, cd_out);
+                }
+            } else if (axis != 0 && (u == q || w == q)) {
+                // earlier shells: edge cells into the octant's private scratch, recomputed axis cells included -- this
+                // octant's later quadrants read them
+                const __amdgpu_buffer_rsrc_t r_ed = make_rsrc(o.edges + ((size_t)ps.s * 8 + ps.oct) * 3 * (kMaxFusedShells - 1) * pitch, 3u * edge_bytes);
+                if (axis == 2) {
+                    if (u == q) buf_store_f64<0>(r_ed, 1u * edge_bytes + (unsigned)(j * pitch + w) * 8u, cd_out);
+                    if (w == q) buf_store_f64<0>(r_ed, 0u * edge_bytes + (unsigned)(j * pitch + u) * 8u, cd_out);
+                } else {
+                    if (u == q) buf_store_f64<0>(r_ed, 2u * edge_bytes + (unsigned)(j * pitch + w) * 8u, cd_out);
+                }
             }
-        } else if (axis != 0 && valid && (u == q || w == q)) {
-            // earlier shells: edge cells into the octant's private scratch, recomputed axis cells included -- this
-            // octant's later quadrants read them
-            const __amdgpu_buffer_rsrc_t r_ed = make_rsrc(o.edges + ((size_t)ps.s * 8 + ps.oct) * 3 * (kMaxFusedShells - 1) * pitch, 3u * edge_bytes);
-            if (axis == 2) {
-                if (u == q) buf_store_f64<0>(r_ed, 1u * edge_bytes + (unsigned)(j * pitch + w) * 8u, cd_out);
-                if (w == q) buf_store_f64<0>(r_ed, 0u * edge_bytes + (unsigned)(j * pitch + u) * 8u, cd_out);
-            } else {
-                if (u == q) buf_store_f64<0>(r_ed, 2u * edge_bytes + (unsigned)(j * pitch + w) * 8u, cd_out);
-            }
-        }
-        rate[c] = own && !stop && !(cd_in > p.max_coldensh) && nflux > 0.0;
-        gam[c] = 0.0;
-        if (rate[c]) {
+            const bool rate = own && !stop && !(cd_in > max_cd) && nflux > 0.0;
+            // both table positions and both thick-table reads unconditionally (straight-line code: the compiler can count
+            // the loads, and a cell that takes no rate is the exception: recomputed axis cells, type_of_LLS = 3)
             const double tau_in = cd_in * sigma, tau_out = cd_out * sigma;
-            const double od_in = od_of(tau_in);
-            const double t_in = table_at(p.thick, od_in);
-            double dT, t_out;
-            if (fabs(tau_out - tau_in) > p.tau_limit) {
-                t_out = table_at(p.thick, od_of(tau_out));
-                dT = t_in - t_out;
-            } else {
+            const double od_in = od_of(tau_in), od_out = od_of(tau_out);
+            typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+            const d2u tk_in = *reinterpret_cast<const d2u *>(thick + (int)od_in);
+            const d2u tk_out = *reinterpret_cast<const d2u *>(thick + (int)od_out);
+            // the row before: its atomic goes out behind this row's table reads; then n_HI of the row after the next
+            buf_atomic_add_f64(r_ph, g_prev != 0.0 ? id_prev * 8u : kOOB, g_prev);
+            id_io = id_col + __umul24(stride_b, wrap_pos(ps.sw_b, n_b, sgb * (w + 2)));
+            nhi_io = buf_load_f64<NA>(r_x, r + 2 < nvalid ? id_io * 8u : kOOB);
+            const double t_in = __builtin_fma(tk_in.y - tk_in.x, __builtin_amdgcn_fract(od_in), tk_in.x);
+            double t_out = __builtin_fma(tk_out.y - tk_out.x, __builtin_amdgcn_fract(od_out), tk_out.x);
+            double dT = t_in - t_out;
+            if (!(fabs(tau_out - tau_in) > tau_limit)) {                          // optically thin cell: the thin table
                 dT = (tau_out - tau_in) * table_at(p.thin, od_in);
                 t_out = t_in - dT;
             }
-            const double area = p.fourpi * dist2;
-            gam[c] = (nflux * dT) * rcp1(area * np);
-            if (last) loss = loss + fdiv((nflux * t_out) * p.vol, area * path);   // the whole last shell lies on the box surface
+            const double area = fourpi * dist2;
+            const double gamma = rate ? (nflux * dT) * rcp1(area * np) : 0.0;
+            if (last && rate) loss = loss + fdiv((nflux * t_out) * p.vol, area * path);   // the whole last shell lies on the box surface
+            g_prev = gamma; id_prev = id;
+        };
+        for (int r = 0; r < nvalid; r += 2) {
+            row_step(r, nhA, idA);
+            if (r + 1 < nvalid) row_step(r + 1, nhB, idB);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        buf_atomic_add_f64(r_ph, g_prev != 0.0 ? id_prev * 8u : kOOB, g_prev);
     }
-    // ---- the next trip's n_HI, issued ahead of this trip's atomics
-    {
-        int jn = j, tn = t0 + kBlock;
-        if (tn >= h.items) { jn = j + 1; tn = 0; }
-        if (jn < nshell) oct_fetch_nhi<STREAM>(kp, ps, w_lo, jn, tn, id_nx, nhi_nx);
-    }
-    asm volatile("" ::: "memory");
-    double *const phih = xf ? p.phih_T : p.phih;
-#pragma unroll
-    for (int c = 0; c < NR; ++c)
-        if (rate[c] && gam[c] != 0.0) atomicAdd(&phih[id[c]], gam[c]);
 }
 
 template <int LLS, bool STREAM>
-__global__ __launch_bounds__(kBlock) void k_sweep_octant_fast(KParams p, OctArgs oa)
+__global__ __launch_bounds__(kBlock, 5) void k_sweep_octant_fast(KParams p, OctArgs oa)
 {
-    extern __shared__ double s_dyn[];                    // [3 groups + 6][pitch]
+    extern __shared__ double s_dyn[];                    // two planes [kOctRows groups][pitch] + ring [6][pitch]
     __shared__ double sm[16];
     __shared__ v2f64 s_log[kBlock];
     const int sl = blockIdx.y;
@@ -1270,8 +1260,8 @@ __global__ __launch_bounds__(kBlock) void k_sweep_octant_fast(KParams p, OctArgs
     const int sx = ps.oct & 1, sy = (ps.oct >> 1) & 1, sz = (ps.oct >> 2) & 1;      // sign classes: 0: >= 0, 1: <= 0
     const int sw0 = p.srcw[3 * ps.s + 0], sw1 = p.srcw[3 * ps.s + 1], sw2 = p.srcw[3 * ps.s + 2];
     ps.nflux = p.normflux[ps.s];
-    const int rows = kRows * oa.groups, nshell = oa.nshell, q0 = oa.q0;
-    for (int i = threadIdx.x; i < 6 * oa.pitch; i += kBlock) s_dyn[rows * oa.pitch + i] = 0.0;
+    const int rows = kOctRows * oa.groups, nshell = oa.nshell, q0 = oa.q0;
+    for (int i = threadIdx.x; i < 6 * oa.pitch; i += kBlock) s_dyn[2 * rows * oa.pitch + i] = 0.0;
     lds_barrier();
     double loss = 0.0;
     for (int axis = 2; axis >= 0; --axis) {              // z, y, x: the order of the edge hand-offs
@@ -1286,16 +1276,10 @@ __global__ __launch_bounds__(kBlock) void k_sweep_octant_fast(KParams p, OctArgs
             st.w_lo = k * rows;
             oct_fill<STREAM>(fresh_kernarg(), s_dyn, ps, st);
             lds_barrier();
-            int j = 0;
-            while (j < nshell && ((axis == 2) ? q0 + j : q0 + j - 1) < st.w_lo) ++j;       // shells in which the strip has no cell yet
-            unsigned id_nx[kRows];
-            double nhi_nx[kRows];
-            if (j < nshell) oct_fetch_nhi<STREAM>(fresh_kernarg(), ps, st.w_lo, j, 0, id_nx, nhi_nx);
-            for (; j < nshell; ++j) {
+            for (int j = 0; j < nshell; ++j) {
                 const int qb = (axis == 2) ? q0 + j : q0 + j - 1;
-                const int items = min(oa.groups, (qb - st.w_lo) / kRows + 1) * ((axis == 0 ? q0 + j - 1 : q0 + j) + 1);
-                for (int t0 = 0; t0 < items; t0 += kBlock)
-                    oct_trip<LLS, STREAM>(fresh_kernarg(), ltab, s_dyn, ps, st, j, t0, id_nx, nhi_nx, loss);
+                if (qb < st.w_lo) continue;                                   // the strip has no cell in this shell yet (block-uniform)
+                oct_shell_items<LLS, STREAM>(fresh_kernarg(), ltab, s_dyn, ps, st, j, loss);
                 lds_barrier();
             }
             st.base = (st.base + 4) % 6;
