@@ -89,9 +89,6 @@ struct Ctx {
     int *d_hnactive = nullptr;                               // the same slots as the device sees them
     std::vector<hipEvent_t> ev_box;                          // 'slot written' events
     double *d_loss_partial = nullptr, *d_loss_acc = nullptr, *d_final_loss = nullptr;
-    // k_sweep_octant_fast (a whole sub-box per launch, shells through LDS): on/off, block partials of the photon loss
-    // [batch_cap][8], the octants' private edge cells [batch_cap][8][3][kMaxFusedShells-1][Qmax+2], row groups per strip (0: auto)
-    bool octant = false; double *d_loss_oct = nullptr, *d_edges = nullptr; int oct_groups = 0;
     int *d_final_nbox = nullptr;
     double *d_photon_loss = nullptr; long long *d_sum_nbox = nullptr;
     // reductions
@@ -137,7 +134,6 @@ size_t grid_bytes(const Ctx *ctx, int which) { return ctx->ncell * (which == 0 ?
 void free_sweep_scratch(Ctx *ctx)
 {
     hipFree(ctx->d_planes); hipFree(ctx->d_gbox); hipFree(ctx->d_gbox_h); hipFree(ctx->d_batch); hipFree(ctx->d_loss_partial);
-    hipFree(ctx->d_loss_oct); hipFree(ctx->d_edges); ctx->d_loss_oct = ctx->d_edges = nullptr;
     if (ctx->h_batch) hipHostFree(ctx->h_batch);
     ctx->d_batch = ctx->h_batch = nullptr; ctx->d_nactive = nullptr;
     ctx->d_planes = nullptr; ctx->d_gbox = nullptr; ctx->d_gbox_h = nullptr; ctx->d_srcpos_b = nullptr; ctx->d_srcw_b = nullptr; ctx->d_nflux_b = nullptr;
@@ -174,10 +170,6 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
     if (ctx->prm.deterministic_rates) HIP_TRY(hipMalloc(&ctx->d_gbox, (size_t)cap * 2 * ctx->ncell * sizeof(double)));
     if (ctx->prm.deterministic_rates && ctx->thermal) HIP_TRY(hipMalloc(&ctx->d_gbox_h, (size_t)cap * 2 * ctx->ncell * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_loss_partial, (size_t)cap * 6 * ctx->tiles_cap * sizeof(double)));
-    if (ctx->octant) {
-        HIP_TRY(hipMalloc(&ctx->d_loss_oct, (size_t)cap * 8 * sizeof(double)));
-        HIP_TRY(hipMalloc(&ctx->d_edges, (size_t)cap * 8 * 3 * (kMaxFusedShells - 1) * (ctx->Qmax + 2) * sizeof(double)));
-    }
     // small per-batch arrays: doubles first, then ints
     //   nflux[cap] final_loss[cap] loss_acc[cap] | srcpos[3cap] srcw[3cap] active0[cap] active1[cap] final_nbox[cap] nactive[2]
     ctx->batch_bytes = (size_t)cap * 3 * sizeof(double) + ((size_t)cap * 9 + 2) * sizeof(int);
@@ -366,50 +358,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             return sa;
         };
         last_bps = 0;
-        // an unclipped sub-box beyond the fused ones, fast mode: ONE launch, a workgroup per (source, octant), shells through LDS
-        const int reach_min = std::min({ctx->hl[0], ctx->hr[0], ctx->hl[1], ctx->hr[1], ctx->hl[2], ctx->hr[2]});
-        const bool use_oct = ctx->octant && ctx->d_edges && ctx->fast && !det && !ctx->thermal && !dbg && q0 > kFusedQmax &&
-                             q1 - q0 + 1 == p.subboxsize && p.subboxsize <= kMaxFusedShells && p.subboxsize >= 2 && q1 <= reach_min;
-        if (use_oct) {
-            OctArgs oa{};
-            oa.q0 = q0; oa.nshell = q1 - q0 + 1;
-            oa.pitch = q1 + 2;
-            // segments (of kOctRows rows) per strip: the count that fills the 256-thread rounds best over the sub-box's shells
-            // and faces, within 48 KB of LDS (two planes + the ring); ties: the larger -- fewer strips to fill
-            int best_g = 1; double best_eff = -1.0;
-            for (int g = 1; g <= 16; ++g) {
-                if ((size_t)(2 * kOctRows * g + 6) * oa.pitch * sizeof(double) > (48u << 10) && g > 1) break;
-                long long work = 0, slots = 0;
-                for (int j = 0; j < oa.nshell; ++j)
-                    for (int ax = 0; ax < 3; ++ax) {
-                        const long long items = (long long)g * ((ax == 0 ? q0 + j - 1 : q0 + j) + 1);
-                        work += items; slots += (items + kBlock - 1) / kBlock * kBlock;
-                    }
-                const double eff = (double)work / (double)slots;
-                if (eff >= best_eff - 1e-9) { best_eff = std::max(eff, best_eff); best_g = g; }
-            }
-            oa.groups = ctx->oct_groups > 0 ? ctx->oct_groups : best_g;
-            for (int j = 0; j < oa.nshell; ++j) {
-                const int q = q0 + j;
-                oa.magic[0][j] = (unsigned)((1ULL << 32) / (unsigned)(q + 1) + 1ULL);
-                oa.magic[1][j] = q > 1 ? (unsigned)((1ULL << 32) / (unsigned)q + 1ULL) : 0u;
-                oa.inv_q[j] = 1.0 / (double)q; oa.path_scale[j] = ctx->dr[0] / (double)q;
-                oa.lls_scale[j] = ctx->lls_type == 2 ? 1.0 / (double)q : ctx->lls / (double)q;
-                for (int d = 0; d < 3; ++d) { const double t = ctx->dr[d] * (double)q; oa.d2axis[d][j] = t * t; }
-            }
-            oa.active = ctx->d_active[cur]; oa.n_active = ctx->d_nactive + cur;
-            oa.loss_partial = ctx->d_loss_oct; oa.edges = ctx->d_edges;
-            const dim3 grid(8, bound), blk(kBlock);
-            const size_t lds = (size_t)(2 * kOctRows * oa.groups + 6) * oa.pitch * sizeof(double);
-            if (ctx->prof) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
-#define C2R_LAUNCH_OCT(L) do { if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_octant_fast<L, true>), grid, blk, lds, st, k, oa); \
-                               else hipLaunchKernelGGL((k_sweep_octant_fast<L, false>), grid, blk, lds, st, k, oa); } while (0)
-            if (ctx->lls_type == 1) C2R_LAUNCH_OCT(1); else if (ctx->lls_type == 2) C2R_LAUNCH_OCT(2); else C2R_LAUNCH_OCT(3);
-#undef C2R_LAUNCH_OCT
-            if (ctx->prof) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(1); }
-            hipLaunchKernelGGL(k_loss_reduce, dim3(bound), dim3(256), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
-                               (const double *)ctx->d_loss_oct, 8, ctx->d_loss_acc);
-        } else if (ctx->fuse_small && q1 <= kFusedQmax && q1 - q0 + 1 <= kMaxFused) {
+        if (ctx->fuse_small && q1 <= kFusedQmax && q1 - q0 + 1 <= kMaxFused) {
             // near the source: the whole sub-box of every active source in ONE launch (k_sweep_box_fused)
             BoxArgs ba{};
             int most = 0;
@@ -709,8 +658,6 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     if (const char *e = getenv("C2R_FUSE_SMALL")) ctx->fuse_small = atoi(e) != 0;
     if (const char *e = getenv("C2R_SCHED_HINT")) ctx->sched_hint = atoi(e) != 0;
     if (const char *e = getenv("C2R_GRAPH")) ctx->use_graph = atoi(e) != 0;
-    if (const char *e = getenv("C2R_OCTANT")) ctx->octant = atoi(e) != 0;
-    if (const char *e = getenv("C2R_OCT_GROUPS")) ctx->oct_groups = atoi(e);
     if (p->sweep_mode != C2R_SWEEP_EXACT && p->sweep_mode != C2R_SWEEP_FAST) { delete ctx; return C2R_EINVAL; }
     ctx->fast = p->sweep_mode == C2R_SWEEP_FAST;          // the caller's choice only: no environment override
     *out = reinterpret_cast<c2r_ctx *>(ctx);     // returned even on failure so c2r_last_error works

@@ -22,7 +22,6 @@ constexpr int kBlock = C2R_BLOCK;   // threads per block of the sweep; a face's 
 
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 constexpr int kLogTab = 64;              // intervals of the log10 table (log10_tab)
-constexpr int kMaxFusedShells = 5;       // most shells one launch walks (a sub-box: c2ray_parameters.f90:54 subboxsize)
 
 struct KParams {
     int n[3];
@@ -367,15 +366,6 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned
 #ifndef C2R_PLANE_AUX
 #define C2R_PLANE_AUX 2
 #endif
-// buffer_atomic_add_f64 (no return): hipcc has no builtin for the f64 form, the LLVM intrinsic is declared by name.  An
-// offset beyond the buffer drops the lane's add, so a predicated-off atomic needs no branch -- and an unconditional
-// instruction is one the compiler can count when it sizes the s_waitcnt vmcnt(N) of the loads around it.
-__device__ double c2r_raw_buffer_atomic_fadd_f64(double v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset, int aux)
-    __asm("llvm.amdgcn.raw.ptr.buffer.atomic.fadd.f64");
-__device__ __forceinline__ void buf_atomic_add_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double v)
-{
-    (void)c2r_raw_buffer_atomic_fadd_f64(v, r, (int)byte_off, 0, 0);
-}
 template <int AUX = 0>
 __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double v)
 {
@@ -591,9 +581,6 @@ __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &
 #define C2R_ROWS 3
 #endif
 constexpr int kRows = C2R_ROWS;
-#ifndef C2R_OCT_ROWS
-#define C2R_OCT_ROWS 6
-#endif
 template <bool DET, int LLS, bool STREAM, bool HEAT>
 __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                              const int face, const int s, const int a, const int b0, const int sgb,
@@ -930,373 +917,13 @@ __global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
     sweep_tile_fast<DET, LLS, STREAM, HEAT>(p, sa, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z);
 }
 
-// ==== a whole sub-box per launch, the shells handed from one to the next through LDS (fast mode) ==================
-// k_sweep_shell_fast round-trips a source's shell planes through HBM between launches: 8 B stored and >= 8 B loaded per
-// visited (cell, source) on top of the 28 algorithmic bytes.  k_sweep_octant_fast walks the shells q0..q0+n-1 of an
-// unclipped sub-box in ONE launch with the column densities in LDS:
-//  * a workgroup owns one OCTANT of one source's cube (sign classes of x, y, z): the quadrant (a, b sign classes) of
-//    the z face, then of the y face, then of the x face.  cinterp's upstream corners are |a|-1, |a| and |b|-1, |b| of
-//    the same face, so a quadrant depends on nothing outside itself except (i) the axis column a = 0 / row b = 0, which
-//    the classes a <= 0 / b <= 0 recompute for themselves (column density only: the classes a, b >= 0 own those cells;
-//    bit-identical values, 1/q of the cells), and (ii) the cube's edge cells, which the face of higher cinterp
-//    priority owns -- and that is the same octant's z (then y) quadrant, done earlier by the same workgroup.
-//  * a quadrant is marched in STRIPS of 3 x groups rows, low |b| first.  A strip's cells of all n shells live in one LDS
-//    plane that is updated IN PLACE: the cells of a shell are walked in DESCENDING (row group, |a|) order, 256 at a time;
-//    a trip reads its upstream corners (old values), passes one LDS-only barrier, computes and writes its own cells.
-//    Every reader of an old value sits in the same or an earlier trip, so one barrier per trip and one per shell suffice,
-//    and they wait for LDS traffic only (n_HI loads and Gamma atomics stay in flight across them).
-//  * the row just below a strip comes from the strip before it: its top row of every shell is kept in a ring of six
-//    LDS rows (slot arithmetic at bnd_slot).  No halo is recomputed, nothing is read twice.
-//  * at the start of a strip its plane is filled from HBM: shell q0-1 where it exists, the edge cells of shells
-//    q0..q0+n-2 that a face of higher priority stored into this face's planes (they sit beyond this face's own cells
-//    until the shell that reads them), 0.0 elsewhere -- exactly what the per-shell kernel's out-of-range read returns.
-//    The last shell's cells go to this face's plane: the input of the next sub-box, whichever kernel runs it.
-//  * per-cell arithmetic is shell_rows_fast's, expression for expression; both table positions and all three table
-//    reads of a cell are issued unconditionally (selects instead of branches) so that the three cells of a thread
-//    stay interleaved, and the next trip's n_HI loads are issued before this trip's atomics (vmcnt retires in order).
-//  Column densities, rates and sub-box counts are bit-identical to the per-shell launches; the photon loss differs by
-//  the order of its block sums.
-struct OctArgs {
-    int q0, nshell;              // shells q0 .. q0+nshell-1: one whole, unclipped sub-box beyond the fused ones (q0 > 10)
-    int groups;                  // row groups (kRows rows each) per strip
-    int pitch;                   // LDS row pitch in doubles (>= q0 + nshell + 1)
-    unsigned magic[2][kMaxFusedShells];   // division by the column count of shell j: [0] z and y faces (q+1), [1] x faces (q)
-    double inv_q[kMaxFusedShells], path_scale[kMaxFusedShells], lls_scale[kMaxFusedShells];
-    double d2axis[3][kMaxFusedShells];    // (dr_axis q)^2
-    const int *active, *n_active;
-    double *loss_partial;        // [n_active][8]
-    // edge cells of the shells q0..q0+nshell-2, private to an octant (the last shell's go to the planes, for the next
-    // sub-box): [source][octant][3 kinds][kMaxFusedShells-1][pitch] -- kind 0: z face -> y face (row |b| = q of the y plane, by
-    // |a|), 1: z face -> x face (row |b| = q of the x plane, by |a|), 2: y face -> x face (column |a| = q of the x plane, by |b|).
-    // A workgroup writes and reads only its own part: no other octant's stores can land between (shared planes would
-    // race on the axis cells, which two octants hold)
-    double *edges;
-};
-
-__device__ __forceinline__ void lds_barrier()
-{
-    // workgroup barrier that orders LDS accesses only: no s_waitcnt vmcnt(0), global loads and atomics stay in flight
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-// Register discipline of k_sweep_octant_fast.  Its three nested loops (strips, shells, trips) would keep ~150 launch-uniform
-// values alive in SGPRs -- the per-cell constants of KParams, three buffer descriptors, the per-shell scalars -- and the
-// 102 a wave has overflow into VGPR lanes: 320 v_readlane / v_writelane in a trip of ~700 vector instructions, measured.
-// So every piece of work inside the loops (fill, trip) reads the kernel arguments afresh through a pointer to the kernarg
-// segment that the optimiser cannot see through (an empty asm redefines it): the scalar loads and the descriptor arithmetic
-// then sit inside the piece, run on the scalar unit beside the vector work, and nothing but a dozen integers is live across it.
-#define C2R_AS4 __attribute__((address_space(4)))
-typedef const C2R_AS4 char *kargp_t;
-__device__ __forceinline__ kargp_t fresh_kernarg()
-{
-    kargp_t k = (kargp_t)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(k));
-    return k;
-}
-
-// what a quadrant pass keeps in SGPRs across its loops
-struct OctPass {
-    int axis;                    // 2 z face, 1 y face, 0 x face
-    int s, oct;                  // source (batch-local), octant
-    int aneg, bneg, fneg;        // sign classes of the plane coordinates a, b and of the face (0: >= 0, 1: <= 0)
-    int sw_a, sw_b, sw_p;        // the source cell, wrapped (KParams.srcw), along the plane coordinates a, b and the face axis
-    double nflux;
-};
-// a strip of a quadrant: rows |b| = w_lo .. w_lo+rows-1; base = ring position of "the row below, shell q0-1"
-struct OctStrip { int w_lo, base; };
-
-constexpr int kOctRows = C2R_OCT_ROWS;       // rows |b| a thread walks in one go (a "segment"); a strip is groups x kOctRows rows
-
-// launch constants of shell j of the pass, from the (fresh) kernel arguments
-struct OctShell { int q, pd, qb, ncol, nseg, items; unsigned magic; };
-__device__ __forceinline__ OctShell oct_shell(const C2R_AS4 OctArgs &o, const OctPass &ps, const int w_lo, const int j)
-{
-    OctShell h;
-    h.q = o.q0 + j;
-    h.pd = ps.fneg ? -h.q : h.q;
-    h.qb = ps.axis == 2 ? h.q : h.q - 1;                     // rows / columns this face owns in shell q
-    h.ncol = (ps.axis == 0 ? h.q - 1 : h.q) + 1;
-    h.nseg = h.qb >= w_lo ? min(o.groups, (h.qb - w_lo) / kOctRows + 1) : 0;
-    h.items = h.nseg * h.ncol;
-    h.magic = o.magic[ps.axis == 0 ? 1 : 0][j];
-    return h;
-}
-
-// Fill a strip's two LDS planes from HBM.  Plane (j+1)&1 holds shell q0+j while it is current: plane 0 receives shell
-// q0-1 where it exists, both planes the edge cells that a face of higher priority left in the octant's scratch (those of
-// shell q0+j into plane (j+1)&1, beyond this face's own cells of that shell), 0.0 elsewhere -- what the per-shell kernel's
-// out-of-range read returns; the row below the strip (shell q0-1) goes into the ring.
-template <bool STREAM>
-__device__ __forceinline__ void oct_fill(const kargp_t kp, double *s_pl, const OctPass &ps, const OctStrip &st)
-{
-    const C2R_AS4 KParams &p = *reinterpret_cast<const C2R_AS4 KParams *>(kp);
-    const C2R_AS4 OctArgs &o = *reinterpret_cast<const C2R_AS4 OctArgs *>(kp + sizeof(KParams));
-    const int tid = threadIdx.x;
-    const int pitch = o.pitch, rows = kOctRows * o.groups, q0 = o.q0, qm = q0 - 1, q1 = q0 + o.nshell - 1;
-    const int sga = ps.aneg ? -1 : 1, sgb = ps.bneg ? -1 : 1;
-    const unsigned plane_bytes = (unsigned)p.PP * 8u;
-    const unsigned in_off = (unsigned)((qm & 1) * 6 + 2 * (2 - ps.axis) + ps.fneg) * plane_bytes;
-    const unsigned edge_bytes = (unsigned)((kMaxFusedShells - 1) * pitch) * 8u;                           // one kind
-    const __amdgpu_buffer_rsrc_t r_pl = make_rsrc(p.planes + (size_t)ps.s * 12 * p.PP, 12u * plane_bytes);      // both parities
-    const __amdgpu_buffer_rsrc_t r_ed = make_rsrc(o.edges + ((size_t)ps.s * 8 + ps.oct) * 3 * (kMaxFusedShells - 1) * pitch, 3u * edge_bytes);
-    const int R = p.R, P = p.P;
-    const bool xf = ps.axis == 0;
-    double *s_bnd = s_pl + 2 * rows * pitch;
-    const int lw = pitch <= 64 ? 6 : (pitch <= 128 ? 7 : 8);
-    const int u0 = tid & ((1 << lw) - 1), rr = tid >> lw, rstep = kBlock >> lw;
-    for (int r = rr; r <= rows; r += rstep) {             // r == rows: the row below the strip, into the ring
-        const int w = r < rows ? st.w_lo + r : st.w_lo - 1;
-        for (int u = u0; u < pitch; u += 1 << lw) {
-            const int m = max(w, u);
-            const bool in = m <= qm && w >= 0;                                          // shell q0-1
-            const double v = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_pl, in ? in_off + (unsigned)((sgb * w + R) * P + (sga * u + R)) * 8u : kOOB);
-            if (r == rows) { s_bnd[st.base * pitch + u] = v; continue; }
-            double e = 0.0;
-            const bool ed = ps.axis != 2 && m >= q0 && m < q1 && (xf || w == m);         // another face's edge cell of shell m
-            if (ps.axis != 2) {
-                const unsigned kind = ps.axis == 1 ? 0u : (w == m ? 1u : 2u);
-                e = buf_load_f64<0>(r_ed, ed ? kind * edge_bytes + (unsigned)((m - q0) * pitch + (w == m ? u : w)) * 8u : kOOB);
-            }
-            const int eb = (m - q0 + 1) & 1;                                            // the plane of shell m
-            s_pl[r * pitch + u] = (ed && eb == 0) ? e : v;
-            s_pl[(rows + r) * pitch + u] = (ed && eb == 1) ? e : 0.0;
-        }
-    }
-}
-
-// Shell j of a strip: every thread takes (column |a| = u, segment of kOctRows rows) items and walks the rows of each
-// upward, carrying the row sums of the interpolation from row to row; reads the plane of shell j-1, writes the plane of
-// shell j (no ordering inside a shell: one barrier per shell, by the caller).
-template <int LLS, bool STREAM>
-__device__ __forceinline__ void oct_shell_items(const kargp_t kp, const v2f64 *__restrict__ ltab, double *s_pl, const OctPass &ps,
-                                                const OctStrip &st, const int j, double &loss)
-{
-    constexpr int L = kOctRows;
-    const C2R_AS4 KParams &p = *reinterpret_cast<const C2R_AS4 KParams *>(kp);
-    const C2R_AS4 OctArgs &o = *reinterpret_cast<const C2R_AS4 OctArgs *>(kp + sizeof(KParams));
-    const int axis = ps.axis;
-    const bool xf = axis == 0;
-    const int ua = xf ? 1 : 0, va = axis == 2 ? 1 : 2;            // mesh axes of the plane coordinates (a, b)
-    const int pitch = o.pitch, rows = L * o.groups;
-    const int w_lo = st.w_lo, w_hi = w_lo + rows - 1;
-    double *const cur = s_pl + ((j + 1) & 1) * rows * pitch;      // shell j, written
-    const double *const prv = s_pl + (j & 1) * rows * pitch;      // shell j-1, read
-    double *const s_bnd = s_pl + 2 * rows * pitch;                // ring of 6 rows
-    const OctShell h = oct_shell(o, ps, w_lo, j);
-    const int q = h.q, pd = h.pd, ncol = h.ncol;
-    const bool last = j == o.nshell - 1;
-    const double *const ring_old = s_bnd + ((st.base + j) % 6) * pitch;       // row w_lo-1 as shell q-1 left it
-    double *const ring_new = s_bnd + ((st.base + j + 5) % 6) * pitch;         // row w_hi of this shell, for the next strip
-    const int sga = ps.aneg ? -1 : 1, sgb = ps.bneg ? -1 : 1;
-    const double sigma = p.sigma, wfloor = p.wfloor;
-    const double inv_q = o.inv_q[j], path_scale = o.path_scale[j], lls_scale = o.lls_scale[j], d2ax = o.d2axis[axis][j];
-    const double dr2u = p.dr2[ua], dr2v = p.dr2[va];
-    const unsigned plane_bytes = (unsigned)p.PP * 8u;
-    const unsigned cur_off = (unsigned)(q & 1) * 6u * plane_bytes;
-    const unsigned face_off = (unsigned)(2 * (2 - axis) + ps.fneg) * plane_bytes;
-    const unsigned edge_bytes = (unsigned)((kMaxFusedShells - 1) * pitch) * 8u;
-    const int PR = p.R, PP_ = p.P;
-    const double nflux = ps.nflux, numtau_d = p.numtau_d, od_per_e = p.od_per_e, od_per_ln = p.od_per_ln;
-    const double tau_limit = p.tau_limit, fourpi = p.fourpi, max_cd = p.max_coldensh;
-    const double *const thick = p.thick;
-    const unsigned na = (unsigned)p.n[ua], nmid = xf ? (unsigned)p.n[0] : (unsigned)p.n[1];
-    const unsigned stride_b = axis == 2 ? na : na * nmid;
-    const unsigned cp = wrap_pos(ps.sw_p, p.n[axis], pd);
-    const unsigned base_p = axis == 2 ? na * nmid * cp : na * cp;
-    const int n_a = p.n[ua], n_b = p.n[va];
-    const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
-    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(xf ? p.nhi_T : p.nhi, ncell * 8u);
-    const __amdgpu_buffer_rsrc_t r_ph = make_rsrc(xf ? p.phih_T : p.phih, ncell * 8u);
-    constexpr int NA = STREAM ? C2R_NHI_AUX : 0;
-    // the table position of tau (tau_od), with the kernel arguments already in registers
-    auto od_of = [&](double tau) {
-        const double x = fmax(1.0e-20, tau);
-        const double m = __builtin_amdgcn_frexp_mant(x);
-        const int e = __builtin_amdgcn_frexp_exp(x);
-        const v2f64 rt = ltab[((unsigned)__double2hiint(m) >> 14) & 63u];
-        const double z = __builtin_fma(m, rt.x, -1.0);
-        double P = __builtin_fma(z, 1.0 / 7.0, -1.0 / 6.0);
-        P = __builtin_fma(z, P, 0.2);
-        P = __builtin_fma(z, P, -0.25);
-        P = __builtin_fma(z, P, 1.0 / 3.0);
-        P = __builtin_fma(z, P, -0.5);
-        const double l1p = __builtin_fma(z * z, P, z);
-        return fmin(numtau_d, __builtin_fma((double)e, od_per_e, __builtin_fma(l1p, od_per_ln, rt.y)));
-    };
-    for (unsigned t = threadIdx.x; t < (unsigned)h.items; t += kBlock) {
-        const unsigned seg = h.magic ? __umulhi(t, h.magic) : t;
-        const int u = (int)(t - __umul24(seg, (unsigned)ncol));
-        const int w0 = w_lo + L * (int)seg;
-        const int nvalid = min(L, h.qb - w0 + 1);
-        const int a = sga * u, um = max(u - 1, 0);
-        const bool own_col = !(ps.aneg && u == 0);
-        const double omu = (double)u * inv_q, ddu = 1.0 - omu;
-        const int a2 = u * u;
-        const double du2 = dr2u * (double)a2;
-        const unsigned id_col = wrap_pos(ps.sw_a, n_a, a) + base_p;
-        // the row below the segment: columns |a|-1, |a| (|a| = 0, |b| = 0: weight 0, any finite value)
-        double Rp, Tp;
-        {
-            const double *below = seg == 0 ? ring_old : prv + (w0 - w_lo - 1) * pitch;
-            const double vm = below[um], va_ = below[u];
-            const double rm = rcp1(fmax(wfloor, vm * sigma)), ra = rcp1(fmax(wfloor, va_ * sigma));
-            Rp = __builtin_fma(omu, rm, ddu * ra);
-            Tp = __builtin_fma(omu, vm * rm, ddu * (va_ * ra));
-        }
-        // n_HI two rows ahead; the atomic of a row is issued one row late, after the next row's table reads (vmcnt retires
-        // in order: no read then waits behind an atomic that was issued less than a row ago)
-        // (two register sets, rows alternate between them: a rotating copy would need the data a row early)
-        unsigned idA = id_col + __umul24(stride_b, wrap_pos(ps.sw_b, n_b, sgb * w0));
-        unsigned idB = id_col + __umul24(stride_b, wrap_pos(ps.sw_b, n_b, sgb * (w0 + 1)));
-        double nhA = buf_load_f64<NA>(r_x, idA * 8u);
-        double nhB = buf_load_f64<NA>(r_x, nvalid > 1 ? idB * 8u : kOOB);
-        double g_prev = 0.0;
-        unsigned id_prev = 0;
-        // one row: the cell (u, w0 + r) with its n_HI and index in (nhi, id); reloads them for row r + 2
-        auto row_step = [&](const int r, double &nhi_io, unsigned &id_io) {
-            const double nhi = nhi_io;
-            const unsigned id = id_io;
-            const int w = w0 + r, b = sgb * w;
-            const double *row = prv + (w - w_lo) * pitch;
-            const double vm = row[um], va_ = row[u];
-            const double rm = rcp1(fmax(wfloor, vm * sigma)), ra = rcp1(fmax(wfloor, va_ * sigma));
-            const double Rc = __builtin_fma(omu, rm, ddu * ra);
-            const double Tc = __builtin_fma(omu, vm * rm, ddu * (va_ * ra));
-            const double omv = (double)w * inv_q, ddv = 1.0 - omv;
-            const double den = __builtin_fma(omv, Rp, ddv * Rc);
-            const double num = __builtin_fma(omv, Tp, ddv * Tc);
-            Rp = Rc; Tp = Tc;
-            const double cdi = num * rcp1(den);                               // (q > 10 here: no sqrt2 / sqrt3 factors)
-            const double pq = sqrt_pos((double)(q * q + a2 + w * w));
-            const double path = pq * path_scale;
-            const double dist2 = __builtin_fma(dr2v, (double)(w * w), du2 + d2ax);
-            bool stop = false;
-            double cd_in;
-            if (LLS == 3) { stop = dist2 > p.R_max2; cd_in = cdi; }
-            else if (LLS == 2) cd_in = __builtin_fma((double)(xf ? p.lls_T : p.lls)[id] * inv_q, pq, cdi);
-            else cd_in = __builtin_fma(lls_scale, pq, cdi);
-            const double np = nhi * path;
-            const double cd_out = cd_in + np;
-            cur[(w - w_lo) * pitch + u] = cd_out;
-            if (w == w_hi) {
-                ring_new[u] = cd_out;
-                // x face: the strip above also reads the y face's edge cell of this row (column |a| = q), which no
-                // thread computes: it sits in this shell's plane since the fill
-                if (xf && u == ncol - 1) ring_new[u + 1] = cur[(w - w_lo) * pitch + u + 1];
-            }
-            const bool own = own_col && !(ps.bneg && w == 0);
-            if (last) {
-                // this face's plane, and the edge cells also into the planes of the faces that read them (as the per-shell
-                // kernel; a recomputed axis cell stores the same bits as its owner): the input of the next sub-box
-                const __amdgpu_buffer_rsrc_t r_pl = make_rsrc(p.planes + (size_t)ps.s * 12 * p.PP, 12u * plane_bytes);
-                constexpr int SA = STREAM ? C2R_STORE_AUX : 0;
-                buf_store_f64<SA>(r_pl, own ? cur_off + face_off + (unsigned)((b + PR) * PP_ + (a + PR)) * 8u : kOOB, cd_out);
-                if (axis == 2) {
-                    if (u == q)
-                        buf_store_f64<SA>(r_pl, cur_off + (ps.aneg ? 5u : 4u) * plane_bytes + (unsigned)((pd + PR) * PP_ + (b + PR)) * 8u, cd_out);
-                    if (w == q)
-                        buf_store_f64<SA>(r_pl, cur_off + (ps.bneg ? 3u : 2u) * plane_bytes + (unsigned)((pd + PR) * PP_ + (a + PR)) * 8u, cd_out);
-                } else if (axis == 1) {
-                    if (u == q)
-                        buf_store_f64<SA>(r_pl, cur_off + (ps.aneg ? 5u : 4u) * plane_bytes + (unsigned)((b + PR) * PP_ + (pd + PR)) * 8u, cd_out);
-                }
-            } else if (axis != 0 && (u == q || w == q)) {
-                // earlier shells: edge cells into the octant's private scratch, recomputed axis cells included -- this
-                // octant's later quadrants read them
-                const __amdgpu_buffer_rsrc_t r_ed = make_rsrc(o.edges + ((size_t)ps.s * 8 + ps.oct) * 3 * (kMaxFusedShells - 1) * pitch, 3u * edge_bytes);
-                if (axis == 2) {
-                    if (u == q) buf_store_f64<0>(r_ed, 1u * edge_bytes + (unsigned)(j * pitch + w) * 8u, cd_out);
-                    if (w == q) buf_store_f64<0>(r_ed, 0u * edge_bytes + (unsigned)(j * pitch + u) * 8u, cd_out);
-                } else {
-                    if (u == q) buf_store_f64<0>(r_ed, 2u * edge_bytes + (unsigned)(j * pitch + w) * 8u, cd_out);
-                }
-            }
-            const bool rate = own && !stop && !(cd_in > max_cd) && nflux > 0.0;
-            // both table positions and both thick-table reads unconditionally (straight-line code: the compiler can count
-            // the loads, and a cell that takes no rate is the exception: recomputed axis cells, type_of_LLS = 3)
-            const double tau_in = cd_in * sigma, tau_out = cd_out * sigma;
-            const double od_in = od_of(tau_in), od_out = od_of(tau_out);
-            typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-            const d2u tk_in = *reinterpret_cast<const d2u *>(thick + (int)od_in);
-            const d2u tk_out = *reinterpret_cast<const d2u *>(thick + (int)od_out);
-            // the row before: its atomic goes out behind this row's table reads; then n_HI of the row after the next
-            buf_atomic_add_f64(r_ph, g_prev != 0.0 ? id_prev * 8u : kOOB, g_prev);
-            id_io = id_col + __umul24(stride_b, wrap_pos(ps.sw_b, n_b, sgb * (w + 2)));
-            nhi_io = buf_load_f64<NA>(r_x, r + 2 < nvalid ? id_io * 8u : kOOB);
-            const double t_in = __builtin_fma(tk_in.y - tk_in.x, __builtin_amdgcn_fract(od_in), tk_in.x);
-            double t_out = __builtin_fma(tk_out.y - tk_out.x, __builtin_amdgcn_fract(od_out), tk_out.x);
-            double dT = t_in - t_out;
-            if (!(fabs(tau_out - tau_in) > tau_limit)) {                          // optically thin cell: the thin table
-                dT = (tau_out - tau_in) * table_at(p.thin, od_in);
-                t_out = t_in - dT;
-            }
-            const double area = fourpi * dist2;
-            const double gamma = rate ? (nflux * dT) * rcp1(area * np) : 0.0;
-            if (last && rate) loss = loss + fdiv((nflux * t_out) * p.vol, area * path);   // the whole last shell lies on the box surface
-            g_prev = gamma; id_prev = id;
-        };
-        for (int r = 0; r < nvalid; r += 2) {
-            row_step(r, nhA, idA);
-            if (r + 1 < nvalid) row_step(r + 1, nhB, idB);
-        }
-        buf_atomic_add_f64(r_ph, g_prev != 0.0 ? id_prev * 8u : kOOB, g_prev);
-    }
-}
-
-template <int LLS, bool STREAM>
-__global__ __launch_bounds__(kBlock, 5) void k_sweep_octant_fast(KParams p, OctArgs oa)
-{
-    extern __shared__ double s_dyn[];                    // two planes [kOctRows groups][pitch] + ring [6][pitch]
-    __shared__ double sm[16];
-    __shared__ v2f64 s_log[kBlock];
-    const int sl = blockIdx.y;
-    if (sl >= *oa.n_active) return;                      // block-uniform
-    OctPass ps;
-    ps.s = oa.active[sl];
-    ps.oct = blockIdx.x & 7;
-    const v2f64 *ltab = wave_log_table(p.odtab, s_log);
-    const int sx = ps.oct & 1, sy = (ps.oct >> 1) & 1, sz = (ps.oct >> 2) & 1;      // sign classes: 0: >= 0, 1: <= 0
-    const int sw0 = p.srcw[3 * ps.s + 0], sw1 = p.srcw[3 * ps.s + 1], sw2 = p.srcw[3 * ps.s + 2];
-    ps.nflux = p.normflux[ps.s];
-    const int rows = kOctRows * oa.groups, nshell = oa.nshell, q0 = oa.q0;
-    for (int i = threadIdx.x; i < 6 * oa.pitch; i += kBlock) s_dyn[2 * rows * oa.pitch + i] = 0.0;
-    lds_barrier();
-    double loss = 0.0;
-    for (int axis = 2; axis >= 0; --axis) {              // z, y, x: the order of the edge hand-offs
-        ps.axis = axis;
-        ps.aneg = axis == 0 ? sy : sx; ps.bneg = axis == 2 ? sy : sz; ps.fneg = axis == 2 ? sz : (axis == 1 ? sy : sx);
-        ps.sw_a = axis == 0 ? sw1 : sw0; ps.sw_b = axis == 2 ? sw1 : sw2; ps.sw_p = axis == 2 ? sw2 : (axis == 1 ? sw1 : sw0);
-        const int qb1 = (axis == 2) ? q0 + nshell - 1 : q0 + nshell - 2;       // rows |b| = 0..qb1 in the last shell
-        const int nstrips = (qb1 + rows) / rows;
-        OctStrip st;
-        st.base = 0;
-        for (int k = 0; k < nstrips; ++k) {
-            st.w_lo = k * rows;
-            oct_fill<STREAM>(fresh_kernarg(), s_dyn, ps, st);
-            lds_barrier();
-            for (int j = 0; j < nshell; ++j) {
-                const int qb = (axis == 2) ? q0 + j : q0 + j - 1;
-                if (qb < st.w_lo) continue;                                   // the strip has no cell in this shell yet (block-uniform)
-                oct_shell_items<LLS, STREAM>(fresh_kernarg(), ltab, s_dyn, ps, st, j, loss);
-                lds_barrier();
-            }
-            st.base = (st.base + 4) % 6;
-        }
-        __syncthreads();                                 // this quadrant's edge cells are visible to the octant's next quadrants
-    }
-    const double tot = block_sum_256(loss, sm);
-    if (threadIdx.x == 0) oa.loss_partial[(size_t)sl * 8 + ps.oct] = tot;
-}
-
 // ---- the first sub-boxes, fused: one workgroup per source, all shells of the sub-box in one launch -----
 // Near the source a shell has few cells (24q^2+2: 26 ... 602 for q = 1..5) and a launch per shell is
 // nothing but latency, with the six faces' 256-thread tiles mostly empty.  Here the cells of a shell are
 // packed over the six faces (face_off = prefix sums of the owned rectangles) and a source's workgroup walks
 // the shells itself, a barrier between them; its photon loss through the box surface is summed in a fixed
 // order and added to loss_acc[source] (no k_loss_reduce).  Same per-cell code as k_sweep_shell.
-constexpr int kMaxFused = kMaxFusedShells;
+constexpr int kMaxFused = 5;
 struct BoxArgs {
     int nshell;
     int ncell[kMaxFused];            // packed cells of each shell
@@ -1459,7 +1086,7 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const int *active, const in
     const int sl = blockIdx.x;
     if (sl >= *n_active) return;
     double v = 0.0;
-    for (int i = threadIdx.x; i < bps; i += 256) v += loss_partial[(size_t)sl * bps + i];   // bps = 6*tiles_max (shells), 8 (octants)
+    for (int i = threadIdx.x; i < bps; i += 256) v += loss_partial[(size_t)sl * bps + i];   // bps = 6*tiles_max
     const double tot = block_sum_256(v, sm);
     if (threadIdx.x == 0) loss_acc[active[sl]] += tot;
 }
