@@ -382,6 +382,14 @@ def main():
         case_evolve_planes("evolve128_std", 128, SRC_STD)
         case_sweep("sweep256_3src_x999", 256, [(200, 30, 77, 1e56), (5, 250, 130, 3e55), (128, 128, 128, 1e57)],
                    x_init=0.999, full=False, ns_dump=3)
+    # BASELINE.json configs[1]: 128^3, ONE source (inputs/test_sources_onesrc.dat): the single-source sweep out to the
+    # limits, and a whole evolve3D step from a field with a 30-cell ionized bubble around the source (conv_criterion = 0:
+    # only Test 2 ends the step, so several outer iterations with growing sub-boxes follow -- the launch-bound regime the
+    # library replays as a hipGraph)
+    if want("onesrc128"):
+        case_sweep("sweep128_onesrc_x999", 128, SRC_ONE, x_init=0.999, full=False)
+        case_evolve_planes("evolve128_onesrc_bubble", 128, SRC_ONE, xfield=bubble_xfield(128, [(50, 50, 50)], 30.0), store_inputs=False,
+                           xfield_recipe="inputs.bubble_xfield(128, [(50, 50, 50)], 30.0)")
     # BASELINE.json configs[2]: 256^3 x 100 sources as WHOLE evolve3D steps: the cold
     # start (x = 2e-4) and a late field (ionized bubbles of 14 cells around every source, sub-boxes grow)
     if want("evolve256"):

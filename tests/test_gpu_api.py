@@ -198,3 +198,96 @@ def test_per_iteration_conservation_line_comes_out_of_the_global_pass(pkg, table
     assert rep.it_photcons[rep.niter - 1] == expect
     assert all(np.isfinite(rep.it_photcons[k]) and rep.it_photcons[k] != 0.0 for k in range(rep.niter))
     b.close()
+
+
+def test_failing_allreduce_callback_surfaces_as_ecallback_and_the_context_survives(pkg, tables):
+    """c2r_set_rank's collective returns non-zero (a dead peer, a failed ncclAllReduce): c2r_allreduce_rates and
+    c2r_evolve3d report C2R_ECALLBACK (-4) with a message, the context stays usable -- a working callback afterwards
+    completes the step -- and destroyable."""
+    m, a = load_case("evolve32_std_bubbles")
+    s, n = m["steps"]["step001"], m["n"]
+    lib, ctx = _ctx_for(pkg, tables, s, n)
+    nd = F(a["step001_ndens"]); xh = F(a["step001_xh_before"])
+    AR = pkg._capi.ALLREDUCE_FN
+    calls = []
+    bad = AR(lambda user, buf, count, stream: calls.append(count) or 7)
+    assert lib.c2r_set_rank(ctx, 0, 2, bad, None) == 0
+    assert lib.c2r_upload(ctx, 0, nd.ctypes.data) == 0 and lib.c2r_upload(ctx, 1, xh.ctypes.data) == 0
+    assert lib.c2r_allreduce_rates(ctx) == -4 and b"all-reduce callback failed" in lib.c2r_last_error(ctx)
+    rep = pkg.Report()
+    xh1 = xh.copy()
+    assert lib.c2r_evolve3d(ctx, s["dt"], nd.ctypes.data, xh1.ctypes.data, None, None, None, C.byref(rep)) == -4
+    assert calls and calls[0] == n ** 3
+    # rank 0 of 2 with a collective that adds nothing (the peer's half is zero): the step now runs to the end
+    good = AR(lambda user, buf, count, stream: 0)
+    assert lib.c2r_set_rank(ctx, 0, 2, good, None) == 0
+    xh2 = xh.copy()
+    assert lib.c2r_evolve3d(ctx, s["dt"], nd.ctypes.data, xh2.ctypes.data, None, None, None, C.byref(rep)) == 0
+    assert rep.niter >= 1 and np.all(np.isfinite(xh2))
+    lib.c2r_destroy(ctx)
+
+
+def test_info_reports_device_mode_and_rank_and_the_library_ignores_the_environment(pkg, tables, monkeypatch):
+    """c2r_info: how the device was chosen, the sweep mode that RUNS, rank/nranks.  c2r_params.sweep_mode is the only
+    switch of the mode: C2R_SWEEP_MODE in the environment is a host-side convention (HipBackend(fast=None), the Fortran shim),
+    and an explicit choice is not overridden by it."""
+    lib = pkg.load_library()
+    for env, mode, want in (("1", 0, b"exact"), ("0", 1, b"fast")):
+        monkeypatch.setenv("C2R_SWEEP_MODE", env)
+        p = pkg.default_params(16); p.sweep_mode = mode
+        ctx = C.c_void_p()
+        assert lib.c2r_create(C.byref(ctx), C.byref(p)) == 0
+        info = lib.c2r_info(ctx)
+        assert b"sweep_mode " + want in info and b"device 0 of" in info and b"(explicit)" in info and b"rank 0 of 1" in info
+        lib.c2r_destroy(ctx)
+    # the Python host: explicit beats the environment, None follows it
+    monkeypatch.setenv("C2R_SWEEP_MODE", "1")
+    b = pkg.HipBackend(16, *tables, device=0, fast=False)
+    assert "sweep_mode exact" in b.info()
+    b.close()
+    b = pkg.HipBackend(16, *tables, device=0)
+    assert "sweep_mode fast" in b.info()
+    b.close()
+    # C2R_DEVICE_AUTO: which launcher variable decided is part of the line; several ranks and none set is a WARNING
+    for var in ("C2R_DEVICE", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "PMI_LOCAL_RANK", "SLURM_LOCALID"):
+        monkeypatch.delenv(var, raising=False)
+    p = pkg.default_params(16); p.device = -1
+    ctx = C.c_void_p()
+    assert lib.c2r_create(C.byref(ctx), C.byref(p)) == 0
+    assert b"no local-rank variable is set" in lib.c2r_info(ctx) and b"WARNING" not in lib.c2r_info(ctx)
+    AR = pkg._capi.ALLREDUCE_FN
+    cb = AR(lambda user, buf, count, stream: 0)
+    assert lib.c2r_set_rank(ctx, 1, 4, cb, None) == 0
+    assert b"WARNING: C2R_DEVICE_AUTO with nranks > 1" in lib.c2r_info(ctx) and b"rank 1 of 4" in lib.c2r_info(ctx)
+    lib.c2r_destroy(ctx)
+    monkeypatch.setenv("SLURM_LOCALID", "0")
+    ctx = C.c_void_p()
+    assert lib.c2r_create(C.byref(ctx), C.byref(p)) == 0
+    assert b"SLURM_LOCALID=0" in lib.c2r_info(ctx)
+    lib.c2r_destroy(ctx)
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_photon_loss_is_bit_reproducible_run_to_run(pkg, tables, fast):
+    """130 sources on a structured field: they retire at different sub-boxes, so the active count crosses 64 (where the
+    last shell's loss partials change hands between k_loss_reduce and k_box_decide) at a sub-box that depends on the data --
+    but not on host timing: the photon loss, the per-source sub-box counts and, with ordered rates, Gamma itself are the same
+    bits in every run."""
+    from tests.golden.inputs import bubble_xfield, density_factor
+    n, S = 64, 130
+    tp = pkg.TestProblem(n); s = tp.step(1)
+    nd = (tp.fields(1)[0].reshape((n, n, n), order="F") * density_factor(n, 21)).astype(np.float32)
+    pos, nf = pkg.seeded_sources(n, S, seed=77)
+    xh = bubble_xfield(n, [tuple(int(v) for v in q) for q in pos[:40]], 9.0)
+    runs = []
+    for rep in range(3):
+        b = pkg.HipBackend(n, *tables, device=0, deterministic=True, fast=fast)
+        b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], 1.0)
+        b.set_sources(pos, nf); b.set_rank(0, 1); b.load(ndens=F(nd), xh=F(xh)); b.begin_step(); b.zero_rates()
+        loss, nbox, vis = b.pass_sources()
+        runs.append((loss, nbox, vis, b.last_nbox().copy(), b.fetch("phih_grid")))
+        b.close()
+    assert len(set(int(v) for v in runs[0][3])) > 2                 # sources do retire at different sub-boxes
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and r[1:3] == runs[0][1:3]
+        assert np.array_equal(r[3], runs[0][3]) and np.array_equal(r[4], runs[0][4])

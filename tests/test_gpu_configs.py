@@ -5,11 +5,15 @@
   configs[3]  the bench workload itself -- 256^3 x 1000 seeded sources, x = 0.999 -- one pass: a 16-source subset
               against the oracle, the other 984 through additivity (Gamma, loss, sub-box counts and visited cells of a
               pass are sums over sources), and the expected trace-to-the-limit sub-box count;
-  configs[4]  504^3 (log-normal density, sigma = 1): two sources traced to the limits against the oracle.
+  configs[1]  128^3, ONE source: the single-source sweep and a whole step (five outer iterations, hipGraph replay and
+              eager launches) against fixtures recorded from the Fortran reference;
+  configs[4]  504^3 (log-normal density, sigma = 1): two sources traced to the limits against the oracle; 48 sources
+              through a scratch that holds 17 (three batches), two vs the oracle, the rest by additivity.
 
 The serial oracle needs ~0.15 us per visited (cell, source) pair, so its results are computed once and shared by
 the two modes (module cache)."""
 import hashlib
+import os
 import numpy as np
 import pytest
 from tests._util import F, load_case, oracle_for, expand, tol, assert_gamma, oracle_pass, STATE_RTOL
@@ -159,3 +163,123 @@ def test_504_cubep3m_format_two_sources_vs_oracle(pkg, tables, tmp_path):
     assert abs(loss - oloss) <= tol("loss") * abs(oloss) + 1e-300
     assert_gamma(b.fetch("phih_grid"), ophih, w, "504^3")
     b.close()
+
+
+def test_128_one_source_sweep_vs_reference_fixture(pkg, tables):
+    """BASELINE configs[1]: 128^3, ONE source (inputs/test_sources_onesrc.dat), x = 0.999 -- the single-source sweep out to
+    sub-box 11 against values recorded from the Fortran reference: sub-box count, photon loss, the source's column
+    densities and rates on three planes through it, checksums (exactly the quantity the 0.44 ms / iteration of the
+    launch-bound regime is quoted for)."""
+    m, a = load_case("sweep128_onesrc_x999")
+    n = m["n"]
+    nd, xh = F(expand(a["ndens"], n)), F(expand(a["xh"], n))
+    b = backend(pkg, tables, m, n, nd, xh, m["srcpos"], m["normflux"])
+    b.begin_step()
+    b.zero_rates()
+    nb, loss, vis, cd = b.do_source(1, want_coldens=True)
+    assert nb == m["sum_nbox"] == 11 and vis == int(pkg.box_cost(np.array([nb]), (n, n, n))[0])
+    assert abs(loss - m["photon_loss"]) <= tol("loss") * abs(m["photon_loss"])
+    c3 = cd.reshape((n, n, n), order="F")
+    assert np.count_nonzero(c3) == m["cd_nonzero"]
+    for tag, sl in _planes(c3, m).items():
+        ref = a["cd_" + tag]
+        assert np.max(np.abs(sl - ref) / np.maximum(ref, 1e-300)) < tol("cd"), tag
+    p3 = b.fetch("phih_grid").reshape((n, n, n), order="F")
+    assert np.count_nonzero(p3) == m["phih_nonzero"]
+    assert abs(float(np.sum(p3, dtype=np.longdouble)) / m["phih_sum"] - 1) < 1e-10
+    w3 = oracle_pass(oracle_for(m, tables, n), nd, xh, m["srcpos"], m["normflux"])[4].reshape((n, n, n), order="F")
+    wp = _planes(w3, m)
+    for tag, sl in _planes(p3, m).items():
+        assert_gamma(sl, a["phih_" + tag], wp[tag], tag)
+    # the pass over the (one-source) list takes the batch path (fused sub-boxes, per-shell launches, decisions): same numbers
+    b.zero_rates()
+    l2, nb2, v2 = b.pass_sources()
+    assert (nb2, v2) == (nb, vis) and l2 == loss
+    assert np.array_equal(b.fetch("phih_grid").reshape((n, n, n), order="F"), p3)
+    b.close()
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_128_one_source_whole_step_vs_reference_fixture(pkg, tables, monkeypatch, graph):
+    """BASELINE configs[1] as a whole evolve3D step (evolve.F90:83-281) from a field with a 30-cell ionized bubble: one
+    source, so conv_criterion = 0 and five outer iterations of six sub-boxes follow.  From the second pass on the library
+    replays the batch's launch sequence as a hipGraph (C2R_GRAPH=1, the default) -- the same history, sub-box counts and
+    photon loss must come out of the replay and of eager launches (C2R_GRAPH=0), and both must be the reference's."""
+    import hashlib
+    from tests.golden.inputs import bubble_xfield
+    monkeypatch.setenv("C2R_GRAPH", graph)
+    m, a = load_case("evolve128_onesrc_bubble")
+    n = m["n"]
+    nd = F(expand(a["ndens"], n))
+    xh0 = F(bubble_xfield(n, [(50, 50, 50)], 30.0))
+    assert hashlib.sha256(xh0.tobytes()).hexdigest() == m["xh_before_sha256"]
+    b = backend(pkg, tables, m, n, nd, xh0, m["srcpos"], m["normflux"])
+    losses = []
+    b.set_iteration_hook(lambda niter, loss: losses.append(loss))
+    rep = b.evolve3d_native(m["dt"])
+    b.set_iteration_hook(None)
+    assert rep.converged and rep.niter == m["niter"] == 5
+    assert list(rep.it_conv_flag[:rep.niter]) == m["log"]["nonconv"]
+    assert list(rep.it_sum_nbox[:rep.niter]) == [6] * 5 and rep.sum_nbox_all == m["sum_nbox_all"]
+    assert abs(rep.photon_loss_all - m["photon_loss_all"]) <= tol("loss") * abs(m["photon_loss_all"])
+    x3 = b.fetch("xh").reshape((n, n, n), order="F")
+    p3 = b.fetch("phih_grid").reshape((n, n, n), order="F")
+    for tag, sl in _planes(x3, m).items():
+        assert np.max(np.abs(sl - a["xh_" + tag])) < tol("x"), tag
+    assert np.count_nonzero(p3) == m["phih_nonzero"]
+    assert abs(float(np.sum(x3, dtype=np.longdouble)) / m["xh_sum"] - 1) < 1e-12
+    for k in ("totrec", "totcollisions"):
+        assert abs(getattr(rep, k) / m[k] - 1) < 1e-9
+    # graph replay and eager launches: the per-iteration photon losses are the same numbers, bit for bit
+    key = "onesrc_losses_" + os.environ.get("C2R_SWEEP_MODE", "0")
+    if key in _cache:
+        assert _cache[key] == losses
+    _cache[key] = losses
+    b.close()
+
+
+def test_504_many_sources_in_three_batches(pkg, tables):
+    """BASELINE configs[4]'s mesh with more sources than the sweep scratch holds at once: 504^3 (log-normal density), 48
+    sources, scratch_bytes sized for 17 of them (24.5 MB of shell planes each) -> three batches through the same scratch
+    (the path the 10 000-source run takes four times over).  Two sources against the oracle, the other 46 by additivity,
+    and the three-batch pass against a one-batch pass of the same 48."""
+    n, S = 504, 48
+    tp = pkg.TestProblem(n)
+    s = tp.step(1)
+    _, xh = tp.fields(1, 0.9995)
+    rng = np.random.default_rng(20261003)
+    nd = (np.float32(s["ndens"]) * np.exp(rng.standard_normal(n ** 3, dtype=np.float32) - 0.5)).astype(np.float32)
+    pos, nf = pkg.seeded_sources(n, S, seed=504)
+    pos[0] = (17, 480, 252); pos[1] = (300, 301, 302)
+    nf[0], nf[1] = 3e8, 1e9
+    per_src = 2 * 6 * 505 * 505 * 8 + 6 * ((505 * 505 + 255) // 256) * 8 + 64
+    res = {}
+    for tag, scratch in (("three", 17 * per_src + 4096), ("one", 0)):
+        b = pkg.HipBackend(n, *tables, device=0, scratch_bytes=scratch)
+        b.set_step((s["dr1"], s["dr2"], s["dr3"]), s["vol"], s["coldensh_LLS"], s["clumping"])
+        b.set_sources(pos, nf); b.set_rank(0, 1); b.load(ndens=nd, xh=xh)
+        b.begin_step(); b.zero_rates()
+        loss, nbox, vis = b.pass_sources()
+        res[tag] = (loss, nbox, vis, b.fetch("phih_grid"), b.last_nbox().copy())
+        if tag == "three":
+            # the first two sources alone, against the oracle; then the other 46
+            if "504many" not in _cache:
+                _cache["504many"] = oracle_pass(oracle_for(s, tables, n), nd, xh, pos[:2], nf[:2])
+            oloss, onb, ovis, ophih, w = _cache["504many"]
+            b.set_sources(pos[:2], nf[:2]); b.zero_rates()
+            l_a, nb_a, v_a = b.pass_sources()
+            g_a = b.fetch("phih_grid")
+            assert (nb_a, v_a) == (onb, ovis) and abs(l_a - oloss) <= tol("loss") * abs(oloss) + 1e-300
+            assert_gamma(g_a, ophih, w, "504^3, 2 of 48")
+            b.set_sources(pos[2:], nf[2:]); b.zero_rates()
+            l_b, nb_b, v_b = b.pass_sources()
+            g_b = b.fetch("phih_grid")
+            assert (nb_a + nb_b, v_a + v_b) == (nbox, vis)
+            assert abs(l_a + l_b - loss) <= 1e-12 * abs(loss)
+            whole = res[tag][3]
+            assert np.all(whole > 0) and np.max(np.abs(g_a + g_b - whole) / whole) < 1e-12
+        b.close()
+    assert list(res["three"][4]) == [51] * S and res["three"][2] == S * n ** 3       # every source traces the whole mesh
+    assert res["three"][1:3] == res["one"][1:3] and np.array_equal(res["three"][4], res["one"][4])
+    assert abs(res["three"][0] / res["one"][0] - 1) < 1e-12
+    assert np.max(np.abs(res["three"][3] / res["one"][3] - 1)) < 1e-12

@@ -199,7 +199,7 @@ def _check_planes(p3, a, m, prefix, key, exact=True, tol=0.0):
             assert relerr(sl, ref, floor=1e-60) < tol, (key, tag)
 
 
-@pytest.mark.parametrize("name", ["sweep128_std_x999", "sweep256_3src_x999"])
+@pytest.mark.parametrize("name", ["sweep128_std_x999", "sweep128_onesrc_x999", "sweep256_3src_x999"])
 def test_sweep_at_baseline_grid_sizes(tables, name):
     """128^3 / 256^3 straight from the reference: planes through a source, checksums, and the known
     answers SURVEY.md records for the 128^3 case (sum_nbox = 110, 2 028 081 cells with a rate)."""
@@ -223,6 +223,26 @@ def test_evolve3d_128(tables):
     xh = F(expand(a["xh_before"], n)); nd = F(expand(a["ndens"], n))
     rep, xav, xint, phih = o.evolve3d(m["dt"], nd, xh, m["srcpos"], m["normflux"])
     assert rep.niter == m["niter"] and list(rep.it_conv_flag[:rep.niter]) == m["log"]["nonconv"]
+    _check_planes(xh.reshape((n, n, n), order="F"), a, m, "xh", "xh")
+    _check_planes(phih.reshape((n, n, n), order="F"), a, m, "phih", "phih")
+    assert np.count_nonzero(phih) == m["phih_nonzero"]
+    for k in ("totrec", "totcollisions", "dh0", "total_ion"):
+        assert getattr(rep, k) == m[k]
+
+
+def test_evolve3d_128_one_source(tables):
+    """BASELINE configs[1] (128^3, ONE source) as a whole step from a field with a 30-cell ionized bubble: conv_criterion
+    = 0, five outer iterations of six sub-boxes each -- bit for bit the reference's history, planes and statistics."""
+    import hashlib
+    from tests.golden.inputs import bubble_xfield
+    m, a = load_case("evolve128_onesrc_bubble")
+    n = m["n"]
+    o = oracle_for(m, tables, n)
+    xh = F(bubble_xfield(n, [(50, 50, 50)], 30.0)); nd = F(expand(a["ndens"], n))
+    assert hashlib.sha256(xh.tobytes()).hexdigest() == m["xh_before_sha256"]
+    rep, xav, xint, phih = o.evolve3d(m["dt"], nd, xh, m["srcpos"], m["normflux"])
+    assert rep.niter == m["niter"] == 5 and list(rep.it_conv_flag[:rep.niter]) == m["log"]["nonconv"]
+    assert rep.sum_nbox_all == m["sum_nbox_all"] == 6 and rep.photon_loss_all == m["photon_loss_all"]
     _check_planes(xh.reshape((n, n, n), order="F"), a, m, "xh", "xh")
     _check_planes(phih.reshape((n, n, n), order="F"), a, m, "phih", "phih")
     assert np.count_nonzero(phih) == m["phih_nonzero"]
