@@ -1180,6 +1180,31 @@ int c2r_do_source_host(c2r_ctx *c, int32_t ns, const float *ndens, const double 
     return C2R_OK;
 }
 
+int c2r_do_grid_host(c2r_ctx *c, const float *ndens, const double *xh_av, double *phih_grid, double *phiheat_grid,
+                     double *photon_loss, int64_t *sum_nbox)
+{
+    if (!c || !ndens || !xh_av || !phih_grid) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (ctx->thermal && !phiheat_grid) FAIL(C2R_EINVAL, "non-isothermal run: do_grid needs phiheat_grid");
+    int rc;
+    if ((rc = c2r_upload(c, 0, ndens))) return rc;
+    if ((rc = c2r_upload(c, 2, xh_av))) return rc;
+    if ((rc = c2r_zero_rates(c))) return rc;
+    double loss = 0.0; int64_t nb = 0;
+    if ((rc = c2r_pass_sources(c, &loss, &nb, nullptr))) return rc;
+    // phih_grid(pos) = phih_grid(pos) + the rates of this rank's sources (evolve_point.F90:283-286), on the host arrays
+    std::vector<double> g(ctx->ncell);
+    if ((rc = c2r_download(c, 4, g.data()))) return rc;
+    for (size_t i = 0; i < ctx->ncell; ++i) phih_grid[i] = phih_grid[i] + g[i];
+    if (ctx->thermal) {
+        if ((rc = c2r_download(c, 5, g.data()))) return rc;
+        for (size_t i = 0; i < ctx->ncell; ++i) phiheat_grid[i] = phiheat_grid[i] + g[i];
+    }
+    if (photon_loss) *photon_loss = loss;
+    if (sum_nbox) *sum_nbox = nb;
+    return C2R_OK;
+}
+
 int c2r_global_pass_host(c2r_ctx *c, double dt, const float *ndens, const double *xh, double *xh_av,
                          double *xh_intermed, const double *phih_grid, int64_t *conv_flag)
 {

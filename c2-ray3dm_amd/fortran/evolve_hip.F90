@@ -197,6 +197,33 @@ module c2ray_hip
        real(c_double), intent(out) :: photon_loss_src
        integer(c_int32_t), intent(out) :: nbox
      end function c2r_do_source_host
+     integer(c_int) function c2r_do_grid_host(ctx, ndens, xh_av, phih_grid, phiheat_grid, photon_loss, sum_nbox) &
+          bind(C, name="c2r_do_grid_host")
+       import :: c_int, c_ptr, c_double, c_float, c_int64_t
+       type(c_ptr), value :: ctx
+       real(c_float), intent(in) :: ndens(*)
+       real(c_double), intent(in) :: xh_av(*)
+       real(c_double), intent(inout) :: phih_grid(*)
+       type(c_ptr), value :: phiheat_grid        ! double* (non-isothermal builds) or NULL
+       real(c_double), intent(out) :: photon_loss
+       integer(c_int64_t), intent(out) :: sum_nbox
+     end function c2r_do_grid_host
+     integer(c_int) function c2r_global_pass_host(ctx, dt, ndens, xh, xh_av, xh_intermed, phih_grid, conv_flag) &
+          bind(C, name="c2r_global_pass_host")
+       import :: c_int, c_ptr, c_double, c_float, c_int64_t
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt
+       real(c_float), intent(in) :: ndens(*)
+       real(c_double), intent(in) :: xh(*), phih_grid(*)
+       real(c_double), intent(inout) :: xh_av(*), xh_intermed(*)
+       integer(c_int64_t), intent(out) :: conv_flag
+     end function c2r_global_pass_host
+     integer(c_int) function c2r_upload(ctx, which, host) bind(C, name="c2r_upload")
+       import :: c_int, c_ptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: which
+       type(*), dimension(*), intent(in) :: host
+     end function c2r_upload
      integer(c_int) function c2r_set_iteration_hook(ctx, fn, user) bind(C, name="c2r_set_iteration_hook")
        import :: c_int, c_ptr, c_funptr
        type(c_ptr), value :: ctx
@@ -311,7 +338,7 @@ contains
          int(NumTau+1, c_int32_t)), "c2r_set_tables")
     call check(c2r_get_device(ctx, dev), "c2r_get_device")
     write(logf,*) "c2ray_hip: evolve hot path on HIP device ", dev
-    write(logf,*) "c2ray_hip: sweep mode ", merge("fast (C2R_SWEEP_FAST) ", "exact (C2R_SWEEP_EXACT)", p%sweep_mode == 1)
+    write(logf,*) "c2ray_hip: sweep mode ", merge("fast (C2R_SWEEP_FAST)  ", "exact (C2R_SWEEP_EXACT)", p%sweep_mode == 1)
     if (.not.isothermal) call thermal_hip_ini()
 #ifdef MPI
     ! Join the RCCL communicator: rank 0 makes the 128-byte token, one broadcast next to those of mpi.F90 hands it
@@ -451,6 +478,118 @@ contains
   end subroutine do_source
 
 end module evolve_source
+
+! =============================================================================================
+
+!> `master_slave_processing` of the reference (master_slave.F90): the ray tracing of all sources.  The reference hands the
+!! sources to do_source one by one -- statically (do ns1=1+rank,NumSrc,npr, :85) or through its master/worker scheduler
+!! (:124-330); here the whole share of this process is ONE pass on the GPU (all sources of a shell in one launch), the
+!! shares being static for the first pass and cost-balanced afterwards when the -DMPI block has attached the ranks.
+module master_slave_processing
+
+  use, intrinsic :: iso_c_binding
+  use precision, only: dp
+  use density_module, only: ndens
+  use photonstatistics, only: photon_loss
+  use evolve_data, only: phih_grid, phiheat_grid, xh_av
+  use c2ray_parameters, only: isothermal
+  use evolve_source, only: sum_nbox
+  use c2ray_hip, only: ctx, check, hip_step_state, c2r_do_grid_host
+
+  implicit none
+
+  private
+
+  public :: do_grid
+
+contains
+
+  !> Ray trace the whole grid for all sources of this process (same contract as master_slave.F90:53): adds their rates
+  !! into phih_grid (phiheat_grid), their escaping photons to photon_loss(1), their sub-box counts to sum_nbox.
+  !! coldensh_out is NOT left behind (the reference leaves the LAST source's: nothing reads it after do_grid).
+  subroutine do_grid (dt,niter)
+
+    real(kind=dp),intent(in) :: dt  !< time step (unused by the transfer, as in the reference)
+    integer,intent(in) :: niter !< iteration counter
+
+    real(c_double) :: loss
+    integer(c_int64_t) :: nbox
+
+    call hip_step_state()
+    if (isothermal) then
+       call check(c2r_do_grid_host(ctx, ndens, xh_av, phih_grid, c_null_ptr, loss, nbox), "c2r_do_grid_host")
+    else
+       call check(c2r_do_grid_host(ctx, ndens, xh_av, phih_grid, heat_address(phiheat_grid), loss, nbox), "c2r_do_grid_host")
+    endif
+    photon_loss(1) = photon_loss(1) + loss                            ! evolve_source.F90:216, summed over the sources
+    sum_nbox = sum_nbox + int(nbox)                                   ! evolve_source.F90:219
+
+  end subroutine do_grid
+
+  function heat_address(g) result(p)
+    real(kind=dp), dimension(:,:,:), allocatable, target, intent(in) :: g
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(g)) p = c_loc(g)
+  end function heat_address
+
+end module master_slave_processing
+
+! =============================================================================================
+
+!> `evolve_point` of the reference (evolve_point.F90).  Its two public routines work on ONE cell: evolve0D(dt,rtpos,ns,niter)
+!! for one (cell, source) pair inside do_source's sweep, evolve0D_global(dt,pos,conv_flag) for one cell inside
+!! global_pass's triple loop.  A GPU has no use for a call per cell (a kernel launch costs what the reference spends on
+!! thirty cells): the per-(cell, source) work is inside do_source / do_grid above (kernels k_sweep_shell*), and the per-cell
+!! chemistry is exported for the WHOLE mesh at once -- the loop global_pass (evolve.F90:499-555) runs around
+!! evolve0D_global -- as evolve0D_global_all.  The module flag local_chemistry (evolve_point.F90:73) is kept: pass_all_sources
+!! resets it and nothing on this path sets it (the local variant of do_chemistry is not used by C2-Ray3Dm's evolve3D).
+module evolve_point
+
+  use, intrinsic :: iso_c_binding
+  use precision, only: dp
+  use density_module, only: ndens
+  use ionfractions_module, only: xh
+  use temperature_module, only: temperature_grid
+  use evolve_data, only: phih_grid, phiheat_grid, xh_av, xh_intermed
+  use c2ray_parameters, only: isothermal
+  use c2ray_hip, only: ctx, check, hip_step_state, c2r_global_pass_host, c2r_upload, c2r_download
+
+  implicit none
+
+  save
+
+  private
+
+  !> Flag to know whether the do_chemistry routine was called with local option (evolve_point.F90:73)
+  logical,public ::local_chemistry=.false.
+
+  public :: evolve0D_global_all
+
+contains
+
+  !> evolve0D_global (evolve_point.F90:305-406: do_chemistry with the collected rates, the global convergence test)
+  !! for every cell of the mesh: reads xh, xh_av, phih_grid (phiheat_grid, temperature_grid), updates xh_av, xh_intermed
+  !! (temperature_grid) and ADDS the number of non-converged cells to conv_flag, as the reference's loop does.
+  subroutine evolve0D_global_all(dt,conv_flag)
+
+    real(kind=dp),intent(in) :: dt !< time step
+    integer,intent(inout) :: conv_flag !< convergence counter
+
+    integer(c_int64_t) :: nonconv
+
+    call hip_step_state()
+    if (.not.isothermal) then
+       call check(c2r_upload(ctx, 5_c_int32_t, phiheat_grid), "c2r_upload")
+       call check(c2r_upload(ctx, 6_c_int32_t, temperature_grid), "c2r_upload")
+    endif
+    call check(c2r_global_pass_host(ctx, dt, ndens, xh, xh_av, xh_intermed, phih_grid, nonconv), "c2r_global_pass_host")
+    if (.not.isothermal) call check(c2r_download(ctx, 6_c_int32_t, temperature_grid), "c2r_download")
+    conv_flag = conv_flag + int(nonconv)
+
+  end subroutine evolve0D_global_all
+
+end module evolve_point
 
 ! =============================================================================================
 

@@ -258,6 +258,13 @@ int  c2r_sum(c2r_ctx *ctx, int32_t which, double *sum);
  * ns = 1..NumSrc as in c2r_do_source. */
 int  c2r_do_source_host(c2r_ctx *ctx, int32_t ns, const float *ndens, const double *xh_av,
                         double *phih_grid, double *coldensh_out, double *photon_loss_src, int32_t *nbox);
+/* do_grid(dt,niter) (master_slave.F90:53-96; do_grid_static's loop `do ns1=1+rank,NumSrc,npr: call do_source`, or the
+ * cost-balanced share once c2r_set_balance has learnt the costs) with the module arrays it touches as arguments: reads
+ * ndens, xh_av; ADDS the rates of all of this rank's sources into phih_grid (and phiheat_grid in a non-isothermal run,
+ * NULL otherwise); returns what the loop adds to photon_loss(1) (evolve_source.F90:216) and to sum_nbox (:219).  One
+ * pass on the device for all of the rank's sources -- not NumSrc separate do_source calls. */
+int  c2r_do_grid_host(c2r_ctx *ctx, const float *ndens, const double *xh_av, double *phih_grid, double *phiheat_grid,
+                      double *photon_loss, int64_t *sum_nbox);
 /* global_pass(conv_flag,dt) (evolve.F90:499): evolve0D_global over the mesh with the host arrays.  In a non-isothermal
  * context phiheat_grid and temperature_grid are used as they lie on the device (c2r_upload arrays 5 and 6 first, c2r_download
  * array 6 afterwards). */

@@ -86,7 +86,7 @@ build_hip_dropin () {   # $1 = mesh[:variant]
   # the shim's evolve.mod / evolve_source.mod land in $B and shadow the reference's ($B before $S)
   ( cd "$B" && $FC $FLAGS -I"$S" -c "$PKG/fortran/evolve_hip.F90" -o evolve_hip.o 2>>build.log \
       && $FC $FLAGS -I"$B" -I"$S" -c "$REF/C2Ray.F90" -o C2Ray.o 2>>build.log \
-      && $FC $FLAGS -I"$B" -I"$S" -c "$HERE/ref_driver.F90" -o ref_driver.o 2>>build.log )
+      && $FC $FLAGS -DC2RAY_HIP_SHIM -I"$B" -I"$S" -c "$HERE/ref_driver.F90" -o ref_driver.o 2>>build.log )
   local objs=""
   for o in "$S"/*.o; do
     case "$(basename "$o")" in

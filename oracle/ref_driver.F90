@@ -13,9 +13,11 @@
 !! Run in a scratch directory holding: results/ , test_sources.dat
 !! (sourceprops.F90:248), the answers file (inputs/input_example_test format)
 !! and driver.nml:
-!!   &ctl mode='evolve'|'sweep'|'point'|'tables', nsteps=, x_init=, dens_file=,
+!!   &ctl mode='evolve'|'sweep'|'grid'|'point'|'tables', nsteps=, x_init=, dens_file=,
 !!        x_file=, dump_first=, dump_last=, ns_dump=, nrep=, out_dir=, t_file= /
-!!   (mode 'sweep' also writes <tag>_nbox.txt: the sub-box count each source ended with)
+!!   (mode 'sweep' also writes <tag>_nbox.txt: the sub-box count each source ended with; mode 'grid' calls
+!!    master_slave_processing::do_grid for all sources at once and then evolve_point::evolve0D_global for every cell --
+!!    with -DC2RAY_HIP_SHIM, the drop-in build, the shim's whole-mesh evolve0D_global_all)
 !! usage: ref_driver <answers-file>
 program ref_driver
 
@@ -49,6 +51,12 @@ program ref_driver
   use evolve_data, only: evolve_ini, phih_grid, phiheat_grid, xh_av, xh_intermed, coldensh_out, &
        photon_loss_all
   use evolve_source, only: do_source, sum_nbox, sum_nbox_all
+  use master_slave_processing, only: do_grid
+#ifdef C2RAY_HIP_SHIM
+  use evolve_point, only: local_chemistry, evolve0D_global_all
+#else
+  use evolve_point, only: local_chemistry, evolve0D_global
+#endif
   use evolve, only: evolve3D
   use column_density, only: cinterp
   use doric_module, only: doric
@@ -64,7 +72,7 @@ program ref_driver
        ns_dump, nrep, out_dir, lls_file, clump_file, t_file
 
   character(len=512) :: answers
-  integer :: restart = 0, nz0 = 1, ierror = 0, nz, u, istep, ns, irep
+  integer :: restart = 0, nz0 = 1, ierror = 0, nz, u, istep, ns, irep, gi, gj, gk, conv_flag
   integer :: nbox_before, nbox_src(4096) = 0
   real(kind=dp) :: end_time, sim_time, output_time, dt, actual_dt
   real(kind=dp) :: t_sweep
@@ -209,6 +217,42 @@ program ref_driver
            do ns = 1, min(NumSrc, size(nbox_src))
               write(u,'(I8)') nbox_src(ns)
            enddo
+           close(u)
+           stop
+        endif
+
+        if (trim(mode) == 'grid') then
+           ! pass_all_sources' core (evolve.F90:462-478: sum_nbox=0, local_chemistry=.false., do_grid) followed by
+           ! global_pass' core (evolve.F90:548-555: evolve0D_global over the mesh), through the modules' public routines
+           call dump_inputs(tag)
+           xh_av = xh
+           xh_intermed = xh
+           phih_grid = 0.0
+           photon_loss = 0.0
+           if (.not.isothermal) phiheat_grid = 0.0
+           sum_nbox = 0
+           local_chemistry = .false.
+           call do_grid(actual_dt, 1)
+           call dump_r8(trim(tag)//'_phih_grid', phih_grid)
+           conv_flag = 0
+#ifdef C2RAY_HIP_SHIM
+           call evolve0D_global_all(actual_dt, conv_flag)
+#else
+           do gk = 1, mesh(3)
+              do gj = 1, mesh(2)
+                 do gi = 1, mesh(1)
+                    call evolve0D_global(actual_dt, (/ gi, gj, gk /), conv_flag)
+                 enddo
+              enddo
+           enddo
+#endif
+           call dump_r8(trim(tag)//'_xh_av', xh_av)
+           call dump_r8(trim(tag)//'_xh_intermed', xh_intermed)
+           open(newunit=u, file=trim(out_dir)//trim(tag)//'_grid.txt', status='replace')
+           write(u,'(A,1X,ES26.17E3)') 'photon_loss', photon_loss(1)
+           write(u,'(A,1X,I12)') 'sum_nbox', sum_nbox
+           write(u,'(A,1X,I12)') 'conv_flag', conv_flag
+           write(u,'(A,1X,L1)') 'local_chemistry', local_chemistry
            close(u)
            stop
         endif

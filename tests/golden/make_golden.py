@@ -200,6 +200,22 @@ def case_sweep(name, n, sources, x_init=None, dens_seed=None, xfield=None, ns_du
     print(name, "sum_nbox", kv["sum_nbox"], "loss", kv["photon_loss"], "phih_nonzero", kv["phih_nonzero"])
 
 
+def case_grid(name, n, sources, dens_seed, xfield, variant=None, tfield=None):
+    """master_slave_processing::do_grid for all sources, then evolve_point::evolve0D_global over the mesh (driver mode
+    'grid'): the two modules' public routines as the reference's pass_all_sources / global_pass call them."""
+    d = run_driver(n, sources, {"mode": "'grid'"}, dens=density_factor(n, dens_seed), xfield=xfield, variant=variant, tfield=tfield)
+    kv = read_kv(d + "/dump/step001_in.txt")
+    for line in open(d + "/dump/step001_grid.txt"):
+        k, v = line.split()
+        kv[k] = (v == "T") if k == "local_chemistry" else (float(v) if "E" in v else int(v))
+    arrays = {"xh": rd(d, "step001_xh_before.f64", n), "ndens": rd(d, "step001_ndens.f32", n, np.float32),
+              "phih": rd(d, "step001_phih_grid.f64", n), "xh_av": rd(d, "step001_xh_av.f64", n),
+              "xh_intermed": rd(d, "step001_xh_intermed.f64", n)}
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    json.dump({"n": n, **kv}, open(os.path.join(HERE, name + ".json"), "w"), indent=1)
+    print(name, "sum_nbox", kv["sum_nbox"], "conv_flag", kv["conv_flag"], "loss", kv["photon_loss"])
+
+
 def read_sm3d(path, dtype):
     """Fortran sequential records: int32 12 | 3 x int32 | int32 12 | int32 nbytes | data | int32 nbytes"""
     raw = open(path, "rb").read()
@@ -372,6 +388,10 @@ def main():
                     tfield=temperature_field(32, 5))
     if want("refrun32thermal"):
         case_refrun("refrun32_thermal", 32, SRC_STD, variant="thermal")
+    # the module surface beside evolve3D / do_source: do_grid (master_slave.F90:53) and evolve0D_global over the mesh
+    if want("grid32"):
+        x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 7.0)
+        case_grid("grid32_bubbles", 32, SRC_STD, 5, x)
     if want("sweep64"):
         x = bubble_xfield(64, [(50, 50, 50), (20, 10, 10), (6, 8, 50), (20, 10, 26)], 14.0)
         srcs = SRC_STD[:8] + [(72, 72, 50, 1e58), (20, 10, 90, 1e54)]

@@ -4,6 +4,8 @@ shim's modules `evolve_source` and `evolve` (c2-ray3dm_amd/fortran/evolve_hip.F9
 oracle/ref_build.sh: ref_driver_hip).  Same inputs, same dumps, compared with the fixtures:
   * do_source(dt,ns,niter) per source: phih_grid accumulation, coldensh_out of one source,
     photon_loss(1), sum_nbox                                       (evolve_source.F90:58-221)
+  * do_grid(dt,niter) for all sources at once and evolve0D_global over the mesh
+                                                                   (master_slave.F90:53, evolve_point.F90:305)
   * evolve3D(time,dt,0) in builds with type_of_LLS=2,3 / type_of_clumping=5 (the shim forwards
     LLS_grid / R_max_LLS / clumping_grid)
   * evolve3D(time,dt,3): the shim's start_from_dump reads iterdump.bin (evolve.F90:328-426)
@@ -58,6 +60,27 @@ def test_fortran_do_source_matches_reference_sweep(rundir):
     assert np.array_equal(cd == 0.0, a["coldensh_out"] == 0.0)                            # same cells reached
     assert relerr(cd, a["coldensh_out"]) < 1e-11
     assert relerr(gi.rd(d, "step001_phih_grid.f64", 32), a["phih"]) < 1e-9
+
+
+def test_fortran_do_grid_and_evolve0d_global_all_match_the_reference_modules(rundir):
+    """The rest of the reference's call surface on this path: master_slave_processing::do_grid(dt,niter) (master_slave.F90:53,
+    one GPU pass for all sources instead of NumSrc do_source calls) and evolve_point (local_chemistry, and evolve0D_global for
+    the whole mesh: evolve0D_global_all) -- the driver's 'grid' mode through the shim's modules against the same mode run
+    with the reference's."""
+    need(32)
+    m = json.load(open(os.path.join(GOLDEN, "grid32_bubbles.json")))
+    a = np.load(os.path.join(GOLDEN, "grid32_bubbles.npz"))
+    d = gi.run_driver(32, gi.SRC_STD, {"mode": "'grid'"}, dens=gi.density_factor(32, 5), xfield=gi.bubble_xfield(32, BUBBLES, 7.0),
+                      hip=True, d=rundir)
+    assert np.array_equal(gi.rd(d, "step001_ndens.f32", 32, np.float32), a["ndens"])      # same inputs
+    assert np.array_equal(gi.rd(d, "step001_xh_before.f64", 32), a["xh"])
+    kv = dict(line.split() for line in open(d + "/dump/step001_grid.txt"))
+    assert int(kv["sum_nbox"]) == m["sum_nbox"] and int(kv["conv_flag"]) == m["conv_flag"] and kv["local_chemistry"] == "F"
+    assert abs(float(kv["photon_loss"]) - m["photon_loss"]) <= 1e-10 * abs(m["photon_loss"])
+    ph = gi.rd(d, "step001_phih_grid.f64", 32)
+    assert np.array_equal(ph == 0.0, a["phih"] == 0.0) and relerr(ph, a["phih"]) < 1e-9
+    assert np.max(np.abs(gi.rd(d, "step001_xh_av.f64", 32) - a["xh_av"])) < 1e-9
+    assert np.max(np.abs(gi.rd(d, "step001_xh_intermed.f64", 32) - a["xh_intermed"])) < 1e-9
 
 
 @pytest.mark.parametrize("variant,name", [("lls2", "evolve32_lls2"), ("lls3", "evolve32_lls3"),

@@ -248,3 +248,19 @@ def test_evolve3d_128_one_source(tables):
     assert np.count_nonzero(phih) == m["phih_nonzero"]
     for k in ("totrec", "totcollisions", "dh0", "total_ion"):
         assert getattr(rep, k) == m[k]
+
+
+def test_do_grid_then_global_pass_module_surface(tables):
+    """master_slave_processing::do_grid (all sources) followed by evolve_point::evolve0D_global over the mesh, as the
+    reference's driver mode 'grid' recorded them: the oracle's pass + global pass, bit for bit."""
+    m, a = load_case("grid32_bubbles")
+    n = m["n"]
+    o = oracle_for(m, tables, n)
+    nd, xh = F(a["ndens"]), F(a["xh"])
+    phih = np.zeros(o.ncell)
+    loss, nb, vis = o.pass_sources(nd, xh, phih, m["srcpos"], m["normflux"])
+    assert (loss, nb) == (m["photon_loss"], m["sum_nbox"]) and m["local_chemistry"] is False
+    assert np.array_equal(phih, F(a["phih"]))
+    xav, xint = xh.copy(), xh.copy()
+    assert o.global_pass(m["dt"], nd, xh, xav, xint, phih) == m["conv_flag"]
+    assert np.array_equal(xav, F(a["xh_av"])) and np.array_equal(xint, F(a["xh_intermed"]))
