@@ -56,6 +56,9 @@ typedef struct {
     float  *temper_grid;      /* temperature_module.F90:35 temperature_grid: (current, average, intermed) f32 per cell */
     double *phiheat;          /* evolve_data.F90:42 phiheat_grid                                */
     double *tolw_heat;        /* checker diagnostic like tolw, for the heating rate: sum_s (1+tau_in) heat_in / vol_ph */
+    long   *thermal_stats;    /* checker diagnostic (NULL = off): [0] thermal() calls, [1] of them left untouched because T_initial <=
+                               * minitemp (thermal.f90:83), [2] of them ended by the sub-step cap i_heating > 10000 (:163), [3] sub-steps
+                               * in all -- what the fixtures exercise; the reference has no such counters */
 } oracle_cfg;
 
 static inline int pmod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
@@ -212,7 +215,8 @@ void oracle_thermal(const oracle_cfg *c, double dt, double t_initial, double *t_
 {
     double e_int = temper2pressr(t_initial, ndens_atom, electrondens(ndens_atom, h_old1)) / C2R_GAMMA1;   /* :66 */
     const double cosmo_cool_rate = cosmo_cool(c, e_int);                       /* :73-76 (cosmological=.true.) */
-    if (!(t_initial > C2R_MINITEMP)) return;
+    if (c->thermal_stats) c->thermal_stats[0]++;
+    if (!(t_initial > C2R_MINITEMP)) { if (c->thermal_stats) c->thermal_stats[1]++; return; }
     double cumulative = 0.0, avg = 0.0, t_int = t_initial;
     int i_heating = 0;
     for (;;) {
@@ -232,8 +236,9 @@ void oracle_thermal(const oracle_cfg *c, double dt, double t_initial, double *t_
         }
         cumulative = cumulative + dt_ode;
         if (cumulative >= dt || fabs(cumulative - dt) < C2R_THERMAL_TIME_TOL * dt) break;   /* :160 */
-        if (i_heating > C2R_THERMAL_MAX_STEPS) break;                          /* :163 */
+        if (i_heating > C2R_THERMAL_MAX_STEPS) { if (c->thermal_stats) c->thermal_stats[2]++; break; }   /* :163 */
     }
+    if (c->thermal_stats) c->thermal_stats[3] += i_heating;
     *t_average = dt > 0.0 ? avg / dt : t_initial;                              /* :168-172 */
     *t_final = pressr2temper(e_int * C2R_GAMMA1, ndens_atom, electrondens(ndens_atom, h1));   /* :175 */
 }

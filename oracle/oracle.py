@@ -26,7 +26,8 @@ class Cfg(C.Structure):
                 ("clump_grid", C.c_void_p), ("tolw", C.c_void_p),
                 ("heat_thick", C.c_void_p), ("heat_thin", C.c_void_p), ("cie_cool", C.c_void_p),
                 ("cool_mintemp", C.c_double), ("cool_dtemp", C.c_double), ("zred", C.c_double),
-                ("temper_grid", C.c_void_p), ("phiheat", C.c_void_p), ("tolw_heat", C.c_void_p)]
+                ("temper_grid", C.c_void_p), ("phiheat", C.c_void_p), ("tolw_heat", C.c_void_p),
+                ("thermal_stats", C.c_void_p)]
 
 
 class Report(C.Structure):
@@ -122,6 +123,13 @@ class Oracle:
         self.tolw = np.zeros(self.ncell, dtype=np.float64)
         self.cfg.tolw = self.tolw.ctypes.data
         return self.tolw
+
+    def enable_thermal_stats(self):
+        """Checker diagnostic (oracle_cfg.thermal_stats): counts, from now on, [calls of thermal(), of them skipped because
+        T_initial <= minitemp, of them ended by the 10 000 sub-step cap, sub-steps in all]."""
+        self.thermal_stats = np.zeros(4, dtype=np.int64)
+        self.cfg.thermal_stats = self.thermal_stats.ctypes.data
+        return self.thermal_stats
 
     def enable_heat_tolerance_weight(self):
         """As enable_tolerance_weight, for the heating rate: W_heat = sum_s (1+tau_in) heat_in / vol_ph per cell."""

@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = os.path.join(ROOT, "oracle", "_ref")
 sys.path.insert(0, HERE)
 from inputs import ANSWERS, SRC_ONE, SRC_STD, density_factor, bubble_xfield, run_driver, \
-    read_kv, rd, parse_log, cooling_table, temperature_field   # noqa: E402
+    read_kv, rd, parse_log, cooling_table, temperature_field, temperature_field_cold   # noqa: E402
 
 
 def case_tables():
@@ -130,16 +130,54 @@ def case_thermal_tables_and_points():
           (out["heat_thick"][0], out["heat_thin"][0], len(photo), len(cool), len(th), tho[0]))
 
 
+def case_thermal_points_steep():
+    """coolin and thermal of the reference (isothermal=.false. build) with the SECOND synthetic cooling table
+    (inputs.cooling_table("steep")): rows above, inside and below the table's range, and thermal rows that start at or below
+    minitemp, that relax in a few sub-steps, and that are driven to minitemp and leave through the 10 000 sub-step cap."""
+    text, lt, ll = cooling_table("steep")
+    pt = np.load(os.path.join(HERE, "point.npz"))
+    rng = np.random.default_rng(20261005)
+    cool = np.array([(10.0 ** rng.uniform(-5, -1), 10.0 ** rng.uniform(-6, -1), T)
+                     for T in list(10.0 ** rng.uniform(0.0, 7.5, 80)) + [1.0, 2.0, 9.99, 10.0, 12.589254117941675, 1e7, 1.0000001e7]])
+    rows = []
+    for T0 in (0.5, 1.0, 1.5, 3.0, 20.0, 60.0, 1e3, 1e4, 3e4, 1e5):
+        for heat in (0.0, 1e-28, 1e-25):
+            for dt in (3.15576e13, 3.15576e10):
+                for x in (2e-4, 0.3, 0.9995):
+                    nh = 10.0 ** rng.uniform(-4, -2)
+                    xav = min(1.0, x * (1.0 + 0.2 * rng.uniform()))
+                    xnew = min(1.0, xav * (1.0 + 0.2 * rng.uniform()))
+                    rows.append((dt, T0, nh * (xav + 7.09999994796817191e-07), nh, x, xav, xnew, heat))
+    th = np.array(rows)
+    def w(arr):
+        def f(p):
+            with open(p, "wb") as fh:
+                np.int32(len(arr)).tofile(fh); arr.tofile(fh)
+        return f
+    d = run_driver(32, SRC_ONE, {"mode": "'point'"}, variant="thermal", cooling="steep",
+                   extra_files={"point_coldens.f64": lambda p: pt["coldens"].T.tofile(p),
+                                "point_cinterp.txt": lambda p: open(p, "w").write("16 17 15 1\n"),
+                                "point_photo.f64": w(pt["photo_in"]), "point_doric.f64": w(pt["doric_in"]),
+                                "point_cool.f64": w(cool), "point_thermal.f64": w(th)})
+    tho = np.fromfile(d + "/dump/point_thermal_out.f64")
+    np.savez_compressed(os.path.join(HERE, "point_thermal_steep.npz"), cool_logT=lt, cool_logL=ll,
+                        cool_in=cool, cool_out=np.fromfile(d + "/dump/point_cool_out.f64"),
+                        thermal_in=th, thermal_zred=tho[0], thermal_out=tho[1:].reshape(-1, 2))
+    out = tho[1:].reshape(-1, 2)
+    print("thermal (steep curve): %d cool rows, %d thermal rows, %d untouched, %d ending at gamma1*minitemp" %
+          (len(cool), len(th), int(np.sum(out[:, 0] == -1.0)), int(np.sum(np.abs(out[:, 0] - 2.0 / 3.0) < 1e-9))))
+
+
 def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, keep=("xh_after", "phih_grid", "xh_av"),
-                variant=None, lls_grid=None, clump_grid=None, tfield=None):
-    dens = density_factor(n, dens_seed) if dens_seed is not None else None
+                variant=None, lls_grid=None, clump_grid=None, tfield=None, cooling="primordial", dens_sigma=0.6):
+    dens = density_factor(n, dens_seed, dens_sigma) if dens_seed is not None else None
     nml = {"mode": "'evolve'", "nsteps": nsteps, "dump_first": dump[0], "dump_last": dump[-1]}
     extra = {}
     if lls_grid is not None:
         extra["lls.f32"] = lambda p: lls_grid.astype(np.float32).T.tofile(p); nml["lls_file"] = "'lls.f32'"
     if clump_grid is not None:
         extra["clump.f32"] = lambda p: clump_grid.astype(np.float32).T.tofile(p); nml["clump_file"] = "'clump.f32'"
-    d = run_driver(n, sources, nml, dens=dens, xfield=xfield, variant=variant, extra_files=extra, tfield=tfield)
+    d = run_driver(n, sources, nml, dens=dens, xfield=xfield, variant=variant, extra_files=extra, tfield=tfield, cooling=cooling)
     log = parse_log(d + "/results/C2Ray.log")
     arrays, meta = {}, {"n": n, "steps": {}}
     for s in dump:
@@ -386,6 +424,13 @@ def main():
         x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 6.0)
         case_evolve("evolve32_thermal", 32, SRC_STD, 3, [1, 3], dens_seed=11, xfield=x, variant="thermal",
                     tfield=temperature_field(32, 5))
+    # the same build with the SECOND synthetic cooling table (steep CIE-like rise, cold-gas coolant): cells that start at or
+    # below minitemp, cold dense cells pinned at minitemp until the sub-step cap, hot cells on the steep part of the curve
+    if want("thermal2"):
+        case_thermal_points_steep()
+        x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 6.0)
+        case_evolve("evolve32_thermal_steep", 32, SRC_STD, 1, [1], dens_seed=12, xfield=x, variant="thermal",
+                    tfield=temperature_field_cold(32, 6), cooling="steep", dens_sigma=1.0, keep=("xh_after", "phih_grid"))
     if want("refrun32thermal"):
         case_refrun("refrun32_thermal", 32, SRC_STD, variant="thermal")
     # the module surface beside evolve3D / do_source: do_grid (master_slave.F90:53) and evolve0D_global over the mesh

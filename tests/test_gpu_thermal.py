@@ -286,3 +286,35 @@ def test_deterministic_rates_in_a_nonisothermal_context(pkg, tables):
     assert np.array_equal(runs[0][1] == 0, ref == 0) and np.max(np.abs(runs[0][1] - ref) / np.maximum(ref, 1e-300)) < 1e-8
     for x, y in zip(runs[0], runs[1]):
         assert np.array_equal(x, y)
+
+
+def test_evolve3d_with_the_steep_cooling_curve_vs_reference(pkg, tables):
+    """The second non-isothermal pin (tests/golden/evolve32_thermal_steep: reference run with the CIE-like synthetic cooling
+    table, inputs.cooling_table("steep")): cells that start at or below minitemp (thermal.f90:83), cold dense cells that are
+    driven to minitemp and leave thermal through the 10 000 sub-step cap (:163, > 10 000 calls of the step do), hot cells on
+    the four-orders-of-magnitude rise between 1e4 and 1e5 K; 35 outer iterations."""
+    m, a = load_case("evolve32_thermal_steep")
+    p = np.load("tests/golden/point_thermal_steep.npz")
+    n, tag = m["n"], "step001"
+    s = m["steps"][tag]
+    tt = load_thermal_tables()
+    b = pkg.HipBackend(n, *tables, device=0)
+    b.set_step((s["dr1"], s["dr2"], s["dr3"]), s["vol"], s["coldensh_LLS"], s["clumping"])
+    b.set_thermal(tt["heat_thick"], tt["heat_thin"], p["cool_logT"], p["cool_logL"])
+    b.set_redshift(s["zred"])
+    b.set_sources(s["srcpos"], s["normflux"]); b.set_rank(0, 1)
+    nd, xh0, t0 = F(a[tag + "_ndens"]), F(a[tag + "_xh_before"]), a[tag + "_temper_before"]
+    assert np.count_nonzero(t0[:, 0] <= 1.0) > 10
+    b.load(ndens=nd, xh=xh0, temperature_grid=t0)
+    rep = b.evolve3d_native(s["dt"])
+    assert rep.converged and rep.niter == s["niter"] == 35
+    assert list(rep.it_conv_flag[:rep.niter]) == s["log"]["nonconv"]
+    assert rep.sum_nbox_all == s["sum_nbox_all"]
+    assert np.max(np.abs(b.fetch("xh") - F(a[tag + "_xh_after"]))) < tol("x")
+    tg = b.fetch("temperature_grid")
+    ref = a[tag + "_temper_after"]
+    untouched = t0[:, 0] <= 1.0                                     # thermal.f90:83
+    assert np.array_equal(tg[untouched], ref[untouched])
+    assert_temper(tg, ref, tag)
+    assert np.count_nonzero(np.abs(ref[:, 0] - 2.0 / 3.0) < 0.2) > 30    # cells the step left pinned at the floor
+    b.close()

@@ -84,3 +84,58 @@ def test_isothermal_oracle_untouched_by_the_switch():
     phih = np.zeros(m["n"] ** 3)
     o.pass_sources(F(a["ndens"]), F(a["xh"]), phih, m["srcpos"], m["normflux"])
     assert np.array_equal(phih, F(a["phih"]))
+
+
+def _steep():
+    p = np.load("tests/golden/point_thermal_steep.npz")
+    return p, p["cool_logT"], p["cool_logL"]
+
+
+def test_coolin_and_thermal_rows_with_the_steep_cooling_curve():
+    """The second synthetic cooling table (tests/golden/inputs.cooling_table("steep"): a CIE-like rise of four orders of
+    magnitude between 1e4 and 1e5 K, a cold-gas coolant whose extrapolation below the first table row stays large): coolin
+    above, inside and BELOW the table's range, and 180 thermal rows of which 36 start at or below minitemp (thermal.f90:83:
+    untouched) and 14 are driven to minitemp, pinned there by :147-153 and ended by the 10 000 sub-step cap (:163)
+    -- all equal to the reference's values."""
+    from oracle.oracle import Oracle
+    p, lt, ll = _steep()
+    tt = load_thermal_tables()
+    o = Oracle(32, 1e24, 1e72, 7e16, *TAB)
+    o.enable_thermal(tt["heat_thick"], tt["heat_thin"], lt, ll, float(p["thermal_zred"]))
+    got = np.array([o.coolin(a, b, t) for a, b, t in p["cool_in"]])
+    assert np.array_equal(got, p["cool_out"])
+    assert np.count_nonzero(p["cool_in"][:, 2] < 10.0) >= 5                 # rows below the table's first temperature
+    st = o.enable_thermal_stats()
+    got = np.array([o.thermal(*r) for r in p["thermal_in"]])
+    assert np.array_equal(got, p["thermal_out"])
+    assert st[0] == len(got) == 180 and st[1] == 36 and np.count_nonzero(got[:, 0] == -1.0) == 36
+    assert st[2] == 14, st                                                   # rows that left through i_heating > 10000
+    assert st[3] > 10001 * st[2]
+    # a row pinned at the floor ends near gamma1 * minitemp: the floor restores the pressure without dividing by
+    # gamma - 1 (thermal.f90:148), so the temperature :175 derives from it is 2/3 K (times the electron-density ratio)
+    assert np.count_nonzero(np.abs(got[:, 0] - 2.0 / 3.0) < 0.2) >= 14
+
+
+def test_evolve3d_nonisothermal_with_the_steep_cooling_curve():
+    """A whole non-isothermal step with that curve on a field with cells at and below minitemp, cold dense cells and hot
+    cells on the steep part of the curve (inputs.temperature_field_cold): 35 outer iterations; the history, xh, Gamma, the
+    heating rates and the three temperature fields equal the reference's -- and the counters say what the step exercised."""
+    m, a = load_case("evolve32_thermal_steep")
+    p, lt, ll = _steep()
+    n, tag = m["n"], "step001"
+    s = m["steps"][tag]
+    tg = np.ascontiguousarray(a[tag + "_temper_before"]).copy()
+    o = oracle_for(s, TAB, n)
+    tt = load_thermal_tables()
+    o.enable_thermal(tt["heat_thick"], tt["heat_thin"], lt, ll, s["zred"], tg)
+    st = o.enable_thermal_stats()
+    assert np.count_nonzero(tg[:, 0] <= 1.0) > 10
+    xh = F(a[tag + "_xh_before"])
+    rep, xav, xint, phih = o.evolve3d(s["dt"], F(a[tag + "_ndens"]), xh, s["srcpos"], s["normflux"])
+    assert rep.converged and rep.niter == s["niter"] == 35
+    assert list(rep.it_conv_flag[:rep.niter]) == s["log"]["nonconv"]
+    assert np.array_equal(xh, F(a[tag + "_xh_after"]))
+    assert np.array_equal(phih, F(a[tag + "_phih_grid"]))
+    assert np.array_equal(o.phiheat, F(a[tag + "_phiheat_grid"]))
+    assert np.array_equal(tg, a[tag + "_temper_after"])
+    assert st[1] > 500 and st[2] > 10000, st          # calls skipped at T <= minitemp; calls ended by the sub-step cap
