@@ -147,6 +147,8 @@ def main():
                          "instead of the synthetic field; scaled as scale_density does (density_unit grid, --n-box fine cells per side)")
     ap.add_argument("--n-box", type=int, default=13824, help="fine N-body cells per side of the density file's simulation (nbody_cubep3m.F90:9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-mode", action="store_true",
+                    help="skip the short leg that times the same steps in the OTHER sweep mode (reported as `other_sweep_mode`)")
     ap.add_argument("--balance", action="store_true",
                     help="cost-balanced source shares (by the previous pass) instead of the static stride")
     ap.add_argument("--deterministic", action="store_true",
@@ -286,7 +288,7 @@ def main():
         if os.path.exists(tpath) and timed:      # PMC counters of the same command, from the latest committed profile
             tj = json.load(open(tpath))
             traffic = (tj["fetch_corrected_bytes_per_visit"] + tj["write_bytes_per_visit"]) * vis_rank / launches
-            traffic_note = tj["source"]
+            traffic_note = "%s (profiled commit %s)" % (tj["source"], tj.get("commit", "?"))
             mix_ceiling = tj.get("mix_ceiling_visits_per_s")
         out = {
             "metric": "cells-traced/sec (grid^3 x sources / wallclock) on 256^3",
@@ -322,6 +324,29 @@ def main():
                                  "(shell planes make a round trip through HBM between launches) and the Gamma atomics cost the memory side a "
                                  "read and a write each: ~47 B per visit at DRAM level, ~5.2 TB/s of the ~6.3 TB/s achievable; see DESIGN.md s5"},
         }
+        if world == 1 and not args.no_other_mode and not args.thermal:
+            # the same steps in the other sweep mode (the library default is exact: column densities bit-identical to the
+            # Fortran; `value` above is the mode named in config.sweep_mode), outside the timed region of the headline
+            b.close()
+            other = "exact" if args.sweep_mode == "fast" else "fast"
+            b2 = pkg.HipBackend(n, thick, thin, device=local_rank, deterministic=args.deterministic, fast=other == "fast")
+            b2.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], s["clumping"], s["temper"])
+            b2.set_sources(srcpos, normflux)
+            b2.load(ndens=nd, xh=xh)
+            ev2 = pkg.Evolve(b2, balance=args.balance)
+            b2.begin_step()
+            k2 = min(args.steps, 3)
+            for k in range(-1, k2 + 1):             # relax + one warm-up, then k2 timed steps
+                if k == 1:
+                    torch.cuda.synchronize(); t2 = time.perf_counter()
+                ev2.set_rates_to_zero(); ev2.pass_all_sources(k, s["dt"]); ev2.global_pass(s["dt"])
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t2
+            out["other_sweep_mode"] = {"sweep_mode": other, "steps": k2, "ms_per_step": 1e3 * dt2 / k2,
+                                       "value": float(n) ** 3 * S * k2 / dt2, "unit": "cells-traced/s",
+                                       "sum_nbox_last_step": int(ev2.sum_nbox_all),
+                                       "xh_av_sum": float(b2.xh_av.sum(dtype=torch.float64))}
+            b2.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, srcpos, normflux, xh_state, nbox_first, pkg.box_cost, nd=nd)
         print(json.dumps(out))

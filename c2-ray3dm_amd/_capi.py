@@ -86,6 +86,8 @@ SYMBOLS = [
     ("c2r_set_final_temperature", C.c_int, [_P]),
     ("c2r_set_sources", C.c_int, [_P, _P, _P, _I32]),
     ("c2r_set_rank", C.c_int, [_P, _I32, _I32, ALLREDUCE_FN, _P]),
+    ("c2r_set_slab_chemistry", C.c_int, [_P, _P, _P, _P]),
+    ("c2r_slab", C.c_int, [_P, _I32, _I32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("c2r_set_source_share", C.c_int, [_P, _P, _I32]),
     ("c2r_last_nbox", C.c_int, [_P, _P, _I32]),
     ("c2r_set_balance", C.c_int, [_P, _I32]),

@@ -66,6 +66,9 @@ struct Ctx {
     double *d_nbox_all = nullptr, *h_nbox_all = nullptr; int nbox_all_cap = 0;   // device buffer + pinned staging
     c2r_allreduce_fn ar = nullptr;
     void *ar_user = nullptr;
+    // slab chemistry (c2r_set_slab_chemistry): reduce-scatter of the rates by z-slabs, the global pass on the own slab,
+    // all-gather of its outputs -- instead of the all-reduce and a replicated global pass
+    c2r_reduce_scatter_fn rs = nullptr; c2r_allgather_fn ag = nullptr; void *slab_user = nullptr;
     c2r_iteration_fn iter_hook = nullptr;
     void *iter_user = nullptr;
     // sweep geometry
@@ -547,6 +550,15 @@ long long visited_for_nbox(const Ctx *ctx, int nbox)
     return v;
 }
 
+// z-slab of rank r of P: whole z-planes, the first (N3 mod P) ranks one plane more; in cells
+void slab_of(const Ctx *ctx, int r, int P, size_t *off, size_t *cnt)
+{
+    const size_t n3 = (size_t)ctx->prm.mesh[2], plane = (size_t)ctx->prm.mesh[0] * ctx->prm.mesh[1];
+    const size_t base = n3 / (size_t)P, rem = n3 % (size_t)P;
+    const size_t z0 = (size_t)r * base + std::min<size_t>((size_t)r, rem), nz = base + ((size_t)r < rem ? 1 : 0);
+    *off = z0 * plane; *cnt = nz * plane;
+}
+
 int check_ready(Ctx *ctx)
 {
     // the context's allocations and launches belong to its device, whatever the caller made current since
@@ -971,6 +983,22 @@ int c2r_set_rank(c2r_ctx *c, int32_t rank, int32_t nranks, c2r_allreduce_fn fn, 
     return C2R_OK;
 }
 
+int c2r_set_slab_chemistry(c2r_ctx *c, c2r_reduce_scatter_fn rs, c2r_allgather_fn ag, void *user)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if ((rs == nullptr) != (ag == nullptr)) FAIL(C2R_EINVAL, "slab chemistry needs both the reduce-scatter and the all-gather callback (or neither)");
+    ctx->rs = rs; ctx->ag = ag; ctx->slab_user = user;
+    return C2R_OK;
+}
+
+int c2r_slab(const c2r_ctx *c, int32_t rank, int32_t nranks, size_t *cell_offset, size_t *cell_count)
+{
+    if (!c || nranks < 1 || rank < 0 || rank >= nranks || !cell_offset || !cell_count) return C2R_EINVAL;
+    slab_of(C(c), rank, nranks, cell_offset, cell_count);
+    return C2R_OK;
+}
+
 int c2r_set_source_share(c2r_ctx *c, const int32_t *idx, int32_t n)
 {
     if (!c) return C2R_EINVAL;
@@ -1263,8 +1291,10 @@ int c2r_photon_sums(c2r_ctx *c, int32_t which_l, int32_t which_r, double out[4])
 
 // global_pass (evolve.F90:499-573); stats_dst (device-visible, 4 doubles, or null): the photon-statistics sums of
 // (xh_intermed, xh_av) as the pass leaves them, from the same kernel
-static int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum_xh1, double *stats_dst)
+static int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum_xh1, double *stats_dst,
+                            size_t cell_off = 0, size_t cell_cnt = (size_t)-1)
 {
+    if (cell_cnt == (size_t)-1) cell_cnt = ctx->ncell;        // (a slab [cell_off, cell_off+cell_cnt): slab chemistry)
     const c2r_params &p = ctx->prm;
     ChemParams cp{};
     cp.dt = dt; cp.eps = p.epsilon; cp.min_frac_change = p.minimum_fractional_change;
@@ -1273,14 +1303,14 @@ static int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum
     // doric.f90:73,78 -- temperature is uniform (isothermal), so both rate coefficients are
     // per-call constants; evaluated with the host libm like the reference does at run time
     cp.brech0 = (double)ctx->clumping * p.bh00 * pow(ctx->temper / 1e4, p.albpow);
-    cp.bh00 = p.bh00; cp.recpow = pow(ctx->temper / 1e4, p.albpow); cp.clump = ctx->d_clump;
+    cp.bh00 = p.bh00; cp.recpow = pow(ctx->temper / 1e4, p.albpow); cp.clump = ctx->d_clump ? ctx->d_clump + cell_off : nullptr;
     cp.acolh0 = p.colh0 * sqrt(ctx->temper) * exp(-p.temph0 / ctx->temper);
     cp.clumping = (double)ctx->clumping; cp.colh0 = p.colh0; cp.sqrtt = sqrt(ctx->temper); cp.expt = exp(-p.temph0 / ctx->temper);
     cp.stat_partial = ctx->d_stat_partial;
     if (ctx->thermal) {
         const c2r_thermal_params &t = ctx->tprm;
         if (t.cosmological && !ctx->have_zred) FAIL(C2R_ESTATE, "non-isothermal run: c2r_set_redshift has not been called (cosmo_cool needs zred)");
-        cp.temper = (float *)ctx->grid[6]; cp.phiheat = (const double *)ctx->grid[5]; cp.cool = ctx->d_cool;
+        cp.temper = (float *)ctx->grid[6] + 3 * cell_off; cp.phiheat = (const double *)ctx->grid[5] + cell_off; cp.cool = ctx->d_cool;
         cp.cool_mintemp = t.cool_mintemp; cp.cool_dtemp = t.cool_dtemp; cp.cool_points = t.cool_points;
         cp.thermal_max_steps = t.thermal_max_steps;
         cp.k_B = t.k_B; cp.gamma1 = t.gamma1; cp.minitemp = t.minitemp; cp.rel_denergy = t.relative_denergy;
@@ -1292,9 +1322,9 @@ static int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum
         cp.tconv_rel = t.temp_conv_rel; cp.tconv_abs = t.temp_conv_abs;
     }
     prof_begin(ctx, ctx->ev_chem, ctx->ev_chem_used);
-#define C2R_LAUNCH_GLOBAL(S, T) hipLaunchKernelGGL((k_global_pass<S, T>), dim3(kSumBlocks), dim3(256), 0, ctx->stream, cp, ctx->ncell, \
-                           (const float *)ctx->grid[0], (const double *)ctx->grid[1], (double *)ctx->grid[2], \
-                           (double *)ctx->grid[3], (const double *)ctx->grid[4], ctx->d_sum_partial, ctx->d_conv, \
+#define C2R_LAUNCH_GLOBAL(S, T) hipLaunchKernelGGL((k_global_pass<S, T>), dim3(kSumBlocks), dim3(256), 0, ctx->stream, cp, cell_cnt, \
+                           (const float *)ctx->grid[0] + cell_off, (const double *)ctx->grid[1] + cell_off, (double *)ctx->grid[2] + cell_off, \
+                           (double *)ctx->grid[3] + cell_off, (const double *)ctx->grid[4] + cell_off, ctx->d_sum_partial, ctx->d_conv, \
                            ctx->d_chemfail)
     if (stats_dst) { if (ctx->thermal) C2R_LAUNCH_GLOBAL(true, true); else C2R_LAUNCH_GLOBAL(true, false); }
     else { if (ctx->thermal) C2R_LAUNCH_GLOBAL(false, true); else C2R_LAUNCH_GLOBAL(false, false); }
@@ -1390,8 +1420,18 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
         double loss = 0; int64_t nb = 0, vis = 0;
         rc = c2r_pass_sources(c, &loss, &nb, &vis);                                    // :246
         if (rc) return rc;
+        const bool slab = ctx->nranks > 1 && ctx->rs && ctx->ag && ctx->ar;
+        size_t so[64], sc[64];                                                         // slabs of all ranks (cells)
+        if (slab) {
+            if (ctx->nranks > 64) FAIL(C2R_EINVAL, "slab chemistry supports up to 64 ranks");
+            for (int r = 0; r < ctx->nranks; ++r) slab_of(ctx, r, ctx->nranks, &so[r], &sc[r]);
+            // reduce-scatter instead of evolve.F90:599's all-reduce: this rank gets the summed rates of its z-slab
+            if (ctx->rs(ctx->slab_user, ctx->grid[4], so, sc, ctx->nranks, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "reduce-scatter callback failed");
+            if (ctx->thermal && ctx->rs(ctx->slab_user, ctx->grid[5], so, sc, ctx->nranks, (void *)ctx->stream) != 0)
+                FAIL(C2R_ECALLBACK, "reduce-scatter callback failed");
+        }
         if (ctx->nranks > 1) {
-            rc = c2r_allreduce_rates(c);                                               // evolve.F90:599
+            if (!slab) rc = c2r_allreduce_rates(c);                                    // evolve.F90:599
             if (rc) return rc;
             // evolve.F90:587,612: photon_loss and sum_nbox ride along as a 2-element f64 vector
             // (sum_nbox is exact in f64)
@@ -1406,8 +1446,36 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
         rep->photon_loss_all = loss; rep->sum_nbox_all = nb; rep->visited += vis;
         // :269 global_pass; evolve.F90:570 calculate_photon_statistics(dt,xh_intermed,xh_av) + report (the conservation
         // line): the sums come out of the same kernel into this iteration's pinned slot
-        rc = global_pass_impl(ctx, dt, &conv_flag, &sum1, niter <= C2R_MAX_ITER_LOG ? ctx->d_hit4 + 4 * (size_t)(niter - 1) : nullptr);
-        if (rc) return rc;
+        if (!slab) {
+            rc = global_pass_impl(ctx, dt, &conv_flag, &sum1, niter <= C2R_MAX_ITER_LOG ? ctx->d_hit4 + 4 * (size_t)(niter - 1) : nullptr);
+            if (rc) return rc;
+        } else {
+            // evolve0D_global on the own slab only (evolve.F90:548-555 visits every cell on every rank), the counts summed
+            // over the ranks, the pass's outputs gathered: xh_av (the next sweep reads all of it), xh_intermed (Test 2 and the
+            // accepted state), the temperatures.  The sums that feed Test 2 and the photon statistics are then taken over
+            // the whole arrays exactly as the replicated pass takes them: bit-identical decisions on every rank.
+            const size_t mo = so[ctx->rank], mc = sc[ctx->rank];
+            int64_t conv_local = 0;
+            rc = global_pass_impl(ctx, dt, &conv_local, nullptr, nullptr, mo, mc);
+            if (rc) return rc;
+            ctx->h_sc->pair[0] = (double)conv_local; ctx->h_sc->pair[1] = (double)ctx->h_sc->chemfail;
+            HIP_TRY(hipMemcpyAsync(ctx->d_pair, ctx->h_sc->pair, 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            if (ctx->ar(ctx->ar_user, ctx->d_pair, 2, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-reduce callback failed");
+            HIP_TRY(hipMemcpyAsync(ctx->h_sc->pair, ctx->d_pair, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            size_t bo[64], bc[64];
+            for (int w = 2; w <= 3; ++w) {
+                for (int r = 0; r < ctx->nranks; ++r) { bo[r] = so[r] * sizeof(double); bc[r] = sc[r] * sizeof(double); }
+                if (ctx->ag(ctx->slab_user, ctx->grid[w], bo, bc, ctx->nranks, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-gather callback failed");
+            }
+            if (ctx->thermal) {
+                for (int r = 0; r < ctx->nranks; ++r) { bo[r] = so[r] * 3 * sizeof(float); bc[r] = sc[r] * 3 * sizeof(float); }
+                if (ctx->ag(ctx->slab_user, ctx->grid[6], bo, bc, ctx->nranks, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-gather callback failed");
+            }
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            conv_flag = (int64_t)llround(ctx->h_sc->pair[0]); ctx->h_sc->chemfail = (unsigned int)llround(ctx->h_sc->pair[1]);
+            if ((rc = c2r_sum(c, 3, &sum1))) return rc;
+            if (niter <= C2R_MAX_ITER_LOG && (rc = photon_sums_launch(ctx, 3, 2, ctx->d_hit4 + 4 * (size_t)(niter - 1)))) return rc;
+        }
         auto t2 = clk::now();
         rep->seconds_sweep += std::chrono::duration<double>(t1 - t0).count();
         rep->seconds_chem += std::chrono::duration<double>(t2 - t1).count();
@@ -1418,6 +1486,13 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             if (ctx->iter_hook(ctx->iter_user, niter, rep->photon_loss_all) != 0) FAIL(C2R_ECALLBACK, "iteration hook failed");
         }
+    }
+    if (ctx->nranks > 1 && ctx->rs && ctx->ag && ctx->ar && niter > (restart_niter > 0 ? restart_niter : 0)) {
+        // the step leaves phih_grid (phiheat_grid) complete on every rank, as the all-reduce does (output.F90 writes them)
+        size_t bo[64], bc[64];
+        for (int r = 0; r < ctx->nranks; ++r) { size_t o, n; slab_of(ctx, r, ctx->nranks, &o, &n); bo[r] = o * sizeof(double); bc[r] = n * sizeof(double); }
+        if (ctx->ag(ctx->slab_user, ctx->grid[4], bo, bc, ctx->nranks, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-gather callback failed");
+        if (ctx->thermal && ctx->ag(ctx->slab_user, ctx->grid[5], bo, bc, ctx->nranks, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-gather callback failed");
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     rep->niter = niter; rep->conv_flag = conv_flag;

@@ -29,9 +29,39 @@ int rccl_cb(void *user, void *dev_buf, size_t count, void *stream)
     Link *l = static_cast<Link *>(user);
     return (int)ncclAllReduce(dev_buf, dev_buf, count, ncclDouble, ncclSum, l->comm, (hipStream_t)stream);
 }
+// c2r_reduce_scatter_fn: rank r receives the sum over ranks of ITS slab, in place.  The slabs are whole z-planes and need
+// not be equal, so this is one ncclReduce per slab (root = the slab's rank) inside a group -- the traffic of a reduce-scatter.
+int rccl_rs(void *user, void *dev_buf, const size_t *off, const size_t *cnt, int32_t nranks, void *stream)
+{
+    Link *l = static_cast<Link *>(user);
+    double *b = static_cast<double *>(dev_buf);
+    ncclResult_t r = ncclGroupStart();
+    for (int k = 0; k < nranks && r == ncclSuccess; ++k)
+        if (cnt[k]) r = ncclReduce(b + off[k], b + off[k], cnt[k], ncclDouble, ncclSum, k, l->comm, (hipStream_t)stream);
+    const ncclResult_t e = ncclGroupEnd();
+    return (int)(r != ncclSuccess ? r : e);
+}
+// c2r_allgather_fn: every rank's slab (bytes) to every rank, in place: one ncclBroadcast per slab inside a group
+int rccl_ag(void *user, void *dev_buf, const size_t *off, const size_t *cnt, int32_t nranks, void *stream)
+{
+    Link *l = static_cast<Link *>(user);
+    char *b = static_cast<char *>(dev_buf);
+    ncclResult_t r = ncclGroupStart();
+    for (int k = 0; k < nranks && r == ncclSuccess; ++k)
+        if (cnt[k]) r = ncclBroadcast(b + off[k], b + off[k], cnt[k], ncclChar, k, l->comm, (hipStream_t)stream);
+    const ncclResult_t e = ncclGroupEnd();
+    return (int)(r != ncclSuccess ? r : e);
+}
 }  // namespace
 
 extern "C" {
+
+int c2r_rccl_slab_chemistry(c2r_ctx *ctx, int32_t on)
+{
+    Link *l = find(ctx);
+    if (!l) return C2R_ESTATE;
+    return on ? c2r_set_slab_chemistry(ctx, rccl_rs, rccl_ag, l) : c2r_set_slab_chemistry(ctx, nullptr, nullptr, nullptr);
+}
 
 int c2r_rccl_unique_id(void *id)
 {
@@ -73,6 +103,7 @@ int c2r_rccl_detach(c2r_ctx *ctx)
         g_links.erase(it);
     }
     c2r_set_rank(ctx, 0, 1, nullptr, nullptr);
+    c2r_set_slab_chemistry(ctx, nullptr, nullptr, nullptr);
     ncclResult_t r = ncclCommDestroy(l->comm);
     delete l;
     return (int)r;

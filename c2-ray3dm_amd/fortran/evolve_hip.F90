@@ -261,6 +261,11 @@ module c2ray_hip
        character(kind=c_char), intent(in) :: id(128)
        integer(c_int32_t), value :: rank, nranks
      end function c2r_rccl_attach
+     integer(c_int) function c2r_rccl_slab_chemistry(ctx, on) bind(C, name="c2r_rccl_slab_chemistry")
+       import :: c_int, c_ptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: on
+     end function c2r_rccl_slab_chemistry
      integer(c_int) function c2r_rccl_detach(ctx) bind(C, name="c2r_rccl_detach")
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx
@@ -351,6 +356,10 @@ contains
        call MPI_BCAST(uid, 128, MPI_BYTE, 0, MPI_COMM_NEW, mympierror)
        call check(c2r_rccl_attach(ctx, uid, int(rank, c_int32_t), int(npr, c_int32_t)), "c2r_rccl_attach")
        call check(c2r_set_balance(ctx, 1_c_int32_t), "c2r_set_balance")
+       ! non-isothermal builds: the global pass is heavy (thermal.f90 per chemistry iteration), so it runs on z-slabs
+       ! (reduce-scatter of the rates, all-gather of xh_av / xh_intermed / temperature_grid) instead of replicated on every
+       ! rank behind an all-reduce (evolve.F90:548-555, :599-609); the isothermal pass costs less than the extra slab it moves
+       if (.not.isothermal) call check(c2r_rccl_slab_chemistry(ctx, 1_c_int32_t), "c2r_rccl_slab_chemistry")
     endif
 #endif
   end subroutine evolve_hip_ini

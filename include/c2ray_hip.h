@@ -193,6 +193,25 @@ int  c2r_set_sources(c2r_ctx *ctx, const int32_t *srcpos, const double *normflux
  * do ns1=1+rank,NumSrc,npr) and the collective that replaces MPI_ALLREDUCE. */
 int  c2r_set_rank(c2r_ctx *ctx, int32_t rank, int32_t nranks, c2r_allreduce_fn fn, void *user);
 
+/* Slab chemistry (an alternative to evolve.F90:548-555 + :599, where every rank all-reduces the rates and then
+ * runs evolve0D_global over the WHOLE mesh): the rates are reduce-scattered by z-slabs (rank r ends up with the sum over
+ * ranks of ITS slab of phih_grid / phiheat_grid), every rank runs the chemistry on its slab only, and the pass's outputs --
+ * xh_av, xh_intermed, temperature_grid -- are all-gathered; the non-converged counts are summed through the all-reduce
+ * callback, the sums that drive the convergence tests and the photon statistics are taken over the gathered arrays exactly
+ * as the replicated pass takes them (the same decisions, bit for bit, on every rank), and when the step ends the rates are
+ * gathered once so that phih_grid is complete everywhere.  Both callbacks work IN PLACE on a full-size device array, the
+ * slabs given as nranks offsets and counts (c2r_slab): reduce-scatter in f64 ELEMENTS (after it only the own slab is
+ * defined), all-gather in BYTES (every rank's slab is valid on entry in its own array).  Return 0 on success.
+ * Worth it where the global pass is heavy (non-isothermal runs: 0.7 ms replicated at 256^3) or the ranks many; it moves
+ * 3 array-slabs per iteration where the all-reduce moves 2.  NULL, NULL switches it off. */
+typedef int (*c2r_reduce_scatter_fn)(void *user, void *dev_buf, const size_t *elem_offset, const size_t *elem_count,
+                                     int32_t nranks, void *hip_stream);
+typedef int (*c2r_allgather_fn)(void *user, void *dev_buf, const size_t *byte_offset, const size_t *byte_count,
+                                int32_t nranks, void *hip_stream);
+int  c2r_set_slab_chemistry(c2r_ctx *ctx, c2r_reduce_scatter_fn rs, c2r_allgather_fn ag, void *user);
+/* The z-slab of `rank` among `nranks`: whole z-planes, the first (mesh(3) mod nranks) ranks one more; in cells. */
+int  c2r_slab(const c2r_ctx *ctx, int32_t rank, int32_t nranks, size_t *cell_offset, size_t *cell_count);
+
 /* Cost-balanced alternative to the static distribution (the reference's answer to
  * imbalance is its master/worker scheduler, master_slave.F90:124-330): the 0-based global indices
  * of the sources THIS rank sweeps, in sweep order.  idx=NULL returns to the static rule.

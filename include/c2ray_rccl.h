@@ -32,6 +32,11 @@ int c2r_rccl_attach(c2r_ctx *ctx, const void *id, int32_t rank, int32_t nranks);
  * exported for tests and for hosts that reduce their own quantities the same way. */
 int c2r_rccl_allreduce(c2r_ctx *ctx, void *dev_buf, size_t count, void *hip_stream);
 
+/* after c2r_rccl_attach: slab chemistry over the same communicator (c2r_set_slab_chemistry: the rates reduce-scattered by
+ * z-slabs -- grouped ncclReduce, one per slab, since whole planes rarely divide evenly --, the chemistry on the own slab, its
+ * outputs all-gathered with grouped ncclBroadcast); on = 0 returns to the all-reduce + replicated global pass. */
+int c2r_rccl_slab_chemistry(c2r_ctx *ctx, int32_t on);
+
 /* leave the communicator; the context goes back to a single rank. */
 int c2r_rccl_detach(c2r_ctx *ctx);
 

@@ -5,7 +5,9 @@
 //     c2r_evolve3d (host-pointer entry, what the Fortran shim calls).
 // Collective:  "rccl"  libc2ray_rccl.so (ncclAllReduce over xGMI; needs one device per rank),
 //              "host"  a rank-ordered sum staged through host memory (any device count, also 1 GPU).
-// usage: mgpu_harness <in.bin> <out.bin> <nranks> <host|rccl> <balance 0|1>
+// Slab chemistry (c2r_set_slab_chemistry: reduce-scatter of the rates, global pass on the own z-slab, all-gather): optional 6th
+// argument 1; host-staged reduce-scatter / all-gather in rank order, or the RCCL binding's.
+// usage: mgpu_harness <in.bin> <out.bin> <nranks> <host|rccl> <balance 0|1> [slab 0|1]
 //   in.bin : int32 mesh, nsrc | f64 dr, vol, lls, dt | f32 ndens[N^3] | f64 xh[N^3] | int32 srcpos[3 nsrc] | f64 normflux[nsrc]
 //   out.bin: int32 niter, converged, nranks_used_rccl | int64 sum_nbox, conv_flag[niter] | f64 loss | f64 xh[N^3] | f64 phih[N^3]
 #include <hip/hip_runtime.h>
@@ -24,7 +26,7 @@ struct Problem {
     std::vector<double> thick, thin;
 };
 struct Shared {
-    int nranks; bool rccl, balance; const Problem *pb;
+    int nranks; bool rccl, balance, slab = false; const Problem *pb;
     pthread_barrier_t bar;
     std::vector<double *> stage; std::vector<size_t> stage_cap;   // host all-reduce: one PINNED staging buffer per rank
     unsigned char uid[C2R_RCCL_ID_BYTES];
@@ -55,6 +57,54 @@ static int host_allreduce(void *user, void *dev_buf, size_t count, void *stream)
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : 1;
 }
 
+static int stage_for(Shared *sh, int rank, size_t doubles)
+{
+    if (sh->stage_cap[rank] < doubles) {
+        if (sh->stage[rank]) (void)hipHostFree(sh->stage[rank]);
+        if (hipHostMalloc((void **)&sh->stage[rank], 2 * doubles * sizeof(double)) != hipSuccess) return 1;
+        sh->stage_cap[rank] = doubles;
+    }
+    return 0;
+}
+// c2r_reduce_scatter_fn: every rank stages its whole array; rank r sums ITS slab over the ranks in rank order
+static int host_reduce_scatter(void *user, void *dev_buf, const size_t *off, const size_t *cnt, int32_t nranks, void *stream)
+{
+    RankArg *a = static_cast<RankArg *>(user);
+    Shared *sh = a->sh;
+    const size_t total = off[nranks - 1] + cnt[nranks - 1];
+    if (stage_for(sh, a->rank, total)) return 1;
+    double *mine = sh->stage[a->rank], *sum = mine + sh->stage_cap[a->rank];
+    if (hipMemcpyAsync(mine, dev_buf, total * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return 1;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;
+    pthread_barrier_wait(&sh->bar);
+    const size_t o = off[a->rank], n = cnt[a->rank];
+    for (size_t i = 0; i < n; ++i) sum[i] = 0.0;
+    for (int r = 0; r < sh->nranks; ++r)
+        for (size_t i = 0; i < n; ++i) sum[i] = sum[i] + sh->stage[r][o + i];
+    pthread_barrier_wait(&sh->bar);
+    if (hipMemcpyAsync(static_cast<double *>(dev_buf) + o, sum, n * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return 1;
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : 1;
+}
+// c2r_allgather_fn: every rank stages its own slab (bytes); every rank then copies the others' slabs up
+static int host_allgather(void *user, void *dev_buf, const size_t *off, const size_t *cnt, int32_t nranks, void *stream)
+{
+    RankArg *a = static_cast<RankArg *>(user);
+    Shared *sh = a->sh;
+    const size_t total = off[nranks - 1] + cnt[nranks - 1];
+    if (stage_for(sh, a->rank, (total + 7) / 8)) return 1;
+    char *mine = reinterpret_cast<char *>(sh->stage[a->rank]);
+    char *dev = static_cast<char *>(dev_buf);
+    if (hipMemcpyAsync(mine + off[a->rank], dev + off[a->rank], cnt[a->rank], hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return 1;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;
+    pthread_barrier_wait(&sh->bar);
+    for (int r = 0; r < sh->nranks; ++r)
+        if (r != a->rank && cnt[r] &&
+            hipMemcpyAsync(dev + off[r], reinterpret_cast<char *>(sh->stage[r]) + off[r], cnt[r], hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return 1;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;
+    pthread_barrier_wait(&sh->bar);                  // nobody restages before everyone has copied
+    return 0;
+}
+
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != 0) { sh->rc[rank] = rc_; sh->err[rank] = std::string(#expr) + ": " + (ctx ? c2r_last_error(ctx) : ""); goto done; } } while (0)
 
 static void *rank_main(void *p)
@@ -77,6 +127,7 @@ static void *rank_main(void *p)
         prm.mesh[0] = prm.mesh[1] = prm.mesh[2] = pb.mesh;
         prm.device = rank % ndev;
         if (const char *e = getenv("C2R_SWEEP_MODE")) prm.sweep_mode = atoi(e) ? C2R_SWEEP_FAST : C2R_SWEEP_EXACT;
+        if (const char *e = getenv("C2R_HARNESS_DETERMINISTIC")) prm.deterministic_rates = atoi(e) ? 1 : 0;   // ordered per-source sums: runs comparable bit for bit
         TRY(c2r_create(&ctx, &prm));
         TRY(c2r_set_tables(ctx, pb.thick.data(), pb.thin.data(), (int32_t)pb.thick.size()));
         const double dr[3] = {pb.dr, pb.dr, pb.dr};
@@ -91,6 +142,10 @@ static void *rank_main(void *p)
                 TRY(c2r_set_rank(ctx, rank, sh->nranks, host_allreduce, a));
             }
             TRY(c2r_set_balance(ctx, sh->balance ? 1 : 0));
+            if (sh->slab) {
+                if (sh->rccl) TRY(c2r_rccl_slab_chemistry(ctx, 1));
+                else TRY(c2r_set_slab_chemistry(ctx, host_reduce_scatter, host_allgather, a));
+            }
         }
         TRY(c2r_evolve3d(ctx, pb.dt, ndens.data(), xh.data(), xh_av.data(), xh_int.data(), phih.data(), &rep));
         if (rank == 0) { sh->rep0 = rep; sh->xh0 = xh; sh->phih0 = phih; }
@@ -120,6 +175,7 @@ int main(int argc, char **argv)
     if (c2r_build_tables(&sed, pb.thick.data(), pb.thin.data(), sed.numtau + 1, nullptr) != 0) { fprintf(stderr, "c2r_build_tables failed\n"); return 1; }
     Shared sh;
     sh.nranks = atoi(argv[3]); sh.rccl = strcmp(argv[4], "rccl") == 0; sh.balance = atoi(argv[5]) != 0; sh.pb = &pb;
+    sh.slab = argc > 6 && atoi(argv[6]) != 0;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { fprintf(stderr, "no HIP device\n"); return 1; }
     if (sh.rccl && ndev < sh.nranks) { printf("SKIP: %d ranks over RCCL need %d devices, %d visible\n", sh.nranks, sh.nranks, ndev); return 77; }
@@ -140,7 +196,8 @@ int main(int argc, char **argv)
     fwrite(sh.xh0.data(), sizeof(double), ncell, f);
     fwrite(sh.phih0.data(), sizeof(double), ncell, f);
     fclose(f);
-    printf("ok: %d rank(s) on %d device(s), %s all-reduce, balance %d: niter %d sum_nbox %lld\n", sh.nranks, ndev < sh.nranks ? ndev : sh.nranks,
-           sh.rccl ? "rccl" : "host", (int)sh.balance, sh.rep0.niter, (long long)sh.rep0.sum_nbox_all);
+    printf("ok: %d rank(s) on %d device(s), %s %s, balance %d: niter %d sum_nbox %lld\n", sh.nranks, ndev < sh.nranks ? ndev : sh.nranks,
+           sh.rccl ? "rccl" : "host", sh.slab ? "reduce-scatter + slab chemistry + all-gather" : "all-reduce", (int)sh.balance, sh.rep0.niter,
+           (long long)sh.rep0.sum_nbox_all);
     return 0;
 }

@@ -35,9 +35,9 @@ def read_output(path, n):
     return dict(niter=int(niter), converged=int(converged), rccl_ranks=int(rccl_ranks), sum_nbox=sum_nbox, conv=list(conv), loss=loss, xh=xh, phih=phih)
 
 
-def run(tmp_path, tag, nranks, coll, balance):
+def run(tmp_path, tag, nranks, coll, balance, slab=0):
     out = str(tmp_path / ("out_%s.bin" % tag))
-    p = subprocess.run([HARNESS, str(tmp_path / "in.bin"), out, str(nranks), coll, str(int(balance))],
+    p = subprocess.run([HARNESS, str(tmp_path / "in.bin"), out, str(nranks), coll, str(int(balance)), str(int(slab))],
                        capture_output=True, text=True, timeout=600)
     if p.returncode == 77:
         pytest.skip(p.stdout.strip())
@@ -68,6 +68,28 @@ def test_ranks_as_threads_match_the_reference_step(tmp_path, case):
         assert np.max(np.abs(res[tag]["phih"][nz] / res["1"]["phih"][nz] - 1)) < 1e-10
 
 
+@pytest.mark.parametrize("case", ["evolve32_std_bubbles", "evolve64_std_bubbles"])
+def test_slab_chemistry_equals_the_replicated_global_pass(tmp_path, case, monkeypatch):
+    """c2r_set_slab_chemistry (reduce-scatter of Gamma by z-slabs, evolve0D_global on the own slab, all-gather of
+    xh_av / xh_intermed) against the all-reduce + replicated global pass of evolve.F90:548-555, :599: 2, 3 (32 planes do not
+    divide by 3: uneven slabs) and 4 ranks as threads with host-staged collectives in rank order -- the same iteration
+    history, sub-box counts and photon loss, xh and the final phih_grid BIT FOR BIT (the convergence sums are taken over the
+    gathered arrays exactly as the replicated pass takes them)."""
+    assert os.path.exists(HARNESS)
+    monkeypatch.setenv("C2R_HARNESS_DETERMINISTIC", "1")     # ordered per-source sums instead of atomics: two RUNS are comparable bit for bit
+    m, a = load_case(case)
+    n, s = m["n"], m["steps"]["step001"]
+    write_input(str(tmp_path / "in.bin"), n, s, F(a["step001_ndens"]), F(a["step001_xh_before"]))
+    for nranks, bal in ((2, 0), (3, 1), (4, 0)):
+        rep = read_output(run(tmp_path, "rep%d" % nranks, nranks, "host", bal, 0), n)
+        slb = read_output(run(tmp_path, "slab%d" % nranks, nranks, "host", bal, 1), n)
+        assert slb["converged"] and slb["niter"] == rep["niter"] == s["niter"]
+        assert slb["conv"] == rep["conv"] == s["log"]["nonconv"]
+        assert slb["sum_nbox"] == rep["sum_nbox"] and slb["loss"] == rep["loss"]
+        assert np.array_equal(slb["xh"], rep["xh"]), nranks
+        assert np.array_equal(slb["phih"], rep["phih"]), nranks
+
+
 def test_two_ranks_over_rccl(tmp_path):
     """ncclAllReduce of phih_grid between two devices of the node (libc2ray_rccl.so); skipped on a one-GPU box."""
     assert os.path.exists(HARNESS)
@@ -77,3 +99,6 @@ def test_two_ranks_over_rccl(tmp_path):
     r = read_output(run(tmp_path, "rccl", 2, "rccl", 1), n)
     assert r["rccl_ranks"] == 2 and r["niter"] == s["niter"] and r["conv"] == s["log"]["nonconv"]
     assert np.max(np.abs(r["xh"] - F(a["step001_xh_after"]))) < tol("x")
+    # the same over grouped ncclReduce / ncclBroadcast (slab chemistry)
+    r2 = read_output(run(tmp_path, "rccl_slab", 2, "rccl", 1, 1), n)
+    assert r2["niter"] == r["niter"] and r2["conv"] == r["conv"] and np.max(np.abs(r2["xh"] - r["xh"])) < 1e-12

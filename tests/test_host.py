@@ -38,7 +38,7 @@ def test_rccl_binding_exports_its_header(pkg):
     """include/c2ray_rccl.h (optional RCCL all-reduce callback) against libc2ray_rccl.so."""
     hdr = open(os.path.join(ROOT, "include", "c2ray_rccl.h")).read()
     declared = set(re.findall(r"\b(c2r_rccl_\w+)\s*\(", hdr))
-    assert declared == {"c2r_rccl_unique_id", "c2r_rccl_attach", "c2r_rccl_allreduce", "c2r_rccl_detach"}
+    assert declared == {"c2r_rccl_unique_id", "c2r_rccl_attach", "c2r_rccl_allreduce", "c2r_rccl_slab_chemistry", "c2r_rccl_detach"}
     lib = os.path.join(os.path.dirname(pkg.LIB_PATH), "libc2ray_rccl.so")
     out = subprocess.check_output(["nm", "-D", "--defined-only", lib]).decode()
     assert declared <= set(re.findall(r"\bT (c2r_rccl_\w+)", out))
