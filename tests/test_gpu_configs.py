@@ -283,3 +283,36 @@ def test_504_many_sources_in_three_batches(pkg, tables):
     assert res["three"][1:3] == res["one"][1:3] and np.array_equal(res["three"][4], res["one"][4])
     assert abs(res["three"][0] / res["one"][0] - 1) < 1e-12
     assert np.max(np.abs(res["three"][3] / res["one"][3] - 1)) < 1e-12
+
+
+@pytest.mark.parametrize("case,tag", [("evolve32_std_bubbles", "step001"), ("evolve32_onesrc", "step001"), ("evolve64_std_bubbles", "step001")])
+def test_graph_replay_equals_eager_launches_while_the_sub_boxes_change(pkg, tables, monkeypatch, case, tag):
+    """Batches of <= 32 sources replay their launch sequence as a hipGraph up to the sub-box the previous pass ended at
+    (box_hint) and continue eagerly beyond it.  On steps whose sub-box counts change from iteration to iteration -- sources
+    retire before the hint or grow past it -- the replay (C2R_GRAPH=1), eager launches (C2R_GRAPH=0) and the schedule without
+    the hint (C2R_SCHED_HINT=0) must give the same iteration history, per-iteration sub-box sums and, with ordered rates,
+    the same xh, Gamma and photon loss bit for bit."""
+    m, a = load_case(case)
+    n, s = m["n"], m["steps"][tag]
+    nd, xh0 = F(a[tag + "_ndens"]), F(a[tag + "_xh_before"])
+    out = []
+    for env in ({"C2R_GRAPH": "1"}, {"C2R_GRAPH": "0"}, {"C2R_SCHED_HINT": "0"}):
+        for k in ("C2R_GRAPH", "C2R_SCHED_HINT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        b = pkg.HipBackend(n, *tables, device=0, deterministic=True)
+        b.set_step((s["dr1"], s["dr2"], s["dr3"]), s["vol"], s["coldensh_LLS"], s["clumping"])
+        b.set_sources(s["srcpos"], s["normflux"]); b.set_rank(0, 1); b.load(ndens=nd, xh=xh0)
+        losses = []
+        b.set_iteration_hook(lambda niter, loss: losses.append(loss))
+        rep = b.evolve3d_native(s["dt"])
+        b.set_iteration_hook(None)
+        assert rep.niter == s["niter"] and list(rep.it_conv_flag[:rep.niter]) == s["log"]["nonconv"]
+        out.append((list(rep.it_sum_nbox[:rep.niter]), losses, b.fetch("xh"), b.fetch("phih_grid")))
+        b.close()
+    if case == "evolve64_std_bubbles":
+        assert len(set(out[0][0])) > 1                                   # the sub-box sums do change during the step (30, 32, 32, 33, 33)
+    for o in out[1:]:
+        assert o[0] == out[0][0] and o[1] == out[0][1]
+        assert np.array_equal(o[2], out[0][2]) and np.array_equal(o[3], out[0][3])
