@@ -65,6 +65,8 @@ class ThermalParams(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+# c2r_reduce_scatter_fn / c2r_allgather_fn: (user, dev_buf, offsets[nranks], counts[nranks], nranks, hip_stream)
+SLAB_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int32, C.c_void_p)
 ITERATION_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_double)
 
 # every symbol include/c2ray_hip.h declares: (name, restype, argtypes)

@@ -237,6 +237,39 @@ class HipBackend:
             self._cb = _capi.ALLREDUCE_FN(0)
         self._check(self.lib.c2r_set_rank(self.ctx, rank, npr, self._cb, None), "c2r_set_rank")
 
+    def set_slab_chemistry(self, reduce_scatter=None, allgather=None):
+        """Slab chemistry of the native loop (c2r_set_slab_chemistry, include/c2ray_hip.h): the rates are reduce-scattered
+        by z-slabs, every rank runs the global pass on its slab, the pass's outputs are all-gathered.
+        reduce_scatter(tensor_f64, offsets, counts): in place, afterwards rank r's slab [offsets[r], +counts[r]) holds
+        the SUM over ranks (other parts undefined); allgather(tensor_u8, offsets, counts): in place, every rank's byte
+        slab is valid in its own array on entry, all are valid everywhere on return.  None, None switches it off."""
+        if reduce_scatter is None or allgather is None:
+            self._rs = self._ag = None
+            self._check(self.lib.c2r_set_slab_chemistry(self.ctx, None, None, None), "c2r_set_slab_chemistry")
+            return
+        torch = self.torch
+
+        def _wrap(fn, typestr):
+            def _cb(user, ptr, off, cnt, nranks, stream):
+                try:
+                    offs = [off[i] for i in range(nranks)]
+                    cnts = [cnt[i] for i in range(nranks)]
+                    t = torch.as_tensor(_DevView(ptr, offs[-1] + cnts[-1], typestr), device=self.device)
+                    if stream:
+                        with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+                            fn(t, offs, cnts)
+                    else:
+                        fn(t, offs, cnts)
+                    return 0
+                except Exception:                 # never unwind through C
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return _capi.SLAB_FN(_cb)
+        self._rs, self._ag = _wrap(reduce_scatter, "<f8"), _wrap(allgather, "|u1")
+        self._check(self.lib.c2r_set_slab_chemistry(self.ctx, C.cast(self._rs, C.c_void_p), C.cast(self._ag, C.c_void_p),
+                                                    None), "c2r_set_slab_chemistry")
+
     def load(self, ndens=None, xh=None, xh_av=None, xh_intermed=None, phih_grid=None, phiheat_grid=None, temperature_grid=None):
         """Host (numpy, Fortran-order flat or (N,N,N) with i fastest when ravelled 'F') -> HBM.
         temperature_grid: (ncell, 3) f32 as temperature_module.F90:35 lays it out, or one field (K) for all three."""
@@ -370,10 +403,10 @@ class HipBackend:
 
 
 class _DevView:
-    """__cuda_array_interface__ view of `count` f64 at a raw device pointer."""
+    """__cuda_array_interface__ view of `count` elements (f64 unless typestr says otherwise) at a raw device pointer."""
 
-    def __init__(self, ptr, count):
-        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False),
+    def __init__(self, ptr, count, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (ptr, False),
                                          "version": 2, "strides": None}
 
 
@@ -384,12 +417,35 @@ def _flat(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
+def slab_collectives(comm):
+    """(reduce_scatter, allgather) for HipBackend.set_slab_chemistry over a torch.distributed-like comm: one reduce per
+    slab to its owner (RCCL: ncclReduce, as c2ray_rccl.cpp groups them), one broadcast per slab from its owner."""
+    no_device_reduce = getattr(comm, "get_backend", lambda: "")() == "gloo"   # gloo: all_reduce / broadcast only on device tensors
+
+    def reduce_scatter(t, offs, cnts):
+        if no_device_reduce:
+            comm.all_reduce(t)        # a superset of the contract: every slab summed everywhere
+            return
+        for r, (o, c) in enumerate(zip(offs, cnts)):
+            if c:
+                comm.reduce(t[o:o + c], dst=r)
+
+    def allgather(t, offs, cnts):
+        for r, (o, c) in enumerate(zip(offs, cnts)):
+            if c:
+                comm.broadcast(t[o:o + c], src=r)
+    return reduce_scatter, allgather
+
+
 class Evolve:
     """The outer loop of one time step over a backend, with the reference's procedure names."""
 
-    def __init__(self, backend, comm=None, balance=False):
+    def __init__(self, backend, comm=None, balance=False, slab=False):
         """comm: None (single process) or a torch.distributed-like module/object exposing
         get_rank(), get_world_size(), all_reduce(tensor) with SUM semantics.
+        slab: slab chemistry for the NATIVE loop (backend.evolve3d_native): needs comm.reduce and
+        comm.broadcast as torch.distributed has them (a backend without device-tensor reduce -- gloo -- falls back
+        to an all-reduce of the whole array, which satisfies the reduce-scatter contract).
         balance: re-partition the sources over the ranks before every pass by the cost each had in the
         previous pass (volume of its final sub-box) instead of the static 1+rank,NumSrc,npr rule."""
         self.b = backend
@@ -403,6 +459,9 @@ class Evolve:
         # the HIP backend balances inside the library (c2r_set_balance: the same LPT rule, one small all-reduce
         # through the same callback), so the Fortran/C hosts get it too; do_grid's Python version below serves
         # backends without it (the CPU test double)
+        self.slab = bool(slab) and self.npr > 1
+        if self.slab:
+            backend.set_slab_chemistry(*slab_collectives(comm))
         self._lib_balance = balance and hasattr(backend, "set_balance")
         if hasattr(backend, "set_balance"):
             backend.set_balance(self._lib_balance)
@@ -509,6 +568,8 @@ class Evolve:
 
     # evolve.F90:83
     def evolve3D(self, time, dt, restart=0):
+        if self.slab:
+            raise ValueError("slab chemistry runs in the native loop: use backend.evolve3d_native(dt)")
         b = self.b
         n = b.mesh
         ncell = n[0] * n[1] * n[2]

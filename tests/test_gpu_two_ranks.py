@@ -22,7 +22,7 @@ def test_two_ranks_on_one_gpu_match_reference(tmp_path):
     got = np.load(out)
     m, a = load_case("evolve32_std_bubbles")
     s = m["steps"]["step001"]
-    for mode in ("python", "native", "balanced"):
+    for mode in ("python", "native", "balanced", "native_slab"):
         assert int(got[mode + "_niter"]) == s["niter"]
         assert list(got[mode + "_conv"]) == s["log"]["nonconv"]
         assert int(got[mode + "_nbox"]) == s["sum_nbox_all"]
@@ -33,7 +33,7 @@ def test_two_ranks_on_one_gpu_match_reference(tmp_path):
     # the non-isothermal step on two ranks (heating rates sharded + all-reduced, evolve.F90:604-609)
     mt, at = load_case("evolve32_thermal")
     st = mt["steps"]["step001"]
-    for mode in ("thermal_python", "thermal_native"):
+    for mode in ("thermal_python", "thermal_native", "thermal_native_slab", "thermal_native_det", "thermal_native_slab_det"):
         assert int(got[mode + "_niter"]) == st["niter"]
         assert list(got[mode + "_conv"]) == st["log"]["nonconv"]
         assert np.max(np.abs(got[mode + "_xh"] - F(at["step001_xh_after"]))) < 1e-9
@@ -41,3 +41,7 @@ def test_two_ranks_on_one_gpu_match_reference(tmp_path):
         assert np.array_equal(got[mode + "_heat"] == 0, ref == 0)
         assert np.max(np.abs(got[mode + "_heat"] - ref) / np.maximum(ref, 1e-60)) < 1e-8
         assert np.max(np.abs(got[mode + "_temper"].astype(np.float64) / at["step001_temper_after"] - 1)) <= 1.5e-7
+    # slab chemistry from the Python host (Evolve(slab=True): reduce-scatter, slab global pass, all-gather) with the rates in
+    # deterministic order: the same step, bit for bit, as the replicated pass -- rates included (gathered when the step ends)
+    for k in ("xh", "xh_av", "temper", "heat", "phih"):
+        assert np.array_equal(got["thermal_native_det_" + k], got["thermal_native_slab_det_" + k]), k
