@@ -214,9 +214,8 @@ def main():
     b.begin_step()
 
     def one_step(k):
-        ev.set_rates_to_zero()
-        ev.pass_all_sources(k, s["dt"])
-        return ev.global_pass(s["dt"])
+        # one rank: c2r_iterate (the three steps in one call; few sources: one replayed graph and one host wait)
+        return ev.iteration(k, s["dt"])
 
     def sync():
         torch.cuda.synchronize()
@@ -253,7 +252,9 @@ def main():
         nbox_hist.append(ev.sum_nbox_all)
         if k == 0 and world == 1:
             nbox_first = b.last_nbox().astype(np.int64)        # per-source sub-box counts of the first timed pass
-        if os.environ.get("C2R_FUSE_SMALL") != "0":
+        # (only where launches are timed: with few sources a step is a few hundred microseconds and this bookkeeping would be
+        # a tenth of it)
+        if prof_mode != 0 and os.environ.get("C2R_FUSE_SMALL") != "0":
             fused_visited += float(np.sum(pkg.box_cost(np.minimum(b.last_nbox(), 2), (n, n, n))))
     sync()
     dt_wall = time.perf_counter() - t0

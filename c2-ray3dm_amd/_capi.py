@@ -105,6 +105,7 @@ SYMBOLS = [
     ("c2r_allreduce_rates", C.c_int, [_P]),
     ("c2r_do_source", C.c_int, [_P, _I32, _P, C.POINTER(_D), C.POINTER(_I32), C.POINTER(_I64)]),
     ("c2r_global_pass", C.c_int, [_P, _D, C.POINTER(_I64), C.POINTER(_D)]),
+    ("c2r_iterate", C.c_int, [_P, _D, C.POINTER(_D), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_D)]),
     ("c2r_evolve3d_restart", C.c_int, [_P, _D, _I32, _D, _P, _P, _P, _P, _P, C.POINTER(Report)]),
     ("c2r_set_iteration_hook", C.c_int, [_P, _P, _P]),
     ("c2r_do_source_host", C.c_int, [_P, _I32, _P, _P, _P, _P, C.POINTER(_D), C.POINTER(_I32)]),

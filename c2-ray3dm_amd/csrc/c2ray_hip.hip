@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -20,6 +21,7 @@ namespace {
 constexpr int kSumBlocks = 1024;      // fixed grid of every deterministic reduction
 constexpr int kFoldLossMax = 64;      // up to this many active sources k_box_decide also sums the last shell's loss partials
 constexpr int kFusedQmax = 10;        // sub-boxes ending at q <= this run in k_sweep_box_fused (one launch per sub-box)
+constexpr int kFewSources = 32;       // a batch of up to this many sources is nothing but launch latency (see sweep_batch)
 
 struct Ctx {
     c2r_params prm{};
@@ -55,10 +57,13 @@ struct Ctx {
     int box_hint = 0;                                            // largest of them: how far the next pass is expected to go
     // hipGraph of a small batch's launch sequence up to box_hint (see sweep_batch); gen counts everything that
     // the captured kernel arguments depend on (step scalars, tables, buffers, stream, scratch, physics switches)
-    struct BatchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long long gen = 0; int count = 0, n_active = 0, hint = 0; };
+    struct BatchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long long gen = 0; int count = 0, n_active = 0, hint = 0;
+                        bool fused = false; double dt = 0.0; bool stats = false; };
     std::map<int, BatchGraph> graphs;
     unsigned long long gen = 1;
     bool use_graph = true;                                       // C2R_GRAPH=0: never (experiments)
+    bool fused_iter = true;                                      // C2R_FUSED_ITER=0: c2r_iterate always runs its three steps in turn (experiments)
+    bool pair_shells = true;                                     // C2R_PAIR_SHELLS=0: never two shells per launch (experiments)
     // cost-balanced distribution inside the library (c2r_set_balance): every rank learns every source's last
     // sub-box count through the all-reduce callback and computes the same LPT partition
     bool balance = false, auto_share = false;                    // auto_share: `share` was set by the balancer, not the caller
@@ -199,7 +204,7 @@ bool udiv_ok(double d)
 }
 
 // The cells face f owns in shell q, clipped to the trace limits (see FaceRect)
-FaceRect face_rect(const Ctx *ctx, int f, int q)
+FaceRect face_rect(const Ctx *ctx, int f, int q, int rows = kRows)
 {
     FaceRect r{};
     const int axis = 2 - (f >> 1), pd = (f & 1) ? -q : q;
@@ -213,8 +218,8 @@ FaceRect face_rect(const Ctx *ctx, int f, int q)
     r.a_lo = a_lo; r.wa = a_hi - a_lo + 1; r.b_lo = b_lo; r.wb = b_hi - b_lo + 1;
     r.magic = r.wa > 1 ? (unsigned)((1ULL << 32) / (unsigned)r.wa + 1ULL) : 0u;
     // k_sweep_shell gives a thread two rows of the same sign: (0,1),(2,3),... and (-1,-2),(-3,-4),...
-    r.pp = (b_hi + kRows) / kRows;              // groups of the rows 0..b_hi
-    r.npr = r.pp + (-b_lo + kRows - 1) / kRows; // + groups of the rows -1..b_lo
+    r.pp = (b_hi + rows) / rows;                // groups of the rows 0..b_hi
+    r.npr = r.pp + (-b_lo + rows - 1) / rows;   // + groups of the rows -1..b_lo
     r.ntiles = (int)(((long long)r.wa * r.npr + kBlock - 1) / kBlock);
     return r;
 }
@@ -270,10 +275,49 @@ void prof_collect(Ctx *ctx)
     ctx->ev_sweep_used = ctx->ev_chem_used = 0;
 }
 
+// Which of a source's two plane sets holds the last shell of sub-box nbox - 1 (shell 0, the source cell, is in set 0).
+// Every launch that stores planes reads one set and writes the other: a single shell, a shell of the fused first
+// sub-boxes, or a look-ahead pair (two shells, one alternation).  The pairing rule is the one of sweep_batch's
+// enqueue_box: neither shell has cells on the sub-box surface, both have tiles.
+int plane_set_before(const Ctx *ctx, int nbox, bool pair_ok)
+{
+    const c2r_params &p = ctx->prm;
+    int set = 0;
+    for (int nb = 1; nb < nbox; ++nb) {
+        const int q0 = p.subboxsize * (nb - 1) + 1, q1 = std::min(p.subboxsize * nb, ctx->Qmax);
+        const bool fused = ctx->fuse_small && q1 <= kFusedQmax && q1 - q0 + 1 <= kMaxFused;
+        auto tiles = [&](int q) { for (int f = 0; f < 6; ++f) if (face_rect(ctx, f, q).ntiles > 0) return true; return false; };
+        auto surface = [&](int q) {
+            for (int d = 0; d < 3; ++d)
+                if (std::min(p.subboxsize * nb, ctx->hr[d]) <= q || std::min(p.subboxsize * nb, ctx->hl[d]) <= q) return true;
+            return false;
+        };
+        for (int q = q0; q <= q1; ++q) {
+            if (!tiles(q)) continue;
+            if (!fused && pair_ok && !surface(q) && q + 1 <= q1 && tiles(q + 1) && !surface(q + 1)) ++q;
+            set ^= 1;
+        }
+    }
+    return set;
+}
+
+// A whole outer iteration around ONE small batch (c2r_iterate): what precedes the batch's launches (the rates set to
+// zero, n_HI prepared) and what follows them (Gamma of the +-x faces folded back, the global pass and its reductions)
+// are recorded into the batch's hipGraph, the tail gated on the device by "no source is active after sub-box `hint`" --
+// the steady state of an outer iteration.  The host then waits ONCE per iteration instead of four times (each wait is
+// 15-25 us of idle GPU in a 0.4 ms iteration, profiles/r03_launch_bound).  tail_done: the gated tail has run.
+struct FusedIter {
+    double dt = 0.0;
+    bool stats = false;
+    std::function<int()> pre;                     // enqueue: zero rates + sweep_prepare
+    std::function<int(const int *gate)> post;     // enqueue: sweep_finish + global pass, each launch a no-op unless *gate == 0 (null: unconditional)
+    bool tail_done = false;
+};
+
 // Sweep one batch: local sources [first, first+count) of this rank's list.
 // dbg: optional device N^3 array receiving coldensh_out (single-source test path).
 int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg, std::vector<int> *nbox_out,
-                std::vector<double> *loss_out)
+                std::vector<double> *loss_out, FusedIter *fz = nullptr)
 {
     const c2r_params &p = ctx->prm;
     // fill the pinned staging block (layout of ensure_sweep_scratch) and send it with one copy
@@ -318,7 +362,6 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
     // where they did last time), only picking up counts that have already arrived; at that sub-box it waits for the
     // box's own count (normally zero: done).  Measured (profiles/r02_launch_bound/): 128^3 x 1 source 0.80 -> 0.73 ms per
     // outer iteration; with 1000 sources the same rule costs 5-20 % (stale large grids), hence the limit.
-    constexpr int kFewSources = 32;
     const bool few = ctx->sched_hint && n_active <= kFewSources;
     const int hint = few ? std::max(1, ctx->box_hint) : 1;
     // every launch of sub-box nbox for `bound` sources at most (no host wait, no event): shells or the fused box, loss
@@ -341,9 +384,15 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
         }
         const int q0 = p.subboxsize * (nbox - 1) + 1, q1 = std::min(p.subboxsize * nbox, ctx->Qmax);
         const bool det = ctx->d_gbox != nullptr;
+        // which plane set holds shell q0 - 1: the shells alternate between the two sets, a look-ahead pair advances two
+        // shells in one alternation -- a pure function of the schedule up to this sub-box (a replayed graph does not run
+        // this code), see plane_set_before
+        const bool pair_ok = ctx->fast && ctx->pair_shells && n_active <= kFewSources && !dbg && ctx->prof != 1;
+        int pbuf = plane_set_before(ctx, nbox, pair_ok);
         auto shell_args = [&](int q) {
             ShellArgs sa{};
             sa.q = q;
+            sa.buf_prev = (q - 1) & 1; sa.buf_cur = q & 1;       // (a look-ahead pair sets its own, below)
             sa.tiles_max = 0;
             for (int f = 0; f < 6; ++f) { sa.face[f] = face_rect(ctx, f, q); sa.tiles_max = std::max(sa.tiles_max, sa.face[f].ntiles); }
             sa.has_boundary = 0;
@@ -400,6 +449,40 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
         for (int q = q0; q <= q1; ++q) {
             ShellArgs sa = shell_args(q);
             if (sa.tiles_max == 0) continue;
+            sa.buf_prev = pbuf; sa.buf_cur = 1 - pbuf;
+            // Few sources, fast mode: shells q and q+1 in ONE launch, both from the planes of shell q-1 (k_sweep_pair_fast:
+            // the second recomputes the first's column densities) -- half the dependent launches where a launch is nothing
+            // but latency.  Not where either shell has cells on the sub-box surface (their loss partials and the order of
+            // the loss sums stay those of the single launches).
+            if (pair_ok && !sa.has_boundary && q + 1 <= q1) {
+                ShellArgs sb = shell_args(q + 1);
+                if (sb.tiles_max > 0 && !sb.has_boundary) {
+                    // the second shell's threads take kPairRows rows each (its per-thread work is the recompute of
+                    // 2 (rows + 1) cells of the first shell: short chains on more threads, the GPU is empty anyway)
+                    sb.tiles_max = 0;
+                    for (int f = 0; f < 6; ++f) { sb.face[f] = face_rect(ctx, f, q + 1, kPairRows); sb.tiles_max = std::max(sb.tiles_max, sb.face[f].ntiles); }
+                    sb.buf_prev = pbuf; sb.buf_cur = 1 - pbuf;        // (buf_prev of the second shell is never read)
+                    ++in_box;
+                    const dim3 grid(std::max(sa.tiles_max, sb.tiles_max), 12, bound), blk(kBlock);
+#define C2R_LAUNCH_PAIR_H(D, L, H) do { if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_pair_fast<D, L, true, H>), grid, blk, 0, st, k, sa, sb); \
+                                    else hipLaunchKernelGGL((k_sweep_pair_fast<D, L, false, H>), grid, blk, 0, st, k, sa, sb); } while (0)
+#define C2R_LAUNCH_PAIR(D, L) do { if (ctx->thermal) C2R_LAUNCH_PAIR_H(D, L, true); else C2R_LAUNCH_PAIR_H(D, L, false); } while (0)
+                    switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
+                        case 2: C2R_LAUNCH_PAIR(false, 1); break;
+                        case 3: C2R_LAUNCH_PAIR(true, 1); break;
+                        case 4: C2R_LAUNCH_PAIR(false, 2); break;
+                        case 5: C2R_LAUNCH_PAIR(true, 2); break;
+                        case 6: C2R_LAUNCH_PAIR(false, 3); break;
+                        default: C2R_LAUNCH_PAIR(true, 3); break;
+                    }
+#undef C2R_LAUNCH_PAIR
+#undef C2R_LAUNCH_PAIR_H
+                    pbuf = 1 - pbuf;
+                    ++q;
+                    continue;
+                }
+            }
+            pbuf = 1 - pbuf;
             ++in_box;
             if (ctx->prof == 1) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
             {
@@ -451,18 +534,40 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
     const bool graph_ok = ctx->use_graph && ctx->sched_hint && n_active > 0 && n_active <= kFewSources && ctx->box_hint >= 1 &&
                           !dbg && ctx->prof == 0;
     bool uploaded = false;
+    // the batch's results travel back through the pinned staging block (same layout as the device block)
+    int *h_fnb = h_pos + 8 * cap;
+    auto enqueue_totals = [&]() -> int {
+        hipLaunchKernelGGL(k_batch_totals, dim3(1), dim3(1024), 0, st, count, ctx->d_final_loss, ctx->d_final_nbox,
+                           ctx->d_photon_loss, ctx->d_sum_nbox, first_of_pass ? 1 : 0, &ctx->d_hsc->photon_loss,
+                           &ctx->d_hsc->sum_nbox);
+        HIP_TRY(hipGetLastError());
+        if (nbox_out) HIP_TRY(hipMemcpyAsync(h_fnb, ctx->d_final_nbox, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, st));
+        if (loss_out) HIP_TRY(hipMemcpyAsync(h_fl, ctx->d_final_loss, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
+        return C2R_OK;
+    };
+    const bool fuse_iter = fz && graph_ok && first_of_pass && !ctx->d_gbox;
+    bool pre_run = false;
     if (graph_ok) {
         Ctx::BatchGraph &bg = ctx->graphs[first];
-        if (!(bg.exec && bg.gen == ctx->gen && bg.count == count && bg.n_active == n_active && bg.hint == hint)) {
+        if (!(bg.exec && bg.gen == ctx->gen && bg.count == count && bg.n_active == n_active && bg.hint == hint &&
+              bg.fused == fuse_iter && (!fuse_iter || (bg.dt == fz->dt && bg.stats == fz->stats)))) {
             if (bg.exec) { hipGraphExecDestroy(bg.exec); bg.exec = nullptr; }
             if (bg.graph) { hipGraphDestroy(bg.graph); bg.graph = nullptr; }
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                int rc = (int)hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st);
+                int rc = fuse_iter ? fz->pre() : C2R_OK;
+                if (rc == C2R_OK) rc = (int)hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st);
                 cur = 0;
                 for (int nbox = 1; nbox <= hint && nbox <= ctx->nbox_max && rc == C2R_OK; ++nbox) rc = enqueue_box(nbox, n_active);
+                if (fuse_iter && rc == C2R_OK) {
+                    // the batch's totals and results, then the gated rest of the iteration: d_nactive[cur] is the count the
+                    // last decision left (cur has been flipped by it)
+                    rc = enqueue_totals();
+                    if (rc == C2R_OK) rc = fz->post(ctx->d_nactive + cur);
+                }
                 const hipError_t e = hipStreamEndCapture(st, &bg.graph);
                 if (rc == C2R_OK && e == hipSuccess && hipGraphInstantiate(&bg.exec, bg.graph, nullptr, nullptr, 0) == hipSuccess) {
                     bg.gen = ctx->gen; bg.count = count; bg.n_active = n_active; bg.hint = hint;
+                    bg.fused = fuse_iter; bg.dt = fuse_iter ? fz->dt : 0.0; bg.stats = fuse_iter && fz->stats;
                 } else {
                     if (bg.graph) { hipGraphDestroy(bg.graph); bg.graph = nullptr; }
                     bg.exec = nullptr;
@@ -474,13 +579,16 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
         if (bg.exec) {
             HIP_TRY(hipGraphLaunch(bg.exec, st));
             uploaded = true;
+            pre_run = bg.fused;
             const int done = std::min(hint, ctx->nbox_max);
             cur = done & 1;
             HIP_TRY(hipStreamSynchronize(st));
             known = done; bound = ctx->h_nactive[done];
             first_box = done + 1;
+            if (bg.fused && bound == 0) fz->tail_done = true;     // the gate was open: the whole iteration has run
         } else cur = 0;
     }
+    if (fz && !pre_run) { const int rc = fz->pre(); if (rc) return rc; }
     if (!uploaded) HIP_TRY(hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st));
     for (int nbox = first_box; nbox <= ctx->nbox_max && bound > 0; ++nbox) {
         { const int rc = enqueue_box(nbox, bound); if (rc) return rc; }
@@ -498,15 +606,10 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
     if (ctx->d_gbox)
         hipLaunchKernelGGL(k_gamma_reduce, dim3((p.mesh[0] + 255) / 256, p.mesh[1], p.mesh[2]), dim3(256), 0, st, k, count,
                            ctx->d_final_nbox, p.subboxsize, (double *)ctx->grid[4], ctx->thermal ? (double *)ctx->grid[5] : nullptr);
-    hipLaunchKernelGGL(k_batch_totals, dim3(1), dim3(1024), 0, st, count, ctx->d_final_loss, ctx->d_final_nbox,
-                       ctx->d_photon_loss, ctx->d_sum_nbox, first_of_pass ? 1 : 0, &ctx->d_hsc->photon_loss,
-                       &ctx->d_hsc->sum_nbox);
-    HIP_TRY(hipGetLastError());
-    // results come back through the pinned staging block (same layout as the device block): no pageable async copies
-    int *h_fnb = h_pos + 8 * cap;
-    if (nbox_out) HIP_TRY(hipMemcpyAsync(h_fnb, ctx->d_final_nbox, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, st));
-    if (loss_out) HIP_TRY(hipMemcpyAsync(h_fl, ctx->d_final_loss, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (!(fz && fz->tail_done)) {          // (the fused iteration's graph has done this already)
+        { const int rc = enqueue_totals(); if (rc) return rc; }
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     if (nbox_out) nbox_out->assign(h_fnb, h_fnb + count);
     if (loss_out) loss_out->assign(h_fl, h_fl + count);
     return C2R_OK;
@@ -525,16 +628,16 @@ int sweep_prepare(Ctx *ctx)
     return C2R_OK;
 }
 
-int sweep_finish(Ctx *ctx)
+int sweep_finish(Ctx *ctx, const int *gate = nullptr)
 {
     const c2r_params &p = ctx->prm;
     // phih_T is [k][i][j]: transposing it back swaps the roles of the two mesh extents
     const dim3 g((p.mesh[1] + 31) / 32, (p.mesh[0] + 31) / 32, p.mesh[2]);
     hipLaunchKernelGGL((k_transpose_xy<double, true>), g, dim3(256), 0, ctx->stream, p.mesh[1], p.mesh[0], p.mesh[2],
-                       (const double *)ctx->d_phih_T, (double *)ctx->grid[4]);
+                       (const double *)ctx->d_phih_T, (double *)ctx->grid[4], gate);
     if (ctx->thermal)
         hipLaunchKernelGGL((k_transpose_xy<double, true>), g, dim3(256), 0, ctx->stream, p.mesh[1], p.mesh[0], p.mesh[2],
-                           (const double *)ctx->d_heat_T, (double *)ctx->grid[5]);
+                           (const double *)ctx->d_heat_T, (double *)ctx->grid[5], gate);
     HIP_TRY(hipGetLastError());
     return C2R_OK;
 }
@@ -670,6 +773,8 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     if (const char *e = getenv("C2R_FUSE_SMALL")) ctx->fuse_small = atoi(e) != 0;
     if (const char *e = getenv("C2R_SCHED_HINT")) ctx->sched_hint = atoi(e) != 0;
     if (const char *e = getenv("C2R_GRAPH")) ctx->use_graph = atoi(e) != 0;
+    if (const char *e = getenv("C2R_FUSED_ITER")) ctx->fused_iter = atoi(e) != 0;
+    if (const char *e = getenv("C2R_PAIR_SHELLS")) ctx->pair_shells = atoi(e) != 0;
     if (p->sweep_mode != C2R_SWEEP_EXACT && p->sweep_mode != C2R_SWEEP_FAST) { delete ctx; return C2R_EINVAL; }
     ctx->fast = p->sweep_mode == C2R_SWEEP_FAST;          // the caller's choice only: no environment override
     *out = reinterpret_cast<c2r_ctx *>(ctx);     // returned even on failure so c2r_last_error works
@@ -1109,12 +1214,11 @@ int c2r_zero_rates(c2r_ctx *c)
     return C2R_OK;
 }
 
-int c2r_pass_sources(c2r_ctx *c, double *photon_loss, int64_t *sum_nbox, int64_t *visited)
+// do_grid over this rank's sources.  fz (c2r_iterate, one small batch): the batch's graph also carries what precedes and
+// follows the pass (sweep_batch); sweep_prepare / sweep_finish are then fz->pre / fz->post, not called here.
+static int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64_t *sum_nbox, int64_t *visited)
 {
-    if (!c) return C2R_EINVAL;
-    Ctx *ctx = C(c);
-    int rc = check_ready(ctx);
-    if (rc) return rc;
+    int rc;
     balance_before_pass(ctx);
     const int nloc = n_local_sources(ctx);
     long long vis = 0;
@@ -1123,25 +1227,35 @@ int c2r_pass_sources(c2r_ctx *c, double *photon_loss, int64_t *sum_nbox, int64_t
     if (nloc > 0) {
         rc = ensure_sweep_scratch(ctx, nloc);
         if (rc) return rc;
-        if ((rc = sweep_prepare(ctx))) return rc;
+        if (fz && nloc > ctx->batch_cap) FAIL(C2R_ESTATE, "fused iteration needs the sources in one batch");
+        if (!fz && (rc = sweep_prepare(ctx))) return rc;
         std::vector<int> nb;
         for (int first = 0; first < nloc; first += ctx->batch_cap) {
             const int count = std::min(ctx->batch_cap, nloc - first);
-            rc = sweep_batch(ctx, first, count, first == 0, nullptr, &nb, nullptr);
+            rc = sweep_batch(ctx, first, count, first == 0, nullptr, &nb, nullptr, fz);
             if (rc) return rc;
             for (int v : nb) { vis += visited_for_nbox(ctx, v); ctx->last_nbox.push_back(v); }
         }
-        if ((rc = sweep_finish(ctx))) return rc;
+        if (!fz && (rc = sweep_finish(ctx))) return rc;
         ctx->box_hint = 0;
         for (int v : ctx->last_nbox) ctx->box_hint = std::max(ctx->box_hint, v);
-    }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));                 // k_batch_totals stored the totals in h_sc
+    } else if (fz && (rc = fz->pre())) return rc;
+    if (!fz) HIP_TRY(hipStreamSynchronize(ctx->stream));        // k_batch_totals stored the totals in h_sc
     prof_collect(ctx);
     if ((rc = balance_after_pass(ctx))) return rc;
     if (photon_loss) *photon_loss = ctx->h_sc->photon_loss;
     if (sum_nbox) *sum_nbox = ctx->h_sc->sum_nbox;
     if (visited) *visited = vis;
     return C2R_OK;
+}
+
+int c2r_pass_sources(c2r_ctx *c, double *photon_loss, int64_t *sum_nbox, int64_t *visited)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    return pass_sources_impl(ctx, nullptr, photon_loss, sum_nbox, visited);
 }
 
 int c2r_allreduce_rates(c2r_ctx *c)
@@ -1289,12 +1403,9 @@ int c2r_photon_sums(c2r_ctx *c, int32_t which_l, int32_t which_r, double out[4])
     return C2R_OK;
 }
 
-// global_pass (evolve.F90:499-573); stats_dst (device-visible, 4 doubles, or null): the photon-statistics sums of
-// (xh_intermed, xh_av) as the pass leaves them, from the same kernel
-static int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum_xh1, double *stats_dst,
-                            size_t cell_off = 0, size_t cell_cnt = (size_t)-1)
+// the launches of a global pass, no host wait; gate: see k_transpose_xy
+static int global_pass_enqueue(Ctx *ctx, double dt, double *stats_dst, size_t cell_off, size_t cell_cnt, const int *gate)
 {
-    if (cell_cnt == (size_t)-1) cell_cnt = ctx->ncell;        // (a slab [cell_off, cell_off+cell_cnt): slab chemistry)
     const c2r_params &p = ctx->prm;
     ChemParams cp{};
     cp.dt = dt; cp.eps = p.epsilon; cp.min_frac_change = p.minimum_fractional_change;
@@ -1325,16 +1436,27 @@ static int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum
 #define C2R_LAUNCH_GLOBAL(S, T) hipLaunchKernelGGL((k_global_pass<S, T>), dim3(kSumBlocks), dim3(256), 0, ctx->stream, cp, cell_cnt, \
                            (const float *)ctx->grid[0] + cell_off, (const double *)ctx->grid[1] + cell_off, (double *)ctx->grid[2] + cell_off, \
                            (double *)ctx->grid[3] + cell_off, (const double *)ctx->grid[4] + cell_off, ctx->d_sum_partial, ctx->d_conv, \
-                           ctx->d_chemfail)
+                           ctx->d_chemfail, gate)
     if (stats_dst) { if (ctx->thermal) C2R_LAUNCH_GLOBAL(true, true); else C2R_LAUNCH_GLOBAL(true, false); }
     else { if (ctx->thermal) C2R_LAUNCH_GLOBAL(false, true); else C2R_LAUNCH_GLOBAL(false, false); }
 #undef C2R_LAUNCH_GLOBAL
     prof_end(ctx, ctx->ev_chem, ctx->ev_chem_used);
     hipLaunchKernelGGL(k_pass_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, ctx->d_conv,
-                       ctx->d_chemfail, &ctx->d_hsc->sum, &ctx->d_hsc->conv, &ctx->d_hsc->chemfail);
+                       ctx->d_chemfail, &ctx->d_hsc->sum, &ctx->d_hsc->conv, &ctx->d_hsc->chemfail, gate);
     if (stats_dst)
-        hipLaunchKernelGGL(k_sum_final, dim3(4), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_stat_partial, stats_dst);
+        hipLaunchKernelGGL(k_sum_final, dim3(4), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_stat_partial, stats_dst, gate);
     HIP_TRY(hipGetLastError());
+    return C2R_OK;
+}
+
+// global_pass (evolve.F90:499-573); stats_dst (device-visible, 4 doubles, or null): the photon-statistics sums of
+// (xh_intermed, xh_av) as the pass leaves them, from the same kernel
+static int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum_xh1, double *stats_dst,
+                            size_t cell_off = 0, size_t cell_cnt = (size_t)-1)
+{
+    if (cell_cnt == (size_t)-1) cell_cnt = ctx->ncell;        // (a slab [cell_off, cell_off+cell_cnt): slab chemistry)
+    const int rc = global_pass_enqueue(ctx, dt, stats_dst, cell_off, cell_cnt, nullptr);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
     if (conv_flag) *conv_flag = (int64_t)ctx->h_sc->conv;
@@ -1349,6 +1471,65 @@ int c2r_global_pass(c2r_ctx *c, double dt, int64_t *conv_flag, double *sum_xh1)
     int rc = check_ready(ctx);
     if (rc) return rc;
     return global_pass_impl(ctx, dt, conv_flag, sum_xh1, nullptr);
+}
+
+// One outer iteration on a single rank: set_rates_to_zero, pass_all_sources, global_pass (evolve.F90:243-269).  With few
+// sources in one batch the whole iteration is ONE replayed hipGraph and ONE host wait (FusedIter); otherwise the three
+// steps in turn.  stats_host (or null): receives the photon-statistics sums of the pass (evolve.F90:570).
+static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, int64_t *nb, int64_t *vis, int64_t *conv,
+                        double *sum1)
+{
+    int rc;
+    const int nloc = n_local_sources(ctx);
+    bool can_fuse = ctx->fused_iter && ctx->nranks == 1 && !ctx->balance && ctx->use_graph && ctx->sched_hint && ctx->prof == 0 && nloc > 0 &&
+                    nloc <= kFewSources && ctx->box_hint >= 1 && !ctx->prm.deterministic_rates &&
+                    !(ctx->thermal && ctx->tprm.cosmological && !ctx->have_zred);
+    if (can_fuse) {
+        if ((rc = ensure_sweep_scratch(ctx, nloc))) return rc;
+        can_fuse = nloc <= ctx->batch_cap;
+    }
+    auto zero_rates = [ctx]() -> int {
+        HIP_TRY(hipMemsetAsync(ctx->grid[4], 0, grid_bytes(ctx, 4), ctx->stream));
+        if (ctx->thermal) HIP_TRY(hipMemsetAsync(ctx->grid[5], 0, grid_bytes(ctx, 5), ctx->stream));     // evolve.F90:435
+        return C2R_OK;
+    };
+    double *four = stats_host ? ctx->d_hsc->four : nullptr;
+    if (!can_fuse) {
+        if ((rc = zero_rates())) return rc;
+        if ((rc = pass_sources_impl(ctx, nullptr, loss, nb, vis))) return rc;
+        if ((rc = global_pass_impl(ctx, dt, conv, sum1, four))) return rc;
+    } else {
+        FusedIter fz;
+        fz.dt = dt; fz.stats = stats_host != nullptr;
+        fz.pre = [ctx, &zero_rates]() -> int { const int r = zero_rates(); return r ? r : sweep_prepare(ctx); };
+        fz.post = [ctx, dt, four](const int *gate) -> int {
+            const int r = sweep_finish(ctx, gate);
+            return r ? r : global_pass_enqueue(ctx, dt, four, 0, ctx->ncell, gate);
+        };
+        if ((rc = pass_sources_impl(ctx, &fz, loss, nb, vis))) return rc;
+        if (!fz.tail_done) {               // no graph, or a source went on beyond the sub-box the graph ends at
+            if ((rc = fz.post(nullptr))) return rc;
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (loss) *loss = ctx->h_sc->photon_loss;
+            if (nb) *nb = ctx->h_sc->sum_nbox;
+        }
+        if (conv) *conv = (int64_t)ctx->h_sc->conv;
+        if (sum1) *sum1 = ctx->h_sc->sum;
+    }
+    if (stats_host) for (int m = 0; m < 4; ++m) stats_host[m] = ctx->h_sc->four[m];
+    return C2R_OK;
+}
+
+int c2r_iterate(c2r_ctx *c, double dt, double *photon_loss, int64_t *sum_nbox, int64_t *visited, int64_t *conv_flag,
+                double *sum_xh1)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    if (ctx->nranks > 1) FAIL(C2R_ESTATE, "c2r_iterate is the single-rank iteration: with several ranks call c2r_zero_rates, "
+                                          "c2r_pass_sources, the collective and c2r_global_pass in turn (or c2r_evolve3d)");
+    return iterate_impl(ctx, dt, nullptr, photon_loss, sum_nbox, visited, conv_flag, sum_xh1);
 }
 
 static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double restart_loss, c2r_report *rep)
@@ -1414,10 +1595,23 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
         }
         prev1 = sum1; prev0 = sum0;
         niter++;
+        double loss = 0; int64_t nb = 0, vis = 0;
+        if (ctx->nranks == 1) {
+            // :243-269 in one piece (iterate_impl): nothing happens between the pass and the global pass on one rank
+            auto t0 = clk::now();
+            rc = iterate_impl(ctx, dt, niter <= C2R_MAX_ITER_LOG ? ctx->h_it4 + 4 * (size_t)(niter - 1) : nullptr, &loss, &nb, &vis,
+                              &conv_flag, &sum1);
+            if (rc) return rc;
+            rep->seconds_sweep += std::chrono::duration<double>(clk::now() - t0).count();     // (sweep and chemistry: one wait)
+            rep->photon_loss_all = loss; rep->sum_nbox_all = nb; rep->visited += vis;
+            rep->chem_not_converged = (int32_t)ctx->h_sc->chemfail;
+            if (niter <= C2R_MAX_ITER_LOG) { rep->it_conv_flag[niter - 1] = conv_flag; rep->it_sum_nbox[niter - 1] = nb; }
+            if (ctx->iter_hook && ctx->iter_hook(ctx->iter_user, niter, rep->photon_loss_all) != 0) FAIL(C2R_ECALLBACK, "iteration hook failed");
+            continue;
+        }
         rc = c2r_zero_rates(c);                                                        // :243
         if (rc) return rc;
         auto t0 = clk::now();
-        double loss = 0; int64_t nb = 0, vis = 0;
         rc = c2r_pass_sources(c, &loss, &nb, &vis);                                    // :246
         if (rc) return rc;
         const bool slab = ctx->nranks > 1 && ctx->rs && ctx->ag && ctx->ar;

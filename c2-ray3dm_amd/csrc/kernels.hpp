@@ -80,6 +80,8 @@ struct FaceRect {
 struct ShellArgs {
     int q;
     int has_boundary;
+    int buf_prev, buf_cur;       // fast mode: which of a source's two plane sets holds the previous shell / receives this one
+                                 // ((q-1)&1, q&1 while every launch is one shell; the look-ahead pairs advance two shells per set)
     int tiles_max;               // grid.x; loss_partial is [n_active][6][tiles_max]
     int boxR[3], boxL[3];        // limits of the current sub-box (last_r/last_l - srcpos)
     double alam;                 // (q-0.5)/q, column_density.f90:112 (sign cancels)
@@ -729,38 +731,108 @@ __device__ __forceinline__ double table_at(const double *__restrict__ tab, doubl
 #ifndef C2R_ABLATE
 #define C2R_ABLATE 0
 #endif
-template <bool DET, int LLS, bool STREAM, int NR, bool HEAT>
-__device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
-                                                  const double *__restrict__ thick,   // p.thick, or the block's LDS copy of it
-                                                  const int face, const int s, const int a, const int b0, const int sgb,
-                                                  const int nvalid)
+// Row sums over the two upstream columns am, a of one upstream row: R = omu r(am) + ddu r(a), T likewise with t = c r
+// (r = 1/max(0.6, c sigma), weightf of column_density.f90:276-293)
+__device__ __forceinline__ void row_sum_fast(const KParams &p, const double omu, const double ddu, const double vm, const double va,
+                                             double &R, double &T)
 {
-    const int q = sa.q, qm = q - 1;
+    const double rm = rcp1(fmax(p.wfloor, vm * p.sigma)), ra = rcp1(fmax(p.wfloor, va * p.sigma));
+    R = __builtin_fma(omu, rm, ddu * ra);
+    T = __builtin_fma(omu, vm * rm, ddu * (va * ra));
+}
+// cinterp + path + the cell's own column for cell (a, b) of a face in shell sa.q, from the row sums of its upstream rows
+// b - sgb (lo) and b (hi).  ONE piece of arithmetic for the shell kernel and for the look-ahead recompute of the same cell
+// (lookahead_cd_out): both must produce the same bits.
+struct CellCd { double cd_in, cd_out, pq, path, np; };
+template <int LLS>
+__device__ __forceinline__ CellCd cell_cd_fast(const KParams &p, const ShellArgs &sa, const int a, const int a2, const int b,
+                                               const double Rlo, const double Tlo, const double Rhi, const double Thi,
+                                               const double nhi, const double lls_cell /* LLS == 2: the cell's LLS_grid value */)
+{
+    CellCd c;
+    const int q = sa.q;
+    const double omv = (double)abs(b) * sa.inv_q, ddv = 1.0 - omv;      // weights of rows b-sgb and b
+    const double den = __builtin_fma(omv, Rlo, ddv * Rhi);
+    const double num = __builtin_fma(omv, Tlo, ddv * Thi);
+    double cdi = num * rcp1(den);
+    if (q == 1 && (abs(a) == 1 || abs(b) == 1))
+        cdi = (abs(a) == 1 && abs(b) == 1) ? p.sqrt3 * cdi : p.sqrt2 * cdi;
+    c.pq = sqrt_pos((double)(q * q + a2 + b * b));                      // |delta| in cells
+    c.path = c.pq * sa.path_scale;
+    if (LLS == 3) c.cd_in = cdi;
+    else if (LLS == 2) c.cd_in = __builtin_fma(lls_cell * sa.inv_q, c.pq, cdi);
+    else c.cd_in = __builtin_fma(sa.lls_scale, c.pq, cdi);
+    c.np = nhi * c.path;                                                // n_HI path: the cell's own column
+    c.cd_out = c.cd_in + c.np;
+    return c;
+}
+
+// Look-ahead (few sources, k_sweep_pair_fast): the column density that shell sq.q leaves in plane `face` at plane
+// coordinates (a, b), recomputed from the planes of shell sq.q - 1 instead of read -- so that shell q+1 can run in the
+// SAME launch as shell q (both depend on shell q-1 only): with few sources the GPU is idle and a launch is pure
+// latency, the redundant arithmetic is free and the chain of dependent launches is halved.  A plane also holds the
+// cells that a neighbouring face owns (the edge rows / columns the owner stores across, shell_rows_fast_core): those
+// are recomputed in the owner's geometry.  Same arithmetic as the owner's own launch (row_sum_fast, cell_cd_fast).
+template <int LLS, bool STREAM>
+__device__ __forceinline__ double lookahead_cd_out(const KParams &p, const ShellArgs &sq, const int face, const int s,
+                                                   const int a, const int b)
+{
+    const int q = sq.q, qm = q - 1;
+    // straight-line code (no early exit): a thread recomputes 8 such cells and all their loads should be in flight together
+    const bool inside = abs(a) <= q && abs(b) <= q;           // else: outside shell q's plane, a zero-weight corner (an OOB load reads 0)
+    const int axis = 2 - (face >> 1);
+    const int pd = (face & 1) ? -q : q;
+    // the owner of the cell and the cell's coordinates on the owner's face
+    int fo = face, ao = a, bo = b;
+    if (axis == 1) { if (abs(b) == q) { fo = b > 0 ? 0 : 1; ao = a; bo = pd; } }
+    else if (axis == 0) {
+        if (abs(b) == q) { fo = b > 0 ? 0 : 1; ao = pd; bo = a; }
+        else if (abs(a) == q) { fo = a > 0 ? 2 : 3; ao = pd; bo = b; }
+    }
+    const int sga = ao < 0 ? -1 : 1, sgb = bo < 0 ? -1 : 1;
+    const int am = ao - sga, bm = bo - sgb;
+    const unsigned plane_bytes = (unsigned)p.PP * 8u;
+    const __amdgpu_buffer_rsrc_t r_prev = make_rsrc(p.planes + ((size_t)s * 2 + sq.buf_prev) * 6 * p.PP, 6u * plane_bytes);
+    const bool ina = abs(ao) <= qm, inam = abs(am) <= qm, inb = abs(bo) <= qm, inbm = abs(bm) <= qm;
+    const unsigned base = (unsigned)fo * plane_bytes;
+    constexpr int PA = STREAM ? C2R_PLANE_AUX : 0;
+    const double v_mm = buf_load_f64<PA>(r_prev, (inam && inbm) ? base + plane_off8(p, am, bm) : kOOB);
+    const double v_am = buf_load_f64<PA>(r_prev, (ina && inbm) ? base + plane_off8(p, ao, bm) : kOOB);
+    const double v_mb = buf_load_f64<PA>(r_prev, (inam && inb) ? base + plane_off8(p, am, bo) : kOOB);
+    const double v_ab = buf_load_f64<PA>(r_prev, (ina && inb) ? base + plane_off8(p, ao, bo) : kOOB);
+    // the cell in the mesh: from its position on the plane it was asked for
+    const Delta3 dl = mesh_delta(axis, pd, a, b);
+    const unsigned c0 = wrap_pos(p.srcw[3 * s + 0], p.n[0], dl.d0), c1 = wrap_pos(p.srcw[3 * s + 1], p.n[1], dl.d1),
+                   c2 = wrap_pos(p.srcw[3 * s + 2], p.n[2], dl.d2);
+    const unsigned id = c0 + (unsigned)p.n[0] * (c1 + (unsigned)p.n[1] * c2);
+    const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
+    const double nhi = buf_load_f64<STREAM ? C2R_NHI_AUX : 0>(make_rsrc(p.nhi, ncell * 8u), id * 8u);
+    const double omu = (double)abs(ao) * sq.inv_q, ddu = 1.0 - omu;
+    double Rlo, Tlo, Rhi, Thi;
+    row_sum_fast(p, omu, ddu, v_mm, v_am, Rlo, Tlo);
+    row_sum_fast(p, omu, ddu, v_mb, v_ab, Rhi, Thi);
+    const double cd_out = cell_cd_fast<LLS>(p, sq, ao, ao * ao, bo, Rlo, Tlo, Rhi, Thi, nhi, LLS == 2 ? (double)p.lls[id] : 0.0).cd_out;
+    return inside ? cd_out : 0.0;
+}
+
+// Everything a thread does for its NR rows once the upstream values are known: vm[r], va_[r] = the previous shell's
+// column densities at columns am = a - sga and a of rows b0 - sgb, b0, ..., b0 + (NR-1) sgb.
+// STORE: write the column densities into the planes (off for the first shell of a look-ahead pair: nothing reads them)
+template <bool DET, int LLS, bool STREAM, int NR, bool HEAT, bool STORE = true>
+__device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
+                                                       const double *__restrict__ thick, const int face, const int s, const int a,
+                                                       const int b0, const int sgb, const int nvalid,
+                                                       const double (&vm)[NR + 1], const double (&va_)[NR + 1])
+{
+    const int q = sa.q;
     const int axis = 2 - (face >> 1);            // 2:z 1:y 0:x  (block-uniform)
     const int pd = (face & 1) ? -q : q;
     const bool xf = (axis == 0);
     const int ua = xf ? 1 : 0, va = (axis == 2) ? 1 : 2;      // mesh axes of the plane coordinates (a, b)
-    const int sga = a < 0 ? -1 : 1;
-    const int am = a - sga;
     const unsigned plane_bytes = (unsigned)p.PP * 8u;
-    const __amdgpu_buffer_rsrc_t r_prev =
-        make_rsrc(p.planes + ((size_t)s * 2 + (qm & 1)) * 6 * p.PP + (size_t)face * p.PP, plane_bytes);
-    const bool ina = abs(a) <= qm, inam = abs(am) <= qm;
     const unsigned p8 = (unsigned)p.P * 8u;
-    const unsigned da8 = (unsigned)(sga * 8), db8 = sgb < 0 ? 0u - p8 : p8;
+    const unsigned db8 = sgb < 0 ? 0u - p8 : p8;
     const unsigned o_first = plane_off8(p, a, b0);
-    unsigned o = o_first - db8;                               // row b0 - sgb
-    double vm[NR + 1], va_[NR + 1];
-#pragma unroll
-    for (int r = 0; r <= NR; ++r) {                        // rows b0-sgb, b0, ..., b0+(NR-1)sgb
-        const bool inr = abs(b0 + (r - 1) * sgb) <= qm;
-        if ((C2R_ABLATE & 16) || ((C2R_ABLATE & 32) && (q & 1))) { vm[r] = 1e17 * (double)(o & 7u); va_[r] = 2e17; }
-        else {
-        vm[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (inam && inr) ? o - da8 : kOOB);
-        va_[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (ina && inr) ? o : kOOB);
-        }
-        o += db8;
-    }
     // cell indices: id = ca + base_p + stride_b * cb (x-fastest array, or the (x,y)-transposed replica for x faces)
     const unsigned na = (unsigned)p.n[ua], nmid = xf ? (unsigned)p.n[0] : (unsigned)p.n[1];
     const unsigned ca = wrap_pos(p.srcw[3 * s + ua], p.n[ua], a);
@@ -781,16 +853,12 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
     const double omu = (double)abs(a) * sa.inv_q, ddu = 1.0 - omu;   // weights of columns am and a
     const int a2 = a * a;
     const double du2 = p.dr2[ua] * (double)a2;
-    // row sums over the two columns: R = omu r(am) + ddu r(a), T likewise with t = c r
+    // row sums over the two columns
     double R[NR + 1], T[NR + 1];
 #pragma unroll
-    for (int r = 0; r <= NR; ++r) {
-        const double rm = rcp1(fmax(p.wfloor, vm[r] * p.sigma)), ra = rcp1(fmax(p.wfloor, va_[r] * p.sigma));
-        R[r] = __builtin_fma(omu, rm, ddu * ra);
-        T[r] = __builtin_fma(omu, vm[r] * rm, ddu * (va_[r] * ra));
-    }
+    for (int r = 0; r <= NR; ++r) row_sum_fast(p, omu, ddu, vm[r], va_[r], R[r], T[r]);
     const double nflux = p.normflux[s];
-    const __amdgpu_buffer_rsrc_t r_cur = make_rsrc(p.planes + ((size_t)s * 2 + (q & 1)) * 6 * p.PP, 6u * plane_bytes);
+    const __amdgpu_buffer_rsrc_t r_cur = make_rsrc(p.planes + ((size_t)s * 2 + sa.buf_cur) * 6 * p.PP, 6u * plane_bytes);
     constexpr int SA = STREAM ? C2R_STORE_AUX : 0;
     const bool bnd_col = sa.has_boundary && (a == sa.boxR[ua] || a == -sa.boxL[ua] || pd == sa.boxR[axis] || pd == -sa.boxL[axis]);
     double loss = 0.0;
@@ -799,23 +867,14 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
     for (int k = 0; k < NR; ++k) {
         const int b = b0 + k * sgb;
         if (k < nvalid) {
-            const double omv = (double)abs(b) * sa.inv_q, ddv = 1.0 - omv;      // weights of rows b-sgb and b
-            const double den = __builtin_fma(omv, R[k], ddv * R[k + 1]);
-            const double num = __builtin_fma(omv, T[k], ddv * T[k + 1]);
-            double cdi = num * rcp1(den);
-            if (q == 1 && (abs(a) == 1 || abs(b) == 1))
-                cdi = (abs(a) == 1 && abs(b) == 1) ? p.sqrt3 * cdi : p.sqrt2 * cdi;
-            const double pq = sqrt_pos((double)(q * q + a2 + b * b));             // |delta| in cells
-            const double path = pq * sa.path_scale;
+            const CellCd cc = cell_cd_fast<LLS>(p, sa, a, a2, b, R[k], T[k], R[k + 1], T[k + 1], nhi[k],
+                                                LLS == 2 ? (double)(xf ? p.lls_T : p.lls)[id[k]] : 0.0);
+            const double pq = cc.pq, path = cc.path, cd_in = cc.cd_in, np = cc.np, cd_out = cc.cd_out;
             const double dist2 = __builtin_fma(p.dr2[va], (double)(b * b), du2 + sa.d2axis[axis]);
-            bool stop = false;
-            double cd_in;
-            if (LLS == 3) { stop = dist2 > p.R_max2; cd_in = cdi; }
-            else if (LLS == 2) cd_in = __builtin_fma((double)(xf ? p.lls_T : p.lls)[id[k]] * sa.inv_q, pq, cdi);
-            else cd_in = __builtin_fma(sa.lls_scale, pq, cdi);
-            const double np = nhi[k] * path;                                      // n_HI path: the cell's own column
-            const double cd_out = cd_in + np;
+            const bool stop = (LLS == 3) && dist2 > p.R_max2;
+            (void)pq;
             // the cell's column density, also into the planes of the faces sharing the cell
+            if (STORE) {
             if (!(C2R_ABLATE & 2) && !((C2R_ABLATE & 32) && !(q & 1)))
             buf_store_f64<SA>(r_cur, (unsigned)face * plane_bytes + o8, cd_out);
             if (C2R_ABLATE & 2) { if (cd_out == 1.2345e-300) buf_store_f64<SA>(r_cur, o8, cd_out); }
@@ -827,6 +886,7 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
             } else if (axis == 1) {
                 if (abs(a) == q)
                     buf_store_f64<SA>(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((b + p.R) * p.P + (pd + p.R)) * 8u, cd_out);
+            }
             }
             if (sa.dbg_cdout) {
                 const Delta3 dl = mesh_delta(axis, pd, a, b);
@@ -875,13 +935,58 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
     return loss;
 }
 
+// LOOK = 0: the upstream values are read from the previous shell's planes (sq unused: pass sa).  LOOK = 1 (sq = the previous
+// shell's arguments, by reference -- a pointer to a kernel argument would force it into scratch): they are recomputed from
+// the planes of the shell before it (lookahead_cd_out).
+template <bool DET, int LLS, bool STREAM, int NR, bool HEAT, int LOOK = 0, bool STORE = true>
+__device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
+                                                  const double *__restrict__ thick,   // p.thick, or the block's LDS copy of it
+                                                  const int face, const int s, const int a, const int b0, const int sgb,
+                                                  const int nvalid, const ShellArgs &sq)
+{
+    const int q = sa.q, qm = q - 1;
+    const int sga = a < 0 ? -1 : 1;
+    const int am = a - sga;
+    double vm[NR + 1], va_[NR + 1];
+    if (LOOK) {
+#pragma unroll
+        for (int r = 0; r <= NR; ++r) {                        // rows b0-sgb, b0, ..., b0+(NR-1)sgb
+            // (rows beyond the thread's valid cells are computed too -- from periodic-wrapped, in-range addresses -- and unused)
+            const int row = b0 + (r - 1) * sgb;
+            vm[r] = lookahead_cd_out<LLS, STREAM>(p, sq, face, s, am, row);
+            va_[r] = lookahead_cd_out<LLS, STREAM>(p, sq, face, s, a, row);
+        }
+    } else {
+        const unsigned plane_bytes = (unsigned)p.PP * 8u;
+        const __amdgpu_buffer_rsrc_t r_prev =
+            make_rsrc(p.planes + ((size_t)s * 2 + sa.buf_prev) * 6 * p.PP + (size_t)face * p.PP, plane_bytes);
+        const bool ina = abs(a) <= qm, inam = abs(am) <= qm;
+        const unsigned p8 = (unsigned)p.P * 8u;
+        const unsigned da8 = (unsigned)(sga * 8), db8 = sgb < 0 ? 0u - p8 : p8;
+        unsigned o = plane_off8(p, a, b0) - db8;                   // row b0 - sgb
+#pragma unroll
+        for (int r = 0; r <= NR; ++r) {                        // rows b0-sgb, b0, ..., b0+(NR-1)sgb
+            const bool inr = abs(b0 + (r - 1) * sgb) <= qm;
+            if ((C2R_ABLATE & 16) || ((C2R_ABLATE & 32) && (q & 1))) { vm[r] = 1e17 * (double)(o & 7u); va_[r] = 2e17; }
+            else {
+            vm[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (inam && inr) ? o - da8 : kOOB);
+            va_[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (ina && inr) ? o : kOOB);
+            }
+            o += db8;
+        }
+    }
+    return shell_rows_fast_core<DET, LLS, STREAM, NR, HEAT, STORE>(p, sa, ltab, thick, face, s, a, b0, sgb, nvalid, vm, va_);
+}
+
 #ifndef C2R_FAST_ATTR
 #define C2R_FAST_ATTR __launch_bounds__(kBlock)
 #endif
 // one (source, face, tile) block of work of k_sweep_shell_fast; sl = position in the active list
-template <bool DET, int LLS, bool STREAM, bool HEAT>
+constexpr int kPairRows = 1;        // rows per thread of the second shell of a look-ahead pair (k_sweep_pair_fast)
+template <bool DET, int LLS, bool STREAM, bool HEAT, int LOOK = 0, bool STORE = true, int NR = kRows>
 __device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArgs &sa, const FaceRect &fr, const v2f64 *ltab,
-                                                const double *thick, double *sm, const int face, const int tile, const int sl)
+                                                const double *thick, double *sm, const int face, const int tile, const int sl,
+                                                const ShellArgs &sq)
 {
     double loss = 0.0;
     const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
@@ -889,11 +994,12 @@ __device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArg
     if (tile < fr.ntiles && bi < (unsigned)fr.npr) {
         const int a = fr.a_lo + (int)(t - __umul24(bi, (unsigned)fr.wa));
         const bool pos = bi < (unsigned)fr.pp;
-        const int k0 = kRows * (pos ? (int)bi : (int)bi - fr.pp);
+        const int k0 = NR * (pos ? (int)bi : (int)bi - fr.pp);
         const int sgb = pos ? 1 : -1;
         const int b0 = pos ? k0 : -1 - k0;
         const int left = pos ? (fr.b_lo + fr.wb - b0) : (b0 - fr.b_lo + 1);
-        loss = shell_rows_fast<DET, LLS, STREAM, kRows, HEAT>(p, sa, ltab, thick, face, sa.active[sl], a, b0, sgb, min(left, kRows));
+        loss = shell_rows_fast<DET, LLS, STREAM, NR, HEAT, LOOK, STORE>(p, sa, ltab, thick, face, sa.active[sl], a, b0, sgb,
+                                                                        min(left, NR), sq);
     }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
@@ -914,7 +1020,35 @@ __global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
     const FaceRect fr = sa.face[face];
     if (tile >= fr.ntiles && !sa.has_boundary) return;
     const v2f64 *ltab = wave_log_table(p.odtab, s_log);
-    sweep_tile_fast<DET, LLS, STREAM, HEAT>(p, sa, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z);
+    sweep_tile_fast<DET, LLS, STREAM, HEAT>(p, sa, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z, sa);
+}
+
+// Look-ahead pair (few sources, no cell of either shell on the sub-box surface): shell sa.q (blockIdx.y 0..5) and shell
+// sb.q = sa.q + 1 (blockIdx.y 6..11) in ONE launch, both from the planes of shell sa.q - 1 -- the second shell recomputes
+// the first shell's column densities where it needs them (lookahead_cd_out).  The first shell's planes are not stored
+// (nobody reads them); the second shell's go to the other plane set, which the next launch reads.
+template <bool DET, int LLS, bool STREAM, bool HEAT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2)))     // latency-bound by design: registers, not occupancy
+void k_sweep_pair_fast(KParams p, ShellArgs sa, ShellArgs sb)
+{
+    __shared__ double sm[16];
+    __shared__ v2f64 s_log[kBlock];                      // kBlock/64 waves x 64 entries
+    const bool second = blockIdx.y >= 6;
+    const int face = second ? (int)blockIdx.y - 6 : (int)blockIdx.y;
+    const int tile = blockIdx.x;
+    const int nact = *sa.n_active;
+    if ((int)blockIdx.z >= nact) return;
+    if (second) {
+        const FaceRect fr = sb.face[face];
+        if (tile >= fr.ntiles) return;
+        const v2f64 *ltab = wave_log_table(p.odtab, s_log);
+        sweep_tile_fast<DET, LLS, STREAM, HEAT, 1, true, kPairRows>(p, sb, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z, sa);
+    } else {
+        const FaceRect fr = sa.face[face];
+        if (tile >= fr.ntiles) return;
+        const v2f64 *ltab = wave_log_table(p.odtab, s_log);
+        sweep_tile_fast<DET, LLS, STREAM, HEAT, 0, false>(p, sa, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z, sa);
+    }
 }
 
 // ---- the first sub-boxes, fused: one workgroup per source, all shells of the sub-box in one launch -----
@@ -955,7 +1089,7 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
             const unsigned bi = fr.magic ? __umulhi(lt, fr.magic) : lt;
             const int a = fr.a_lo + (int)(lt - __umul24(bi, (unsigned)fr.wa));
             const int b = fr.b_lo + (int)bi;
-            if (FAST) loss = loss + shell_rows_fast<DET, LLS, false, 1, HEAT>(p, sa, ltab, p.thick, f, s, a, b, b < 0 ? -1 : 1, 1);
+            if (FAST) loss = loss + shell_rows_fast<DET, LLS, false, 1, HEAT>(p, sa, ltab, p.thick, f, s, a, b, b < 0 ? -1 : 1, 1, sa);
             else loss = loss + shell_cell<DET, LLS, 0, HEAT>(p, sa, ltab, f, s, a, b);
         }
         if (sa.has_boundary) {
@@ -1032,10 +1166,14 @@ __global__ __launch_bounds__(256) void k_prepare_nhi(int n0, int n1, int n2, dou
 }
 
 // out[j + N1*(i + N0*k)] = in[i + N0*(j + N1*k)]: (x,y) transpose of every z-plane through LDS.
+// gate (or null): the launch does nothing unless *gate == 0 -- kernels enqueued behind a sweep before the host knows
+// whether every source has retired (the fused outer iteration, c2ray_hip.hip iterate_impl)
 template <typename T, bool ACCUM>
-__global__ __launch_bounds__(256) void k_transpose_xy(int n0, int n1, int n2, const T *__restrict__ in, T *__restrict__ out)
+__global__ __launch_bounds__(256) void k_transpose_xy(int n0, int n1, int n2, const T *__restrict__ in, T *__restrict__ out,
+                                                      const int *gate = nullptr)
 {
     __shared__ T tile[32][33];
+    if (gate && *gate != 0) return;
     const int k = blockIdx.z;
     const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
@@ -1251,9 +1389,11 @@ __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell,
                                                      const double *__restrict__ xh, double *__restrict__ xh_av,
                                                      double *__restrict__ xh_intermed,
                                                      const double *__restrict__ phih, double *sum_partial,
-                                                     unsigned long long *conv_flag, unsigned int *chem_fail)
+                                                     unsigned long long *conv_flag, unsigned int *chem_fail,
+                                                     const int *gate = nullptr)
 {
     __shared__ double sm[4];
+    if (gate && *gate != 0) return;
     double lsum = 0.0;
     double st_h0 = 0.0, st_h1 = 0.0, st_tr = 0.0, st_tc = 0.0;
     unsigned int nconv = 0, nfail = 0;
@@ -1406,9 +1546,10 @@ __global__ __launch_bounds__(256) void k_sum_partial(size_t n, const double *__r
 }
 
 // out[m] = sum of partial[m][0..n) in a fixed order, m = blockIdx.x; `out` may be mapped host memory.
-__global__ __launch_bounds__(256) void k_sum_final(int n, const double *partial, double *out)
+__global__ __launch_bounds__(256) void k_sum_final(int n, const double *partial, double *out, const int *gate = nullptr)
 {
     __shared__ double sm[4];
+    if (gate && *gate != 0) return;
     partial += (size_t)blockIdx.x * n;
     double v = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
@@ -1420,9 +1561,11 @@ __global__ __launch_bounds__(256) void k_sum_final(int n, const double *partial,
 // (mapped pointers); the counters are left at zero for the next pass.
 __global__ __launch_bounds__(256) void k_pass_final(int n, const double *partial, unsigned long long *conv,
                                                     unsigned int *chem_fail, double *host_sum,
-                                                    unsigned long long *host_conv, unsigned int *host_fail)
+                                                    unsigned long long *host_conv, unsigned int *host_fail,
+                                                    const int *gate = nullptr)
 {
     __shared__ double sm[4];
+    if (gate && *gate != 0) return;
     double v = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
     const double tot = block_sum_256(v, sm);

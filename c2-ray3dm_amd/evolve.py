@@ -342,6 +342,14 @@ class HipBackend:
         self._check(self.lib.c2r_global_pass(self.ctx, dt, C.byref(conv), C.byref(s)), "c2r_global_pass")
         return conv.value, s.value
 
+    def iterate(self, dt):
+        """One outer iteration on a single rank (c2r_iterate): zero_rates + pass_sources + global_pass with one host wait
+        where the sources are few.  Returns (photon_loss, sum_nbox, visited, conv_flag, sum_xh1)."""
+        loss, nb, vis, conv, s = C.c_double(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_double()
+        self._check(self.lib.c2r_iterate(self.ctx, dt, C.byref(loss), C.byref(nb), C.byref(vis), C.byref(conv), C.byref(s)),
+                    "c2r_iterate")
+        return loss.value, nb.value, vis.value, conv.value, s.value
+
     def rates_tensor(self):
         return self.phih_grid
 
@@ -542,6 +550,21 @@ class Evolve:
     def global_pass(self, dt):
         return self.b.global_pass(dt)
 
+    # evolve.F90:243-269 on one rank, nothing in between (no collective, no dump due): the backend's single call
+    def iteration(self, niter, dt):
+        """set_rates_to_zero + pass_all_sources + global_pass -> (conv_flag, sum_xh1).  A single rank with the HIP backend
+        goes through c2r_iterate (one host wait per iteration where the sources are few); otherwise the three steps."""
+        if self.npr == 1 and not self.balance and hasattr(self.b, "iterate"):
+            loss, nb, vis, conv, s1 = self.b.iterate(dt)
+            self.photon_loss = self.photon_loss_all = loss
+            self.sum_nbox = self.sum_nbox_all = nb
+            self.visited += vis
+            self.nbox_per_source = None
+            return conv, s1
+        self.set_rates_to_zero()
+        self.pass_all_sources(niter, dt)
+        return self.global_pass(dt)
+
     # evolve.F90:285-324
     def write_iteration_dump(self, niter):
         from . import fileio
@@ -610,16 +633,22 @@ class Evolve:
             prev1, prev0 = sum1, sum0
             niter += 1
             t0 = _time.perf_counter()
-            self.set_rates_to_zero()
-            self.pass_all_sources(niter, dt)
-            t1 = _time.perf_counter()
-            # evolve.F90:253-266: rank 0 writes iterdump1/2.bin alternately when the interval has passed
-            if self.rank == 0 and self.dump_interval_s is not None and \
-                    _time.perf_counter() - t_last_dump > self.dump_interval_s:
-                self.write_iteration_dump(niter)
-                t_last_dump = _time.perf_counter()
-            conv_flag, sum1 = self.global_pass(dt)
-            t2 = _time.perf_counter()
+            # evolve.F90:253-266: rank 0 writes iterdump1/2.bin alternately when the interval has passed -- between the
+            # pass and the global pass, so an iteration in which a dump is due runs as its three steps
+            dump_due = self.rank == 0 and self.dump_interval_s is not None and \
+                _time.perf_counter() - t_last_dump > self.dump_interval_s
+            if not dump_due and self.npr == 1:
+                conv_flag, sum1 = self.iteration(niter, dt)
+                t1 = t2 = _time.perf_counter()
+            else:
+                self.set_rates_to_zero()
+                self.pass_all_sources(niter, dt)
+                t1 = _time.perf_counter()
+                if dump_due:
+                    self.write_iteration_dump(niter)
+                    t_last_dump = _time.perf_counter()
+                conv_flag, sum1 = self.global_pass(dt)
+                t2 = _time.perf_counter()
             t_sweep += t1 - t0
             t_chem += t2 - t1
             self.log.append(dict(conv_flag=conv_flag, sum_nbox=self.sum_nbox_all,

@@ -97,8 +97,8 @@ typedef struct c2r_report {
     int64_t sum_nbox_all;            /* evolve_source.F90:46 */
     int64_t visited;                 /* (cell,source) pairs executed over all iterations (this rank) */
     double  photon_loss_all;         /* evolve_data.F90 photon_loss_all(1) */
-    double  seconds_sweep;           /* wall time inside pass_all_sources, all iterations */
-    double  seconds_chem;            /* wall time inside global_pass, all iterations */
+    double  seconds_sweep;           /* wall time inside pass_all_sources, all iterations (one rank: the whole iteration, see c2r_iterate) */
+    double  seconds_chem;            /* wall time inside global_pass, all iterations (one rank: 0, it is not waited for separately) */
     int32_t chem_not_converged;      /* cells that hit max_chem_iter in the last global pass */
     int32_t reserved0;
     int64_t it_conv_flag[C2R_MAX_ITER_LOG];        /* [k]: global pass of iteration k+1; after a restart from
@@ -263,6 +263,14 @@ int  c2r_do_source(c2r_ctx *ctx, int32_t ns, double *coldensh_out_host, double *
 /* global_pass (evolve.F90:499-573): evolve0D_global + do_chemistry + doric over the mesh.
  * sum_xh1 (optional) receives sum(xh_intermed) after the pass. */
 int  c2r_global_pass(c2r_ctx *ctx, double dt, int64_t *conv_flag, double *sum_xh1);
+/* One outer iteration of evolve3D's loop on a SINGLE rank (evolve.F90:243-269): set_rates_to_zero + pass_all_sources +
+ * global_pass, the results of c2r_pass_sources and c2r_global_pass together.  Same arithmetic as the three calls; where
+ * the sources are few (<= 32, one batch) the whole iteration is one replayed hipGraph with one host wait -- the launches
+ * after the pass are recorded behind it and gated on the device by "every source has retired" -- which is what a
+ * 128^3 x 1-source iteration is made of.  C2R_ESTATE with more than one rank (a collective belongs between
+ * the pass and the global pass there). */
+int  c2r_iterate(c2r_ctx *ctx, double dt, double *photon_loss, int64_t *sum_nbox, int64_t *visited, int64_t *conv_flag,
+                 double *sum_xh1);
 /* The four mesh sums of photonstatistics.F90 in one pass over device arrays `which_l`/`which_r`
  * (1 xh, 2 xh_av, 3 xh_intermed): out = { sum n(1-x_l), sum n x_l, recombination sum, collisional
  * ionization sum } (state_before/_after :104-217, total_rates :137-185), unscaled by vol and dt. */
