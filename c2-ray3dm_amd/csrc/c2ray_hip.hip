@@ -279,13 +279,23 @@ void prof_collect(Ctx *ctx)
 // Every launch that stores planes reads one set and writes the other: a single shell, a shell of the fused first
 // sub-boxes, or a look-ahead pair (two shells, one alternation).  The pairing rule is the one of sweep_batch's
 // enqueue_box: neither shell has cells on the sub-box surface, both have tiles.
+// Sub-boxes ending at q <= kFusedQmax run in k_sweep_box_fused (one workgroup per source walks the shells).  With few
+// sources and look-ahead pairs only the first sub-box does: beyond it three pair launches (22 us at 128^3 x 1 source) beat
+// the single workgroup's five shells (36 us).
+bool box_is_fused(const Ctx *ctx, int nbox, bool pair_ok)
+{
+    const c2r_params &p = ctx->prm;
+    const int q0 = p.subboxsize * (nbox - 1) + 1, q1 = std::min(p.subboxsize * nbox, ctx->Qmax);
+    return ctx->fuse_small && q1 <= kFusedQmax && q1 - q0 + 1 <= kMaxFused && !(pair_ok && nbox > 1);
+}
+
 int plane_set_before(const Ctx *ctx, int nbox, bool pair_ok)
 {
     const c2r_params &p = ctx->prm;
     int set = 0;
     for (int nb = 1; nb < nbox; ++nb) {
         const int q0 = p.subboxsize * (nb - 1) + 1, q1 = std::min(p.subboxsize * nb, ctx->Qmax);
-        const bool fused = ctx->fuse_small && q1 <= kFusedQmax && q1 - q0 + 1 <= kMaxFused;
+        const bool fused = box_is_fused(ctx, nb, pair_ok);
         auto tiles = [&](int q) { for (int f = 0; f < 6; ++f) if (face_rect(ctx, f, q).ntiles > 0) return true; return false; };
         auto surface = [&](int q) {
             for (int d = 0; d < 3; ++d)
@@ -410,7 +420,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             return sa;
         };
         last_bps = 0;
-        if (ctx->fuse_small && q1 <= kFusedQmax && q1 - q0 + 1 <= kMaxFused) {
+        if (box_is_fused(ctx, nbox, pair_ok)) {
             // near the source: the whole sub-box of every active source in ONE launch (k_sweep_box_fused)
             BoxArgs ba{};
             int most = 0;
@@ -545,7 +555,13 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
         if (loss_out) HIP_TRY(hipMemcpyAsync(h_fl, ctx->d_final_loss, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
         return C2R_OK;
     };
-    const bool fuse_iter = fz && graph_ok && first_of_pass && !ctx->d_gbox;
+    // deterministic rates: the per-source grids are summed in source order once every source has its final sub-box
+    auto gamma_reduce = [&](const int *gate) {
+        if (ctx->d_gbox)
+            hipLaunchKernelGGL(k_gamma_reduce, dim3((p.mesh[0] + 255) / 256, p.mesh[1], p.mesh[2]), dim3(256), 0, st, k, count,
+                               ctx->d_final_nbox, p.subboxsize, (double *)ctx->grid[4], ctx->thermal ? (double *)ctx->grid[5] : nullptr, gate);
+    };
+    const bool fuse_iter = fz && graph_ok && first_of_pass;
     bool pre_run = false;
     if (graph_ok) {
         Ctx::BatchGraph &bg = ctx->graphs[first];
@@ -561,6 +577,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                 if (fuse_iter && rc == C2R_OK) {
                     // the batch's totals and results, then the gated rest of the iteration: d_nactive[cur] is the count the
                     // last decision left (cur has been flipped by it)
+                    gamma_reduce(ctx->d_nactive + cur);
                     rc = enqueue_totals();
                     if (rc == C2R_OK) rc = fz->post(ctx->d_nactive + cur);
                 }
@@ -603,10 +620,8 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             known = need; bound = ctx->h_nactive[need];
         }
     }
-    if (ctx->d_gbox)
-        hipLaunchKernelGGL(k_gamma_reduce, dim3((p.mesh[0] + 255) / 256, p.mesh[1], p.mesh[2]), dim3(256), 0, st, k, count,
-                           ctx->d_final_nbox, p.subboxsize, (double *)ctx->grid[4], ctx->thermal ? (double *)ctx->grid[5] : nullptr);
     if (!(fz && fz->tail_done)) {          // (the fused iteration's graph has done this already)
+        gamma_reduce(nullptr);
         { const int rc = enqueue_totals(); if (rc) return rc; }
         HIP_TRY(hipStreamSynchronize(st));
     }
@@ -617,14 +632,24 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
 
 // +-x faces read (x,y)-transposed replicas so that their waves, which run along y, touch unit
 // stride: refresh the replicas before a pass, fold their Gamma back after it.
-int sweep_prepare(Ctx *ctx)
+// zero_rates: also set_rates_to_zero (evolve.F90:430-440) -- and every clearing inside the one kernel instead of memsets
+// (the fused iteration, where a launch more or less is what counts)
+int sweep_prepare(Ctx *ctx, bool zero_rates = false)
 {
     const c2r_params &p = ctx->prm;
     const dim3 g((p.mesh[0] + 31) / 32, (p.mesh[1] + 31) / 32, p.mesh[2]);
+    ZeroGrids z{};
+    if (zero_rates) {
+        z.g[0] = (double *)ctx->grid[4]; z.g[1] = ctx->d_phih_T;
+        if (ctx->thermal) { z.g[2] = (double *)ctx->grid[5]; z.g[3] = ctx->d_heat_T; }
+    }
     hipLaunchKernelGGL(k_prepare_nhi, g, dim3(256), 0, ctx->stream, p.mesh[0], p.mesh[1], p.mesh[2], p.epsilon,
-                       (const float *)ctx->grid[0], (const double *)ctx->grid[2], ctx->d_nhi, ctx->d_nhi_T);
-    HIP_TRY(hipMemsetAsync(ctx->d_phih_T, 0, grid_bytes(ctx, 4), ctx->stream));
-    if (ctx->thermal) HIP_TRY(hipMemsetAsync(ctx->d_heat_T, 0, grid_bytes(ctx, 5), ctx->stream));
+                       (const float *)ctx->grid[0], (const double *)ctx->grid[2], ctx->d_nhi, ctx->d_nhi_T, z);
+    HIP_TRY(hipGetLastError());
+    if (!zero_rates) {
+        HIP_TRY(hipMemsetAsync(ctx->d_phih_T, 0, grid_bytes(ctx, 4), ctx->stream));
+        if (ctx->thermal) HIP_TRY(hipMemsetAsync(ctx->d_heat_T, 0, grid_bytes(ctx, 5), ctx->stream));
+    }
     return C2R_OK;
 }
 
@@ -1482,7 +1507,7 @@ static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, i
     int rc;
     const int nloc = n_local_sources(ctx);
     bool can_fuse = ctx->fused_iter && ctx->nranks == 1 && !ctx->balance && ctx->use_graph && ctx->sched_hint && ctx->prof == 0 && nloc > 0 &&
-                    nloc <= kFewSources && ctx->box_hint >= 1 && !ctx->prm.deterministic_rates &&
+                    nloc <= kFewSources && ctx->box_hint >= 1 &&
                     !(ctx->thermal && ctx->tprm.cosmological && !ctx->have_zred);
     if (can_fuse) {
         if ((rc = ensure_sweep_scratch(ctx, nloc))) return rc;
@@ -1501,7 +1526,7 @@ static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, i
     } else {
         FusedIter fz;
         fz.dt = dt; fz.stats = stats_host != nullptr;
-        fz.pre = [ctx, &zero_rates]() -> int { const int r = zero_rates(); return r ? r : sweep_prepare(ctx); };
+        fz.pre = [ctx]() -> int { return sweep_prepare(ctx, true); };
         fz.post = [ctx, dt, four](const int *gate) -> int {
             const int r = sweep_finish(ctx, gate);
             return r ? r : global_pass_enqueue(ctx, dt, four, 0, ctx->ncell, gate);

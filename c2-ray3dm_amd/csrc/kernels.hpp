@@ -1104,8 +1104,10 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
 // of the serial reference, evolve_point.F90:283 inside master_slave.F90:85's loop).  One thread per
 // cell; a source contributes where the cell lies inside its final sub-box (evolve_source.F90:135-136).
 __global__ __launch_bounds__(256) void k_gamma_reduce(KParams p, int nsrc, const int *final_nbox, int subbox,
-                                                      double *phih, double *heat /* phiheat_grid, or null */)
+                                                      double *phih, double *heat /* phiheat_grid, or null */,
+                                                      const int *gate = nullptr /* see k_transpose_xy */)
 {
+    if (gate && *gate != 0) return;
     // block = 256 cells along x of one (y,z) row: the y and z parts of the box test are block-uniform
     const int c0 = blockIdx.x * 256 + threadIdx.x, c1 = blockIdx.y, c2 = blockIdx.z;
     const bool live = c0 < p.n[0];
@@ -1139,9 +1141,12 @@ __global__ __launch_bounds__(256) void k_gamma_reduce(KParams p, int nsrc, const
 
 // nhi[i,j,k] = max(1-max(xh_av,eps),eps) * ndens (ion%h_av(0)*ndens_p of evolve0D) and its (x,y)-transposed
 // replica, one z-plane tile at a time through LDS.
+// zero (null or 4 pointers): arrays of the mesh's size to clear on the way -- phih_grid and phiheat_grid (x fastest) in [0], [2],
+// their (x,y)-transposed accumulators in [1], [3] (any of them null) -- where launches are what an iteration costs (c2r_iterate)
+struct ZeroGrids { double *g[4]; };
 __global__ __launch_bounds__(256) void k_prepare_nhi(int n0, int n1, int n2, double eps, const float *__restrict__ ndens,
                                                      const double *__restrict__ xh_av, double *__restrict__ nhi,
-                                                     double *__restrict__ nhi_T)
+                                                     double *__restrict__ nhi_T, ZeroGrids zero)
 {
     __shared__ double tile[32][33];
     const int k = blockIdx.z;
@@ -1156,12 +1161,19 @@ __global__ __launch_bounds__(256) void k_prepare_nhi(int n0, int n1, int n2, dou
             const double v = xav0 * (double)ndens[id];
             nhi[id] = v;
             tile[r][tx] = v;
+            if (zero.g[0]) zero.g[0][id] = 0.0;
+            if (zero.g[2]) zero.g[2][id] = 0.0;
         }
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int j = j0 + tx, i = i0 + r;
-        if (i < n0 && j < n1) nhi_T[(size_t)j + (size_t)n1 * ((size_t)i + (size_t)n0 * k)] = tile[tx][r];
+        if (i < n0 && j < n1) {
+            const size_t idt = (size_t)j + (size_t)n1 * ((size_t)i + (size_t)n0 * k);
+            nhi_T[idt] = tile[tx][r];
+            if (zero.g[1]) zero.g[1][idt] = 0.0;
+            if (zero.g[3]) zero.g[3][idt] = 0.0;
+        }
     }
 }
 
