@@ -63,6 +63,7 @@ struct Ctx {
     unsigned long long gen = 1;
     bool use_graph = true;                                       // C2R_GRAPH=0: never (experiments)
     bool fused_iter = true;                                      // C2R_FUSED_ITER=0: c2r_iterate always runs its three steps in turn (experiments)
+    bool fold_source_cell = true;                                // C2R_FOLD_SOURCE_CELL=0: k_source_cells is always its own launch (experiments)
     bool pair_shells = true;                                     // C2R_PAIR_SHELLS=0: never two shells per launch (experiments)
     // cost-balanced distribution inside the library (c2r_set_balance): every rank learns every source's last
     // sub-box count through the all-reduce callback and computes the same LPT partition
@@ -91,6 +92,7 @@ struct Ctx {
     double *d_gbox_h = nullptr; // ... and the per-source heating rates of a non-isothermal run
     // one device block + one pinned staging block hold the small per-batch arrays below (one copy per batch)
     char *d_batch = nullptr, *h_batch = nullptr; size_t batch_bytes = 0;
+    char *d_hbatch = nullptr;                                // h_batch as the device sees it (k_box_decide_small writes results there)
     int *d_active[2] = {nullptr, nullptr};
     int *d_nactive = nullptr;                                // [2]: length of d_active[0/1]
     int *h_nactive = nullptr;                                // pinned, one slot per sub-box
@@ -182,7 +184,8 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
     //   nflux[cap] final_loss[cap] loss_acc[cap] | srcpos[3cap] srcw[3cap] active0[cap] active1[cap] final_nbox[cap] nactive[2]
     ctx->batch_bytes = (size_t)cap * 3 * sizeof(double) + ((size_t)cap * 9 + 2) * sizeof(int);
     HIP_TRY(hipMalloc(&ctx->d_batch, ctx->batch_bytes));
-    HIP_TRY(hipHostMalloc((void **)&ctx->h_batch, ctx->batch_bytes));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_batch, ctx->batch_bytes, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void **)&ctx->d_hbatch, ctx->h_batch, 0));
     {
         double *d = reinterpret_cast<double *>(ctx->d_batch);
         ctx->d_nflux_b = d; ctx->d_final_loss = d + cap; ctx->d_loss_acc = d + 2 * (size_t)cap;
@@ -376,13 +379,21 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
     const int hint = few ? std::max(1, ctx->box_hint) : 1;
     // every launch of sub-box nbox for `bound` sources at most (no host wait, no event): shells or the fused box, loss
     // reduction, the decision; flips `cur`
+    int totals_at_box = 0;         // fused iteration: the sub-box whose decision also writes the batch's totals (0: none)
     auto enqueue_box = [&](const int nbox, const int bound) -> int {
         int boxR[3], boxL[3];
         for (int d = 0; d < 3; ++d) {
             boxR[d] = std::min(p.subboxsize * nbox, ctx->hr[d]);
             boxL[d] = std::min(p.subboxsize * nbox, ctx->hl[d]);
         }
-        if (nbox == 1) {
+        // which plane set holds shell q0 - 1: the shells alternate between the two sets, a look-ahead pair advances two
+        // shells in one alternation -- a pure function of the schedule up to this sub-box (a replayed graph does not run
+        // this code), see plane_set_before
+        const bool pair_ok = ctx->fast && ctx->pair_shells && n_active <= kFewSources && !dbg && ctx->prof != 1;
+        int pbuf = plane_set_before(ctx, nbox, pair_ok);
+        const bool fused_box = box_is_fused(ctx, nbox, pair_ok);
+        // (the fused first sub-box does the source cells itself: one launch less)
+        if (nbox == 1 && !(fused_box && ctx->fold_source_cell)) {
             if (ctx->thermal)
                 hipLaunchKernelGGL(k_source_cells<true>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
                                    ctx->d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
@@ -394,11 +405,6 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
         }
         const int q0 = p.subboxsize * (nbox - 1) + 1, q1 = std::min(p.subboxsize * nbox, ctx->Qmax);
         const bool det = ctx->d_gbox != nullptr;
-        // which plane set holds shell q0 - 1: the shells alternate between the two sets, a look-ahead pair advances two
-        // shells in one alternation -- a pure function of the schedule up to this sub-box (a replayed graph does not run
-        // this code), see plane_set_before
-        const bool pair_ok = ctx->fast && ctx->pair_shells && n_active <= kFewSources && !dbg && ctx->prof != 1;
-        int pbuf = plane_set_before(ctx, nbox, pair_ok);
         auto shell_args = [&](int q) {
             ShellArgs sa{};
             sa.q = q;
@@ -420,7 +426,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             return sa;
         };
         last_bps = 0;
-        if (box_is_fused(ctx, nbox, pair_ok)) {
+        if (fused_box) {
             // near the source: the whole sub-box of every active source in ONE launch (k_sweep_box_fused)
             BoxArgs ba{};
             int most = 0;
@@ -433,6 +439,17 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                 ba.face_off[k][6] = ba.face_off[k][7] = off;
                 ba.ncell[k] = off; most = std::max(most, off);
                 ba.sh[k] = sa;
+            }
+            if (nbox == 1 && ctx->fold_source_cell) {
+                if (ba.nshell > 0) ba.source_cell = 1;
+                else {      // no shell at all to walk (degenerate limits): the plain kernel after all
+                    if (ctx->thermal)
+                        hipLaunchKernelGGL(k_source_cells<true>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, ctx->d_active[cur],
+                                           boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], ctx->d_loss_acc, dbg);
+                    else
+                        hipLaunchKernelGGL(k_source_cells<false>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, ctx->d_active[cur],
+                                           boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], ctx->d_loss_acc, dbg);
+                }
             }
             if (ba.nshell > 0) {
                 ba.active = ctx->d_active[cur]; ba.n_active = ctx->d_nactive + cur; ba.loss_acc = ctx->d_loss_acc;
@@ -529,6 +546,21 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
         if (ctx->prof == 2) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(in_box); }
         }
         const int can_grow = (p.subboxsize * nbox < ctx->hr[2]) && (p.subboxsize * nbox < ctx->hl[2]);
+        if (n_active <= 64) {
+            // one wave decides; at the sub-box a fused iteration's graph ends with it also leaves the batch's totals and
+            // results (SmallTotals) -- host_final_*: the staging block's final_nbox / final_loss through its mapped alias
+            SmallTotals tot{};
+            if (nbox == totals_at_box) {
+                tot.on = 1; tot.nsrc = count; tot.photon_loss = ctx->d_photon_loss; tot.sum_nbox = ctx->d_sum_nbox;
+                tot.host_loss = &ctx->d_hsc->photon_loss; tot.host_nbox = &ctx->d_hsc->sum_nbox;
+                tot.host_final_loss = reinterpret_cast<double *>(ctx->d_hbatch) + cap;
+                tot.host_final_nbox = reinterpret_cast<int *>(reinterpret_cast<double *>(ctx->d_hbatch) + 3 * cap) + 8 * cap;
+            }
+            hipLaunchKernelGGL(k_box_decide_small, dim3(1), dim3(64), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
+                               ctx->d_active[1 - cur], ctx->d_nactive + (1 - cur), ctx->d_hnactive + nbox, ctx->d_nflux_b,
+                               p.S_star, p.loss_fraction, can_grow, nbox, ctx->d_loss_acc, ctx->d_final_loss, ctx->d_final_nbox,
+                               (const double *)ctx->d_loss_partial, last_bps, tot);
+        } else
         hipLaunchKernelGGL(k_box_decide, dim3(1), dim3(1024), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
                            ctx->d_active[1 - cur], ctx->d_nactive + (1 - cur), ctx->d_hnactive + nbox, ctx->d_nflux_b,
                            p.S_star, p.loss_fraction, can_grow, nbox, ctx->d_loss_acc, ctx->d_final_loss, ctx->d_final_nbox,
@@ -571,6 +603,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             if (bg.graph) { hipGraphDestroy(bg.graph); bg.graph = nullptr; }
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 int rc = fuse_iter ? fz->pre() : C2R_OK;
+                totals_at_box = fuse_iter ? std::min(hint, ctx->nbox_max) : 0;
                 if (rc == C2R_OK) rc = (int)hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st);
                 cur = 0;
                 for (int nbox = 1; nbox <= hint && nbox <= ctx->nbox_max && rc == C2R_OK; ++nbox) rc = enqueue_box(nbox, n_active);
@@ -578,9 +611,9 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                     // the batch's totals and results, then the gated rest of the iteration: d_nactive[cur] is the count the
                     // last decision left (cur has been flipped by it)
                     gamma_reduce(ctx->d_nactive + cur);
-                    rc = enqueue_totals();
-                    if (rc == C2R_OK) rc = fz->post(ctx->d_nactive + cur);
+                    rc = fz->post(ctx->d_nactive + cur);
                 }
+                totals_at_box = 0;
                 const hipError_t e = hipStreamEndCapture(st, &bg.graph);
                 if (rc == C2R_OK && e == hipSuccess && hipGraphInstantiate(&bg.exec, bg.graph, nullptr, nullptr, 0) == hipSuccess) {
                     bg.gen = ctx->gen; bg.count = count; bg.n_active = n_active; bg.hint = hint;
@@ -800,6 +833,7 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     if (const char *e = getenv("C2R_GRAPH")) ctx->use_graph = atoi(e) != 0;
     if (const char *e = getenv("C2R_FUSED_ITER")) ctx->fused_iter = atoi(e) != 0;
     if (const char *e = getenv("C2R_PAIR_SHELLS")) ctx->pair_shells = atoi(e) != 0;
+    if (const char *e = getenv("C2R_FOLD_SOURCE_CELL")) ctx->fold_source_cell = atoi(e) != 0;
     if (p->sweep_mode != C2R_SWEEP_EXACT && p->sweep_mode != C2R_SWEEP_FAST) { delete ctx; return C2R_EINVAL; }
     ctx->fast = p->sweep_mode == C2R_SWEEP_FAST;          // the caller's choice only: no environment override
     *out = reinterpret_cast<c2r_ctx *>(ctx);     // returned even on failure so c2r_last_error works

@@ -295,16 +295,12 @@ __device__ __forceinline__ double block_sum_256(double v, double *sm /* >= 4 dou
 }
 
 // ---- source cells (q = 0) ------------------------------------------------------------------
-// evolve_point.F90:151-160 (source cell) + the common tail of evolve0D.  One thread per source.
+// evolve_point.F90:151-160 (source cell) + the common tail of evolve0D, for source s; ltab: log10_tab's table (LDS or global).
+// on_surface: degenerate meshes only, the source cell itself sits on the sub-box surface
 template <bool HEAT>
-__global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0, int boxR1, int boxR2,
-                               int boxL0, int boxL1, int boxL2, double *loss_acc, double *dbg_cdout)
+__device__ __forceinline__ void source_cell(const KParams &p, const v2f64 *__restrict__ ltab, const int s, const bool on_surface,
+                                            double *loss_acc, double *dbg_cdout)
 {
-    __shared__ v2f64 s_log[kLogTab];                          // blocks of one wave
-    const v2f64 *ltab = wave_log_table(p.logtab, s_log);
-    const int sl = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sl >= nsrc) return;
-    const int s = active[sl];
     const int i = pmod(p.srcpos[3 * s + 0] - 1, p.n[0]);
     const int j = pmod(p.srcpos[3 * s + 1] - 1, p.n[1]);
     const int k = pmod(p.srcpos[3 * s + 2] - 1, p.n[2]);
@@ -328,9 +324,20 @@ __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0
         if (HEAT && p.gbox) p.gbox_h[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = heat;
     } else if (HEAT && p.gbox) p.gbox_h[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = 0.0;
     if (p.gbox) p.gbox[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = gamma;
-    // degenerate meshes only: the source cell itself sits on the sub-box surface
-    if (boxR0 == 0 || boxR1 == 0 || boxR2 == 0 || boxL0 == 0 || boxL1 == 0 || boxL2 == 0)
-        loss_acc[s] += p_out * p.vol / vol_ph;
+    if (on_surface) loss_acc[s] += p_out * p.vol / vol_ph;
+}
+
+// One thread per source (the fused first sub-box does the same itself: BoxArgs::source_cell).
+template <bool HEAT>
+__global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0, int boxR1, int boxR2,
+                               int boxL0, int boxL1, int boxL2, double *loss_acc, double *dbg_cdout)
+{
+    __shared__ v2f64 s_log[kLogTab];                          // blocks of one wave
+    const v2f64 *ltab = wave_log_table(p.logtab, s_log);
+    const int sl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sl >= nsrc) return;
+    source_cell<HEAT>(p, ltab, active[sl], boxR0 == 0 || boxR1 == 0 || boxR2 == 0 || boxL0 == 0 || boxL1 == 0 || boxL2 == 0,
+                      loss_acc, dbg_cdout);
 }
 
 // ---- buffer addressing (SRSRC descriptor + 32-bit byte offset) ---------------------------------------
@@ -1059,6 +1066,7 @@ void k_sweep_pair_fast(KParams p, ShellArgs sa, ShellArgs sb)
 // order and added to loss_acc[source] (no k_loss_reduce).  Same per-cell code as k_sweep_shell.
 constexpr int kMaxFused = 5;
 struct BoxArgs {
+    int source_cell;                 // 1: the workgroup first does its source's own cell (sub-box 1; else k_source_cells has)
     int nshell;
     int ncell[kMaxFused];            // packed cells of each shell
     int face_off[kMaxFused][8];      // [f]: first packed index of face f; [6] = ncell
@@ -1077,6 +1085,14 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
     if (sl >= *ba.n_active) return;
     const int s = ba.active[sl];
     const v2f64 *ltab = wave_log_table(FAST ? p.odtab : p.logtab, s_log);
+    if (ba.source_cell) {
+        if (threadIdx.x == 0) {
+            const ShellArgs &s0 = ba.sh[0];
+            source_cell<HEAT>(p, p.logtab, s, s0.boxR[0] == 0 || s0.boxR[1] == 0 || s0.boxR[2] == 0 || s0.boxL[0] == 0 ||
+                              s0.boxL[1] == 0 || s0.boxL[2] == 0, ba.loss_acc, s0.dbg_cdout);
+        }
+        __syncthreads();             // shell 0's plane entries are visible to the waves that read them in shell 1
+    }
     for (int k = 0; k < ba.nshell; ++k) {
         const ShellArgs &sa = ba.sh[k];
         double loss = 0.0;
@@ -1293,6 +1309,58 @@ __global__ __launch_bounds__(1024) void k_box_decide(const int *active_in, const
     }
     // n_out_host: the schedule's pinned slot for this sub-box, written straight through the mapped pointer
     if (threadIdx.x == 0) { *n_out = base; *n_out_host = base; }
+}
+
+// k_box_decide for up to 64 active sources (one wave, no scan through LDS): the same sums in the same order, the same
+// decisions.  tot.on: when the decision leaves no source active, the batch's totals (k_batch_totals for a pass of ONE batch:
+// the running sums restart from zero) and the per-source results go out with it -- to the device scalars and, through
+// mapped pointers, to the host -- so that the launches behind a small batch need neither k_batch_totals nor two copies.
+struct SmallTotals {
+    int on, nsrc;
+    double *photon_loss; long long *sum_nbox;         // device running totals
+    double *host_loss; long long *host_nbox;          // the host's pinned scalars
+    int *host_final_nbox; double *host_final_loss;    // the host's pinned staging arrays [nsrc]
+};
+__global__ __launch_bounds__(64) void k_box_decide_small(const int *active_in, const int *n_in_dev, int *active_out,
+                                                         int *n_out, int *n_out_host, const double *normflux, double S_star,
+                                                         double loss_fraction, int can_grow, int nbox,
+                                                         double *loss_acc, double *final_loss, int *final_nbox,
+                                                         const double *loss_partial, int bps, SmallTotals tot)
+{
+    const int n_in = *n_in_dev;                       // <= 64
+    const int i = threadIdx.x;
+    int keep = 0, s = -1;
+    if (i < n_in) {
+        s = active_in[i];
+        const double flux = normflux[s] * S_star;
+        double loss = loss_acc[s];
+        if (bps > 0) {
+            const double *pp = loss_partial + (size_t)i * bps;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int j = 0;
+            for (; j + 3 < bps; j += 4) { a0 += pp[j]; a1 += pp[j + 1]; a2 += pp[j + 2]; a3 += pp[j + 3]; }
+            for (; j < bps; ++j) a0 += pp[j];
+            loss = loss + ((a0 + a1) + (a2 + a3));
+            loss_acc[s] = loss;
+        }
+        keep = (loss > loss_fraction * flux) && can_grow;
+        if (keep) loss_acc[s] = 0.0;                      // evolve_source.F90:133
+        else { final_loss[s] = loss; final_nbox[s] = nbox; }
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (keep) active_out[__popcll(mask & ((1ULL << i) - 1ULL))] = s;
+    const int n_keep = __popcll(mask);
+    if (i == 0) { *n_out = n_keep; *n_out_host = n_keep; }
+    if (tot.on && n_keep == 0) {
+        __threadfence_block();                            // (one wave: the stores above are ordered before the loads below)
+        for (int t = i; t < tot.nsrc; t += 64) { tot.host_final_nbox[t] = final_nbox[t]; tot.host_final_loss[t] = final_loss[t]; }
+        if (i == 0) {
+            double L = 0.0; long long NB = 0;
+            for (int t = 0; t < tot.nsrc; ++t) { L = L + (0.0 + final_loss[t]); NB += final_nbox[t]; }
+            *tot.photon_loss = L; *tot.sum_nbox = NB;
+            *tot.host_loss = L; *tot.host_nbox = NB;
+        }
+    }
 }
 
 // photon_loss(1) += photon_loss_src, in source order (evolve_source.F90:216); sum_nbox (:219).
