@@ -292,22 +292,41 @@ bool box_is_fused(const Ctx *ctx, int nbox, bool pair_ok)
     return ctx->fuse_small && q1 <= kFusedQmax && q1 - q0 + 1 <= kMaxFused && !(pair_ok && nbox > 1);
 }
 
-int plane_set_before(const Ctx *ctx, int nbox, bool pair_ok)
+// Shells q and q + 1 of sub-box nb as one look-ahead launch (k_sweep_pair_fast)?  Neither shell has cells on the sub-box
+// surface (their loss partials and the order of the loss sums stay those of single launches), both have cells, and the
+// second shell's threads -- one per cell and source, each redoing the arithmetic of ~5 cells -- fit the GPU at once: the
+// pair trades arithmetic for a dependent launch, which pays only while a launch is latency (measured, profiles/
+// r03_launch_bound: 128^3 x 1 source 0.385 -> 0.305 ms per iteration, 256^3 x 32 sources 6.4 -> 17.9 ms without this limit).
+constexpr long long kPairMaxCells = 160000;
+long long shell_cells(const Ctx *ctx, int q)
+{
+    long long c = 0;
+    for (int f = 0; f < 6; ++f) { const FaceRect r = face_rect(ctx, f, q); if (r.ntiles > 0) c += (long long)r.wa * r.wb; }
+    return c;
+}
+bool shell_on_surface(const Ctx *ctx, int nb, int q)
+{
+    for (int d = 0; d < 3; ++d)
+        if (std::min(ctx->prm.subboxsize * nb, ctx->hr[d]) <= q || std::min(ctx->prm.subboxsize * nb, ctx->hl[d]) <= q) return true;
+    return false;
+}
+bool pair_here(const Ctx *ctx, int nb, int q, int q1, int n_active, bool pair_ok)
+{
+    if (!pair_ok || q + 1 > q1 || shell_on_surface(ctx, nb, q) || shell_on_surface(ctx, nb, q + 1)) return false;
+    const long long c0 = shell_cells(ctx, q), c1 = shell_cells(ctx, q + 1);
+    return c0 > 0 && c1 > 0 && (long long)n_active * c1 <= kPairMaxCells;
+}
+
+int plane_set_before(const Ctx *ctx, int nbox, int n_active, bool pair_ok)
 {
     const c2r_params &p = ctx->prm;
     int set = 0;
     for (int nb = 1; nb < nbox; ++nb) {
         const int q0 = p.subboxsize * (nb - 1) + 1, q1 = std::min(p.subboxsize * nb, ctx->Qmax);
         const bool fused = box_is_fused(ctx, nb, pair_ok);
-        auto tiles = [&](int q) { for (int f = 0; f < 6; ++f) if (face_rect(ctx, f, q).ntiles > 0) return true; return false; };
-        auto surface = [&](int q) {
-            for (int d = 0; d < 3; ++d)
-                if (std::min(p.subboxsize * nb, ctx->hr[d]) <= q || std::min(p.subboxsize * nb, ctx->hl[d]) <= q) return true;
-            return false;
-        };
         for (int q = q0; q <= q1; ++q) {
-            if (!tiles(q)) continue;
-            if (!fused && pair_ok && !surface(q) && q + 1 <= q1 && tiles(q + 1) && !surface(q + 1)) ++q;
+            if (shell_cells(ctx, q) == 0) continue;
+            if (!fused && pair_here(ctx, nb, q, q1, n_active, pair_ok)) ++q;
             set ^= 1;
         }
     }
@@ -390,7 +409,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
         // shells in one alternation -- a pure function of the schedule up to this sub-box (a replayed graph does not run
         // this code), see plane_set_before
         const bool pair_ok = ctx->fast && ctx->pair_shells && n_active <= kFewSources && !dbg && ctx->prof != 1;
-        int pbuf = plane_set_before(ctx, nbox, pair_ok);
+        int pbuf = plane_set_before(ctx, nbox, n_active, pair_ok);
         const bool fused_box = box_is_fused(ctx, nbox, pair_ok);
         // (the fused first sub-box does the source cells itself: one launch less)
         if (nbox == 1 && !(fused_box && ctx->fold_source_cell)) {
@@ -481,9 +500,9 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             // the second recomputes the first's column densities) -- half the dependent launches where a launch is nothing
             // but latency.  Not where either shell has cells on the sub-box surface (their loss partials and the order of
             // the loss sums stay those of the single launches).
-            if (pair_ok && !sa.has_boundary && q + 1 <= q1) {
+            if (pair_here(ctx, nbox, q, q1, n_active, pair_ok)) {
                 ShellArgs sb = shell_args(q + 1);
-                if (sb.tiles_max > 0 && !sb.has_boundary) {
+                {
                     // the second shell's threads take kPairRows rows each (its per-thread work is the recompute of
                     // 2 (rows + 1) cells of the first shell: short chains on more threads, the GPU is empty anyway)
                     sb.tiles_max = 0;

@@ -1035,7 +1035,7 @@ __global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
 // the first shell's column densities where it needs them (lookahead_cd_out).  The first shell's planes are not stored
 // (nobody reads them); the second shell's go to the other plane set, which the next launch reads.
 template <bool DET, int LLS, bool STREAM, bool HEAT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2)))     // latency-bound by design: registers, not occupancy
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 4)))     // latency-bound by design: registers before occupancy
 void k_sweep_pair_fast(KParams p, ShellArgs sa, ShellArgs sb)
 {
     __shared__ double sm[16];
