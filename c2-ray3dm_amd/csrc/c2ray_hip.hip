@@ -104,9 +104,12 @@ struct Ctx {
     // reductions
     double *d_sum_partial = nullptr, *d_sum_out = nullptr, *d_stat_partial = nullptr;
     unsigned long long *d_conv = nullptr; unsigned int *d_chemfail = nullptr;
-    struct HostScalars { double sum; double photon_loss; long long sum_nbox; unsigned long long conv; unsigned int chemfail; double pair[2]; double four[4]; } *h_sc = nullptr,  // pinned
+    struct HostScalars { double sum; double photon_loss; long long sum_nbox; unsigned long long conv; unsigned int chemfail; double pair[2]; double four[4];
+                         unsigned long long seq; } *h_sc = nullptr,  // pinned
       *d_hsc = nullptr;                       // ... and its device alias: kernels store results there directly
     double *d_dbg = nullptr, *d_pair = nullptr;
+    unsigned long long *d_seq = nullptr, seq_seen = 0;           // passes completed by fused iterations (k_pass_final counts, the host polls h_sc->seq)
+    bool spin_wait = true;                                       // C2R_SPIN_WAIT=0: always hipStreamSynchronize (experiments)
     double *h_it4 = nullptr, *d_hit4 = nullptr;   // pinned [C2R_MAX_ITER_LOG][4]: per-iteration photon-statistics sums, written by the device
     // profiling
     int prof = 0;               // 0 off; 1 an event pair around every k_sweep_shell launch; 2 one pair per sub-box
@@ -646,15 +649,33 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             } else { (void)hipGetLastError(); ctx->use_graph = false; }
         }
         if (bg.exec) {
+            const int done = std::min(hint, ctx->nbox_max);
+            if (bg.fused) ctx->h_nactive[done] = -1;              // (so that a stale zero is not taken for this launch's count)
             HIP_TRY(hipGraphLaunch(bg.exec, st));
             uploaded = true;
             pre_run = bg.fused;
-            const int done = std::min(hint, ctx->nbox_max);
             cur = done & 1;
-            HIP_TRY(hipStreamSynchronize(st));
+            bool arrived = false;
+            if (bg.fused && ctx->spin_wait) {
+                // The last kernel of the gated tail stores the count of completed passes to pinned memory as its final
+                // act: poll it (and the sub-box count, which tells a shut gate) instead of blocking -- the wake-up of a
+                // stream synchronize is a tenth of a 0.26 ms iteration.  Bounded: after 2 ms the ordinary wait takes over.
+                const unsigned long long want = ctx->seq_seen + 1;
+                const auto t0 = std::chrono::steady_clock::now();
+                for (unsigned spins = 0;; ++spins) {
+                    if (__atomic_load_n(&ctx->h_sc->seq, __ATOMIC_ACQUIRE) == want) { arrived = true; break; }
+                    if (__atomic_load_n(&ctx->h_nactive[done], __ATOMIC_ACQUIRE) > 0) break;
+                    if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+                    __builtin_ia32_pause();
+                }
+            }
+            if (!arrived) {
+                HIP_TRY(hipStreamSynchronize(st));
+                arrived = bg.fused && __atomic_load_n(&ctx->h_sc->seq, __ATOMIC_ACQUIRE) == ctx->seq_seen + 1;
+            }
             known = done; bound = ctx->h_nactive[done];
             first_box = done + 1;
-            if (bg.fused && bound == 0) fz->tail_done = true;     // the gate was open: the whole iteration has run
+            if (bg.fused && arrived) { ctx->seq_seen += 1; bound = 0; fz->tail_done = true; }   // the gate was open: the whole iteration has run
         } else cur = 0;
     }
     if (fz && !pre_run) { const int rc = fz->pre(); if (rc) return rc; }
@@ -852,6 +873,7 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     if (const char *e = getenv("C2R_GRAPH")) ctx->use_graph = atoi(e) != 0;
     if (const char *e = getenv("C2R_FUSED_ITER")) ctx->fused_iter = atoi(e) != 0;
     if (const char *e = getenv("C2R_PAIR_SHELLS")) ctx->pair_shells = atoi(e) != 0;
+    if (const char *e = getenv("C2R_SPIN_WAIT")) ctx->spin_wait = atoi(e) != 0;
     if (const char *e = getenv("C2R_FOLD_SOURCE_CELL")) ctx->fold_source_cell = atoi(e) != 0;
     if (p->sweep_mode != C2R_SWEEP_EXACT && p->sweep_mode != C2R_SWEEP_FAST) { delete ctx; return C2R_EINVAL; }
     ctx->fast = p->sweep_mode == C2R_SWEEP_FAST;          // the caller's choice only: no environment override
@@ -921,6 +943,8 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipMalloc(&ctx->d_conv, sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&ctx->d_chemfail, sizeof(unsigned int)));
     HIP_TRY(hipMalloc(&ctx->d_pair, 2 * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_seq, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ctx->d_seq, 0, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(ctx->d_conv, 0, sizeof(unsigned long long)));     // k_pass_final leaves them at zero again
     HIP_TRY(hipMemset(ctx->d_chemfail, 0, sizeof(unsigned int)));
     // pinned host scalars that kernels write straight through their mapped device pointers
@@ -964,7 +988,7 @@ void c2r_destroy(c2r_ctx *c)
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
     hipFree(ctx->d_photon_loss); hipFree(ctx->d_sum_nbox); hipFree(ctx->d_sum_partial); hipFree(ctx->d_sum_out); hipFree(ctx->d_stat_partial);
-    hipFree(ctx->d_conv); hipFree(ctx->d_chemfail); hipFree(ctx->d_dbg); hipFree(ctx->d_pair); hipFree(ctx->d_nbox_all);
+    hipFree(ctx->d_conv); hipFree(ctx->d_chemfail); hipFree(ctx->d_dbg); hipFree(ctx->d_pair); hipFree(ctx->d_seq); hipFree(ctx->d_nbox_all);
     if (ctx->h_nbox_all) hipHostFree(ctx->h_nbox_all);
     if (ctx->h_sc) hipHostFree(ctx->h_sc);
     if (ctx->h_it4) hipHostFree(ctx->h_it4);
@@ -1482,7 +1506,8 @@ int c2r_photon_sums(c2r_ctx *c, int32_t which_l, int32_t which_r, double out[4])
 }
 
 // the launches of a global pass, no host wait; gate: see k_transpose_xy
-static int global_pass_enqueue(Ctx *ctx, double dt, double *stats_dst, size_t cell_off, size_t cell_cnt, const int *gate)
+static int global_pass_enqueue(Ctx *ctx, double dt, double *stats_dst, size_t cell_off, size_t cell_cnt, const int *gate,
+                               bool count_pass = false)
 {
     const c2r_params &p = ctx->prm;
     ChemParams cp{};
@@ -1519,10 +1544,12 @@ static int global_pass_enqueue(Ctx *ctx, double dt, double *stats_dst, size_t ce
     else { if (ctx->thermal) C2R_LAUNCH_GLOBAL(false, true); else C2R_LAUNCH_GLOBAL(false, false); }
 #undef C2R_LAUNCH_GLOBAL
     prof_end(ctx, ctx->ev_chem, ctx->ev_chem_used);
-    hipLaunchKernelGGL(k_pass_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, ctx->d_conv,
-                       ctx->d_chemfail, &ctx->d_hsc->sum, &ctx->d_hsc->conv, &ctx->d_hsc->chemfail, gate);
     if (stats_dst)
         hipLaunchKernelGGL(k_sum_final, dim3(4), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_stat_partial, stats_dst, gate);
+    // last: its final store is the pass counter a fused iteration's host polls (count_pass)
+    hipLaunchKernelGGL(k_pass_final, dim3(1), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, ctx->d_conv,
+                       ctx->d_chemfail, &ctx->d_hsc->sum, &ctx->d_hsc->conv, &ctx->d_hsc->chemfail, gate,
+                       count_pass ? ctx->d_seq : nullptr, count_pass ? &ctx->d_hsc->seq : nullptr);
     HIP_TRY(hipGetLastError());
     return C2R_OK;
 }
@@ -1582,7 +1609,7 @@ static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, i
         fz.pre = [ctx]() -> int { return sweep_prepare(ctx, true); };
         fz.post = [ctx, dt, four](const int *gate) -> int {
             const int r = sweep_finish(ctx, gate);
-            return r ? r : global_pass_enqueue(ctx, dt, four, 0, ctx->ncell, gate);
+            return r ? r : global_pass_enqueue(ctx, dt, four, 0, ctx->ncell, gate, gate != nullptr);
         };
         if ((rc = pass_sources_impl(ctx, &fz, loss, nb, vis))) return rc;
         if (!fz.tail_done) {               // no graph, or a source went on beyond the sub-box the graph ends at

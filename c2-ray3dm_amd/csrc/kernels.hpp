@@ -1642,8 +1642,11 @@ __global__ __launch_bounds__(256) void k_sum_final(int n, const double *partial,
 __global__ __launch_bounds__(256) void k_pass_final(int n, const double *partial, unsigned long long *conv,
                                                     unsigned int *chem_fail, double *host_sum,
                                                     unsigned long long *host_conv, unsigned int *host_fail,
-                                                    const int *gate = nullptr)
+                                                    const int *gate = nullptr, unsigned long long *dev_seq = nullptr,
+                                                    unsigned long long *host_seq = nullptr)
 {
+    // dev_seq / host_seq (fused iteration): a counter of completed passes, stored to the host LAST -- the host polls it
+    // instead of blocking in a stream synchronize (whose wake-up is a tenth of a 0.26 ms iteration)
     __shared__ double sm[4];
     if (gate && *gate != 0) return;
     double v = 0.0;
@@ -1652,6 +1655,12 @@ __global__ __launch_bounds__(256) void k_pass_final(int n, const double *partial
     if (threadIdx.x == 0) {
         *host_sum = tot; *host_conv = *conv; *host_fail = *chem_fail;
         *conv = 0ULL; *chem_fail = 0u;
+        if (host_seq) {
+            const unsigned long long sq = *dev_seq + 1ULL;
+            *dev_seq = sq;
+            __threadfence_system();
+            __hip_atomic_store(host_seq, sq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
