@@ -411,7 +411,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
         // which plane set holds shell q0 - 1: the shells alternate between the two sets, a look-ahead pair advances two
         // shells in one alternation -- a pure function of the schedule up to this sub-box (a replayed graph does not run
         // this code), see plane_set_before
-        const bool pair_ok = ctx->fast && ctx->pair_shells && n_active <= kFewSources && !dbg && ctx->prof != 1;
+        const bool pair_ok = ctx->pair_shells && n_active <= kFewSources && !dbg && ctx->prof != 1;
         int pbuf = plane_set_before(ctx, nbox, n_active, pair_ok);
         const bool fused_box = box_is_fused(ctx, nbox, pair_ok);
         // (the fused first sub-box does the source cells itself: one launch less)
@@ -513,8 +513,11 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                     sb.buf_prev = pbuf; sb.buf_cur = 1 - pbuf;        // (buf_prev of the second shell is never read)
                     ++in_box;
                     const dim3 grid(std::max(sa.tiles_max, sb.tiles_max), 12, bound), blk(kBlock);
-#define C2R_LAUNCH_PAIR_H(D, L, H) do { if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_pair_fast<D, L, true, H>), grid, blk, 0, st, k, sa, sb); \
-                                    else hipLaunchKernelGGL((k_sweep_pair_fast<D, L, false, H>), grid, blk, 0, st, k, sa, sb); } while (0)
+#define C2R_LAUNCH_PAIR_H(D, L, H) do { \
+    if (ctx->fast) { if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_pair_fast<D, L, true, H>), grid, blk, 0, st, k, sa, sb); \
+                     else hipLaunchKernelGGL((k_sweep_pair_fast<D, L, false, H>), grid, blk, 0, st, k, sa, sb); } \
+    else if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_pair<D, L, true, H>), grid, blk, 0, st, k, sa, sb); \
+    else hipLaunchKernelGGL((k_sweep_pair<D, L, false, H>), grid, blk, 0, st, k, sa, sb); } while (0)
 #define C2R_LAUNCH_PAIR(D, L) do { if (ctx->thermal) C2R_LAUNCH_PAIR_H(D, L, true); else C2R_LAUNCH_PAIR_H(D, L, false); } while (0)
                     switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
                         case 2: C2R_LAUNCH_PAIR(false, 1); break;

@@ -427,7 +427,9 @@ __device__ __forceinline__ unsigned plane_off8(const KParams &p, int a, int b)
     return ((unsigned)((int)__umul24((unsigned)(b + p.R), (unsigned)p.P) + (a + p.R))) * 8u;   // factors in [0, 2^24)
 }
 
-template <int LLS, bool STREAM>
+// XONLY: read n_HI and the LLS grid from the x-fastest arrays whatever the face (same values; the look-ahead recompute
+// calls this with a per-lane face and must not pick a buffer per lane)
+template <int LLS, bool STREAM, bool XONLY = false>
 __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArgs &sa, const int face, const int s,
                                                 const int a, const int b, const double c1v, const double c2v,
                                                 const double c3v, const double c4v, const double r1, const double r2,
@@ -447,7 +449,7 @@ __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArg
     const unsigned c2 = wrap_pos(p.srcw[3 * s + 2], p.n[2], dl.d2);
     // cell index in the array this face reads: x-fastest, or y-fastest in the transposed replicas
     // (block-uniform choice; 24-bit multiplies: every factor is below 2^24)
-    const bool xf = (axis == 0);
+    const bool xf = !XONLY && (axis == 0);
     const unsigned ca = xf ? c1 : c0, cb = xf ? c0 : c1;
     const unsigned na = xf ? (unsigned)p.n[1] : (unsigned)p.n[0], nb = xf ? (unsigned)p.n[0] : (unsigned)p.n[1];
     cs.id = ca + __umul24(na, cb + __umul24(nb, c2));
@@ -502,7 +504,7 @@ __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArg
 }
 
 // Returns the cell's photon-loss contribution (0 unless it lies on the sub-box surface).
-template <bool DET, int LLS, bool STREAM, bool HEAT>
+template <bool DET, int LLS, bool STREAM, bool HEAT, bool STORE = true>
 __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                               const int face, const int s, const int a, const int b, const CellState &cs)
 {
@@ -515,8 +517,9 @@ __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs 
     const unsigned plane_bytes = (unsigned)p.PP * 8u;
     const double cd_out = cs.cd_out;
     // store into this face's plane and into the planes of the faces sharing the cell
-    const __amdgpu_buffer_rsrc_t r_cur = make_rsrc(p.planes + ((size_t)s * 2 + (q & 1)) * 6 * p.PP, 6u * plane_bytes);
+    const __amdgpu_buffer_rsrc_t r_cur = make_rsrc(p.planes + ((size_t)s * 2 + sa.buf_cur) * 6 * p.PP, 6u * plane_bytes);
     constexpr int SA = STREAM ? C2R_STORE_AUX : 0;
+    if (STORE) {                 // (off for the first shell of a look-ahead pair: nothing reads its planes)
     buf_store_f64<SA>(r_cur, (unsigned)face * plane_bytes + cs.o8, cd_out);
     if (axis == 2) {
         if (abs(a) == q)   // x-face (u=y=b, v=z=pd)
@@ -526,6 +529,7 @@ __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs 
     } else if (axis == 1) {
         if (abs(a) == q)   // x-face (u=y=pd, v=z=b)
             buf_store_f64<SA>(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((b + p.R) * p.P + (pd + p.R)) * 8u, cd_out);
+    }
     }
     const Delta3 dl = mesh_delta(axis, pd, a, b);          // recomputed, not carried in CellState
     if (sa.dbg_cdout) {                                     // single-source test path: the N^3 coldensh_out
@@ -566,7 +570,7 @@ __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &
     const int am = a - sga, bm = b - sgb;
     const unsigned plane_bytes = (unsigned)p.PP * 8u;
     const __amdgpu_buffer_rsrc_t r_prev =
-        make_rsrc(p.planes + ((size_t)s * 2 + (qm & 1)) * 6 * p.PP + (size_t)face * p.PP, plane_bytes);
+        make_rsrc(p.planes + ((size_t)s * 2 + sa.buf_prev) * 6 * p.PP + (size_t)face * p.PP, plane_bytes);
     const bool ina = abs(a) <= qm, inam = abs(am) <= qm, inb = abs(b) <= qm, inbm = abs(bm) <= qm;
     const unsigned p8 = (unsigned)p.P * 8u;
     const unsigned o8 = plane_off8(p, a, b), da8 = (unsigned)(sga * 8), db8 = b < 0 ? 0u - p8 : p8;
@@ -590,7 +594,8 @@ __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &
 #define C2R_ROWS 3
 #endif
 constexpr int kRows = C2R_ROWS;
-template <bool DET, int LLS, bool STREAM, bool HEAT>
+constexpr int kPairRows = 1;        // rows per thread of the second shell of a look-ahead pair (k_sweep_pair, k_sweep_pair_fast)
+template <bool DET, int LLS, bool STREAM, bool HEAT, bool STORE = true>
 __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                              const int face, const int s, const int a, const int b0, const int sgb,
                                              const int nvalid)
@@ -600,7 +605,7 @@ __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &
     const int am = a - sga;
     const unsigned plane_bytes = (unsigned)p.PP * 8u;
     const __amdgpu_buffer_rsrc_t r_prev =
-        make_rsrc(p.planes + ((size_t)s * 2 + (qm & 1)) * 6 * p.PP + (size_t)face * p.PP, plane_bytes);
+        make_rsrc(p.planes + ((size_t)s * 2 + sa.buf_prev) * 6 * p.PP + (size_t)face * p.PP, plane_bytes);
     const bool ina = abs(a) <= qm, inam = abs(am) <= qm;
     const unsigned p8 = (unsigned)p.P * 8u;
     const unsigned da8 = (unsigned)(sga * 8), db8 = sgb < 0 ? 0u - p8 : p8;
@@ -623,21 +628,70 @@ __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &
 #if C2R_ROWS >= 4
     const CellState c3 = cell_state<LLS, STREAM>(p, sa, face, s, a, b0 + 3 * sgb, vm[3], va[3], vm[4], va[4], rm[3], ra[3], rm[4], ra[4]);
 #endif
-    double loss = cell_commit<DET, LLS, STREAM, HEAT>(p, sa, ltab, face, s, a, b0, c0);
-    if (nvalid > 1) loss = loss + cell_commit<DET, LLS, STREAM, HEAT>(p, sa, ltab, face, s, a, b0 + sgb, c1);
+    double loss = cell_commit<DET, LLS, STREAM, HEAT, STORE>(p, sa, ltab, face, s, a, b0, c0);
+    if (nvalid > 1) loss = loss + cell_commit<DET, LLS, STREAM, HEAT, STORE>(p, sa, ltab, face, s, a, b0 + sgb, c1);
 #if C2R_ROWS >= 3
-    if (nvalid > 2) loss = loss + cell_commit<DET, LLS, STREAM, HEAT>(p, sa, ltab, face, s, a, b0 + 2 * sgb, c2);
+    if (nvalid > 2) loss = loss + cell_commit<DET, LLS, STREAM, HEAT, STORE>(p, sa, ltab, face, s, a, b0 + 2 * sgb, c2);
 #endif
 #if C2R_ROWS >= 4
-    if (nvalid > 3) loss = loss + cell_commit<DET, LLS, STREAM, HEAT>(p, sa, ltab, face, s, a, b0 + 3 * sgb, c3);
+    if (nvalid > 3) loss = loss + cell_commit<DET, LLS, STREAM, HEAT, STORE>(p, sa, ltab, face, s, a, b0 + 3 * sgb, c3);
 #endif
     return loss;
 }
 
-// STREAM: the non-temporal cache policy above (the host turns it on for meshes whose n_HI array outgrows the L2s)
+// Look-ahead of the exact mode (k_sweep_pair; see lookahead_cd_out of the fast mode below for the idea): the column density that
+// shell sq.q leaves in plane `face` at (a, b), recomputed from the planes of shell sq.q - 1 with cell_state -- the arithmetic of
+// the launch that owns the cell, in the owner's geometry.  Straight-line code: a thread's four recomputes share their waits.
+template <int LLS, bool STREAM>
+__device__ __forceinline__ double lookahead_cd_out_exact(const KParams &p, const ShellArgs &sq, const int face, const int s,
+                                                         const int a, const int b)
+{
+    const int q = sq.q, qm = q - 1;
+    const bool inside = abs(a) <= q && abs(b) <= q;           // else a zero-weight corner (an OOB load reads 0)
+    const int axis = 2 - (face >> 1);
+    const int pd = (face & 1) ? -q : q;
+    int fo = face, ao = a, bo = b;                            // the owner of the cell and its coordinates there
+    if (axis == 1) { if (abs(b) == q) { fo = b > 0 ? 0 : 1; ao = a; bo = pd; } }
+    else if (axis == 0) {
+        if (abs(b) == q) { fo = b > 0 ? 0 : 1; ao = pd; bo = a; }
+        else if (abs(a) == q) { fo = a > 0 ? 2 : 3; ao = pd; bo = b; }
+    }
+    const int sga = ao < 0 ? -1 : 1, sgb = bo < 0 ? -1 : 1;
+    const int am = ao - sga, bm = bo - sgb;
+    const unsigned plane_bytes = (unsigned)p.PP * 8u;
+    const __amdgpu_buffer_rsrc_t r_prev = make_rsrc(p.planes + ((size_t)s * 2 + sq.buf_prev) * 6 * p.PP, 6u * plane_bytes);
+    const bool ina = abs(ao) <= qm, inam = abs(am) <= qm, inb = abs(bo) <= qm, inbm = abs(bm) <= qm;
+    const unsigned base = (unsigned)fo * plane_bytes;
+    constexpr int PA = STREAM ? C2R_PLANE_AUX : 0;
+    const double c1v = buf_load_f64<PA>(r_prev, (inam && inbm) ? base + plane_off8(p, am, bm) : kOOB);
+    const double c2v = buf_load_f64<PA>(r_prev, (ina && inbm) ? base + plane_off8(p, ao, bm) : kOOB);
+    const double c3v = buf_load_f64<PA>(r_prev, (inam && inb) ? base + plane_off8(p, am, bo) : kOOB);
+    const double c4v = buf_load_f64<PA>(r_prev, (ina && inb) ? base + plane_off8(p, ao, bo) : kOOB);
+    const CellState cs = cell_state<LLS, STREAM, true>(p, sq, fo, s, ao, bo, c1v, c2v, c3v, c4v, weight_rcp(p, c1v),
+                                                       weight_rcp(p, c2v), weight_rcp(p, c3v), weight_rcp(p, c4v));
+    return inside ? cs.cd_out : 0.0;
+}
+// one cell of the second shell of a pair: its four upstream corners recomputed
 template <bool DET, int LLS, bool STREAM, bool HEAT>
+__device__ __forceinline__ double shell_cell_look(const KParams &p, const ShellArgs &sa, const ShellArgs &sq,
+                                                  const v2f64 *__restrict__ ltab, const int face, const int s, const int a, const int b)
+{
+    const int sga = a < 0 ? -1 : 1, sgb = b < 0 ? -1 : 1;
+    const int am = a - sga, bm = b - sgb;
+    const double c1v = lookahead_cd_out_exact<LLS, STREAM>(p, sq, face, s, am, bm);
+    const double c2v = lookahead_cd_out_exact<LLS, STREAM>(p, sq, face, s, a, bm);
+    const double c3v = lookahead_cd_out_exact<LLS, STREAM>(p, sq, face, s, am, b);
+    const double c4v = lookahead_cd_out_exact<LLS, STREAM>(p, sq, face, s, a, b);
+    const CellState cs = cell_state<LLS, STREAM>(p, sa, face, s, a, b, c1v, c2v, c3v, c4v, weight_rcp(p, c1v), weight_rcp(p, c2v),
+                                                 weight_rcp(p, c3v), weight_rcp(p, c4v));
+    return cell_commit<DET, LLS, STREAM, HEAT>(p, sa, ltab, face, s, a, b, cs);
+}
+
+// STREAM: the non-temporal cache policy above (the host turns it on for meshes whose n_HI array outgrows the L2s)
+// LOOK (sq = the previous shell's arguments): one row per thread (FaceRect built for kPairRows), corners recomputed
+template <bool DET, int LLS, bool STREAM, bool HEAT, int LOOK = 0, bool STORE = true>
 __device__ __forceinline__ void sweep_tile(const KParams &p, const ShellArgs &sa, const FaceRect &fr, const v2f64 *ltab,
-                                           double *sm, const int face, const int tile, const int sl)
+                                           double *sm, const int face, const int tile, const int sl, const ShellArgs &sq)
 {
     double loss = 0.0;
     const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
@@ -646,11 +700,13 @@ __device__ __forceinline__ void sweep_tile(const KParams &p, const ShellArgs &sa
         const int a = fr.a_lo + (int)(t - __umul24(bi, (unsigned)fr.wa));
         // rows are grouped outward from 0 within each sign class: (0..kRows-1), ... then (-1..-kRows), ...
         const bool pos = bi < (unsigned)fr.pp;
-        const int k0 = kRows * (pos ? (int)bi : (int)bi - fr.pp);
+        constexpr int NR = LOOK ? kPairRows : kRows;
+        const int k0 = NR * (pos ? (int)bi : (int)bi - fr.pp);
         const int sgb = pos ? 1 : -1;
         const int b0 = pos ? k0 : -1 - k0;
         const int left = pos ? (fr.b_lo + fr.wb - b0) : (b0 - fr.b_lo + 1);     // rows from b0 to the end of the class
-        loss = shell_rows<DET, LLS, STREAM, HEAT>(p, sa, ltab, face, sa.active[sl], a, b0, sgb, min(left, kRows));
+        if (LOOK) loss = shell_cell_look<DET, LLS, STREAM, HEAT>(p, sa, sq, ltab, face, sa.active[sl], a, b0);
+        else loss = shell_rows<DET, LLS, STREAM, HEAT, STORE>(p, sa, ltab, face, sa.active[sl], a, b0, sgb, min(left, kRows));
     }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
@@ -671,7 +727,33 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
     const FaceRect fr = sa.face[face];
     if (tile >= fr.ntiles && !sa.has_boundary) return;   // block-uniform: nothing to do and no partial to write
     const v2f64 *ltab = wave_log_table(p.logtab, s_log);
-    sweep_tile<DET, LLS, STREAM, HEAT>(p, sa, fr, ltab, sm, face, tile, (int)blockIdx.z);
+    sweep_tile<DET, LLS, STREAM, HEAT>(p, sa, fr, ltab, sm, face, tile, (int)blockIdx.z, sa);
+}
+
+// The look-ahead pair of the exact mode (see k_sweep_pair_fast below): shell sa.q in blockIdx.y 0..5 (planes not stored),
+// shell sb.q = sa.q + 1 in 6..11 (corners recomputed, one row per thread).
+template <bool DET, int LLS, bool STREAM, bool HEAT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 4)))
+void k_sweep_pair(KParams p, ShellArgs sa, ShellArgs sb)
+{
+    __shared__ double sm[16];
+    __shared__ v2f64 s_log[kBlock];
+    const bool second = blockIdx.y >= 6;
+    const int face = second ? (int)blockIdx.y - 6 : (int)blockIdx.y;
+    const int tile = blockIdx.x;
+    const int nact = *sa.n_active;
+    if ((int)blockIdx.z >= nact) return;
+    if (second) {
+        const FaceRect fr = sb.face[face];
+        if (tile >= fr.ntiles) return;
+        const v2f64 *ltab = wave_log_table(p.logtab, s_log);
+        sweep_tile<DET, LLS, STREAM, HEAT, 1, true>(p, sb, fr, ltab, sm, face, tile, (int)blockIdx.z, sa);
+    } else {
+        const FaceRect fr = sa.face[face];
+        if (tile >= fr.ntiles) return;
+        const v2f64 *ltab = wave_log_table(p.logtab, s_log);
+        sweep_tile<DET, LLS, STREAM, HEAT, 0, false>(p, sa, fr, ltab, sm, face, tile, (int)blockIdx.z, sa);
+    }
 }
 
 // ==== tolerance ("fast") mode of the sweep =======================================================
@@ -989,7 +1071,6 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
 #define C2R_FAST_ATTR __launch_bounds__(kBlock)
 #endif
 // one (source, face, tile) block of work of k_sweep_shell_fast; sl = position in the active list
-constexpr int kPairRows = 1;        // rows per thread of the second shell of a look-ahead pair (k_sweep_pair_fast)
 template <bool DET, int LLS, bool STREAM, bool HEAT, int LOOK = 0, bool STORE = true, int NR = kRows>
 __device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArgs &sa, const FaceRect &fr, const v2f64 *ltab,
                                                 const double *thick, double *sm, const int face, const int tile, const int sl,

@@ -49,14 +49,15 @@ def _backend(pkg, n, S, seed, x, fast, det, monkeypatch, env, lls=1, thermal=Fal
     return b, s
 
 
+@pytest.mark.parametrize("fast", [True, False])
 @pytest.mark.parametrize("n,S,x,lls,thermal", [(64, 5, 0.9995, 1, False), (96, 12, 0.9995, 2, False), (64, 9, 0.999, 3, False),
                                                (64, 6, 0.9995, 1, True), (130, 3, 0.99995, 1, False), (48, 30, 0.99, 2, True)])
-def test_lookahead_pairs_equal_one_launch_per_shell(pkg, monkeypatch, n, S, x, lls, thermal):
-    """One pass with C2R_PAIR_SHELLS=0 (one launch per shell) and =1 (the default): every template variant of the pair kernel
-    (LLS type x heating) leaves the same sub-box counts, the same loss and -- rates in source order -- the same bits."""
+def test_lookahead_pairs_equal_one_launch_per_shell(pkg, monkeypatch, fast, n, S, x, lls, thermal):
+    """One pass with C2R_PAIR_SHELLS=0 (one launch per shell) and =1 (the default): every template variant of the pair kernels
+    (sweep mode x LLS type x heating) leaves the same sub-box counts, the same loss and -- rates in source order -- the same bits."""
     out = []
     for pair in ("0", "1"):
-        b, _ = _backend(pkg, n, S, 11 * n + S, x, True, True, monkeypatch, {"C2R_PAIR_SHELLS": pair}, lls, thermal)
+        b, _ = _backend(pkg, n, S, 11 * n + S, x, fast, True, monkeypatch, {"C2R_PAIR_SHELLS": pair}, lls, thermal)
         b.zero_rates()
         loss, nb, vis = b.pass_sources()
         loss2, nb2, vis2 = b.pass_sources()              # a second pass takes the hipGraph path (box_hint known)
