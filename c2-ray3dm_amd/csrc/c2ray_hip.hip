@@ -1321,7 +1321,10 @@ int c2r_zero_rates(c2r_ctx *c)
 
 // do_grid over this rank's sources.  fz (c2r_iterate, one small batch): the batch's graph also carries what precedes and
 // follows the pass (sweep_batch); sweep_prepare / sweep_finish are then fz->pre / fz->post, not called here.
-static int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64_t *sum_nbox, int64_t *visited)
+// no_wait (iterate_impl): return with sweep_finish enqueued and not waited for -- the caller enqueues the global pass behind
+// it, waits once and reads the totals itself (they are in h_sc after that wait).
+static int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64_t *sum_nbox, int64_t *visited,
+                             bool no_wait = false)
 {
     int rc;
     balance_before_pass(ctx);
@@ -1345,6 +1348,8 @@ static int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64
         ctx->box_hint = 0;
         for (int v : ctx->last_nbox) ctx->box_hint = std::max(ctx->box_hint, v);
     } else if (fz && (rc = fz->pre())) return rc;
+    if (visited) *visited = vis;
+    if (no_wait) return C2R_OK;
     if (!fz) HIP_TRY(hipStreamSynchronize(ctx->stream));        // k_batch_totals stored the totals in h_sc
     prof_collect(ctx);
     if ((rc = balance_after_pass(ctx))) return rc;
@@ -1603,9 +1608,12 @@ static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, i
     };
     double *four = stats_host ? ctx->d_hsc->four : nullptr;
     if (!can_fuse) {
+        // the three steps, with one wait behind the global pass instead of one behind each of the last two
         if ((rc = zero_rates())) return rc;
-        if ((rc = pass_sources_impl(ctx, nullptr, loss, nb, vis))) return rc;
+        if ((rc = pass_sources_impl(ctx, nullptr, nullptr, nullptr, vis, ctx->nranks == 1 && !ctx->balance))) return rc;
         if ((rc = global_pass_impl(ctx, dt, conv, sum1, four))) return rc;
+        if (loss) *loss = ctx->h_sc->photon_loss;
+        if (nb) *nb = ctx->h_sc->sum_nbox;
     } else {
         FusedIter fz;
         fz.dt = dt; fz.stats = stats_host != nullptr;
