@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true",
                     help="skip the short leg that times the same steps in the OTHER sweep mode (reported as `other_sweep_mode`)")
+    ap.add_argument("--no-small-leg", action="store_true",
+                    help="skip the short leg that times BASELINE configs[1] (128^3, one source: the launch-bound regime; reported "
+                         "as `configs1_128_1src`; only the default workload runs it)")
     ap.add_argument("--balance", action="store_true",
                     help="cost-balanced source shares (by the previous pass) instead of the static stride")
     ap.add_argument("--deterministic", action="store_true",
@@ -348,6 +351,32 @@ def main():
                                        "sum_nbox_last_step": int(ev2.sum_nbox_all),
                                        "xh_av_sum": float(b2.xh_av.sum(dtype=torch.float64))}
             b2.close()
+        if world == 1 and not args.no_small_leg and (n, S) == (256, 1000) and not args.thermal and not args.density_file:
+            # BASELINE configs[1] -- 128^3, one source, the reference's own CPU-runnable case -- is bound by the number of
+            # dependent launches, not by bytes: informational, outside the timed region of the headline
+            b.close()
+            n3 = 128
+            tp3 = pkg.TestProblem(n3); s3 = tp3.step(1)
+            nd3, xh3 = tp3.fields(1, args.x_init)
+            pos3, nf3 = pkg.seeded_sources(n3, 1)
+            out["configs1_128_1src"] = {"workload": "128^3 mesh, 1 source, same test problem and pre-ionisation, one outer iteration per step"}
+            for mode in (args.sweep_mode, "exact" if args.sweep_mode == "fast" else "fast"):
+                b3 = pkg.HipBackend(n3, thick, thin, device=local_rank, fast=mode == "fast")
+                b3.set_step(s3["dr1"], s3["vol"], s3["coldensh_LLS"], s3["clumping"], s3["temper"])
+                b3.set_sources(pos3, nf3)
+                b3.load(ndens=nd3, xh=xh3)
+                ev3 = pkg.Evolve(b3)
+                b3.begin_step()
+                k3 = 200
+                for k in range(-10, k3):
+                    if k == 0:
+                        torch.cuda.synchronize(); t3 = time.perf_counter()
+                    ev3.iteration(k, s3["dt"])
+                torch.cuda.synchronize()
+                dt3 = time.perf_counter() - t3
+                out["configs1_128_1src"][mode] = {"steps": k3, "ms_per_step": 1e3 * dt3 / k3, "value": float(n3) ** 3 * k3 / dt3,
+                                                  "unit": "cells-traced/s", "sum_nbox_last_step": int(ev3.sum_nbox_all)}
+                b3.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, srcpos, normflux, xh_state, nbox_first, pkg.box_cost, nd=nd)
         print(json.dumps(out))
