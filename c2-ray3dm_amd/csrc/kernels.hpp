@@ -594,6 +594,9 @@ __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &
 #define C2R_ROWS 3
 #endif
 constexpr int kRows = C2R_ROWS;
+#ifndef C2R_PAIR_LDS_TABLE
+#define C2R_PAIR_LDS_TABLE 0        // 1: the pair kernels fill the per-wave LDS table like the single-shell kernels (experiments)
+#endif
 constexpr int kPairRows = 1;        // rows per thread of the second shell of a look-ahead pair (k_sweep_pair, k_sweep_pair_fast)
 template <bool DET, int LLS, bool STREAM, bool HEAT, bool STORE = true>
 __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
@@ -743,15 +746,14 @@ void k_sweep_pair(KParams p, ShellArgs sa, ShellArgs sb)
     const int tile = blockIdx.x;
     const int nact = *sa.n_active;
     if ((int)blockIdx.z >= nact) return;
+    const v2f64 *ltab = (C2R_PAIR_LDS_TABLE) ? wave_log_table(p.logtab, s_log) : p.logtab;     // see k_sweep_pair_fast
     if (second) {
         const FaceRect fr = sb.face[face];
         if (tile >= fr.ntiles) return;
-        const v2f64 *ltab = wave_log_table(p.logtab, s_log);
         sweep_tile<DET, LLS, STREAM, HEAT, 1, true>(p, sb, fr, ltab, sm, face, tile, (int)blockIdx.z, sa);
     } else {
         const FaceRect fr = sa.face[face];
         if (tile >= fr.ntiles) return;
-        const v2f64 *ltab = wave_log_table(p.logtab, s_log);
         sweep_tile<DET, LLS, STREAM, HEAT, 0, false>(p, sa, fr, ltab, sm, face, tile, (int)blockIdx.z, sa);
     }
 }
@@ -1126,15 +1128,16 @@ void k_sweep_pair_fast(KParams p, ShellArgs sa, ShellArgs sb)
     const int tile = blockIdx.x;
     const int nact = *sa.n_active;
     if ((int)blockIdx.z >= nact) return;
+    // the position table straight from global memory (it is a few L1 lines): filling the per-wave LDS copy is a memory round
+    // trip in front of everything else, and a launch of this kernel is made of round trips
+    const v2f64 *ltab = (C2R_PAIR_LDS_TABLE) ? wave_log_table(p.odtab, s_log) : p.odtab;
     if (second) {
         const FaceRect fr = sb.face[face];
         if (tile >= fr.ntiles) return;
-        const v2f64 *ltab = wave_log_table(p.odtab, s_log);
         sweep_tile_fast<DET, LLS, STREAM, HEAT, 1, true, kPairRows>(p, sb, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z, sa);
     } else {
         const FaceRect fr = sa.face[face];
         if (tile >= fr.ntiles) return;
-        const v2f64 *ltab = wave_log_table(p.odtab, s_log);
         sweep_tile_fast<DET, LLS, STREAM, HEAT, 0, false>(p, sa, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z, sa);
     }
 }
