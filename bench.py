@@ -230,9 +230,11 @@ def main():
     # first pass over a uniform x stops at a smaller sub-box than all later ones), so that warm-up and
     # timed steps -- and a profiler that sees both -- do the same work
     one_step(-1)
+    t_w = time.perf_counter()
     for k in range(args.warmup):
         one_step(k)
     sync()
+    warm_ms = 1e3 * (time.perf_counter() - t_w) / max(1, args.warmup)      # (0 warm-up steps: 0 ms -- treated as a long step)
     # roofline timing: per-launch events on one GPU (the measurement the contract asks for); with several
     # GPUs the launches are 1/N as long and the per-launch barrier packets would cost ~3 %, so one event pair
     # per sub-box is used there (C2R_BENCH_PROFILE overrides: 0, 1, 2)
@@ -243,6 +245,10 @@ def main():
     prof_mode = int(os.environ.get("C2R_BENCH_PROFILE", "1" if (world == 1 and S >= 64) else "2"))
     if prof_mode == 2 and S < 64 and "C2R_BENCH_PROFILE" not in os.environ:
         prof_mode = 0
+    # ... and where a whole step takes a few milliseconds the launches are tens of microseconds: an event pair around each
+    # costs a quarter of a cold 256^3 x 1000 step (1.20 ms with them, 1.03 per sub-box, 0.95 without): per sub-box there
+    if prof_mode == 1 and args.warmup > 0 and warm_ms < 5.0 and "C2R_BENCH_PROFILE" not in os.environ:
+        prof_mode = 2
     b.profile(prof_mode)
     visited_before = ev.visited
     ev.visited = 0

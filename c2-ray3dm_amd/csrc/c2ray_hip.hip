@@ -59,7 +59,7 @@ struct Ctx {
     // the captured kernel arguments depend on (step scalars, tables, buffers, stream, scratch, physics switches)
     struct BatchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long long gen = 0; int count = 0, n_active = 0, hint = 0;
                         bool fused = false; double dt = 0.0; bool stats = false; };
-    std::map<int, BatchGraph> graphs;
+    std::map<int, BatchGraph> graphs;                            // key: 2 x (first source of the batch) + (fused iteration ? 1 : 0)
     unsigned long long gen = 1;
     bool use_graph = true;                                       // C2R_GRAPH=0: never (experiments)
     bool fused_iter = true;                                      // C2R_FUSED_ITER=0: c2r_iterate always runs its three steps in turn (experiments)
@@ -621,7 +621,9 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
     const bool fuse_iter = fz && graph_ok && first_of_pass;
     bool pre_run = false;
     if (graph_ok) {
-        Ctx::BatchGraph &bg = ctx->graphs[first];
+        // (one slot for the batch's plain pass, one for the fused iteration around it: a host that alternates between
+        // c2r_pass_sources and c2r_iterate does not re-capture every time)
+        Ctx::BatchGraph &bg = ctx->graphs[2 * first + (fuse_iter ? 1 : 0)];
         if (!(bg.exec && bg.gen == ctx->gen && bg.count == count && bg.n_active == n_active && bg.hint == hint &&
               bg.fused == fuse_iter && (!fuse_iter || (bg.dt == fz->dt && bg.stats == fz->stats)))) {
             if (bg.exec) { hipGraphExecDestroy(bg.exec); bg.exec = nullptr; }
