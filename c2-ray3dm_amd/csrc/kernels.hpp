@@ -960,10 +960,9 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
         if (k < nvalid) {
             const CellCd cc = cell_cd_fast<LLS>(p, sa, a, a2, b, R[k], T[k], R[k + 1], T[k + 1], nhi[k],
                                                 LLS == 2 ? (double)(xf ? p.lls_T : p.lls)[id[k]] : 0.0);
-            const double pq = cc.pq, path = cc.path, cd_in = cc.cd_in, np = cc.np, cd_out = cc.cd_out;
+            const double path = cc.path, cd_in = cc.cd_in, np = cc.np, cd_out = cc.cd_out;
             const double dist2 = __builtin_fma(p.dr2[va], (double)(b * b), du2 + sa.d2axis[axis]);
             const bool stop = (LLS == 3) && dist2 > p.R_max2;
-            (void)pq;
             // the cell's column density, also into the planes of the faces sharing the cell
             if (STORE) {
             if (!(C2R_ABLATE & 2) && !((C2R_ABLATE & 32) && !(q & 1)))
