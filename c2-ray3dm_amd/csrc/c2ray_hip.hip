@@ -281,10 +281,6 @@ void prof_collect(Ctx *ctx)
     ctx->ev_sweep_used = ctx->ev_chem_used = 0;
 }
 
-// Which of a source's two plane sets holds the last shell of sub-box nbox - 1 (shell 0, the source cell, is in set 0).
-// Every launch that stores planes reads one set and writes the other: a single shell, a shell of the fused first
-// sub-boxes, or a look-ahead pair (two shells, one alternation).  The pairing rule is the one of sweep_batch's
-// enqueue_box: neither shell has cells on the sub-box surface, both have tiles.
 // Sub-boxes ending at q <= kFusedQmax run in k_sweep_box_fused (one workgroup per source walks the shells).  With few
 // sources and look-ahead pairs only the first sub-box does: beyond it three pair launches (22 us at 128^3 x 1 source) beat
 // the single workgroup's five shells (36 us).
@@ -320,6 +316,10 @@ bool pair_here(const Ctx *ctx, int nb, int q, int q1, int n_active, bool pair_ok
     return c0 > 0 && c1 > 0 && (long long)n_active * c1 <= kPairMaxCells;
 }
 
+// Which of a source's two plane sets holds the last shell of sub-box nbox - 1 (shell 0, the source cell, is in set 0).
+// Every launch that stores planes reads one set and writes the other: a single shell, a shell of the fused first
+// sub-boxes, or a look-ahead pair (two shells, one alternation) -- the rules of sweep_batch's enqueue_box
+// (box_is_fused, pair_here), replayed for the sub-boxes before nbox.
 int plane_set_before(const Ctx *ctx, int nbox, int n_active, bool pair_ok)
 {
     const c2r_params &p = ctx->prm;
