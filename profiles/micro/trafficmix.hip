@@ -11,6 +11,12 @@
 #include <cstdint>
 #define CK(e) do { hipError_t r = (e); if (r != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(r), __LINE__); return 1; } } while (0)
 
+// Round 3, one box: all four streams 1.192e11 visits/s with 512-B aligned runs, 1.142e11 (-4 %) with runs that start anywhere
+// (atomics alone 1.86e11 -> 1.69e11, -9 %).  The kernel's runs start anywhere: its real no-compute ceiling is ~4 % below the
+// aligned figure.  Aligning them would cost 3.5 - 7 % idle lanes (rows padded to 8 cells at q = 100): not pursued.
+// MASK bit 16 (round 3): the 64-cell runs of the n_HI loads and of the atomics start at a pseudo-random cell of the row instead
+// of a 512-byte boundary, as in the kernel, where a run starts wherever the source's shell does (9 64-byte sectors per
+// wave instruction instead of 8, 5 128-byte lines instead of 4)
 template <int MASK>      // 1: n_HI loads  2: plane loads  4: plane stores  8: atomics
 __global__ __launch_bounds__(256) void k_mix(const double *__restrict__ nhi, double *__restrict__ gam, const double *__restrict__ pin,
                                               double *__restrict__ pout, unsigned nrows, size_t plane_elems, unsigned seed)
@@ -32,7 +38,7 @@ __global__ __launch_bounds__(256) void k_mix(const double *__restrict__ nhi, dou
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         x = x * 1664525u + 1013904223u;
-        const size_t id = (size_t)((x >> 8) % nrows) * 64 + lane;
+        const size_t id = (size_t)((x >> 8) % (nrows - 1)) * 64 + lane + ((MASK & 16) ? ((x >> 3) & 7u) : 0u);
         double v = 1.0;
         if (MASK & 1) v = __builtin_nontemporal_load(nhi + id);
         if (MASK & 4) __builtin_nontemporal_store(v + acc, pout + o + c);
@@ -122,6 +128,9 @@ int main()
     const unsigned nrows = (unsigned)(n / 64);
 #define RUN(M, what) printf("%-58s %.3e visits/s\n", what, run<M>(nhi, gam, pin, pout, nrows, plane_elems, nthreads))
     RUN(15, "all four streams (the shipped design's mix)");
+    RUN(31, "all four streams, n_HI / atomic runs not 512-B aligned");
+    RUN(24, "atomics only, runs not 512-B aligned");
+    RUN(25, "n_HI loads + atomics only, runs not 512-B aligned");
     RUN(7,  "without the Gamma atomics");
     RUN(13, "without the plane loads");
     RUN(11, "without the plane stores");
