@@ -51,7 +51,10 @@ def _backend(pkg, n, S, seed, x, fast, det, monkeypatch, env, lls=1, thermal=Fal
 
 @pytest.mark.parametrize("fast", [True, False])
 @pytest.mark.parametrize("n,S,x,lls,thermal", [(64, 5, 0.9995, 1, False), (96, 12, 0.9995, 2, False), (64, 9, 0.999, 3, False),
-                                               (64, 6, 0.9995, 1, True), (130, 3, 0.99995, 1, False), (48, 30, 0.99, 2, True)])
+                                               (64, 6, 0.9995, 1, True), (130, 3, 0.99995, 1, False), (48, 30, 0.99, 2, True),
+                                               # ... and passes that cross the pairs' work limit (n_active x cells of the second
+                                               # shell <= 160000): pairs near the source, single launches beyond
+                                               (256, 1, 0.99995, 1, False), (128, 4, 0.9999, 1, False)])
 def test_lookahead_pairs_equal_one_launch_per_shell(pkg, monkeypatch, fast, n, S, x, lls, thermal):
     """One pass with C2R_PAIR_SHELLS=0 (one launch per shell) and =1 (the default): every template variant of the pair kernels
     (sweep mode x LLS type x heating) leaves the same sub-box counts, the same loss and -- rates in source order -- the same bits."""
