@@ -92,6 +92,7 @@ struct Ctx {
     double *d_gbox_h = nullptr; // ... and the per-source heating rates of a non-isothermal run
     // one device block + one pinned staging block hold the small per-batch arrays below (one copy per batch)
     char *d_batch = nullptr, *h_batch = nullptr; size_t batch_bytes = 0;
+    char *d_batch_init = nullptr; std::vector<char> batch_image;   // fused iteration: the state block a small batch starts from, on the device / as last sent
     char *d_hbatch = nullptr;                                // h_batch as the device sees it (k_box_decide_small writes results there)
     int *d_active[2] = {nullptr, nullptr};
     int *d_nactive = nullptr;                                // [2]: length of d_active[0/1]
@@ -146,7 +147,8 @@ size_t grid_bytes(const Ctx *ctx, int which) { return ctx->ncell * (which == 0 ?
 
 void free_sweep_scratch(Ctx *ctx)
 {
-    hipFree(ctx->d_planes); hipFree(ctx->d_gbox); hipFree(ctx->d_gbox_h); hipFree(ctx->d_batch); hipFree(ctx->d_loss_partial);
+    hipFree(ctx->d_planes); hipFree(ctx->d_gbox); hipFree(ctx->d_gbox_h); hipFree(ctx->d_batch); hipFree(ctx->d_batch_init); hipFree(ctx->d_loss_partial);
+    ctx->d_batch_init = nullptr; ctx->batch_image.clear();
     if (ctx->h_batch) hipHostFree(ctx->h_batch);
     ctx->d_batch = ctx->h_batch = nullptr; ctx->d_nactive = nullptr;
     ctx->d_planes = nullptr; ctx->d_gbox = nullptr; ctx->d_gbox_h = nullptr; ctx->d_srcpos_b = nullptr; ctx->d_srcw_b = nullptr; ctx->d_nflux_b = nullptr;
@@ -187,6 +189,8 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
     //   nflux[cap] final_loss[cap] loss_acc[cap] | srcpos[3cap] srcw[3cap] active0[cap] active1[cap] final_nbox[cap] nactive[2]
     ctx->batch_bytes = (size_t)cap * 3 * sizeof(double) + ((size_t)cap * 9 + 2) * sizeof(int);
     HIP_TRY(hipMalloc(&ctx->d_batch, ctx->batch_bytes));
+    HIP_TRY(hipMalloc(&ctx->d_batch_init, ctx->batch_bytes));
+    ctx->batch_image.clear();
     HIP_TRY(hipHostMalloc((void **)&ctx->h_batch, ctx->batch_bytes, hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void **)&ctx->d_hbatch, ctx->h_batch, 0));
     {
@@ -344,6 +348,7 @@ int plane_set_before(const Ctx *ctx, int nbox, int n_active, bool pair_ok)
 struct FusedIter {
     double dt = 0.0;
     bool stats = false;
+    bool batch_in_prepare = false;                // set by sweep_batch while it captures: pre() also restores the batch's state block
     std::function<int()> pre;                     // enqueue: zero rates + sweep_prepare
     std::function<int(const int *gate)> post;     // enqueue: sweep_finish + global pass, each launch a no-op unless *gate == 0 (null: unconditional)
     bool tail_done = false;
@@ -634,9 +639,12 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             if (bg.exec) { hipGraphExecDestroy(bg.exec); bg.exec = nullptr; }
             if (bg.graph) { hipGraphDestroy(bg.graph); bg.graph = nullptr; }
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                // fused iteration: no upload node -- k_prepare_nhi restores the batch's state block from its device image
+                if (fuse_iter) fz->batch_in_prepare = true;
                 int rc = fuse_iter ? fz->pre() : C2R_OK;
+                if (fuse_iter) fz->batch_in_prepare = false;
                 totals_at_box = fuse_iter ? std::min(hint, ctx->nbox_max) : 0;
-                if (rc == C2R_OK) rc = (int)hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st);
+                if (rc == C2R_OK && !fuse_iter) rc = (int)hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st);
                 cur = 0;
                 for (int nbox = 1; nbox <= hint && nbox <= ctx->nbox_max && rc == C2R_OK; ++nbox) rc = enqueue_box(nbox, n_active);
                 if (fuse_iter && rc == C2R_OK) {
@@ -660,7 +668,15 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
         }
         if (bg.exec) {
             const int done = std::min(hint, ctx->nbox_max);
-            if (bg.fused) ctx->h_nactive[done] = -1;              // (so that a stale zero is not taken for this launch's count)
+            if (bg.fused) {
+                ctx->h_nactive[done] = -1;                        // (so that a stale zero is not taken for this launch's count)
+                // the device image of the state block: sent only when it differs from what was sent last (steady state: never)
+                if (ctx->batch_image.size() != ctx->batch_bytes || memcmp(ctx->batch_image.data(), ctx->h_batch, ctx->batch_bytes) != 0) {
+                    ctx->batch_image.assign(ctx->h_batch, ctx->h_batch + ctx->batch_bytes);
+                    // (from the pinned block itself: it is not touched again before this iteration's kernels have run)
+                    HIP_TRY(hipMemcpyAsync(ctx->d_batch_init, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st));
+                }
+            }
             HIP_TRY(hipGraphLaunch(bg.exec, st));
             uploaded = true;
             pre_run = bg.fused;
@@ -717,7 +733,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
 // stride: refresh the replicas before a pass, fold their Gamma back after it.
 // zero_rates: also set_rates_to_zero (evolve.F90:430-440) -- and every clearing inside the one kernel instead of memsets
 // (the fused iteration, where a launch more or less is what counts)
-int sweep_prepare(Ctx *ctx, bool zero_rates = false)
+int sweep_prepare(Ctx *ctx, bool zero_rates = false, bool copy_batch = false)
 {
     const c2r_params &p = ctx->prm;
     const dim3 g((p.mesh[0] + 31) / 32, (p.mesh[1] + 31) / 32, p.mesh[2]);
@@ -726,8 +742,11 @@ int sweep_prepare(Ctx *ctx, bool zero_rates = false)
         z.g[0] = (double *)ctx->grid[4]; z.g[1] = ctx->d_phih_T;
         if (ctx->thermal) { z.g[2] = (double *)ctx->grid[5]; z.g[3] = ctx->d_heat_T; }
     }
+    // copy_batch (fused iteration): the batch's pristine state block (d_batch_init, kept current by sweep_batch) over the working one
+    WordCopy wc{};
+    if (copy_batch) { wc.src = (const unsigned *)ctx->d_batch_init; wc.dst = (unsigned *)ctx->d_batch; wc.n = (unsigned)(ctx->batch_bytes / 4); }
     hipLaunchKernelGGL(k_prepare_nhi, g, dim3(256), 0, ctx->stream, p.mesh[0], p.mesh[1], p.mesh[2], p.epsilon,
-                       (const float *)ctx->grid[0], (const double *)ctx->grid[2], ctx->d_nhi, ctx->d_nhi_T, z);
+                       (const float *)ctx->grid[0], (const double *)ctx->grid[2], ctx->d_nhi, ctx->d_nhi_T, z, wc);
     HIP_TRY(hipGetLastError());
     if (!zero_rates) {
         HIP_TRY(hipMemsetAsync(ctx->d_phih_T, 0, grid_bytes(ctx, 4), ctx->stream));
@@ -1624,7 +1643,7 @@ static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, i
     } else {
         FusedIter fz;
         fz.dt = dt; fz.stats = stats_host != nullptr;
-        fz.pre = [ctx]() -> int { return sweep_prepare(ctx, true); };
+        fz.pre = [ctx, &fz]() -> int { return sweep_prepare(ctx, true, fz.batch_in_prepare); };
         fz.post = [ctx, dt, four](const int *gate) -> int {
             const int r = sweep_finish(ctx, gate);
             return r ? r : global_pass_enqueue(ctx, dt, four, 0, ctx->ncell, gate, gate != nullptr);

@@ -1243,12 +1243,17 @@ __global__ __launch_bounds__(256) void k_gamma_reduce(KParams p, int nsrc, const
 // zero (null or 4 pointers): arrays of the mesh's size to clear on the way -- phih_grid and phiheat_grid (x fastest) in [0], [2],
 // their (x,y)-transposed accumulators in [1], [3] (any of them null) -- where launches are what an iteration costs (c2r_iterate)
 struct ZeroGrids { double *g[4]; };
+// copy (or null pointers): n 32-bit words that block (0,0,0) copies on the way -- the pristine image of a small batch's state
+// block (active lists, counters, accumulators) over the working one, instead of a host-to-device copy node in the graph
+struct WordCopy { const unsigned *src; unsigned *dst; unsigned n; };
 __global__ __launch_bounds__(256) void k_prepare_nhi(int n0, int n1, int n2, double eps, const float *__restrict__ ndens,
                                                      const double *__restrict__ xh_av, double *__restrict__ nhi,
-                                                     double *__restrict__ nhi_T, ZeroGrids zero)
+                                                     double *__restrict__ nhi_T, ZeroGrids zero, WordCopy copy)
 {
     __shared__ double tile[32][33];
     const int k = blockIdx.z;
+    if (copy.n && blockIdx.x == 0 && blockIdx.y == 0 && k == 0)
+        for (unsigned w = threadIdx.x; w < copy.n; w += 256) copy.dst[w] = copy.src[w];
     const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int r = ty; r < 32; r += 8) {
