@@ -11,9 +11,34 @@ from tests._util import F, load_case, oracle_for, load_tables, thermal_oracle_fo
 from tests._cpu_backend import OracleBackend                   # noqa: E402
 
 
+def slab_contract(pkg, out):
+    """The collectives Evolve(slab=True) hands to c2r_set_slab_chemistry (evolve.slab_collectives), on CPU tensors: unequal
+    slabs, in place; after the reduce-scatter the OWN slab holds the sum over ranks, after the all-gather every slab is its
+    owner's bytes everywhere."""
+    import torch
+    rank, npr = dist.get_rank(), dist.get_world_size()
+    rs, ag = pkg.evolve.slab_collectives(dist)
+    offs, cnts = [0, 6], [6, 4]
+    t = torch.arange(10, dtype=torch.float64) * (rank + 1)          # rank 0: k, rank 1: 2k -> sum 3k
+    rs(t, offs, cnts)
+    own = t[offs[rank]:offs[rank] + cnts[rank]].clone()
+    u = torch.full((40,), 7 + rank, dtype=torch.uint8)              # every rank's own byte slab is valid, the rest garbage
+    boffs, bcnts = [0, 24], [24, 16]
+    ag(u, boffs, bcnts)
+    gathered = [torch.zeros(6, dtype=torch.float64) for _ in range(npr)]
+    pad = torch.zeros(6, dtype=torch.float64); pad[:own.numel()] = own
+    dist.all_gather(gathered, pad)
+    if rank == 0:
+        np.savez(out, own0=gathered[0].numpy(), own1=gathered[1].numpy()[:4], bytes=u.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     dist.init_process_group("gloo")
     pkg = g.load_package()
+    if len(sys.argv) > 2 and sys.argv[2] == "slab":
+        return slab_contract(pkg, sys.argv[1])
     tables = load_tables()
     m, a = load_case("evolve32_std_bubbles")
     s = m["steps"]["step001"]

@@ -267,6 +267,21 @@ def test_two_ranks_gloo_nonisothermal_step(pkg, tmp_path):
     assert np.array_equal(got["xh_rank1"], got["xh"])
 
 
+@pytest.mark.timeout(300)
+def test_slab_collectives_contract_two_ranks_gloo(tmp_path):
+    """evolve.slab_collectives (what Evolve(slab=True) registers for the slab chemistry) over gloo, two ranks, unequal slabs:
+    reduce-scatter leaves the sum over ranks in the own slab, all-gather leaves every owner's bytes everywhere."""
+    script = os.path.join(ROOT, "tests", "_gloo_worker.py")
+    out = tmp_path / "slab.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29735")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29735", script, str(out), "slab"],
+                          env=env, cwd=ROOT, timeout=280)
+    got = np.load(out)
+    assert np.array_equal(got["own0"], 3.0 * np.arange(0, 6)) and np.array_equal(got["own1"], 3.0 * np.arange(6, 10))
+    assert np.array_equal(got["bytes"], np.array([7] * 24 + [8] * 16, dtype=np.uint8))
+
+
 def test_bench_plain_multi_gpu_form_is_a_launcher():
     """`python bench.py --gpus 2` with no WORLD_SIZE starts its ranks as child processes (torch.distributed.run) instead of
     refusing; here, without a GPU, both ranks fail loudly (no CPU fallback) and the parent reports that with a non-zero
