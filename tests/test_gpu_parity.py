@@ -136,7 +136,7 @@ def _random_case(n, nsrc, seed, pkg):
     return s, nd, F(x3), pos, nf
 
 
-@pytest.mark.parametrize("n,nsrc,seed", [(24, 7, 1), (40, 20, 2), (48, 33, 3), (21, 5, 4)])
+@pytest.mark.parametrize("n,nsrc,seed", [(24, 7, 1), (40, 20, 2), (48, 33, 3), (21, 5, 4), (40, 64, 5), (40, 65, 6)])   # 32 | 33: graph + look-ahead pairs or not; 64 | 65: one-wave decision kernel or k_box_decide
 def test_pass_and_global_vs_oracle_seeded(pkg, tables, n, nsrc, seed):
     """Seeded random density / ionization / sources at meshes the fixtures do not cover
     (odd and even, sources anywhere incl. next to the periodic seam)."""
