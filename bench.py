@@ -107,6 +107,47 @@ def cpu_baseline(mesh, srcpos, normflux, xfield, gpu_nbox, box_cost, nd=None):
                       "relaxed xh_av field the timed GPU steps start from" % (nsamp, mesh)}
 
 
+def parity_check(pkg, mesh, step, nd, xh_init, xfield, srcpos, normflux, tables, device, fast, nsub=16):
+    """The second half of BASELINE.json's metric -- "xh L-inf error vs Fortran ref" -- for THIS workload, outside the timed
+    region: one pass over the first `nsub` sources of the bench's list plus one global pass (evolve0D_global over the mesh,
+    evolve_point.F90:305-406) on the relaxed field the timed steps start from, on the GPU and in the oracle (the pinned C
+    restatement of the reference, the checker).  Reports max |dxh| over the mesh, the worst rate error in units of the
+    tolerance weight W (tests/_util.py: |dGamma| <= rtol Gamma + wtol W) and whether the integer results agree."""
+    from oracle.oracle import Oracle
+    thick, thin = tables
+    o = Oracle(mesh, step["dr1"], step["vol"], step["coldensh_LLS"], thick, thin)
+    w = o.enable_tolerance_weight()
+    pos, nf = srcpos[:nsub], normflux[:nsub]
+    t0 = time.perf_counter()
+    phih_o = np.zeros(o.ncell)
+    oloss, onb, ovis = o.pass_sources(nd, xfield, phih_o, pos, nf)
+    xav, xint = xfield.copy(), xh_init.copy()
+    oconv = o.global_pass(step["dt"], nd, xh_init, xav, xint, phih_o)
+    sec = time.perf_counter() - t0
+    b = pkg.HipBackend(mesh, thick, thin, device=device, fast=fast)
+    b.set_step(step["dr1"], step["vol"], step["coldensh_LLS"], step["clumping"], step["temper"])
+    b.set_sources(pos, nf)
+    b.load(ndens=nd, xh=xh_init)
+    b.begin_step()
+    b.load(xh_av=xfield)
+    b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    phih = b.fetch("phih_grid")
+    conv, _ = b.global_pass(step["dt"])
+    dx = float(np.max(np.abs(b.fetch("xh_intermed") - xint)))
+    dxav = float(np.max(np.abs(b.fetch("xh_av") - xav)))
+    b.close()
+    live = w > 0
+    return {"xh_linf": max(dx, dxav), "gamma_max_over_W": float(np.max(np.abs(phih - phih_o)[live] / w[live])),
+            "gamma_max_rel": float(np.max(np.abs(phih - phih_o)[live] / np.maximum(phih_o[live], 1e-300))),
+            "photon_loss_rel": abs(loss - oloss) / abs(oloss) if oloss else 0.0,
+            "integers_equal": bool((nbox, vis, conv) == (onb, ovis, oconv)), "sum_nbox": int(nbox), "nonconverged_cells": int(conv),
+            "sources": int(len(nf)), "checker": "oracle", "oracle_seconds": sec,
+            "what": "one pass over the first %d sources + one global pass on the relaxed xh_av field of the timed steps, GPU vs the "
+                    "pinned C restatement of the reference (oracle/c2ray_oracle.c); xh_linf = max |xh_intermed, xh_av difference| "
+                    "(north_star: 1e-5), gamma_max_over_W in units of the tolerance weight (stated bound 2e-14)" % len(nf)}
+
+
 def self_launch(ngpus):
     """Start `ngpus` ranks of this script under torch.distributed.run as a child process and relay its output."""
     import socket
@@ -186,6 +227,9 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if os.environ.get("C2R_BENCH_TEST_FAIL_RANK") == str(rank):       # CI only: a rank that dies must fail the whole run
+        sys.stderr.write("bench.py: rank %d fails on purpose (C2R_BENCH_TEST_FAIL_RANK)\n" % rank)
+        os._exit(3)
     n, S = args.mesh, args.sources
     tp = pkg.TestProblem(n)
     s = tp.step(1)
@@ -274,7 +318,12 @@ def main():
     # max over ranks of the wall time; sum over ranks of the visited pairs
     stats = torch.tensor([dt_wall, float(ev.visited), prof["sweep_ms"], float(prof["sweep_launches"])],
                          dtype=torch.float64, device=b.device)
+    shares = None
     if world > 1:
+        # the source shares of the last pass (static stride or the library's LPT partition): they must partition the list
+        mine = [int(i) for i in b.local_sources()]
+        shares = [None] * world
+        dist.all_gather_object(shares, mine)
         tmax = stats.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = stats.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt_wall = float(tmax[0]); visited_all = float(tsum[1])
@@ -311,6 +360,8 @@ def main():
                        "mesh": n, "sources": S, "sweep_mode": args.sweep_mode, "isothermal": not args.thermal, "gamma_accumulation": "ordered" if args.deterministic else "atomic", "sources_per_gpu": len(pkg.static_source_share(S, 0, world)),
                        "parallelism": "sources sharded over %d GPU(s), RCCL all-reduce of Gamma" % world,
                        "ranks": dist.get_world_size() if world > 1 else 1,
+                       "source_share_sizes": [len(x) for x in shares] if shares else [S],
+                       "shares_partition_sources": (sorted(i for x in shares for i in x) == list(range(S))) if shares else True,
                        "collective": None if world == 1 else ("gloo (C2R_BENCH_TEST_ONE_GPU)" if one_gpu_test else "nccl (RCCL)"),
                        "visited_cell_sources_per_step": visited_all / args.steps,
                        "visited_per_s": visited_all / dt_wall,
@@ -385,6 +436,9 @@ def main():
                 b3.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, srcpos, normflux, xh_state, nbox_first, pkg.box_cost, nd=nd)
+            # ... and, in the same CPU leg, the oracle as the CHECKER of this workload's results (never timed as the product)
+            b.close()               # (idempotent: the other legs may have closed the context already)
+            out["parity"] = parity_check(pkg, n, s, nd, xh, xh_state, srcpos, normflux, (thick, thin), local_rank, args.sweep_mode == "fast")
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -21,6 +21,7 @@ namespace {
 constexpr int kSumBlocks = 1024;      // fixed grid of every deterministic reduction
 constexpr int kFoldLossMax = 64;      // up to this many active sources k_box_decide also sums the last shell's loss partials
 constexpr int kFusedQmax = 10;        // sub-boxes ending at q <= this run in k_sweep_box_fused (one launch per sub-box)
+constexpr int kMaxSlabRanks = 64;     // slab chemistry keeps every rank's slab offsets in fixed arrays (evolve3d_worker)
 constexpr int kFewSources = 32;       // a batch of up to this many sources is nothing but launch latency (see sweep_batch)
 
 struct Ctx {
@@ -125,6 +126,18 @@ struct Ctx {
     // c2r_info: how the device was chosen, the sweep mode, warnings (e.g. C2R_DEVICE_AUTO without a local-rank variable)
     bool device_auto = false; std::string device_var, info_device, info_warn, info;
 };
+
+// the polling loop's pause: the x86 hint, its aarch64 counterpart, nothing elsewhere
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
 
 inline Ctx *C(c2r_ctx *c) { return reinterpret_cast<Ctx *>(c); }
 inline const Ctx *C(const c2r_ctx *c) { return reinterpret_cast<const Ctx *>(c); }
@@ -692,7 +705,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                     if (__atomic_load_n(&ctx->h_sc->seq, __ATOMIC_ACQUIRE) == want) { arrived = true; break; }
                     if (__atomic_load_n(&ctx->h_nactive[done], __ATOMIC_ACQUIRE) > 0) break;
                     if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-                    __builtin_ia32_pause();
+                    cpu_relax();
                 }
             }
             if (!arrived) {
@@ -1205,6 +1218,7 @@ int c2r_set_rank(c2r_ctx *c, int32_t rank, int32_t nranks, c2r_allreduce_fn fn, 
     Ctx *ctx = C(c);
     if (nranks < 1 || rank < 0 || rank >= nranks) FAIL(C2R_EINVAL, "need 0 <= rank < nranks");
     if (nranks > 1 && !fn) FAIL(C2R_EINVAL, "nranks > 1 needs an all-reduce callback");
+    if (nranks > kMaxSlabRanks && ctx->rs) FAIL(C2R_EINVAL, "slab chemistry supports up to 64 ranks (c2r_set_slab_chemistry is on)");
     ctx->rank = rank; ctx->nranks = nranks; ctx->ar = fn; ctx->ar_user = user;
     if (nranks > 1 && ctx->device_auto && ctx->device_var.empty() && ctx->info_warn.empty()) {
         // several ranks, one process per GPU, and nothing told this process which GPU is its own: every rank of the
@@ -1224,6 +1238,7 @@ int c2r_set_slab_chemistry(c2r_ctx *c, c2r_reduce_scatter_fn rs, c2r_allgather_f
     if (!c) return C2R_EINVAL;
     Ctx *ctx = C(c);
     if ((rs == nullptr) != (ag == nullptr)) FAIL(C2R_EINVAL, "slab chemistry needs both the reduce-scatter and the all-gather callback (or neither)");
+    if (rs && ctx->nranks > kMaxSlabRanks) FAIL(C2R_EINVAL, "slab chemistry supports up to 64 ranks");   // (checked here and in c2r_set_rank: a rank failing inside the loop would leave the others in their collectives)
     ctx->rs = rs; ctx->ag = ag; ctx->slab_user = user;
     return C2R_OK;
 }
@@ -1757,9 +1772,9 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
         rc = c2r_pass_sources(c, &loss, &nb, &vis);                                    // :246
         if (rc) return rc;
         const bool slab = ctx->nranks > 1 && ctx->rs && ctx->ag && ctx->ar;
-        size_t so[64], sc[64];                                                         // slabs of all ranks (cells)
+        size_t so[kMaxSlabRanks], sc[kMaxSlabRanks];                                                         // slabs of all ranks (cells)
         if (slab) {
-            if (ctx->nranks > 64) FAIL(C2R_EINVAL, "slab chemistry supports up to 64 ranks");
+            // (nranks <= kMaxSlabRanks: c2r_set_slab_chemistry / c2r_set_rank refuse anything else)
             for (int r = 0; r < ctx->nranks; ++r) slab_of(ctx, r, ctx->nranks, &so[r], &sc[r]);
             // reduce-scatter instead of evolve.F90:599's all-reduce: this rank gets the summed rates of its z-slab
             if (ctx->rs(ctx->slab_user, ctx->grid[4], so, sc, ctx->nranks, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "reduce-scatter callback failed");
@@ -1798,7 +1813,7 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
             HIP_TRY(hipMemcpyAsync(ctx->d_pair, ctx->h_sc->pair, 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
             if (ctx->ar(ctx->ar_user, ctx->d_pair, 2, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-reduce callback failed");
             HIP_TRY(hipMemcpyAsync(ctx->h_sc->pair, ctx->d_pair, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            size_t bo[64], bc[64];
+            size_t bo[kMaxSlabRanks], bc[kMaxSlabRanks];
             for (int w = 2; w <= 3; ++w) {
                 for (int r = 0; r < ctx->nranks; ++r) { bo[r] = so[r] * sizeof(double); bc[r] = sc[r] * sizeof(double); }
                 if (ctx->ag(ctx->slab_user, ctx->grid[w], bo, bc, ctx->nranks, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-gather callback failed");
@@ -1825,7 +1840,7 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
     }
     if (ctx->nranks > 1 && ctx->rs && ctx->ag && ctx->ar && niter > (restart_niter > 0 ? restart_niter : 0)) {
         // the step leaves phih_grid (phiheat_grid) complete on every rank, as the all-reduce does (output.F90 writes them)
-        size_t bo[64], bc[64];
+        size_t bo[kMaxSlabRanks], bc[kMaxSlabRanks];
         for (int r = 0; r < ctx->nranks; ++r) { size_t o, n; slab_of(ctx, r, ctx->nranks, &o, &n); bo[r] = o * sizeof(double); bc[r] = n * sizeof(double); }
         if (ctx->ag(ctx->slab_user, ctx->grid[4], bo, bc, ctx->nranks, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-gather callback failed");
         if (ctx->thermal && ctx->ag(ctx->slab_user, ctx->grid[5], bo, bc, ctx->nranks, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-gather callback failed");

@@ -294,6 +294,77 @@ __device__ __forceinline__ double block_sum_256(double v, double *sm /* >= 4 dou
     return r;   // valid in thread 0
 }
 
+// ---- the rate arithmetic of one (cell, source), shared by both sweep modes -------------------------------------
+// radiation_photoionrates.F90:71-317 + evolve_point.F90:262 restated so that it costs ~60 instead of ~150 vector
+// instructions; what it gives up against the statement-by-statement form (photoion above, kept for the source cell) is
+// far inside the Gamma tolerance both modes state (tests/_util.TOL: the rounding of the table position dominates either):
+//  * the table position 1+(log10 tau-minlogtau)/dlogtau (:195-199) comes straight out of the log evaluation: the per-wave
+//    LDS table holds positions instead of logarithms, the two scale factors are folded into the last two FMAs;
+//  * reciprocals by v_rcp_f64 + one Newton step (2^-48) instead of the correctly rounded quotient;
+//  * Gamma = NormFlux (T_in - T_out) / (vol_ph n_HI) with ONE reciprocal (:262-263, evolve_point.F90:262).
+__device__ __forceinline__ double rcp1(double d)        // 1/d to 2^-48
+{
+    const double r = __builtin_amdgcn_rcp(d);
+    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+}
+// table position od = min(numtau, 1 + (log10(max(1e-20,tau)) - minlogtau)/dlogtau); tab = wave's LDS copy of p.odtab
+__device__ __forceinline__ double tau_od(double tau, const KParams &p, const v2f64 *__restrict__ tab)
+{
+    const double x = fmax(1.0e-20, tau);
+    const double m = __builtin_amdgcn_frexp_mant(x);        // [0.5, 1)
+    const int e = __builtin_amdgcn_frexp_exp(x);
+    const unsigned i = ((unsigned)__double2hiint(m) >> 14) & 63u;
+    const v2f64 rt = tab[i];
+    const double z = __builtin_fma(m, rt.x, -1.0);
+    double P = __builtin_fma(z, 1.0 / 7.0, -1.0 / 6.0);
+    P = __builtin_fma(z, P, 0.2);
+    P = __builtin_fma(z, P, -0.25);
+    P = __builtin_fma(z, P, 1.0 / 3.0);
+    P = __builtin_fma(z, P, -0.5);
+    const double l1p = __builtin_fma(z * z, P, z);
+    const double od = __builtin_fma((double)e, p.od_per_e, __builtin_fma(l1p, p.od_per_ln, rt.y));
+    return fmin(p.numtau_d, od);
+}
+// read_table at position od >= 1 (radiation_photoionrates.F90:212-228); tables padded by one element
+__device__ __forceinline__ double table_at(const double *__restrict__ tab, double od)
+{
+    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+    const d2u v = *reinterpret_cast<const d2u *>(tab + (int)od);
+    return __builtin_fma(v.y - v.x, __builtin_amdgcn_fract(od), v.x);
+}
+
+// photo-ionization (and heating) rate of a cell from its entry / exit columns; vol_ph = 4 pi dist2 path; volnhi = vol_ph n_HI.
+// t_out: the thick-table value at the exit column times 1 (photo_out / NormFlux), for the photon loss.
+template <bool HEAT>
+__device__ __forceinline__ double rates_fast(const KParams &p, const v2f64 *__restrict__ ltab, const double *__restrict__ thick,
+                                             const double cd_in, const double cd_out, const double nflux, const double volnhi,
+                                             const double vol_ph, double &t_out, double &heat)
+{
+    const double tau_in = cd_in * p.sigma, tau_out = cd_out * p.sigma;
+    const double od_in = tau_od(tau_in, p, ltab);
+    const double t_in = table_at(thick, od_in);
+    double dT, od_out = od_in;
+    const bool thick_cell = fabs(tau_out - tau_in) > p.tau_limit;
+    if (thick_cell) {
+        od_out = tau_od(tau_out, p, ltab);
+        t_out = table_at(thick, od_out);
+        dT = t_in - t_out;
+    } else {
+        dT = (tau_out - tau_in) * table_at(p.thin, od_in);
+        t_out = t_in - dT;
+    }
+    if (HEAT) {       // heat_lookuptable (radiation_photoionrates.F90:323-417) at the same table positions
+        const double h_in = table_at(p.hthick, od_in);
+        double dH;
+        if (fabs(tau_out - tau_in) > p.tau_heat_limit) {
+            if (!thick_cell) od_out = tau_od(tau_out, p, ltab);
+            dH = h_in - table_at(p.hthick, od_out);
+        } else dH = ((cd_out - cd_in) * p.sigma) * table_at(p.hthin, od_in);
+        heat = (nflux * dH) * rcp1(vol_ph);                                // phi%heat = .../vol_ph
+    }
+    return (nflux * dT) * rcp1(volnhi);                                    // photo_cell_HI / (n_HI vol_ph)
+}
+
 // ---- source cells (q = 0) ------------------------------------------------------------------
 // evolve_point.F90:151-160 (source cell) + the common tail of evolve0D, for source s; ltab: log10_tab's table (LDS or global).
 // on_surface: degenerate meshes only, the source cell itself sits on the sub-box surface
@@ -541,14 +612,14 @@ __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs 
     const double nflux = p.normflux[s];
     double gamma = 0.0, heat = 0.0;
     if (!cs.stop_far && !(cs.cd_in > p.max_coldensh) && nflux > 0.0) {
-        double p_out;
-        gamma = fdiv(photoion<HEAT>(p, ltab, cs.cd_in, cd_out, cs.vol_ph, nflux, p_out, &heat), cs.nhi);
+        double t_out;
+        gamma = rates_fast<HEAT>(p, ltab, p.thick, cs.cd_in, cd_out, nflux, cs.vol_ph * cs.nhi, cs.vol_ph, t_out, heat);
         if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[cs.id], gamma);
         if (HEAT && !DET && heat != 0.0) atomicAdd(&(xf ? p.heat_T : p.heat)[cs.id], heat);      // evolve_point.F90:285-286
         if (sa.has_boundary) {
             const bool bnd = dl.d0 == sa.boxR[0] || dl.d1 == sa.boxR[1] || dl.d2 == sa.boxR[2] ||
                              dl.d0 == -sa.boxL[0] || dl.d1 == -sa.boxL[1] || dl.d2 == -sa.boxL[2];
-            if (bnd) loss = fdiv(p_out * p.vol, cs.vol_ph);
+            if (bnd) loss = fdiv((nflux * t_out) * p.vol, cs.vol_ph);
         }
     }
     // deterministic mode: every visited cell records its rate (zero included) for k_gamma_reduce
@@ -729,7 +800,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
     if ((int)blockIdx.z >= nact) return;         // block-uniform: this source retired after the launch was sized
     const FaceRect fr = sa.face[face];
     if (tile >= fr.ntiles && !sa.has_boundary) return;   // block-uniform: nothing to do and no partial to write
-    const v2f64 *ltab = wave_log_table(p.logtab, s_log);
+    const v2f64 *ltab = wave_log_table(p.odtab, s_log);      // (table positions: rates_fast)
     sweep_tile<DET, LLS, STREAM, HEAT>(p, sa, fr, ltab, sm, face, tile, (int)blockIdx.z, sa);
 }
 
@@ -746,7 +817,7 @@ void k_sweep_pair(KParams p, ShellArgs sa, ShellArgs sb)
     const int tile = blockIdx.x;
     const int nact = *sa.n_active;
     if ((int)blockIdx.z >= nact) return;
-    const v2f64 *ltab = (C2R_PAIR_LDS_TABLE) ? wave_log_table(p.logtab, s_log) : p.logtab;     // see k_sweep_pair_fast
+    const v2f64 *ltab = (C2R_PAIR_LDS_TABLE) ? wave_log_table(p.odtab, s_log) : p.odtab;     // see k_sweep_pair_fast
     if (second) {
         const FaceRect fr = sb.face[face];
         if (tile >= fr.ntiles) return;
@@ -774,11 +845,6 @@ void k_sweep_pair(KParams p, ShellArgs sa, ShellArgs sb)
 //    reciprocal (radiation_photoionrates.F90:262-263, evolve_point.F90:262);
 //  * the table position 1+(log10 tau-minlogtau)/dlogtau (radiation_photoionrates.F90:195-199) comes
 //    straight out of the log evaluation: the LDS table holds positions instead of logarithms.
-__device__ __forceinline__ double rcp1(double d)        // 1/d to 2^-48
-{
-    const double r = __builtin_amdgcn_rcp(d);
-    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-}
 __device__ __forceinline__ double sqrt_pos(double x)    // sqrt(x), x >= 1 normal: Goldschmidt step + one correction (~1 ulp)
 {
     const double y = __builtin_amdgcn_rsq(x);
@@ -787,41 +853,6 @@ __device__ __forceinline__ double sqrt_pos(double x)    // sqrt(x), x >= 1 norma
     g = __builtin_fma(g, __builtin_fma(-h, g, 0.5), g);
     return __builtin_fma(__builtin_fma(-g, g, x), h, g);
 }
-// table position od = min(numtau, 1 + (log10(max(1e-20,tau)) - minlogtau)/dlogtau); tab = wave's LDS copy of p.odtab
-__device__ __forceinline__ double tau_od(double tau, const KParams &p, const v2f64 *__restrict__ tab)
-{
-    const double x = fmax(1.0e-20, tau);
-    const double m = __builtin_amdgcn_frexp_mant(x);        // [0.5, 1)
-    const int e = __builtin_amdgcn_frexp_exp(x);
-    const unsigned i = ((unsigned)__double2hiint(m) >> 14) & 63u;
-    const v2f64 rt = tab[i];
-    const double z = __builtin_fma(m, rt.x, -1.0);
-    double P = __builtin_fma(z, 1.0 / 7.0, -1.0 / 6.0);
-    P = __builtin_fma(z, P, 0.2);
-    P = __builtin_fma(z, P, -0.25);
-    P = __builtin_fma(z, P, 1.0 / 3.0);
-    P = __builtin_fma(z, P, -0.5);
-    const double l1p = __builtin_fma(z * z, P, z);
-    const double od = __builtin_fma((double)e, p.od_per_e, __builtin_fma(l1p, p.od_per_ln, rt.y));
-    return fmin(p.numtau_d, od);
-}
-// read_table at position od >= 1 (radiation_photoionrates.F90:212-228); tables padded by one element
-__device__ __forceinline__ double table_at(const double *__restrict__ tab, double od)
-{
-#if defined(C2R_ABLATE) && (C2R_ABLATE & 8)
-    return 1.0e48 * (1.0 - 1.0e-4 * od);
-#endif
-    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-    const d2u v = *reinterpret_cast<const d2u *>(tab + (int)od);
-    return __builtin_fma(v.y - v.x, __builtin_amdgcn_fract(od), v.x);
-}
-
-// Timing experiments only (profiles/micro/ablate.sh; results are WRONG with any bit set): -DC2R_ABLATE=<mask>
-//   1 no Gamma atomics   2 no plane stores   4 no n_HI loads   8 no rate-table reads   16 no plane loads
-//   32 plane stores and loads only on even shells (upper bound of what a two-shell on-chip hand-off could save)
-#ifndef C2R_ABLATE
-#define C2R_ABLATE 0
-#endif
 // Row sums over the two upstream columns am, a of one upstream row: R = omu r(am) + ddu r(a), T likewise with t = c r
 // (r = 1/max(0.6, c sigma), weightf of column_density.f90:276-293)
 __device__ __forceinline__ void row_sum_fast(const KParams &p, const double omu, const double ddu, const double vm, const double va,
@@ -938,7 +969,7 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
     for (int k = 0; k < NR; ++k) {
         const unsigned cb = wrap_pos(p.srcw[3 * s + va], p.n[va], b0 + k * sgb);
         id[k] = ca + base_p + __umul24(stride_b, cb);
-        nhi[k] = (C2R_ABLATE & 4) ? 1e-7 * (double)(1u + (id[k] & 3u)) : buf_load_f64<STREAM ? C2R_NHI_AUX : 0>(r_x, id[k] * 8u);
+        nhi[k] = buf_load_f64<STREAM ? C2R_NHI_AUX : 0>(r_x, id[k] * 8u);
     }
     // column part of the interpolation and of the geometry
     const double omu = (double)abs(a) * sa.inv_q, ddu = 1.0 - omu;   // weights of columns am and a
@@ -965,10 +996,8 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
             const bool stop = (LLS == 3) && dist2 > p.R_max2;
             // the cell's column density, also into the planes of the faces sharing the cell
             if (STORE) {
-            if (!(C2R_ABLATE & 2) && !((C2R_ABLATE & 32) && !(q & 1)))
             buf_store_f64<SA>(r_cur, (unsigned)face * plane_bytes + o8, cd_out);
-            if (C2R_ABLATE & 2) { if (cd_out == 1.2345e-300) buf_store_f64<SA>(r_cur, o8, cd_out); }
-            else if (axis == 2) {
+            if (axis == 2) {
                 if (abs(a) == q)
                     buf_store_f64<SA>(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((pd + p.R) * p.P + (b + p.R)) * 8u, cd_out);
                 if (abs(b) == q)
@@ -986,34 +1015,11 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
             }
             double gamma = 0.0, heat = 0.0;
             if (!stop && !(cd_in > p.max_coldensh) && nflux > 0.0) {
-                const double tau_in = cd_in * p.sigma, tau_out = cd_out * p.sigma;
-                const double od_in = tau_od(tau_in, p, ltab);
-                const double t_in = table_at(thick, od_in);
-                double dT, t_out, od_out = od_in;
-                const bool thick_cell = fabs(tau_out - tau_in) > p.tau_limit;
-                if (thick_cell) {
-                    od_out = tau_od(tau_out, p, ltab);
-                    t_out = table_at(thick, od_out);
-                    dT = t_in - t_out;
-                } else {
-                    dT = (tau_out - tau_in) * table_at(p.thin, od_in);
-                    t_out = t_in - dT;
-                }
                 const double area = p.fourpi * dist2;                             // vol_ph = area path
-                gamma = (nflux * dT) * rcp1(area * np);                           // photo_cell_HI / (n_HI vol_ph)
-                if (C2R_ABLATE & 1) { if (gamma == 1.2345e-300) atomicAdd(&p.phih[id[k]], gamma); }
-                else
+                double t_out;
+                gamma = rates_fast<HEAT>(p, ltab, thick, cd_in, cd_out, nflux, area * np, area * path, t_out, heat);
                 if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id[k]], gamma);
-                if (HEAT) {       // heat_lookuptable (radiation_photoionrates.F90:323-417) at the same table positions
-                    const double h_in = table_at(p.hthick, od_in);
-                    double dH;
-                    if (fabs(tau_out - tau_in) > p.tau_heat_limit) {
-                        if (!thick_cell) od_out = tau_od(tau_out, p, ltab);
-                        dH = h_in - table_at(p.hthick, od_out);
-                    } else dH = ((cd_out - cd_in) * p.sigma) * table_at(p.hthin, od_in);
-                    heat = (nflux * dH) * rcp1(area * path);                       // phi%heat = .../vol_ph
-                    if (!DET && heat != 0.0) atomicAdd(&(xf ? p.heat_T : p.heat)[id[k]], heat);
-                }
+                if (HEAT && !DET && heat != 0.0) atomicAdd(&(xf ? p.heat_T : p.heat)[id[k]], heat);
                 if (sa.has_boundary && (bnd_col || b == sa.boxR[va] || b == -sa.boxL[va]))
                     loss = loss + fdiv((nflux * t_out) * p.vol, area * path);
             }
@@ -1057,11 +1063,8 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
 #pragma unroll
         for (int r = 0; r <= NR; ++r) {                        // rows b0-sgb, b0, ..., b0+(NR-1)sgb
             const bool inr = abs(b0 + (r - 1) * sgb) <= qm;
-            if ((C2R_ABLATE & 16) || ((C2R_ABLATE & 32) && (q & 1))) { vm[r] = 1e17 * (double)(o & 7u); va_[r] = 2e17; }
-            else {
             vm[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (inam && inr) ? o - da8 : kOOB);
             va_[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (ina && inr) ? o : kOOB);
-            }
             o += db8;
         }
     }
@@ -1167,7 +1170,7 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
     const int sl = blockIdx.x;
     if (sl >= *ba.n_active) return;
     const int s = ba.active[sl];
-    const v2f64 *ltab = wave_log_table(FAST ? p.odtab : p.logtab, s_log);
+    const v2f64 *ltab = wave_log_table(p.odtab, s_log);       // both modes: the table positions of rates_fast
     if (ba.source_cell) {
         if (threadIdx.x == 0) {
             const ShellArgs &s0 = ba.sh[0];
@@ -1415,6 +1418,9 @@ __global__ __launch_bounds__(64) void k_box_decide_small(const int *active_in, c
                                                          double *loss_acc, double *final_loss, int *final_nbox,
                                                          const double *loss_partial, int bps, SmallTotals tot)
 {
+#if defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
+#error "k_box_decide_small is one 64-lane wave (ballot, cross-lane reads of final_loss): build for a wave64 target (gfx950)"
+#endif
     const int n_in = *n_in_dev;                       // <= 64
     const int i = threadIdx.x;
     int keep = 0, s = -1;
@@ -1441,6 +1447,7 @@ __global__ __launch_bounds__(64) void k_box_decide_small(const int *active_in, c
     if (i == 0) { *n_out = n_keep; *n_out_host = n_keep; }
     if (tot.on && n_keep == 0) {
         __threadfence_block();                            // (one wave: the stores above are ordered before the loads below)
+        __syncthreads();
         for (int t = i; t < tot.nsrc; t += 64) { tot.host_final_nbox[t] = final_nbox[t]; tot.host_final_loss[t] = final_loss[t]; }
         if (i == 0) {
             double L = 0.0; long long NB = 0;

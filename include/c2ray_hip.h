@@ -58,18 +58,22 @@ typedef struct c2r_params {
                                       * 1: per-source Gamma grids reduced in source order: bit-reproducible, and
                                       *    the summation order of the serial reference (evolve_point.F90:283);
                                       *    costs 16 B x N^3 of scratch per source in flight */
-    int32_t sweep_mode;              /* C2R_SWEEP_EXACT (0, default): every f64 operation of evolve0D/cinterp/photoion_rates
-                                      *    in the reference's order, IEEE-exact division and sqrt: column densities
-                                      *    bit-identical to the Fortran;
-                                      * C2R_SWEEP_FAST (1): algebraically re-associated arithmetic (factored
-                                      *    interpolation weights, 2^-48 reciprocals, fused table position): same
-                                      *    integer results, column densities within 1e-11 and rates within
-                                      *    |dGamma| <= 1e-12 Gamma + 2e-14 W of the oracle (W = sum_s (1+tau_in) photo_in /
-                                      *    (vol_ph n_HI): the rate that passes THROUGH the cell; worst plain relative error
-                                      *    measured 7.6e-8, in cells whose own rate is ~1e-7 of W; exact mode 1e-13 / 1.8e-8):
-                                      *    the tolerances the GPU tests apply live in tests/_util.py (TOL); ~1.3x the
-                                      *    throughput.  Only this field selects the mode: the library reads no environment
-                                      *    variable for it (the Fortran shim and the Python host have their own switches) */
+    int32_t sweep_mode;              /* C2R_SWEEP_EXACT (0, default): every f64 operation of evolve0D's geometry and of cinterp
+                                      *    (column_density.f90:29-271) in the reference's order, IEEE-exact division and
+                                      *    sqrt: column densities bit-identical to the Fortran.  The RATE of a cell
+                                      *    (photoion_rates, radiation_photoionrates.F90:71-317) is evaluated by the routine both
+                                      *    modes share (kernels.hpp rates_fast: table position straight out of the logarithm,
+                                      *    one 2^-48 reciprocal): inside |dGamma| <= 1e-13 Gamma + 2e-14 W of the oracle, the
+                                      *    bound this mode has always stated (the rounding of the table position dominates it
+                                      *    in the reference's own libm too);
+                                      * C2R_SWEEP_FAST (1): the interpolation and the geometry re-associated as well (factored
+                                      *    weights, 2^-48 reciprocals): same integer results, column densities within 1e-11 and
+                                      *    rates within |dGamma| <= 1e-12 Gamma + 2e-14 W of the oracle (W = sum_s (1+tau_in)
+                                      *    photo_in / (vol_ph n_HI): the rate that passes THROUGH the cell; worst plain relative
+                                      *    error measured 7.6e-8, in cells whose own rate is ~1e-7 of W): the tolerances the GPU
+                                      *    tests apply live in tests/_util.py (TOL); ~1.2x the throughput.  Only this field
+                                      *    selects the mode: the library reads no environment variable for it (the Fortran shim
+                                      *    and the Python host have their own switches) */
     int32_t reserved1;
     double  epsilon;                 /* c2ray_parameters.f90:31 */
     double  convergence_fraction;    /* :25 */

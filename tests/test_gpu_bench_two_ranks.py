@@ -56,3 +56,46 @@ def test_bench_plain_form_launches_its_own_ranks():
     assert a["check"]["sum_nbox_last_step"] == b["check"]["sum_nbox_last_step"]
     for k in ("phih_grid_sum", "xh_intermed_sum", "xh_av_sum"):
         assert abs(a["check"][k] / b["check"][k] - 1) < 1e-11, k
+
+
+ARGS8 = ["--steps", "2", "--warmup", "1", "--mesh", "64", "--sources", "64", "--no-cpu-baseline", "--no-other-mode"]
+
+
+@pytest.mark.parametrize("form,balance", [("launcher", False), ("plain", True)])
+def test_bench_eight_ranks_equal_one_rank(form, balance):
+    """The driver's scaling step runs 1 / 2 / 4 / 8 ranks; only two had ever been tried.  Eight ranks (all on the box's one GPU,
+    gloo) through both launch forms: the line says 8 ranks, the checksums equal the one-rank line's to the order of the sums,
+    the shares (static stride, or the library's LPT partition with --balance: master_slave.F90:74-96 / :124-330) partition the
+    source list."""
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + ARGS8, capture_output=True,
+                         text=True, timeout=900, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    extra = ["--balance"] if balance else []
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(C2R_BENCH_TEST_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    if form == "launcher":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+               "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "8"] + ARGS8 + extra
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + ARGS8 + extra
+    eight = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert eight.returncode == 0, eight.stderr[-2000:]
+    a, b = line(one.stdout), line(eight.stdout)
+    assert (a["n_gpus"], b["n_gpus"]) == (1, 8) and b["config"]["ranks"] == 8 and b["scaling"] == "strong"
+    assert a["check"]["sum_nbox_last_step"] == b["check"]["sum_nbox_last_step"]
+    assert a["config"]["visited_cell_sources_per_step"] == b["config"]["visited_cell_sources_per_step"]
+    for k in ("phih_grid_sum", "xh_intermed_sum", "xh_av_sum"):
+        assert abs(a["check"][k] / b["check"][k] - 1) < 1e-11, k
+    assert b["config"]["shares_partition_sources"] is True and sum(b["config"]["source_share_sizes"]) == 64
+    assert len(b["config"]["source_share_sizes"]) == 8
+    if not balance:
+        assert b["config"]["source_share_sizes"] == [8] * 8
+
+
+def test_bench_a_failing_rank_fails_the_run():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(C2R_BENCH_TEST_ONE_GPU="1", C2R_BENCH_TEST_FAIL_RANK="3")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"] + ARGS8, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.split("\n") if l.startswith("{")]

@@ -285,6 +285,43 @@ def test_504_many_sources_in_three_batches(pkg, tables):
     assert np.max(np.abs(res["three"][3] / res["one"][3] - 1)) < 1e-12
 
 
+def test_504_ten_thousand_sources(pkg, tables):
+    """BASELINE configs[4] at its own size: 504^3, log-normal density, **10 000 sources** -- one pass through the ~4 scratch
+    batches the library cuts by itself (24.5 MB of shell planes per source against a quarter of the free HBM).  Every source
+    traces the whole mesh (51 sub-boxes, N^3 cells each), every cell receives a rate, two of the sources are checked
+    against the oracle (cached: the same two as in the 48-source test) and the other 9 998 by additivity."""
+    n, S = 504, 10000
+    tp = pkg.TestProblem(n)
+    s = tp.step(1)
+    _, xh = tp.fields(1, 0.9995)
+    rng = np.random.default_rng(20261003)
+    nd = (np.float32(s["ndens"]) * np.exp(rng.standard_normal(n ** 3, dtype=np.float32) - 0.5)).astype(np.float32)
+    pos, nf = pkg.seeded_sources(n, S, seed=504)
+    pos[0] = (17, 480, 252); pos[1] = (300, 301, 302)
+    nf[0], nf[1] = 3e8, 1e9
+    b = backend(pkg, tables, s, n, nd, xh, pos, nf)
+    b.begin_step(); b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    assert nbox == 51 * S and vis == S * n ** 3 and np.all(b.last_nbox() == 51)
+    whole = b.fetch("phih_grid")
+    assert np.all(whole > 0)
+    if "504many" not in _cache:
+        _cache["504many"] = oracle_pass(oracle_for(s, tables, n), nd, xh, pos[:2], nf[:2])
+    oloss, onb, ovis, ophih, w = _cache["504many"]
+    b.set_sources(pos[:2], nf[:2]); b.zero_rates()
+    l_a, nb_a, v_a = b.pass_sources()
+    g_a = b.fetch("phih_grid")
+    assert (nb_a, v_a) == (onb, ovis) and abs(l_a - oloss) <= tol("loss") * abs(oloss) + 1e-300
+    assert_gamma(g_a, ophih, w, "504^3, 2 of 10 000")
+    b.set_sources(pos[2:], nf[2:]); b.zero_rates()
+    l_b, nb_b, v_b = b.pass_sources()
+    g_a += b.fetch("phih_grid")
+    assert (nb_a + nb_b, v_a + v_b) == (nbox, vis)
+    assert abs(l_a + l_b - loss) <= 1e-12 * abs(loss)
+    assert np.max(np.abs(g_a - whole) / whole) < 1e-11       # 10 000 atomic adds per cell in either order
+    b.close()
+
+
 @pytest.mark.parametrize("case,tag", [("evolve32_std_bubbles", "step001"), ("evolve32_onesrc", "step001"), ("evolve64_std_bubbles", "step001")])
 def test_graph_replay_equals_eager_launches_while_the_sub_boxes_change(pkg, tables, monkeypatch, case, tag):
     """Batches of <= 32 sources replay their launch sequence as a hipGraph up to the sub-box the previous pass ended at
