@@ -296,6 +296,7 @@ def main():
     b.profile(prof_mode)
     visited_before = ev.visited
     ev.visited = 0
+    xchg0 = b.exchange_stats()
     nbox_hist = []
     t0 = time.perf_counter()
     fused_visited = 0.0        # pairs traced by k_sweep_box_fused (sub-boxes 1 and 2), this rank, timed steps
@@ -312,6 +313,7 @@ def main():
     sync()
     dt_wall = time.perf_counter() - t0
     prof = b.profile_read()
+    xchg1 = b.exchange_stats()
     # checksums of the state the timed steps leave (the same on every rank: Gamma is all-reduced, the global pass replicated)
     check = {"phih_grid_sum": float(b.phih_grid.sum(dtype=torch.float64)), "xh_intermed_sum": float(b.xh_intermed.sum(dtype=torch.float64)),
              "xh_av_sum": float(b.xh_av.sum(dtype=torch.float64)), "sum_nbox_last_step": int(nbox_hist[-1]) if nbox_hist else 0}
@@ -360,6 +362,10 @@ def main():
                        "mesh": n, "sources": S, "sweep_mode": args.sweep_mode, "isothermal": not args.thermal, "gamma_accumulation": "ordered" if args.deterministic else "atomic", "sources_per_gpu": len(pkg.static_source_share(S, 0, world)),
                        "parallelism": "sources sharded over %d GPU(s), RCCL all-reduce of Gamma" % world,
                        "ranks": dist.get_world_size() if world > 1 else 1,
+                       # evolve.F90:599 through c2r_allreduce_rates: the whole grid, or the sources' packed sub-boxes while those are few
+                       "gamma_exchange": {"calls": xchg1["calls"] - xchg0["calls"], "packed_calls": xchg1["sparse_calls"] - xchg0["sparse_calls"],
+                                          "bytes_per_step": (xchg1["bytes_total"] - xchg0["bytes_total"]) / max(1, args.steps),
+                                          "full_grid_bytes": 8 * n ** 3} if world > 1 else None,
                        "source_share_sizes": [len(x) for x in shares] if shares else [S],
                        "shares_partition_sources": (sorted(i for x in shares for i in x) == list(range(S))) if shares else True,
                        "collective": None if world == 1 else ("gloo (C2R_BENCH_TEST_ONE_GPU)" if one_gpu_test else "nccl (RCCL)"),

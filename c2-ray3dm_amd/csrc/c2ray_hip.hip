@@ -57,11 +57,12 @@ struct Ctx {
     std::vector<int32_t> last_nbox;                              // final sub-box count per local source, last pass
     int box_hint = 0;                                            // largest of them: how far the next pass is expected to go
     // hipGraph of a small batch's launch sequence up to box_hint (see sweep_batch); gen counts everything that
-    // the captured kernel arguments depend on (step scalars, tables, buffers, stream, scratch, physics switches)
+    // the captured kernel arguments depend on (tables, buffers, stream, scratch, physics switches; NOT the step's scalars: sync_step)
     struct BatchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long long gen = 0; int count = 0, n_active = 0, hint = 0;
-                        bool fused = false; double dt = 0.0; bool stats = false; };
+                        bool fused = false; bool stats = false; };
     std::map<int, BatchGraph> graphs;                            // key: 2 x (first source of the batch) + (fused iteration ? 1 : 0)
     unsigned long long gen = 1;
+    long long captures = 0;                                      // launch sequences captured so far (c2r_info; tests: a new time step must not add one)
     bool use_graph = true;                                       // C2R_GRAPH=0: never (experiments)
     bool fused_iter = true;                                      // C2R_FUSED_ITER=0: c2r_iterate always runs its three steps in turn (experiments)
     bool fold_source_cell = true;                                // C2R_FOLD_SOURCE_CELL=0: k_source_cells is always its own launch (experiments)
@@ -73,6 +74,14 @@ struct Ctx {
     double *d_nbox_all = nullptr, *h_nbox_all = nullptr; int nbox_all_cap = 0;   // device buffer + pinned staging
     c2r_allreduce_fn ar = nullptr;
     void *ar_user = nullptr;
+    // sparse exchange of the rates (c2r_allreduce_rates): while the sources' final sub-boxes cover a small part of the mesh only
+    // the boxes travel (C2R_SPARSE_EXCHANGE=0: always the whole grid; C2R_SPARSE_FRACTION: the largest sum of box volumes, in
+    // units of the mesh, that still goes packed)
+    bool sparse_exchange = true; double sparse_fraction = 0.5;
+    long long pass_id = 0, nbox_all_pass = -1;                   // passes swept so far; the pass nbox_all was gathered for
+    bool sparse_valid = false;                                   // the rates in phih_grid are those of the last c2r_pass_sources over zeroed rates
+    double *d_pack = nullptr; size_t pack_cap = 0; BoxDesc *d_boxdesc = nullptr; int boxdesc_cap = 0;
+    long long xchg_calls = 0, xchg_sparse = 0, xchg_bytes_last = 0, xchg_bytes_total = 0;
     // slab chemistry (c2r_set_slab_chemistry): reduce-scatter of the rates by z-slabs, the global pass on the own slab,
     // all-gather of its outputs -- instead of the all-reduce and a replicated global pass
     c2r_reduce_scatter_fn rs = nullptr; c2r_allgather_fn ag = nullptr; void *slab_user = nullptr;
@@ -88,6 +97,8 @@ struct Ctx {
     bool fuse_small = true;     // C2R_FUSE_SMALL=0 disables the fused first sub-boxes (experiments, A/B tests)
     bool sched_hint = true;     // C2R_SCHED_HINT=0: always one sub-box ahead (experiments, see sweep_batch)
     double *d_planes = nullptr;
+    // the time step's scalars as the kernels read them (kernels.hpp StepBlock + ShellStep[Qmax + 1]): device copy, the image last sent
+    char *d_step = nullptr; std::vector<char> step_image; double step_dt = 0.0;
     int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr;
     double *d_gbox = nullptr;   // deterministic mode: [batch_cap][2][ncell]
     double *d_gbox_h = nullptr; // ... and the per-source heating rates of a non-isothermal run
@@ -251,15 +262,18 @@ KParams make_kparams(const Ctx *ctx)
 {
     KParams k{};
     const c2r_params &p = ctx->prm;
-    for (int d = 0; d < 3; ++d) { k.n[d] = p.mesh[d]; k.hl[d] = ctx->hl[d]; k.hr[d] = ctx->hr[d]; k.dr[d] = ctx->dr[d]; }
-    k.vol = ctx->vol; k.coldensh_LLS = ctx->lls;
+    for (int d = 0; d < 3; ++d) { k.n[d] = p.mesh[d]; k.hl[d] = ctx->hl[d]; k.hr[d] = ctx->hr[d]; }
+    // dr, vol, coldensh_LLS, inv_dr0, dr2 stay zero here: the kernels read them from the device-resident step block
+    // (load_step), so that captured launches do not depend on the time step
+    k.step = reinterpret_cast<const StepBlock *>(ctx->d_step);
+    k.shell_step = reinterpret_cast<const ShellStep *>(ctx->d_step + sizeof(StepBlock));
     k.sigma = p.sigma_HI; k.wfloor = p.weight_floor; k.sqrt2 = p.sqrt2; k.sqrt3 = p.sqrt3;
     k.fourpi = 4.0 * p.pi;                      // evolve_point.F90:177: 4.0*pi*dist2*path, left to right
     k.max_coldensh = p.max_coldensh; k.tau_limit = p.tau_photo_limit;
     k.minlogtau = p.minlogtau; k.dlogtau = p.dlogtau; k.numtau = p.numtau; k.numtau_d = (double)p.numtau;
     k.eps = p.epsilon;
-    k.inv_dlogtau = 1.0 / p.dlogtau; k.inv_dr0 = 1.0 / ctx->dr[0];
-    k.exact_udiv = udiv_ok(p.dlogtau) && udiv_ok(ctx->dr[0]);
+    k.inv_dlogtau = 1.0 / p.dlogtau;
+    k.exact_udiv = udiv_ok(p.dlogtau);               // (load_step adds udiv_ok(dr[0]))
     k.R = ctx->R; k.P = ctx->P; k.PP = ctx->PP;
     k.nhi = ctx->d_nhi; k.nhi_T = ctx->d_nhi_T; k.phih = (double *)ctx->grid[4]; k.phih_T = ctx->d_phih_T;
     k.gbox = ctx->d_gbox; k.gbox_h = ctx->thermal ? ctx->d_gbox_h : nullptr;
@@ -270,9 +284,43 @@ KParams make_kparams(const Ctx *ctx)
     k.odtab = ctx->d_odtab;
     k.od_per_e = (double)(0.301029995663981195213738894724493027L / (long double)p.dlogtau);
     k.od_per_ln = (double)(0.434294481903251827651128918916605082L / (long double)p.dlogtau);
-    for (int d = 0; d < 3; ++d) k.dr2[d] = ctx->dr[d] * ctx->dr[d];
     k.srcpos = ctx->d_srcpos_b; k.srcw = ctx->d_srcw_b; k.normflux = ctx->d_nflux_b; k.planes = ctx->d_planes;
     return k;
+}
+
+// The step block as the device should hold it now: sent only when it differs from what was sent last (once per time step, or
+// when a setter changed something).  Ordered on the context's stream before whatever is enqueued next; never inside a capture.
+int sync_step(Ctx *ctx)
+{
+    const c2r_params &p = ctx->prm;
+    const int nsh = ctx->Qmax + 1;
+    std::vector<char> img(sizeof(StepBlock) + (size_t)nsh * sizeof(ShellStep), 0);
+    StepBlock *st = reinterpret_cast<StepBlock *>(img.data());
+    ShellStep *sh = reinterpret_cast<ShellStep *>(img.data() + sizeof(StepBlock));
+    for (int d = 0; d < 3; ++d) { st->dr[d] = ctx->dr[d]; st->dr2[d] = ctx->dr[d] * ctx->dr[d]; }
+    st->vol = ctx->vol; st->coldensh_LLS = ctx->lls; st->inv_dr0 = 1.0 / ctx->dr[0];
+    st->exact_udiv_dr0 = udiv_ok(ctx->dr[0]) ? 1 : 0; st->n_shell = nsh;
+    for (int q = 1; q < nsh; ++q) {
+        for (int d = 0; d < 3; ++d) { const double t = ctx->dr[d] * (double)q; sh[q].d2axis[d] = t * t; }   // sign drops out
+        sh[q].path_scale = ctx->dr[0] / (double)q;
+        sh[q].lls_scale = ctx->lls_type == 2 ? 1.0 / (double)q : ctx->lls / (double)q;
+    }
+    // doric.f90:73,78 -- temperature is uniform (isothermal), so both rate coefficients are per-step constants; evaluated
+    // with the host libm like the reference does at run time
+    ChemStep &c = st->chem;
+    c.dt = ctx->step_dt;
+    c.recpow = pow(ctx->temper / 1e4, p.albpow);
+    c.brech0 = (double)ctx->clumping * p.bh00 * c.recpow;
+    c.acolh0 = p.colh0 * sqrt(ctx->temper) * exp(-p.temph0 / ctx->temper);
+    c.clumping = (double)ctx->clumping; c.sqrtt = sqrt(ctx->temper); c.expt = exp(-p.temph0 / ctx->temper);
+    // cosmology.F90:220: dzdt = H0*(1.+zred)*sqrt(Omega0*(1.+zred)**3+1.-Omega0)
+    c.zp = 1.0 + ctx->zred;
+    c.dzdt = (ctx->thermal && ctx->tprm.cosmological) ? ctx->tprm.H0 * c.zp * sqrt(ctx->tprm.Omega0 * (c.zp * c.zp * c.zp) + 1.0 - ctx->tprm.Omega0) : 0.0;
+    if (img == ctx->step_image) return C2R_OK;
+    // (from pageable memory: the runtime stages a copy this small before the call returns)
+    HIP_TRY(hipMemcpyAsync(ctx->d_step, img.data(), img.size(), hipMemcpyHostToDevice, ctx->stream));
+    ctx->step_image.swap(img);
+    return C2R_OK;
 }
 
 void prof_begin(Ctx *ctx, std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool, size_t &used)
@@ -458,9 +506,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             }
             sa.alam = (double)((float)(q - 1) + 0.5f) / (double)(float)q;
             sa.dp2 = (double)q * (double)q; sa.inv_dp2 = 1.0 / sa.dp2;
-            for (int d = 0; d < 3; ++d) { const double t = ctx->dr[d] * (double)q; sa.d2axis[d] = t * t; }   // sign drops out
-            sa.inv_q = 1.0 / (double)q; sa.path_scale = ctx->dr[0] / (double)q;
-            sa.lls_scale = ctx->lls_type == 2 ? 1.0 / (double)q : ctx->lls / (double)q;
+            sa.inv_q = 1.0 / (double)q;                  // ((dr_d q)^2, dr[0]/q, coldensh_LLS/q: the step block, sync_step)
             sa.active = ctx->d_active[cur]; sa.n_active = ctx->d_nactive + cur;
             sa.loss_partial = ctx->d_loss_partial; sa.dbg_cdout = dbg;
             return sa;
@@ -648,10 +694,11 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
         // c2r_pass_sources and c2r_iterate does not re-capture every time)
         Ctx::BatchGraph &bg = ctx->graphs[2 * first + (fuse_iter ? 1 : 0)];
         if (!(bg.exec && bg.gen == ctx->gen && bg.count == count && bg.n_active == n_active && bg.hint == hint &&
-              bg.fused == fuse_iter && (!fuse_iter || (bg.dt == fz->dt && bg.stats == fz->stats)))) {
+              bg.fused == fuse_iter && (!fuse_iter || bg.stats == fz->stats))) {
             if (bg.exec) { hipGraphExecDestroy(bg.exec); bg.exec = nullptr; }
             if (bg.graph) { hipGraphDestroy(bg.graph); bg.graph = nullptr; }
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                ++ctx->captures;
                 // fused iteration: no upload node -- k_prepare_nhi restores the batch's state block from its device image
                 if (fuse_iter) fz->batch_in_prepare = true;
                 int rc = fuse_iter ? fz->pre() : C2R_OK;
@@ -670,7 +717,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                 const hipError_t e = hipStreamEndCapture(st, &bg.graph);
                 if (rc == C2R_OK && e == hipSuccess && hipGraphInstantiate(&bg.exec, bg.graph, nullptr, nullptr, 0) == hipSuccess) {
                     bg.gen = ctx->gen; bg.count = count; bg.n_active = n_active; bg.hint = hint;
-                    bg.fused = fuse_iter; bg.dt = fuse_iter ? fz->dt : 0.0; bg.stats = fuse_iter && fz->stats;
+                    bg.fused = fuse_iter; bg.stats = fuse_iter && fz->stats;
                 } else {
                     if (bg.graph) { hipGraphDestroy(bg.graph); bg.graph = nullptr; }
                     bg.exec = nullptr;
@@ -849,10 +896,10 @@ void balance_before_pass(Ctx *ctx)
 }
 
 // After a pass: every rank contributes the sub-box counts of the sources it swept (zero elsewhere); the sum over
-// ranks through the all-reduce callback is the full list (exact in f64).
-int balance_after_pass(Ctx *ctx)
+// ranks through the all-reduce callback is the full list (exact in f64).  Once per pass (nbox_all_pass).
+int gather_nbox_all(Ctx *ctx)
 {
-    if (!ctx->balance || ctx->nranks <= 1 || !ctx->ar || (ctx->explicit_share && !ctx->auto_share) || ctx->nsrc == 0) return C2R_OK;
+    if (ctx->nbox_all_pass == ctx->pass_id && (int)ctx->nbox_all.size() == ctx->nsrc) return C2R_OK;
     if (ctx->nbox_all_cap < ctx->nsrc) {
         hipFree(ctx->d_nbox_all); ctx->d_nbox_all = nullptr; ctx->nbox_all_cap = 0;
         if (ctx->h_nbox_all) { hipHostFree(ctx->h_nbox_all); ctx->h_nbox_all = nullptr; }
@@ -874,7 +921,14 @@ int balance_after_pass(Ctx *ctx)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->nbox_all.resize(ctx->nsrc);
     for (int i = 0; i < ctx->nsrc; ++i) ctx->nbox_all[i] = (int32_t)llround(mine[i]);
+    ctx->nbox_all_pass = ctx->pass_id;
     return C2R_OK;
+}
+
+int balance_after_pass(Ctx *ctx)
+{
+    if (!ctx->balance || ctx->nranks <= 1 || !ctx->ar || (ctx->explicit_share && !ctx->auto_share) || ctx->nsrc == 0) return C2R_OK;
+    return gather_nbox_all(ctx);
 }
 
 }  // namespace
@@ -917,6 +971,8 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     if (const char *e = getenv("C2R_PAIR_SHELLS")) ctx->pair_shells = atoi(e) != 0;
     if (const char *e = getenv("C2R_SPIN_WAIT")) ctx->spin_wait = atoi(e) != 0;
     if (const char *e = getenv("C2R_FOLD_SOURCE_CELL")) ctx->fold_source_cell = atoi(e) != 0;
+    if (const char *e = getenv("C2R_SPARSE_EXCHANGE")) ctx->sparse_exchange = atoi(e) != 0;
+    if (const char *e = getenv("C2R_SPARSE_FRACTION")) ctx->sparse_fraction = std::max(0.0, atof(e));
     if (p->sweep_mode != C2R_SWEEP_EXACT && p->sweep_mode != C2R_SWEEP_FAST) { delete ctx; return C2R_EINVAL; }
     ctx->fast = p->sweep_mode == C2R_SWEEP_FAST;          // the caller's choice only: no environment override
     *out = reinterpret_cast<c2r_ctx *>(ctx);     // returned even on failure so c2r_last_error works
@@ -1008,10 +1064,13 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     ctx->Qmax = std::min(ctx->nbox_max * p->subboxsize, reach);
     ctx->R = ctx->Qmax; ctx->P = 2 * ctx->R + 1; ctx->PP = (size_t)ctx->P * ctx->P;
     ctx->tiles_cap = (int)((ctx->PP + kBlock - 1) / kBlock);
+    HIP_TRY(hipMalloc(&ctx->d_step, sizeof(StepBlock) + (size_t)(ctx->Qmax + 1) * sizeof(ShellStep)));
     HIP_TRY(hipHostMalloc((void **)&ctx->h_nactive, (size_t)(ctx->nbox_max + 2) * sizeof(int), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void **)&ctx->d_hnactive, ctx->h_nactive, 0));
     ctx->ev_box.resize(ctx->nbox_max + 2);
     for (auto &e : ctx->ev_box) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipLaunchKernelGGL(k_load_code_object, dim3(1), dim3(1), 0, ctx->stream, (int *)nullptr);      // (loads the library's code object now)
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return C2R_OK;
 }
 
@@ -1026,7 +1085,7 @@ void c2r_destroy(c2r_ctx *c)
     for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
     hipFree(ctx->grid[5]); hipFree(ctx->grid[6]); hipFree(ctx->d_hthick); hipFree(ctx->d_hthin); hipFree(ctx->d_cool); hipFree(ctx->d_heat_T);
     hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_logtab); hipFree(ctx->d_odtab);
-    hipFree(ctx->d_nhi); hipFree(ctx->d_nhi_T); hipFree(ctx->d_phih_T);
+    hipFree(ctx->d_nhi); hipFree(ctx->d_nhi_T); hipFree(ctx->d_phih_T); hipFree(ctx->d_step); hipFree(ctx->d_pack); hipFree(ctx->d_boxdesc);
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
     hipFree(ctx->d_photon_loss); hipFree(ctx->d_sum_nbox); hipFree(ctx->d_sum_partial); hipFree(ctx->d_sum_out); hipFree(ctx->d_stat_partial);
@@ -1049,7 +1108,8 @@ const char *c2r_info(c2r_ctx *c)
     Ctx *ctx = C(c);
     ctx->info = ctx->info_device + "; sweep_mode " + (ctx->fast ? "fast (C2R_SWEEP_FAST)" : "exact (C2R_SWEEP_EXACT)") +
                 "; rates " + (ctx->prm.deterministic_rates ? "ordered per-source sums" : "f64 atomics") +
-                "; rank " + std::to_string(ctx->rank) + " of " + std::to_string(ctx->nranks);
+                "; rank " + std::to_string(ctx->rank) + " of " + std::to_string(ctx->nranks) +
+                "; graph captures " + std::to_string(ctx->captures);
     if (!ctx->info_warn.empty()) ctx->info += "; " + ctx->info_warn;
     return ctx->info.c_str();
 }
@@ -1087,7 +1147,7 @@ int c2r_set_step(c2r_ctx *c, const double dr[3], double vol, double lls, float c
     if (!c || !dr) return C2R_EINVAL;
     Ctx *ctx = C(c);
     if (!(dr[0] > 0) || !(dr[1] > 0) || !(dr[2] > 0) || !(vol > 0) || !(temper > 0)) FAIL(C2R_EINVAL, "dr, vol and temper must be positive");
-    if (ctx->dr[0] != dr[0] || ctx->dr[1] != dr[1] || ctx->dr[2] != dr[2] || ctx->vol != vol || ctx->lls != lls) ++ctx->gen;
+    // (no captured launch depends on these: they reach the kernels through the device-resident step block, sync_step)
     for (int d = 0; d < 3; ++d) ctx->dr[d] = dr[d];
     ctx->vol = vol; ctx->lls = lls; ctx->clumping = clumping; ctx->temper = temper;
     ctx->have_step = true;
@@ -1122,8 +1182,10 @@ int c2r_set_clumping_grid(c2r_ctx *c, const float *clump_grid)
     Ctx *ctx = C(c);
     HIP_TRY(hipSetDevice(ctx->prm.device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (!clump_grid) { hipFree(ctx->d_clump); ctx->d_clump = nullptr; return C2R_OK; }
-    if (!ctx->d_clump) HIP_TRY(hipMalloc(&ctx->d_clump, grid_bytes(ctx, 0)));
+    // (a captured iteration holds the grid's pointer, or its absence, in the global pass's arguments: a new generation when it
+    // appears or goes; a refill of the same allocation is seen by every launch)
+    if (!clump_grid) { if (ctx->d_clump) ++ctx->gen; hipFree(ctx->d_clump); ctx->d_clump = nullptr; return C2R_OK; }
+    if (!ctx->d_clump) { HIP_TRY(hipMalloc(&ctx->d_clump, grid_bytes(ctx, 0))); ++ctx->gen; }
     HIP_TRY(hipMemcpy(ctx->d_clump, clump_grid, grid_bytes(ctx, 0), hipMemcpyHostToDevice));
     return C2R_OK;
 }
@@ -1209,6 +1271,13 @@ int c2r_set_sources(c2r_ctx *c, const int32_t *srcpos, const double *normflux, i
     ctx->nflux.assign(normflux, normflux + nsrc);
     ctx->nsrc = nsrc;
     ctx->explicit_share = false; ctx->auto_share = false; ctx->share.clear(); ctx->last_nbox.clear(); ctx->nbox_all.clear(); ctx->box_hint = 0;
+    // set-up belongs here, not in the first evolve3D of a run (the reference allocates in evolve_ini, evolve_data.F90:75-90): the
+    // sweep scratch of this rank's share -- device planes, the pinned staging block -- is a few milliseconds of allocation calls
+    if (nsrc > 0 && n_local_sources(ctx) > 0) {
+        HIP_TRY(hipSetDevice(ctx->prm.device));
+        const int rc = ensure_sweep_scratch(ctx, n_local_sources(ctx));
+        if (rc) return rc;
+    }
     return C2R_OK;
 }
 
@@ -1368,9 +1437,11 @@ static int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64
                              bool no_wait = false)
 {
     int rc;
+    if ((rc = sync_step(ctx))) return rc;
     balance_before_pass(ctx);
     const int nloc = n_local_sources(ctx);
     long long vis = 0;
+    ++ctx->pass_id; ctx->sparse_valid = true;
     ctx->last_nbox.clear();
     ctx->h_sc->photon_loss = 0.0; ctx->h_sc->sum_nbox = 0;      // (the stream is idle between calls)
     if (nloc > 0) {
@@ -1414,9 +1485,73 @@ int c2r_allreduce_rates(c2r_ctx *c)
     if (!c) return C2R_EINVAL;
     Ctx *ctx = C(c);
     if (ctx->nranks <= 1 || !ctx->ar) return C2R_OK;
+    const c2r_params &p = ctx->prm;
+    ++ctx->xchg_calls;
+    // Sparse form: every rank learns every source's final sub-box (one small all-reduce), so all ranks agree on the same list
+    // of boxes; while their volumes add up to a fraction of the mesh, only they travel -- packed box after box in source
+    // order, reduced, written back (a cell of two overlapping boxes travels twice and comes back with the same sum).  The
+    // rates are zero everywhere else on every rank (set_rates_to_zero, evolve.F90:430): the result is the all-reduce's.
+    if (ctx->sparse_exchange && ctx->nsrc > 0 && ctx->sparse_valid) {
+        HIP_TRY(hipSetDevice(ctx->prm.device));
+        int rc = gather_nbox_all(ctx);
+        if (rc) return rc;
+        long long total = 0;
+        std::vector<BoxDesc> desc(ctx->nsrc);
+        for (int i = 0; i < ctx->nsrc; ++i) {
+            BoxDesc &d = desc[i];
+            for (int a = 0; a < 3; ++a) { const int m = (ctx->srcpos[3 * (size_t)i + a] - 1) % p.mesh[a]; d.c[a] = m < 0 ? m + p.mesh[a] : m; }
+            d.nbox = ctx->nbox_all[i]; d.off = total;
+            total += visited_for_nbox(ctx, d.nbox);
+        }
+        if ((double)total <= ctx->sparse_fraction * (double)ctx->ncell) {
+            if (total > 0) {
+                if ((size_t)total > ctx->pack_cap) {
+                    hipFree(ctx->d_pack); ctx->d_pack = nullptr; ctx->pack_cap = 0;
+                    const size_t cap = std::max<size_t>((size_t)total, (size_t)(ctx->sparse_fraction * (double)ctx->ncell));
+                    HIP_TRY(hipMalloc(&ctx->d_pack, cap * sizeof(double)));
+                    ctx->pack_cap = cap;
+                }
+                if (ctx->nsrc > ctx->boxdesc_cap) {
+                    hipFree(ctx->d_boxdesc); ctx->d_boxdesc = nullptr; ctx->boxdesc_cap = 0;
+                    HIP_TRY(hipMalloc(&ctx->d_boxdesc, (size_t)ctx->nsrc * sizeof(BoxDesc)));
+                    ctx->boxdesc_cap = ctx->nsrc;
+                }
+                HIP_TRY(hipMemcpyAsync(ctx->d_boxdesc, desc.data(), desc.size() * sizeof(BoxDesc), hipMemcpyHostToDevice, ctx->stream));
+                int nb_max = 0;
+                for (const BoxDesc &d : desc) nb_max = std::max(nb_max, d.nbox);
+                const long long vmax = visited_for_nbox(ctx, nb_max);
+                const dim3 grid((unsigned)std::min<long long>((vmax + 255) / 256, 4096), (unsigned)ctx->nsrc), blk(256);
+                for (int w = 4; w <= (ctx->thermal ? 5 : 4); ++w) {               // phih_grid, phiheat_grid (evolve.F90:599, :604-609)
+                    hipLaunchKernelGGL(k_pack_boxes<false>, grid, blk, 0, ctx->stream, p.mesh[0], p.mesh[1], p.mesh[2], ctx->hl[0], ctx->hl[1],
+                                       ctx->hl[2], ctx->hr[0], ctx->hr[1], ctx->hr[2], p.subboxsize, ctx->d_boxdesc, (double *)ctx->grid[w], ctx->d_pack);
+                    if (ctx->ar(ctx->ar_user, ctx->d_pack, (size_t)total, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-reduce callback failed");
+                    hipLaunchKernelGGL(k_pack_boxes<true>, grid, blk, 0, ctx->stream, p.mesh[0], p.mesh[1], p.mesh[2], ctx->hl[0], ctx->hl[1],
+                                       ctx->hl[2], ctx->hr[0], ctx->hr[1], ctx->hr[2], p.subboxsize, ctx->d_boxdesc, (double *)ctx->grid[w], ctx->d_pack);
+                }
+                HIP_TRY(hipGetLastError());
+            }
+            ++ctx->xchg_sparse;
+            ctx->xchg_bytes_last = (total * (ctx->thermal ? 2 : 1) + ctx->nsrc) * (long long)sizeof(double);
+            ctx->xchg_bytes_total += ctx->xchg_bytes_last;
+            return C2R_OK;
+        }
+    }
     if (ctx->ar(ctx->ar_user, ctx->grid[4], ctx->ncell, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-reduce callback failed");
     if (ctx->thermal && ctx->ar(ctx->ar_user, ctx->grid[5], ctx->ncell, (void *)ctx->stream) != 0)     // evolve.F90:604-609
         FAIL(C2R_ECALLBACK, "all-reduce callback failed");
+    ctx->xchg_bytes_last = ((long long)ctx->ncell * (ctx->thermal ? 2 : 1) + (ctx->sparse_exchange ? ctx->nsrc : 0)) * (long long)sizeof(double);
+    ctx->xchg_bytes_total += ctx->xchg_bytes_last;
+    return C2R_OK;
+}
+
+int c2r_exchange_stats(c2r_ctx *c, int64_t *calls, int64_t *sparse_calls, int64_t *bytes_last, int64_t *bytes_total)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (calls) *calls = ctx->xchg_calls;
+    if (sparse_calls) *sparse_calls = ctx->xchg_sparse;
+    if (bytes_last) *bytes_last = ctx->xchg_bytes_last;
+    if (bytes_total) *bytes_total = ctx->xchg_bytes_total;
     return C2R_OK;
 }
 
@@ -1429,6 +1564,8 @@ int c2r_do_source(c2r_ctx *c, int32_t ns, double *cd_host, double *loss, int32_t
     if (ns < 1 || ns > ctx->nsrc) FAIL(C2R_EINVAL, "source number out of range");
     rc = ensure_sweep_scratch(ctx, 1);
     if (rc) return rc;
+    if ((rc = sync_step(ctx))) return rc;
+    ctx->sparse_valid = false;                    // (one source, addressed directly: the per-rank sub-box list no longer describes phih_grid)
     double *dbg = nullptr;
     if (cd_host) {
         if (!ctx->d_dbg) HIP_TRY(hipMalloc(&ctx->d_dbg, ctx->ncell * sizeof(double)));
@@ -1560,15 +1697,16 @@ static int global_pass_enqueue(Ctx *ctx, double dt, double *stats_dst, size_t ce
 {
     const c2r_params &p = ctx->prm;
     ChemParams cp{};
-    cp.dt = dt; cp.eps = p.epsilon; cp.min_frac_change = p.minimum_fractional_change;
+    // (dt and the step's rate coefficients reach the kernel through the step block -- callers have run sync_step with this
+    // dt --; the by-value copies below only document what the kernel overwrites at entry)
+    cp.step = reinterpret_cast<const StepBlock *>(ctx->d_step);
+    cp.dt = 0.0 * dt; cp.eps = p.epsilon; cp.min_frac_change = p.minimum_fractional_change;
     cp.min_frac_atoms = p.minimum_fraction_of_atoms; cp.abu_c = p.abu_c; cp.deltht_small = C2R_DELTHT_SMALL;
     cp.max_iter = p.max_chem_iter;
     // doric.f90:73,78 -- temperature is uniform (isothermal), so both rate coefficients are
     // per-call constants; evaluated with the host libm like the reference does at run time
-    cp.brech0 = (double)ctx->clumping * p.bh00 * pow(ctx->temper / 1e4, p.albpow);
-    cp.bh00 = p.bh00; cp.recpow = pow(ctx->temper / 1e4, p.albpow); cp.clump = ctx->d_clump ? ctx->d_clump + cell_off : nullptr;
-    cp.acolh0 = p.colh0 * sqrt(ctx->temper) * exp(-p.temph0 / ctx->temper);
-    cp.clumping = (double)ctx->clumping; cp.colh0 = p.colh0; cp.sqrtt = sqrt(ctx->temper); cp.expt = exp(-p.temph0 / ctx->temper);
+    cp.bh00 = p.bh00; cp.clump = ctx->d_clump ? ctx->d_clump + cell_off : nullptr;
+    cp.colh0 = p.colh0;
     cp.stat_partial = ctx->d_stat_partial;
     if (ctx->thermal) {
         const c2r_thermal_params &t = ctx->tprm;
@@ -1578,9 +1716,6 @@ static int global_pass_enqueue(Ctx *ctx, double dt, double *stats_dst, size_t ce
         cp.thermal_max_steps = t.thermal_max_steps;
         cp.k_B = t.k_B; cp.gamma1 = t.gamma1; cp.minitemp = t.minitemp; cp.rel_denergy = t.relative_denergy;
         cp.rate_floor = t.thermal_rate_floor; cp.time_tol = t.thermal_time_tol;
-        // cosmology.F90:220: dzdt = H0*(1.+zred)*sqrt(Omega0*(1.+zred)**3+1.-Omega0)
-        cp.zp = 1.0 + ctx->zred;
-        cp.dzdt = t.cosmological ? t.H0 * cp.zp * sqrt(t.Omega0 * (cp.zp * cp.zp * cp.zp) + 1.0 - t.Omega0) : 0.0;
         cp.temph0 = p.temph0; cp.albpow = p.albpow;
         cp.tconv_rel = t.temp_conv_rel; cp.tconv_abs = t.temp_conv_abs;
     }
@@ -1609,7 +1744,10 @@ static int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum
                             size_t cell_off = 0, size_t cell_cnt = (size_t)-1)
 {
     if (cell_cnt == (size_t)-1) cell_cnt = ctx->ncell;        // (a slab [cell_off, cell_off+cell_cnt): slab chemistry)
-    const int rc = global_pass_enqueue(ctx, dt, stats_dst, cell_off, cell_cnt, nullptr);
+    ctx->step_dt = dt;
+    int rc = sync_step(ctx);
+    if (rc) return rc;
+    rc = global_pass_enqueue(ctx, dt, stats_dst, cell_off, cell_cnt, nullptr);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
@@ -1634,6 +1772,8 @@ static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, i
                         double *sum1)
 {
     int rc;
+    ctx->step_dt = dt;
+    if ((rc = sync_step(ctx))) return rc;
     const int nloc = n_local_sources(ctx);
     bool can_fuse = ctx->fused_iter && ctx->nranks == 1 && !ctx->balance && ctx->use_graph && ctx->sched_hint && ctx->prof == 0 && nloc > 0 &&
                     nloc <= kFewSources && ctx->box_hint >= 1 &&

@@ -23,17 +23,32 @@ constexpr int kBlock = C2R_BLOCK;   // threads per block of the sweep; a face's 
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 constexpr int kLogTab = 64;              // intervals of the log10 table (log10_tab)
 
+// The scalars of a time step live in DEVICE memory, not in the kernel arguments: the cell size and volume (cosmological
+// expansion: C2Ray.F90:360-376 changes them every step), the homogeneous LLS column, what a shell derives from them, and
+// the global pass's step constants (dt; doric.f90:73-78 at the step's temperature; cosmo_cool's redshift).  A replayed
+// hipGraph bakes its kernel arguments in; with these behind a pointer the captured launch sequence of a small batch stays
+// valid from time step to time step (no re-capture: 0.15 ms per step where an outer iteration takes 0.1 - 0.25 ms) and no
+// setter can leave a stale constant in a captured node.  The host refreshes the block when a value changes (sync_step).
+// Kernels read it through constant-address-space views (step_of, shell_step): scalar loads.
+struct ShellStep { double d2axis[3]; double path_scale, lls_scale; };      // per shell q: (dr_d q)^2, dr[0]/q, coldensh_LLS/q (1/q with an LLS grid)
+struct ChemStep { double dt, brech0, acolh0, recpow, clumping, sqrtt, expt, zp, dzdt; };
+struct StepBlock {
+    double dr[3], dr2[3], vol, coldensh_LLS, inv_dr0;
+    int exact_udiv_dr0, n_shell;
+    ChemStep chem;
+    // ShellStep shell[n_shell] follows (KParams::shell_step points at it)
+};
+
 struct KParams {
     int n[3];
     int hl[3], hr[3];          // trace limits around a source: -hl..+hr (evolve_source.F90:100-102)
-    double dr[3];
-    double vol;
-    double coldensh_LLS;
+    const StepBlock *step;         // dr, dr2, vol, coldensh_LLS, inv_dr0 (step_of)
+    const ShellStep *shell_step;   // [Qmax + 1]
     double sigma, wfloor, sqrt2, sqrt3, fourpi;
     double max_coldensh, tau_limit, minlogtau, dlogtau, numtau_d, eps;
     // correctly rounded reciprocals of launch-invariant divisors (exact division in 3 FMAs, see udiv)
-    double inv_dlogtau, inv_dr0;
-    int exact_udiv;            // 0: a divisor fails the precondition of udiv -> plain IEEE division
+    double inv_dlogtau;
+    int exact_udiv;            // 0: dlogtau fails the precondition of udiv -> plain IEEE division (dr[0]: StepBlock::exact_udiv_dr0)
     int numtau;
     int R, P;                  // plane centre offset and pitch (P = 2R+1)
     size_t PP;                 // P*P
@@ -61,7 +76,6 @@ struct KParams {
     // tolerance ("fast") mode of the sweep (c2r_params.sweep_mode = 1, k_sweep_shell_fast)
     const v2f64 *odtab;       // [kLogTab] {r_i, 1 + (-log10 r_i - minlogtau)/dlogtau}: table position of tau = 1/r_i
     double od_per_e, od_per_ln; // log10(2)/dlogtau, log10(e)/dlogtau
-    double dr2[3];            // dr_d^2
     const int    *srcpos;      // 3 x S_batch (unwrapped, 1-based: cinterp's real(i0) needs it)
     const int    *srcw;        // 3 x S_batch wrapped to 0..N-1
     const double *normflux;    // S_batch
@@ -86,8 +100,7 @@ struct ShellArgs {
     int boxR[3], boxL[3];        // limits of the current sub-box (last_r/last_l - srcpos)
     double alam;                 // (q-0.5)/q, column_density.f90:112 (sign cancels)
     double dp2, inv_dp2;         // q*q and its correctly rounded reciprocal
-    double d2axis[3];            // (dr_d * q)^2: the own-axis term of dist2 for faces normal to d
-    double inv_q, path_scale, lls_scale;   // fast mode: 1/q, dr[0]/q, coldensh_LLS/q
+    double inv_q;                // fast mode: 1/q  (what else a shell derives from the step's scalars: KParams::shell_step[q])
     FaceRect face[6];
     const int *active;           // compacted list of local source indices
     const int *n_active;         // its length on the device: the grid may be sized by an older, larger count
@@ -96,6 +109,11 @@ struct ShellArgs {
 };
 
 __device__ __forceinline__ int pmod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
+
+#define C2R_AS4 __attribute__((address_space(4)))
+// constant-address-space views of the step block: uniform addresses, so the loads are scalar (s_load) whatever else the kernel writes
+__device__ __forceinline__ const C2R_AS4 StepBlock &step_of(const KParams &p) { return *(const C2R_AS4 StepBlock *)p.step; }
+__device__ __forceinline__ const C2R_AS4 ShellStep &shell_step(const KParams &p, int q) { return ((const C2R_AS4 ShellStep *)p.shell_step)[q]; }
 
 // ---- IEEE-exact f64 division without the generic expansion ---------------------------------------
 // hipcc expands a/b into div_scale x2, rcp, 4 fma, mul, fma, div_fmas, div_fixup.  The scaling and
@@ -378,8 +396,8 @@ __device__ __forceinline__ void source_cell(const KParams &p, const v2f64 *__res
     const size_t id = (size_t)i + (size_t)p.n[0] * ((size_t)j + (size_t)p.n[1] * (size_t)k);
     const double nhi = p.nhi[id];
     const double cd_in = 0.0;
-    const double path = 0.5 * p.dr[0];
-    const double vol_ph = p.dr[0] * p.dr[1] * p.dr[2];
+    const double path = 0.5 * step_of(p).dr[0];
+    const double vol_ph = step_of(p).dr[0] * step_of(p).dr[1] * step_of(p).dr[2];
     const double cd_out = cd_in + nhi * path;
     // plane q=0 of every face is the single cell (0,0)
     for (int f = 0; f < 6; ++f)
@@ -395,7 +413,7 @@ __device__ __forceinline__ void source_cell(const KParams &p, const v2f64 *__res
         if (HEAT && p.gbox) p.gbox_h[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = heat;
     } else if (HEAT && p.gbox) p.gbox_h[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = 0.0;
     if (p.gbox) p.gbox[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = gamma;
-    if (on_surface) loss_acc[s] += p_out * p.vol / vol_ph;
+    if (on_surface) loss_acc[s] += p_out * step_of(p).vol / vol_ph;
 }
 
 // One thread per source (the fused first sub-box does the same itself: BoxArgs::source_cell).
@@ -549,15 +567,16 @@ __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArg
     double path = fsqrt(udiv(du * du + dv * dv, sa.dp2, sa.inv_dp2, p.exact_udiv) + 1.0);
 
     // evolve0D
-    path = path * p.dr[0];
+    path = path * step_of(p).dr[0];
     // dist2 = xs*xs + ys*ys + zs*zs (evolve_point.F90:171-174); the term of the face's own axis
-    // is the same for the whole launch (sa.d2axis = (dr_axis * q)^2)
-    const double xs = p.dr[0] * (double)dl.d0;
-    const double ys = p.dr[1] * (double)dl.d1;
-    const double zs = p.dr[2] * (double)dl.d2;
-    const double xx = (axis == 0) ? sa.d2axis[0] : xs * xs;
-    const double yy = (axis == 1) ? sa.d2axis[1] : ys * ys;
-    const double zz = (axis == 2) ? sa.d2axis[2] : zs * zs;
+    // is the same for the whole launch (ShellStep::d2axis = (dr_axis * q)^2)
+    const double xs = step_of(p).dr[0] * (double)dl.d0;
+    const double ys = step_of(p).dr[1] * (double)dl.d1;
+    const double zs = step_of(p).dr[2] * (double)dl.d2;
+    const C2R_AS4 ShellStep &ss = shell_step(p, q);
+    const double xx = (axis == 0) ? ss.d2axis[0] : xs * xs;
+    const double yy = (axis == 1) ? ss.d2axis[1] : ys * ys;
+    const double zz = (axis == 2) ? ss.d2axis[2] : zs * zs;
     const double dist2 = xx + yy + zz;
     cs.vol_ph = p.fourpi * dist2 * path;
     // LLS opacity (evolve_point.F90:186-196): homogeneous column, per-cell column (LLS_point), or a
@@ -567,8 +586,8 @@ __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArg
     if (LLS == 3) {
         cs.stop_far = dist2 > p.R_max2;
     } else {
-        const double lls = (LLS == 2) ? (double)(xf ? p.lls_T : p.lls)[cs.id] : p.coldensh_LLS;
-        cs.cd_in = cdi + udiv(lls * path, p.dr[0], p.inv_dr0, p.exact_udiv);
+        const double lls = (LLS == 2) ? (double)(xf ? p.lls_T : p.lls)[cs.id] : step_of(p).coldensh_LLS;
+        cs.cd_in = cdi + udiv(lls * path, step_of(p).dr[0], step_of(p).inv_dr0, step_of(p).exact_udiv_dr0);
     }
     cs.cd_out = cs.cd_in + cs.nhi * path;
     return cs;
@@ -619,7 +638,7 @@ __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs 
         if (sa.has_boundary) {
             const bool bnd = dl.d0 == sa.boxR[0] || dl.d1 == sa.boxR[1] || dl.d2 == sa.boxR[2] ||
                              dl.d0 == -sa.boxL[0] || dl.d1 == -sa.boxL[1] || dl.d2 == -sa.boxL[2];
-            if (bnd) loss = fdiv((nflux * t_out) * p.vol, cs.vol_ph);
+            if (bnd) loss = fdiv((nflux * t_out) * step_of(p).vol, cs.vol_ph);
         }
     }
     // deterministic mode: every visited cell records its rate (zero included) for k_gamma_reduce
@@ -880,10 +899,11 @@ __device__ __forceinline__ CellCd cell_cd_fast(const KParams &p, const ShellArgs
     if (q == 1 && (abs(a) == 1 || abs(b) == 1))
         cdi = (abs(a) == 1 && abs(b) == 1) ? p.sqrt3 * cdi : p.sqrt2 * cdi;
     c.pq = sqrt_pos((double)(q * q + a2 + b * b));                      // |delta| in cells
-    c.path = c.pq * sa.path_scale;
+    const C2R_AS4 ShellStep &ss = shell_step(p, q);
+    c.path = c.pq * ss.path_scale;
     if (LLS == 3) c.cd_in = cdi;
     else if (LLS == 2) c.cd_in = __builtin_fma(lls_cell * sa.inv_q, c.pq, cdi);
-    else c.cd_in = __builtin_fma(sa.lls_scale, c.pq, cdi);
+    else c.cd_in = __builtin_fma(ss.lls_scale, c.pq, cdi);
     c.np = nhi * c.path;                                                // n_HI path: the cell's own column
     c.cd_out = c.cd_in + c.np;
     return c;
@@ -974,7 +994,7 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
     // column part of the interpolation and of the geometry
     const double omu = (double)abs(a) * sa.inv_q, ddu = 1.0 - omu;   // weights of columns am and a
     const int a2 = a * a;
-    const double du2 = p.dr2[ua] * (double)a2;
+    const double du2 = step_of(p).dr2[ua] * (double)a2;
     // row sums over the two columns
     double R[NR + 1], T[NR + 1];
 #pragma unroll
@@ -992,7 +1012,7 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
             const CellCd cc = cell_cd_fast<LLS>(p, sa, a, a2, b, R[k], T[k], R[k + 1], T[k + 1], nhi[k],
                                                 LLS == 2 ? (double)(xf ? p.lls_T : p.lls)[id[k]] : 0.0);
             const double path = cc.path, cd_in = cc.cd_in, np = cc.np, cd_out = cc.cd_out;
-            const double dist2 = __builtin_fma(p.dr2[va], (double)(b * b), du2 + sa.d2axis[axis]);
+            const double dist2 = __builtin_fma(step_of(p).dr2[va], (double)(b * b), du2 + shell_step(p, q).d2axis[axis]);
             const bool stop = (LLS == 3) && dist2 > p.R_max2;
             // the cell's column density, also into the planes of the faces sharing the cell
             if (STORE) {
@@ -1021,7 +1041,7 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
                 if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id[k]], gamma);
                 if (HEAT && !DET && heat != 0.0) atomicAdd(&(xf ? p.heat_T : p.heat)[id[k]], heat);
                 if (sa.has_boundary && (bnd_col || b == sa.boxR[va] || b == -sa.boxL[va]))
-                    loss = loss + fdiv((nflux * t_out) * p.vol, area * path);
+                    loss = loss + fdiv((nflux * t_out) * step_of(p).vol, area * path);
             }
             if (DET) p.gbox[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + id[k]] = gamma;
             if (DET && HEAT) p.gbox_h[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + id[k]] = heat;
@@ -1310,6 +1330,34 @@ __global__ __launch_bounds__(256) void k_transpose_xy(int n0, int n1, int n2, co
     }
 }
 
+// ---- sparse exchange of the rates (cold regime, big meshes) --------------------------------------------------------
+// evolve.F90:599 all-reduces the whole N^3 phih_grid after every pass, also while the rates are non-zero only inside a few
+// sub-boxes.  Every rank knows every source's final sub-box (one small all-reduce of the sub-box counts), so all ranks agree
+// on the same list of boxes: pack the rates of those boxes (box after box, in source order), all-reduce the packed
+// buffer, write it back.  Cells of overlapping boxes travel once per box and come back with the same sum.
+struct BoxDesc { int c[3]; int nbox; long long off; };      // wrapped source cell, final sub-box count, first packed element
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void k_pack_boxes(int n0, int n1, int n2, int hl0, int hl1, int hl2, int hr0, int hr1, int hr2,
+                                                    int subbox, const BoxDesc *__restrict__ box, double *grid, double *packed)
+{
+    const BoxDesc b = box[blockIdx.y];
+    if (b.nbox <= 0) return;
+    const int ext = subbox * b.nbox;
+    const int l0 = min(ext, hl0), l1 = min(ext, hl1), l2 = min(ext, hl2);
+    const int e0 = l0 + min(ext, hr0) + 1, e1 = l1 + min(ext, hr1) + 1, e2 = l2 + min(ext, hr2) + 1;
+    const long long vol = (long long)e0 * e1 * e2;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < vol; t += (long long)gridDim.x * 256) {
+        const int i = (int)(t % e0), j = (int)((t / e0) % e1), k = (int)(t / ((long long)e0 * e1));
+        const unsigned c0 = wrap_pos(b.c[0], n0, i - l0), c1 = wrap_pos(b.c[1], n1, j - l1), c2 = wrap_pos(b.c[2], n2, k - l2);
+        const size_t id = (size_t)c0 + (size_t)n0 * ((size_t)c1 + (size_t)n1 * (size_t)c2);
+        if (UNPACK) grid[id] = packed[b.off + t]; else packed[b.off + t] = grid[id];
+    }
+}
+
+// c2r_create launches this once: the first launch of any kernel of the library makes the runtime load the whole code object
+// onto the device (milliseconds) -- set-up, not something the first evolve3D of a run should pay
+__global__ void k_load_code_object(int *out) { if (out) *out = 1; }
+
 // Device self-test of the division helpers against the compiler's IEEE division (c2r_selftest).
 __global__ void k_selftest_div(int n, double d_uniform, double rd_uniform, unsigned long long seed,
                                unsigned int *mismatch)
@@ -1486,6 +1534,7 @@ __global__ __launch_bounds__(1024) void k_batch_totals(int nsrc, const double *f
 
 // ---- global pass -------------------------------------------------------------------------------
 struct ChemParams {
+    const StepBlock *step;        // dt, brech0, acolh0, recpow, clumping, sqrtt, expt, zp, dzdt below are filled from step->chem at kernel entry
     double dt, eps, min_frac_change, min_frac_atoms, abu_c, deltht_small;
     double brech0, acolh0;        // doric.f90:73,78 evaluated on the host for the step's temperature
     double bh00, recpow;          // brech0 = clumping*bh00*recpow when clumping comes from a grid
@@ -1569,6 +1618,11 @@ __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell,
 {
     __shared__ double sm[4];
     if (gate && *gate != 0) return;
+    {   // the step's constants (dt, doric's rate coefficients at the step's temperature, cosmo_cool's redshift): device-resident
+        const C2R_AS4 ChemStep &st = ((const C2R_AS4 StepBlock *)c.step)->chem;
+        c.dt = st.dt; c.brech0 = st.brech0; c.acolh0 = st.acolh0; c.recpow = st.recpow; c.clumping = st.clumping;
+        c.sqrtt = st.sqrtt; c.expt = st.expt; c.zp = st.zp; c.dzdt = st.dzdt;
+    }
     double lsum = 0.0;
     double st_h0 = 0.0, st_h1 = 0.0, st_tr = 0.0, st_tc = 0.0;
     unsigned int nconv = 0, nfail = 0;

@@ -314,6 +314,16 @@ class HipBackend:
         self._check(self.lib.c2r_sum(self.ctx, _capi.GRID_XH_INTERMED, C.byref(s)), "c2r_sum")
         return s.value
 
+    def allreduce_rates(self):
+        """mpi_accumulate_grid_quantities' array part through the library (c2r_allreduce_rates: the whole grids, or only the
+        sources' sub-boxes while those are a small part of the mesh) -- over the all-reduce given to set_rank."""
+        self._check(self.lib.c2r_allreduce_rates(self.ctx), "c2r_allreduce_rates")
+
+    def exchange_stats(self):
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.c2r_exchange_stats(self.ctx, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "c2r_exchange_stats")
+        return {"calls": a.value, "sparse_calls": b.value, "bytes_last": c.value, "bytes_total": d.value}
+
     def zero_rates(self):
         self._check(self.lib.c2r_zero_rates(self.ctx), "c2r_zero_rates")
 
@@ -529,10 +539,13 @@ class Evolve:
     # evolve.F90:577
     def mpi_accumulate_grid_quantities(self):
         if self.npr > 1:
-            self.comm.all_reduce(self.b.rates_tensor())                        # :599 phih_grid
-            heat = self.b.heat_tensor() if hasattr(self.b, "heat_tensor") else None
-            if heat is not None:
-                self.comm.all_reduce(heat)                                     # :604-609 phiheat_grid
+            if hasattr(self.b, "allreduce_rates"):
+                self.b.allreduce_rates()                                       # :599, :604-609 (packed sub-boxes while they are few)
+            else:
+                self.comm.all_reduce(self.b.rates_tensor())                    # :599 phih_grid
+                heat = self.b.heat_tensor() if hasattr(self.b, "heat_tensor") else None
+                if heat is not None:
+                    self.comm.all_reduce(heat)                                 # :604-609 phiheat_grid
             t = self.b.scalars_tensor([self.photon_loss, float(self.sum_nbox)])  # :587, :612
             self.comm.all_reduce(t)
             vals = t.tolist()

@@ -258,8 +258,14 @@ int  c2r_zero_rates(c2r_ctx *ctx);
  * (radiation_photoionrates.F90:71).  Reads ndens, xh_av; accumulates into phih_grid.
  * Does NOT reduce across ranks (c2r_allreduce_rates does). */
 int  c2r_pass_sources(c2r_ctx *ctx, double *photon_loss, int64_t *sum_nbox, int64_t *visited);
-/* mpi_accumulate_grid_quantities (evolve.F90:577-616) through the callback; no-op for 1 rank. */
+/* mpi_accumulate_grid_quantities (evolve.F90:577-616) through the callback; no-op for 1 rank.
+ * Sparse form (on by default): the rates of a pass are non-zero only inside the sources' final sub-boxes, which every rank
+ * learns through one small all-reduce of the sub-box counts; while the boxes' volumes add up to at most half the mesh only
+ * they travel (packed box after box in source order, reduced through the same callback, written back) -- the result is the
+ * all-reduce's, element by element the same sum over the ranks.  A cold 256^3 x 1000 step exchanges 8 % of N^3 x 8 B per
+ * iteration instead of all of it.  c2r_exchange_stats: calls so far, how many went packed, bytes of the last call / in all. */
 int  c2r_allreduce_rates(c2r_ctx *ctx);
+int  c2r_exchange_stats(c2r_ctx *ctx, int64_t *calls, int64_t *sparse_calls, int64_t *bytes_last, int64_t *bytes_total);
 /* do_source (evolve_source.F90:58) for ONE source ns (1-based), for tests: optionally returns
  * the source's full coldensh_out grid (evolve_data.F90 coldensh_out) to a host array. */
 int  c2r_do_source(c2r_ctx *ctx, int32_t ns, double *coldensh_out_host, double *photon_loss_src,

@@ -46,7 +46,7 @@ def main():
         row = {"step": step, "outer_iterations": rep.niter, "converged": rep.converged, "wall_s": wall,
                "visited": int(rep.visited), "mean_subboxes_last": rep.sum_nbox_all / S,
                "seconds_sweep": rep.seconds_sweep, "seconds_chem": rep.seconds_chem,
-               "mean_x": float(b.fetch("xh").mean()), "photcons": rep.photcons}
+               "mean_x": float(b.fetch("xh").mean()), "photcons": rep.photcons, "info": b.info().split("; ")[-1]}
         rows.append(row)
         print(json.dumps(row), flush=True)
     print(json.dumps({"mesh": n, "sources": S, "total_wall_s": sum(r["wall_s"] for r in rows),

@@ -32,6 +32,7 @@ struct Shared {
     unsigned char uid[C2R_RCCL_ID_BYTES];
     std::vector<int> rc; std::vector<std::string> err;
     c2r_report rep0; std::vector<double> xh0, phih0;
+    int64_t xchg[4] = {0, 0, 0, 0};                               // rank 0's c2r_exchange_stats: calls, packed calls, bytes of the last call, bytes in all
 };
 struct RankArg { Shared *sh; int rank; };
 
@@ -148,7 +149,10 @@ static void *rank_main(void *p)
             }
         }
         TRY(c2r_evolve3d(ctx, pb.dt, ndens.data(), xh.data(), xh_av.data(), xh_int.data(), phih.data(), &rep));
-        if (rank == 0) { sh->rep0 = rep; sh->xh0 = xh; sh->phih0 = phih; }
+        if (rank == 0) {
+            sh->rep0 = rep; sh->xh0 = xh; sh->phih0 = phih;
+            (void)c2r_exchange_stats(ctx, &sh->xchg[0], &sh->xchg[1], &sh->xchg[2], &sh->xchg[3]);
+        }
         if (sh->rccl && sh->nranks > 1) c2r_rccl_detach(ctx);
     }
 done:
@@ -199,5 +203,7 @@ int main(int argc, char **argv)
     printf("ok: %d rank(s) on %d device(s), %s %s, balance %d: niter %d sum_nbox %lld\n", sh.nranks, ndev < sh.nranks ? ndev : sh.nranks,
            sh.rccl ? "rccl" : "host", sh.slab ? "reduce-scatter + slab chemistry + all-gather" : "all-reduce", (int)sh.balance, sh.rep0.niter,
            (long long)sh.rep0.sum_nbox_all);
+    printf("exchange: calls %lld packed %lld bytes_last %lld bytes_total %lld\n", (long long)sh.xchg[0], (long long)sh.xchg[1],
+           (long long)sh.xchg[2], (long long)sh.xchg[3]);
     return 0;
 }

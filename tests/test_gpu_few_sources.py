@@ -108,6 +108,55 @@ def test_iterate_equals_zero_rates_pass_global_pass(pkg, monkeypatch, fast, n, S
     assert np.array_equal(a[5], t[5])
 
 
+@pytest.mark.parametrize("thermal", [False, True])
+def test_setters_between_fused_iterations_take_effect(pkg, monkeypatch, thermal):
+    """The fused iteration replays a captured launch sequence: nothing a setter changes between two iterations may stay
+    behind in it.  The step's scalars (dr, vol, LLS column, dt, clumping, temperature, redshift) reach the kernels through the
+    device-resident step block, so the graph is NOT re-captured when they change -- and must still see them; the clumping
+    grid's pointer is a kernel argument, so the graph IS re-captured when the grid appears or goes.  Same sequence of calls
+    with C2R_FUSED_ITER=0 (three steps, arguments rebuilt on every call): the same numbers and bits."""
+    n, S = 48, 3
+    res = []
+    for env in ({}, {"C2R_FUSED_ITER": "0"}):
+        b, s = _backend(pkg, n, S, 77, 0.9995, True, True, monkeypatch, env, 1, thermal)
+        rng = np.random.default_rng(5)
+        grid = (1.0 + rng.random(n ** 3)).astype(np.float32)
+        dr = np.ravel(s["dr1"])[0]
+        hist = []
+        def it(dt):
+            hist.append(b.iterate(dt))
+        captures = lambda: int(b.info().split("graph captures ")[1])
+        for _ in range(3): it(s["dt"])                                   # steady state: the graph replays
+        c0 = captures()
+        b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], 2.5, 2.0e4)     # clumping and temperature
+        it(s["dt"]); it(s["dt"])
+        it(0.5 * s["dt"]); it(0.5 * s["dt"])                              # dt
+        c1 = captures()
+        b.set_step(1.01 * dr, 1.01 ** 3 * s["vol"], 0.9 * s["coldensh_LLS"], 2.5, 2.0e4)    # the mesh expands, the LLS column changes
+        it(0.5 * s["dt"]); it(0.5 * s["dt"])
+        if not env:
+            assert c0 >= 1 and c1 == c0          # new step scalars: the same captured sequence (re-captured only if a sub-box count moved)
+        b.set_clumping_grid(grid)                                         # a clumping grid appears ...
+        it(s["dt"]); it(s["dt"])
+        b.set_clumping_grid(2.0 * grid)                                   # ... is refilled ...
+        it(s["dt"])
+        b.set_clumping_grid(None)                                         # ... and goes
+        it(s["dt"]); it(s["dt"])
+        if thermal:
+            b.set_redshift(7.5)
+            it(s["dt"]); it(s["dt"])
+        res.append((hist, b.fetch("phih_grid"), b.fetch("xh_av"), b.fetch("xh_intermed"),
+                    b.fetch("temperature_grid") if thermal else None))
+        b.close()
+    a, t = res
+    assert a[0] == t[0]
+    assert len({h[4] for h in a[0]}) >= 5                                 # (the changes did change the chemistry)
+    for k in (1, 2, 3):
+        assert np.array_equal(a[k], t[k])
+    if thermal:
+        assert np.array_equal(a[4], t[4])
+
+
 def test_iterate_is_the_single_rank_call(pkg, monkeypatch):
     """With more than one rank a collective belongs between the pass and the global pass: C2R_ESTATE, with a message."""
     import ctypes as C

@@ -35,13 +35,16 @@ def read_output(path, n):
     return dict(niter=int(niter), converged=int(converged), rccl_ranks=int(rccl_ranks), sum_nbox=sum_nbox, conv=list(conv), loss=loss, xh=xh, phih=phih)
 
 
-def run(tmp_path, tag, nranks, coll, balance, slab=0):
+def run(tmp_path, tag, nranks, coll, balance, slab=0, stats=None):
     out = str(tmp_path / ("out_%s.bin" % tag))
     p = subprocess.run([HARNESS, str(tmp_path / "in.bin"), out, str(nranks), coll, str(int(balance)), str(int(slab))],
                        capture_output=True, text=True, timeout=600)
     if p.returncode == 77:
         pytest.skip(p.stdout.strip())
     assert p.returncode == 0, p.stdout + p.stderr
+    if stats is not None:        # rank 0's c2r_exchange_stats
+        w = [l for l in p.stdout.split("\n") if l.startswith("exchange:")][0].split()
+        stats.update(calls=int(w[2]), packed=int(w[4]), bytes_last=int(w[6]), bytes_total=int(w[8]))
     return out
 
 
@@ -88,6 +91,35 @@ def test_slab_chemistry_equals_the_replicated_global_pass(tmp_path, case, monkey
         assert slb["sum_nbox"] == rep["sum_nbox"] and slb["loss"] == rep["loss"]
         assert np.array_equal(slb["xh"], rep["xh"]), nranks
         assert np.array_equal(slb["phih"], rep["phih"]), nranks
+
+
+# a cold one-source start (41 iterations inside sub-box 1: 4 % of the mesh travels); ten sources in bubbles whose boxes overlap and
+# add up to more than the mesh (packed all the same, by a fraction no run would use: every overlapping cell travels several times)
+@pytest.mark.parametrize("case,fraction", [("evolve32_onesrc", "0.5"), ("evolve64_std_bubbles", "50")])
+def test_sparse_exchange_equals_the_full_all_reduce(tmp_path, case, fraction, monkeypatch):
+    """c2r_allreduce_rates packs the sources' final sub-boxes while they are a small part of the mesh (evolve.F90:599 reduces
+    all of phih_grid whatever it holds).  Same step with C2R_SPARSE_EXCHANGE=0 (always the whole grid): 2, 3 and 4 ranks as
+    threads with the rank-ordered host-staged sum -- iteration history, sub-box counts, photon loss, xh and phih_grid BIT FOR
+    BIT; the packed calls moved fewer bytes."""
+    assert os.path.exists(HARNESS)
+    monkeypatch.setenv("C2R_HARNESS_DETERMINISTIC", "1")     # ordered per-source sums: two RUNS are comparable bit for bit
+    m, a = load_case(case)
+    n, s = m["n"], m["steps"]["step001"]
+    write_input(str(tmp_path / "in.bin"), n, s, F(a["step001_ndens"]), F(a["step001_xh_before"]))
+    for nranks, bal in ((2, 0), (3, 1), (4, 0)):
+        monkeypatch.setenv("C2R_SPARSE_EXCHANGE", "0")
+        st_full, st_sp = {}, {}
+        full = read_output(run(tmp_path, "full%d" % nranks, nranks, "host", bal, 0, st_full), n)
+        monkeypatch.setenv("C2R_SPARSE_EXCHANGE", "1")
+        monkeypatch.setenv("C2R_SPARSE_FRACTION", fraction)
+        sp = read_output(run(tmp_path, "sparse%d" % nranks, nranks, "host", bal, 0, st_sp), n)
+        assert sp["converged"] and sp["niter"] == full["niter"] == s["niter"]
+        assert sp["conv"] == full["conv"] == s["log"]["nonconv"]
+        assert sp["sum_nbox"] == full["sum_nbox"] and sp["loss"] == full["loss"]
+        assert np.array_equal(sp["xh"], full["xh"]), nranks
+        assert np.array_equal(sp["phih"], full["phih"]), nranks
+        assert st_full["packed"] == 0 and st_full["calls"] == st_sp["calls"] == s["niter"]
+        assert st_sp["packed"] >= 1 and (fraction != "0.5" or st_sp["bytes_total"] < 0.1 * st_full["bytes_total"])
 
 
 def test_two_ranks_over_rccl(tmp_path):
