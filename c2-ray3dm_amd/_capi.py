@@ -104,6 +104,10 @@ SYMBOLS = [
     ("c2r_pass_sources", C.c_int, [_P, C.POINTER(_D), C.POINTER(_I64), C.POINTER(_I64)]),
     ("c2r_allreduce_rates", C.c_int, [_P]),
     ("c2r_exchange_stats", C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
+    ("c2r_evolve0d_host", C.c_int, [_P, _I32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.POINTER(_D)]),
+    ("c2r_global_pass_cell_host", C.c_int, [_P, _D, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.POINTER(_I32)]),
     ("c2r_do_source", C.c_int, [_P, _I32, _P, C.POINTER(_D), C.POINTER(_I32), C.POINTER(_I64)]),
     ("c2r_global_pass", C.c_int, [_P, _D, C.POINTER(_I64), C.POINTER(_D)]),
     ("c2r_iterate", C.c_int, [_P, _D, C.POINTER(_D), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_D)]),

@@ -415,73 +415,89 @@ struct FusedIter {
     bool tail_done = false;
 };
 
-// Sweep one batch: local sources [first, first+count) of this rank's list.
-// dbg: optional device N^3 array receiving coldensh_out (single-source test path).
-int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg, std::vector<int> *nbox_out,
-                std::vector<double> *loss_out, FusedIter *fz = nullptr)
-{
-    const c2r_params &p = ctx->prm;
-    // fill the pinned staging block (layout of ensure_sweep_scratch) and send it with one copy
-    const size_t cap = (size_t)ctx->batch_cap;
-    memset(ctx->h_batch, 0, ctx->batch_bytes);                     // loss_acc = 0, final_nbox = 0, active lists
-    double *h_nf = reinterpret_cast<double *>(ctx->h_batch), *h_fl = h_nf + cap;
-    int *h_pos = reinterpret_cast<int *>(h_nf + 3 * cap), *h_posw = h_pos + 3 * cap, *h_act = h_pos + 6 * cap,
-        *h_na = h_pos + 9 * cap;
-    const bool can_trace = ctx->hr[2] > 0 && ctx->hl[2] > 0;       // while condition, evolve_source.F90:130-131
+// One batch of sources through the sweep -- local sources [first, first+count) of this rank's list: the staging block, the
+// launches of a sub-box (source cells, fused first sub-boxes, shells and look-ahead pairs, loss sums, the decision), the
+// captured launch sequence of a small batch and the wait behind a fused iteration, the run-ahead schedule.  sweep_batch()
+// below is its only user.  dbg: optional device N^3 array receiving coldensh_out (single-source test path).
+struct BatchSweep {
+    Ctx *ctx; const c2r_params &p;
+    const int first, count; const bool first_of_pass; double *const dbg; FusedIter *const fz;
+    const size_t cap; hipStream_t st; KParams k;
+    // the pinned staging block (layout of ensure_sweep_scratch)
+    double *h_nf, *h_fl; int *h_pos, *h_posw, *h_act, *h_na, *h_fnb;
     int n_active = 0;
-    for (int i = 0; i < count; ++i) {
-        const int g = ctx->explicit_share ? ctx->share[first + i]
-                                          : ctx->rank + (first + i) * ctx->nranks;      // master_slave.F90:85
-        for (int d = 0; d < 3; ++d) {
-            h_pos[3 * i + d] = ctx->srcpos[3 * (size_t)g + d];
-            const int m = (h_pos[3 * i + d] - 1) % p.mesh[d];
-            h_posw[3 * i + d] = m < 0 ? m + p.mesh[d] : m;         // evolve_point.F90:122 for the source cell
-        }
-        h_nf[i] = ctx->nflux[g];
-        const double flux = h_nf[i] * p.S_star;
-        if (flux > p.loss_fraction * flux && can_trace) h_act[n_active++] = i;
-        else h_fl[i] = flux;                                       // loop never entered: loss = initial value
-    }
-    h_na[0] = n_active; h_na[1] = 0;
-    hipStream_t st = ctx->stream;
-    // (the staging block is next written by the next sweep_batch, after this one's final synchronize; it is uploaded
-    // below, by the graph's copy node or directly)
-
-    KParams k = make_kparams(ctx);
-    int cur = 0, last_bps = 0;     // last_bps: size of the last shell's loss partials per source (0: none), for k_box_decide
-    // The active count lives on the device (d_nactive[cur]); the host only needs an upper bound to
-    // size the grids.  It runs ONE sub-box ahead: box n+1 is enqueued (sized by the count known
-    // after box n-1) before the count after box n is read back, so the GPU never drains while the
-    // host waits; blocks of sources that retired in between return at once.
-    int bound = n_active;          // upper bound of the device count for the launches being enqueued
-    int known = 0;                 // sub-boxes whose resulting count has been read back
-    // How far ahead of the device the host runs.  Normally ONE sub-box: box n+1 is enqueued, sized by the count known
-    // after box n-1, before the count after box n is read back -- the GPU never drains while the host waits, and
-    // blocks of sources that retired in between return at once.  A batch of FEW sources (<= kFewSources) is nothing but
-    // launch latency, and every wait is a host round trip with the GPU idle: there the host does not wait at all up to
-    // the sub-box the previous pass ended at (box_hint: in the steady state of an outer iteration the sources retire
-    // where they did last time), only picking up counts that have already arrived; at that sub-box it waits for the
-    // box's own count (normally zero: done).  Measured (profiles/r02_launch_bound/): 128^3 x 1 source 0.80 -> 0.73 ms per
-    // outer iteration; with 1000 sources the same rule costs 5-20 % (stale large grids), hence the limit.
-    const bool few = ctx->sched_hint && n_active <= kFewSources;
-    const int hint = few ? std::max(1, ctx->box_hint) : 1;
-    // every launch of sub-box nbox for `bound` sources at most (no host wait, no event): shells or the fused box, loss
-    // reduction, the decision; flips `cur`
+    int cur = 0, last_bps = 0;     // which active list is current; size of the last shell's loss partials per source (0: none), for k_box_decide
     int totals_at_box = 0;         // fused iteration: the sub-box whose decision also writes the batch's totals (0: none)
-    auto enqueue_box = [&](const int nbox, const int bound) -> int {
-        int boxR[3], boxL[3];
-        for (int d = 0; d < 3; ++d) {
-            boxR[d] = std::min(p.subboxsize * nbox, ctx->hr[d]);
-            boxL[d] = std::min(p.subboxsize * nbox, ctx->hl[d]);
+
+    BatchSweep(Ctx *c, int first_, int count_, bool first_of_pass_, double *dbg_, FusedIter *fz_)
+        : ctx(c), p(c->prm), first(first_), count(count_), first_of_pass(first_of_pass_), dbg(dbg_), fz(fz_),
+          cap((size_t)c->batch_cap), st(c->stream), k(make_kparams(c))
+    {
+        h_nf = reinterpret_cast<double *>(ctx->h_batch); h_fl = h_nf + cap;
+        h_pos = reinterpret_cast<int *>(h_nf + 3 * cap); h_posw = h_pos + 3 * cap; h_act = h_pos + 6 * cap; h_na = h_pos + 9 * cap;
+        h_fnb = h_pos + 8 * cap;   // the batch's results travel back through the same block (same layout as the device block)
+    }
+
+    // ---- 1. the staging block: sources, wrapped positions, the initial active list ---------------------------------
+    // (it is next written by the next sweep_batch, after this one's final synchronize; it is uploaded by the graph's copy
+    // node, by k_prepare_nhi from its device image, or directly)
+    void stage()
+    {
+        memset(ctx->h_batch, 0, ctx->batch_bytes);                     // loss_acc = 0, final_nbox = 0, active lists
+        const bool can_trace = ctx->hr[2] > 0 && ctx->hl[2] > 0;       // while condition, evolve_source.F90:130-131
+        n_active = 0;
+        for (int i = 0; i < count; ++i) {
+            const int g = ctx->explicit_share ? ctx->share[first + i]
+                                              : ctx->rank + (first + i) * ctx->nranks;      // master_slave.F90:85
+            for (int d = 0; d < 3; ++d) {
+                h_pos[3 * i + d] = ctx->srcpos[3 * (size_t)g + d];
+                const int m = (h_pos[3 * i + d] - 1) % p.mesh[d];
+                h_posw[3 * i + d] = m < 0 ? m + p.mesh[d] : m;         // evolve_point.F90:122 for the source cell
+            }
+            h_nf[i] = ctx->nflux[g];
+            const double flux = h_nf[i] * p.S_star;
+            if (flux > p.loss_fraction * flux && can_trace) h_act[n_active++] = i;
+            else h_fl[i] = flux;                                       // loop never entered: loss = initial value
         }
-        // which plane set holds shell q0 - 1: the shells alternate between the two sets, a look-ahead pair advances two
-        // shells in one alternation -- a pure function of the schedule up to this sub-box (a replayed graph does not run
-        // this code), see plane_set_before
-        const bool pair_ok = ctx->pair_shells && n_active <= kFewSources && !dbg && ctx->prof != 1;
-        int pbuf = plane_set_before(ctx, nbox, n_active, pair_ok);
-        const bool fused_box = box_is_fused(ctx, nbox, pair_ok);
-        // (the fused first sub-box does the source cells itself: one launch less)
-        if (nbox == 1 && !(fused_box && ctx->fold_source_cell)) {
+        h_na[0] = n_active; h_na[1] = 0;
+    }
+
+    // ---- 2. the launches of one sub-box -----------------------------------------------------------------------------
+    // what the launches of sub-box nbox share
+    struct Box {
+        int nbox, bound;               // the sub-box; upper bound of the device's active count (sizes the grids)
+        int boxR[3], boxL[3];          // last_r / last_l - srcpos (evolve_source.F90:135-136)
+        bool pair_ok, fused_box, det;
+        int pbuf;                      // which plane set holds shell q0 - 1
+        int q0, q1;
+    };
+
+    ShellArgs shell_args(const Box &bx, int q) const
+    {
+        const int (&boxR)[3] = bx.boxR, (&boxL)[3] = bx.boxL;
+        ShellArgs sa{};
+        sa.q = q;
+        sa.buf_prev = (q - 1) & 1; sa.buf_cur = q & 1;       // (a look-ahead pair sets its own, below)
+        sa.tiles_max = 0;
+        for (int f = 0; f < 6; ++f) { sa.face[f] = face_rect(ctx, f, q); sa.tiles_max = std::max(sa.tiles_max, sa.face[f].ntiles); }
+        sa.has_boundary = 0;
+        for (int d = 0; d < 3; ++d) {
+            sa.boxR[d] = boxR[d]; sa.boxL[d] = boxL[d];
+            if (boxR[d] <= q || boxL[d] <= q) sa.has_boundary = 1;
+        }
+        sa.alam = (double)((float)(q - 1) + 0.5f) / (double)(float)q;
+        sa.dp2 = (double)q * (double)q; sa.inv_dp2 = 1.0 / sa.dp2;
+        sa.inv_q = 1.0 / (double)q;                  // ((dr_d q)^2, dr[0]/q, coldensh_LLS/q: the step block, sync_step)
+        sa.active = ctx->d_active[cur]; sa.n_active = ctx->d_nactive + cur;
+        sa.loss_partial = ctx->d_loss_partial; sa.dbg_cdout = dbg;
+        return sa;
+    }
+
+    void launch_source_cells(const Box &bx)
+    {
+        const int (&boxR)[3] = bx.boxR, (&boxL)[3] = bx.boxL;
+        const int bound = bx.bound;
+        {
             if (ctx->thermal)
                 hipLaunchKernelGGL(k_source_cells<true>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
                                    ctx->d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
@@ -491,81 +507,74 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                                    ctx->d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
                                    ctx->d_loss_acc, dbg);
         }
-        const int q0 = p.subboxsize * (nbox - 1) + 1, q1 = std::min(p.subboxsize * nbox, ctx->Qmax);
-        const bool det = ctx->d_gbox != nullptr;
-        auto shell_args = [&](int q) {
-            ShellArgs sa{};
-            sa.q = q;
-            sa.buf_prev = (q - 1) & 1; sa.buf_cur = q & 1;       // (a look-ahead pair sets its own, below)
-            sa.tiles_max = 0;
-            for (int f = 0; f < 6; ++f) { sa.face[f] = face_rect(ctx, f, q); sa.tiles_max = std::max(sa.tiles_max, sa.face[f].ntiles); }
-            sa.has_boundary = 0;
-            for (int d = 0; d < 3; ++d) {
-                sa.boxR[d] = boxR[d]; sa.boxL[d] = boxL[d];
-                if (boxR[d] <= q || boxL[d] <= q) sa.has_boundary = 1;
+    }
+
+    // near the source: the whole sub-box of every active source in ONE launch (k_sweep_box_fused)
+    void launch_fused_box(const Box &bx)
+    {
+        const int (&boxR)[3] = bx.boxR, (&boxL)[3] = bx.boxL;
+        const int nbox = bx.nbox, bound = bx.bound, q0 = bx.q0, q1 = bx.q1;
+        const bool det = bx.det;
+        // near the source: the whole sub-box of every active source in ONE launch (k_sweep_box_fused)
+        BoxArgs ba{};
+        int most = 0;
+        for (int q = q0; q <= q1; ++q) {
+            ShellArgs sa = shell_args(bx, q);
+            if (sa.tiles_max == 0) continue;
+            const int k = ba.nshell++;
+            int off = 0;
+            for (int f = 0; f < 6; ++f) { ba.face_off[k][f] = off; off += sa.face[f].ntiles ? sa.face[f].wa * sa.face[f].wb : 0; }
+            ba.face_off[k][6] = ba.face_off[k][7] = off;
+            ba.ncell[k] = off; most = std::max(most, off);
+            ba.sh[k] = sa;
+        }
+        if (nbox == 1 && ctx->fold_source_cell) {
+            if (ba.nshell > 0) ba.source_cell = 1;
+            else {      // no shell at all to walk (degenerate limits): the plain kernel after all
+                if (ctx->thermal)
+                    hipLaunchKernelGGL(k_source_cells<true>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, ctx->d_active[cur],
+                                       boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], ctx->d_loss_acc, dbg);
+                else
+                    hipLaunchKernelGGL(k_source_cells<false>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, ctx->d_active[cur],
+                                       boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], ctx->d_loss_acc, dbg);
             }
-            sa.alam = (double)((float)(q - 1) + 0.5f) / (double)(float)q;
-            sa.dp2 = (double)q * (double)q; sa.inv_dp2 = 1.0 / sa.dp2;
-            sa.inv_q = 1.0 / (double)q;                  // ((dr_d q)^2, dr[0]/q, coldensh_LLS/q: the step block, sync_step)
-            sa.active = ctx->d_active[cur]; sa.n_active = ctx->d_nactive + cur;
-            sa.loss_partial = ctx->d_loss_partial; sa.dbg_cdout = dbg;
-            return sa;
-        };
-        last_bps = 0;
-        if (fused_box) {
-            // near the source: the whole sub-box of every active source in ONE launch (k_sweep_box_fused)
-            BoxArgs ba{};
-            int most = 0;
-            for (int q = q0; q <= q1; ++q) {
-                ShellArgs sa = shell_args(q);
-                if (sa.tiles_max == 0) continue;
-                const int k = ba.nshell++;
-                int off = 0;
-                for (int f = 0; f < 6; ++f) { ba.face_off[k][f] = off; off += sa.face[f].ntiles ? sa.face[f].wa * sa.face[f].wb : 0; }
-                ba.face_off[k][6] = ba.face_off[k][7] = off;
-                ba.ncell[k] = off; most = std::max(most, off);
-                ba.sh[k] = sa;
-            }
-            if (nbox == 1 && ctx->fold_source_cell) {
-                if (ba.nshell > 0) ba.source_cell = 1;
-                else {      // no shell at all to walk (degenerate limits): the plain kernel after all
-                    if (ctx->thermal)
-                        hipLaunchKernelGGL(k_source_cells<true>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, ctx->d_active[cur],
-                                           boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], ctx->d_loss_acc, dbg);
-                    else
-                        hipLaunchKernelGGL(k_source_cells<false>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, ctx->d_active[cur],
-                                           boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], ctx->d_loss_acc, dbg);
-                }
-            }
-            if (ba.nshell > 0) {
-                ba.active = ctx->d_active[cur]; ba.n_active = ctx->d_nactive + cur; ba.loss_acc = ctx->d_loss_acc;
-                // one workgroup per source: 256 / 512 / 1024 threads by the largest shell; with many sources 512 at most (two
-                // workgroups per CU hide each other's shell-to-shell latency: cold 256^3 x 1000 0.973 -> 0.939 ms per
-                // iteration).  By the batch's INITIAL count: the block size shapes the loss sums, which must not depend on timing.
-                int bt = most <= 256 ? 256 : (most <= 512 ? 512 : 1024);
-                if (n_active >= 256) bt = std::min(bt, 512);
-                const dim3 grid(bound), blk(bt);
-                // (not in the k_sweep_shell launch timing of c2r_profile: a different kernel, 21^3 cells per source)
+        }
+        if (ba.nshell > 0) {
+            ba.active = ctx->d_active[cur]; ba.n_active = ctx->d_nactive + cur; ba.loss_acc = ctx->d_loss_acc;
+            // one workgroup per source: 256 / 512 / 1024 threads by the largest shell; with many sources 512 at most (two
+            // workgroups per CU hide each other's shell-to-shell latency: cold 256^3 x 1000 0.973 -> 0.939 ms per
+            // iteration).  By the batch's INITIAL count: the block size shapes the loss sums, which must not depend on timing.
+            int bt = most <= 256 ? 256 : (most <= 512 ? 512 : 1024);
+            if (n_active >= 256) bt = std::min(bt, 512);
+            const dim3 grid(bound), blk(bt);
+            // (not in the k_sweep_shell launch timing of c2r_profile: a different kernel, 21^3 cells per source)
 #define C2R_LAUNCH_FUSED_H(D, L, H) do { if (ctx->fast) hipLaunchKernelGGL((k_sweep_box_fused<D, L, true, H>), grid, blk, 0, st, k, ba); \
-                                    else hipLaunchKernelGGL((k_sweep_box_fused<D, L, false, H>), grid, blk, 0, st, k, ba); } while (0)
+                                else hipLaunchKernelGGL((k_sweep_box_fused<D, L, false, H>), grid, blk, 0, st, k, ba); } while (0)
 #define C2R_LAUNCH_FUSED(D, L) do { if (ctx->thermal) C2R_LAUNCH_FUSED_H(D, L, true); else C2R_LAUNCH_FUSED_H(D, L, false); } while (0)
-                switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
-                    case 2: C2R_LAUNCH_FUSED(false, 1); break;
-                    case 3: C2R_LAUNCH_FUSED(true, 1); break;
-                    case 4: C2R_LAUNCH_FUSED(false, 2); break;
-                    case 5: C2R_LAUNCH_FUSED(true, 2); break;
-                    case 6: C2R_LAUNCH_FUSED(false, 3); break;
-                    default: C2R_LAUNCH_FUSED(true, 3); break;
-                }
+            switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
+                case 2: C2R_LAUNCH_FUSED(false, 1); break;
+                case 3: C2R_LAUNCH_FUSED(true, 1); break;
+                case 4: C2R_LAUNCH_FUSED(false, 2); break;
+                case 5: C2R_LAUNCH_FUSED(true, 2); break;
+                case 6: C2R_LAUNCH_FUSED(false, 3); break;
+                default: C2R_LAUNCH_FUSED(true, 3); break;
+            }
 #undef C2R_LAUNCH_FUSED
 #undef C2R_LAUNCH_FUSED_H
-            }
-        } else {
+        }
+    }
+
+    // one launch per shell (or per look-ahead pair), the loss sums of shells that touch the sub-box surface
+    void launch_shells(Box &bx)
+    {
+        const int nbox = bx.nbox, bound = bx.bound, q0 = bx.q0, q1 = bx.q1;
+        const bool det = bx.det, pair_ok = bx.pair_ok;
+        int &pbuf = bx.pbuf;
         int in_box = 0;                         // k_sweep_shell launches of this sub-box (coarse timing)
         last_bps = 0;
         if (ctx->prof == 2) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
         for (int q = q0; q <= q1; ++q) {
-            ShellArgs sa = shell_args(q);
+            ShellArgs sa = shell_args(bx, q);
             if (sa.tiles_max == 0) continue;
             sa.buf_prev = pbuf; sa.buf_cur = 1 - pbuf;
             // Few sources, fast mode: shells q and q+1 in ONE launch, both from the planes of shell q-1 (k_sweep_pair_fast:
@@ -573,7 +582,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             // but latency.  Not where either shell has cells on the sub-box surface (their loss partials and the order of
             // the loss sums stay those of the single launches).
             if (pair_here(ctx, nbox, q, q1, n_active, pair_ok)) {
-                ShellArgs sb = shell_args(q + 1);
+                ShellArgs sb = shell_args(bx, q + 1);
                 {
                     // the second shell's threads take kPairRows rows each (its per-thread work is the recompute of
                     // 2 (rows + 1) cells of the first shell: short chains on more threads, the GPU is empty anyway)
@@ -638,7 +647,12 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             if (q == q1 && sa.has_boundary && fold) last_bps = 6 * sa.tiles_max;
         }
         if (ctx->prof == 2) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(in_box); }
-        }
+    }
+
+    // k_box_decide: which sources go on to the next sub-box (evolve_source.F90:128-131)
+    void launch_decision(const Box &bx)
+    {
+        const int nbox = bx.nbox;
         const int can_grow = (p.subboxsize * nbox < ctx->hr[2]) && (p.subboxsize * nbox < ctx->hl[2]);
         if (n_active <= 64) {
             // one wave decides; at the sub-box a fused iteration's graph ends with it also leaves the batch's totals and
@@ -659,9 +673,138 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
                            ctx->d_active[1 - cur], ctx->d_nactive + (1 - cur), ctx->d_hnactive + nbox, ctx->d_nflux_b,
                            p.S_star, p.loss_fraction, can_grow, nbox, ctx->d_loss_acc, ctx->d_final_loss, ctx->d_final_nbox,
                            (const double *)ctx->d_loss_partial, last_bps);
+    }
+
+    // every launch of sub-box nbox for `bound` sources at most (no host wait, no event); flips `cur`
+    int enqueue_box(const int nbox, const int bound)
+    {
+        Box bx{};
+        bx.nbox = nbox; bx.bound = bound;
+        for (int d = 0; d < 3; ++d) {
+            bx.boxR[d] = std::min(p.subboxsize * nbox, ctx->hr[d]);
+            bx.boxL[d] = std::min(p.subboxsize * nbox, ctx->hl[d]);
+        }
+        // which plane set holds shell q0 - 1: the shells alternate between the two sets, a look-ahead pair advances two
+        // shells in one alternation -- a pure function of the schedule up to this sub-box (a replayed graph does not run
+        // this code), see plane_set_before
+        bx.pair_ok = ctx->pair_shells && n_active <= kFewSources && !dbg && ctx->prof != 1;
+        bx.pbuf = plane_set_before(ctx, nbox, n_active, bx.pair_ok);
+        bx.fused_box = box_is_fused(ctx, nbox, bx.pair_ok);
+        bx.q0 = p.subboxsize * (nbox - 1) + 1; bx.q1 = std::min(p.subboxsize * nbox, ctx->Qmax);
+        bx.det = ctx->d_gbox != nullptr;
+        // (the fused first sub-box does the source cells itself: one launch less)
+        if (nbox == 1 && !(bx.fused_box && ctx->fold_source_cell)) launch_source_cells(bx);
+        last_bps = 0;
+        if (bx.fused_box) launch_fused_box(bx); else launch_shells(bx);
+        launch_decision(bx);
         cur = 1 - cur;
         return C2R_OK;
-    };
+    }
+
+    int enqueue_totals(std::vector<int> *nbox_out, std::vector<double> *loss_out)
+    {
+        hipLaunchKernelGGL(k_batch_totals, dim3(1), dim3(1024), 0, st, count, ctx->d_final_loss, ctx->d_final_nbox,
+                           ctx->d_photon_loss, ctx->d_sum_nbox, first_of_pass ? 1 : 0, &ctx->d_hsc->photon_loss,
+                           &ctx->d_hsc->sum_nbox);
+        HIP_TRY(hipGetLastError());
+        if (nbox_out) HIP_TRY(hipMemcpyAsync(h_fnb, ctx->d_final_nbox, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, st));
+        if (loss_out) HIP_TRY(hipMemcpyAsync(h_fl, ctx->d_final_loss, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
+        return C2R_OK;
+    }
+    // deterministic rates: the per-source grids are summed in source order once every source has its final sub-box
+    void gamma_reduce(const int *gate)
+    {
+        if (ctx->d_gbox)
+            hipLaunchKernelGGL(k_gamma_reduce, dim3((p.mesh[0] + 255) / 256, p.mesh[1], p.mesh[2]), dim3(256), 0, st, k, count,
+                               ctx->d_final_nbox, p.subboxsize, (double *)ctx->grid[4], ctx->thermal ? (double *)ctx->grid[5] : nullptr, gate);
+    }
+
+    // ---- 3. a small batch's launch sequence up to sub-box `hint` as ONE hipGraph ---------------------------------------
+    // (re)capture into bg: the batch upload (plain pass) or what precedes the pass (fused iteration), sub-boxes 1..hint, and --
+    // fused iteration -- the gated rest of the iteration.  On failure the context falls back to eager launches for good.
+    void capture(Ctx::BatchGraph &bg, const bool fuse_iter, const int hint)
+    {
+        if (bg.exec) { hipGraphExecDestroy(bg.exec); bg.exec = nullptr; }
+        if (bg.graph) { hipGraphDestroy(bg.graph); bg.graph = nullptr; }
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            ++ctx->captures;
+            // fused iteration: no upload node -- k_prepare_nhi restores the batch's state block from its device image
+            if (fuse_iter) fz->batch_in_prepare = true;
+            int rc = fuse_iter ? fz->pre() : C2R_OK;
+            if (fuse_iter) fz->batch_in_prepare = false;
+            totals_at_box = fuse_iter ? std::min(hint, ctx->nbox_max) : 0;
+            if (rc == C2R_OK && !fuse_iter) rc = (int)hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st);
+            cur = 0;
+            for (int nbox = 1; nbox <= hint && nbox <= ctx->nbox_max && rc == C2R_OK; ++nbox) rc = enqueue_box(nbox, n_active);
+            if (fuse_iter && rc == C2R_OK) {
+                // the batch's totals and results, then the gated rest of the iteration: d_nactive[cur] is the count the
+                // last decision left (cur has been flipped by it)
+                gamma_reduce(ctx->d_nactive + cur);
+                rc = fz->post(ctx->d_nactive + cur);
+            }
+            totals_at_box = 0;
+            const hipError_t e = hipStreamEndCapture(st, &bg.graph);
+            if (rc == C2R_OK && e == hipSuccess && hipGraphInstantiate(&bg.exec, bg.graph, nullptr, nullptr, 0) == hipSuccess) {
+                bg.gen = ctx->gen; bg.count = count; bg.n_active = n_active; bg.hint = hint;
+                bg.fused = fuse_iter; bg.stats = fuse_iter && fz->stats;
+            } else {
+                if (bg.graph) { hipGraphDestroy(bg.graph); bg.graph = nullptr; }
+                bg.exec = nullptr;
+                (void)hipGetLastError();
+                ctx->use_graph = false;            // this runtime / stream cannot capture: eager from now on
+            }
+        } else { (void)hipGetLastError(); ctx->use_graph = false; }
+    }
+
+    // behind a fused iteration's graph: the last kernel of the gated tail stores the count of completed passes to pinned
+    // memory as its final act -- poll it instead of blocking (bounded); true: the gate was open, the whole iteration has run
+    int wait_fused(const Ctx::BatchGraph &bg, const int done, bool &arrived_out)
+    {
+        bool arrived = false;
+        if (bg.fused && ctx->spin_wait) {
+            // The last kernel of the gated tail stores the count of completed passes to pinned memory as its final
+            // act: poll it (and the sub-box count, which tells a shut gate) instead of blocking -- the wake-up of a
+            // stream synchronize is a tenth of a 0.26 ms iteration.  Bounded: after 2 ms the ordinary wait takes over.
+            const unsigned long long want = ctx->seq_seen + 1;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0;; ++spins) {
+                if (__atomic_load_n(&ctx->h_sc->seq, __ATOMIC_ACQUIRE) == want) { arrived = true; break; }
+                if (__atomic_load_n(&ctx->h_nactive[done], __ATOMIC_ACQUIRE) > 0) break;
+                if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+                cpu_relax();
+            }
+        }
+        if (!arrived) {
+            HIP_TRY(hipStreamSynchronize(st));
+            arrived = bg.fused && __atomic_load_n(&ctx->h_sc->seq, __ATOMIC_ACQUIRE) == ctx->seq_seen + 1;
+        }
+        arrived_out = arrived;
+        return C2R_OK;
+    }
+
+    // ---- 4. the schedule ---------------------------------------------------------------------------------------------
+    int run(std::vector<int> *nbox_out, std::vector<double> *loss_out);
+};
+
+int BatchSweep::run(std::vector<int> *nbox_out, std::vector<double> *loss_out)
+{
+    stage();
+    // The active count lives on the device (d_nactive[cur]); the host only needs an upper bound to
+    // size the grids.  It runs ONE sub-box ahead: box n+1 is enqueued (sized by the count known
+    // after box n-1) before the count after box n is read back, so the GPU never drains while the
+    // host waits; blocks of sources that retired in between return at once.
+    int bound = n_active;          // upper bound of the device count for the launches being enqueued
+    int known = 0;                 // sub-boxes whose resulting count has been read back
+    // How far ahead of the device the host runs.  Normally ONE sub-box: box n+1 is enqueued, sized by the count known
+    // after box n-1, before the count after box n is read back -- the GPU never drains while the host waits, and
+    // blocks of sources that retired in between return at once.  A batch of FEW sources (<= kFewSources) is nothing but
+    // launch latency, and every wait is a host round trip with the GPU idle: there the host does not wait at all up to
+    // the sub-box the previous pass ended at (box_hint: in the steady state of an outer iteration the sources retire
+    // where they did last time), only picking up counts that have already arrived; at that sub-box it waits for the
+    // box's own count (normally zero: done).  Measured (profiles/r02_launch_bound/): 128^3 x 1 source 0.80 -> 0.73 ms per
+    // outer iteration; with 1000 sources the same rule costs 5-20 % (stale large grids), hence the limit.
+    const bool few = ctx->sched_hint && n_active <= kFewSources;
+    const int hint = few ? std::max(1, ctx->box_hint) : 1;
     int first_box = 1;
     // A batch of few sources whose previous pass ended at sub-box `hint` replays that whole launch sequence (the batch
     // upload, the source cells, sub-boxes 1..hint) as ONE hipGraph: the arguments of every launch are the same from
@@ -670,23 +813,6 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
     const bool graph_ok = ctx->use_graph && ctx->sched_hint && n_active > 0 && n_active <= kFewSources && ctx->box_hint >= 1 &&
                           !dbg && ctx->prof == 0;
     bool uploaded = false;
-    // the batch's results travel back through the pinned staging block (same layout as the device block)
-    int *h_fnb = h_pos + 8 * cap;
-    auto enqueue_totals = [&]() -> int {
-        hipLaunchKernelGGL(k_batch_totals, dim3(1), dim3(1024), 0, st, count, ctx->d_final_loss, ctx->d_final_nbox,
-                           ctx->d_photon_loss, ctx->d_sum_nbox, first_of_pass ? 1 : 0, &ctx->d_hsc->photon_loss,
-                           &ctx->d_hsc->sum_nbox);
-        HIP_TRY(hipGetLastError());
-        if (nbox_out) HIP_TRY(hipMemcpyAsync(h_fnb, ctx->d_final_nbox, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, st));
-        if (loss_out) HIP_TRY(hipMemcpyAsync(h_fl, ctx->d_final_loss, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
-        return C2R_OK;
-    };
-    // deterministic rates: the per-source grids are summed in source order once every source has its final sub-box
-    auto gamma_reduce = [&](const int *gate) {
-        if (ctx->d_gbox)
-            hipLaunchKernelGGL(k_gamma_reduce, dim3((p.mesh[0] + 255) / 256, p.mesh[1], p.mesh[2]), dim3(256), 0, st, k, count,
-                               ctx->d_final_nbox, p.subboxsize, (double *)ctx->grid[4], ctx->thermal ? (double *)ctx->grid[5] : nullptr, gate);
-    };
     const bool fuse_iter = fz && graph_ok && first_of_pass;
     bool pre_run = false;
     if (graph_ok) {
@@ -694,38 +820,8 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
         // c2r_pass_sources and c2r_iterate does not re-capture every time)
         Ctx::BatchGraph &bg = ctx->graphs[2 * first + (fuse_iter ? 1 : 0)];
         if (!(bg.exec && bg.gen == ctx->gen && bg.count == count && bg.n_active == n_active && bg.hint == hint &&
-              bg.fused == fuse_iter && (!fuse_iter || bg.stats == fz->stats))) {
-            if (bg.exec) { hipGraphExecDestroy(bg.exec); bg.exec = nullptr; }
-            if (bg.graph) { hipGraphDestroy(bg.graph); bg.graph = nullptr; }
-            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                ++ctx->captures;
-                // fused iteration: no upload node -- k_prepare_nhi restores the batch's state block from its device image
-                if (fuse_iter) fz->batch_in_prepare = true;
-                int rc = fuse_iter ? fz->pre() : C2R_OK;
-                if (fuse_iter) fz->batch_in_prepare = false;
-                totals_at_box = fuse_iter ? std::min(hint, ctx->nbox_max) : 0;
-                if (rc == C2R_OK && !fuse_iter) rc = (int)hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st);
-                cur = 0;
-                for (int nbox = 1; nbox <= hint && nbox <= ctx->nbox_max && rc == C2R_OK; ++nbox) rc = enqueue_box(nbox, n_active);
-                if (fuse_iter && rc == C2R_OK) {
-                    // the batch's totals and results, then the gated rest of the iteration: d_nactive[cur] is the count the
-                    // last decision left (cur has been flipped by it)
-                    gamma_reduce(ctx->d_nactive + cur);
-                    rc = fz->post(ctx->d_nactive + cur);
-                }
-                totals_at_box = 0;
-                const hipError_t e = hipStreamEndCapture(st, &bg.graph);
-                if (rc == C2R_OK && e == hipSuccess && hipGraphInstantiate(&bg.exec, bg.graph, nullptr, nullptr, 0) == hipSuccess) {
-                    bg.gen = ctx->gen; bg.count = count; bg.n_active = n_active; bg.hint = hint;
-                    bg.fused = fuse_iter; bg.stats = fuse_iter && fz->stats;
-                } else {
-                    if (bg.graph) { hipGraphDestroy(bg.graph); bg.graph = nullptr; }
-                    bg.exec = nullptr;
-                    (void)hipGetLastError();
-                    ctx->use_graph = false;            // this runtime / stream cannot capture: eager from now on
-                }
-            } else { (void)hipGetLastError(); ctx->use_graph = false; }
-        }
+              bg.fused == fuse_iter && (!fuse_iter || bg.stats == fz->stats)))
+            capture(bg, fuse_iter, hint);
         if (bg.exec) {
             const int done = std::min(hint, ctx->nbox_max);
             if (bg.fused) {
@@ -742,23 +838,7 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
             pre_run = bg.fused;
             cur = done & 1;
             bool arrived = false;
-            if (bg.fused && ctx->spin_wait) {
-                // The last kernel of the gated tail stores the count of completed passes to pinned memory as its final
-                // act: poll it (and the sub-box count, which tells a shut gate) instead of blocking -- the wake-up of a
-                // stream synchronize is a tenth of a 0.26 ms iteration.  Bounded: after 2 ms the ordinary wait takes over.
-                const unsigned long long want = ctx->seq_seen + 1;
-                const auto t0 = std::chrono::steady_clock::now();
-                for (unsigned spins = 0;; ++spins) {
-                    if (__atomic_load_n(&ctx->h_sc->seq, __ATOMIC_ACQUIRE) == want) { arrived = true; break; }
-                    if (__atomic_load_n(&ctx->h_nactive[done], __ATOMIC_ACQUIRE) > 0) break;
-                    if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-                    cpu_relax();
-                }
-            }
-            if (!arrived) {
-                HIP_TRY(hipStreamSynchronize(st));
-                arrived = bg.fused && __atomic_load_n(&ctx->h_sc->seq, __ATOMIC_ACQUIRE) == ctx->seq_seen + 1;
-            }
+            { const int rc = wait_fused(bg, done, arrived); if (rc) return rc; }
             known = done; bound = ctx->h_nactive[done];
             first_box = done + 1;
             if (bg.fused && arrived) { ctx->seq_seen += 1; bound = 0; fz->tail_done = true; }   // the gate was open: the whole iteration has run
@@ -781,12 +861,19 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
     }
     if (!(fz && fz->tail_done)) {          // (the fused iteration's graph has done this already)
         gamma_reduce(nullptr);
-        { const int rc = enqueue_totals(); if (rc) return rc; }
+        { const int rc = enqueue_totals(nbox_out, loss_out); if (rc) return rc; }
         HIP_TRY(hipStreamSynchronize(st));
     }
     if (nbox_out) nbox_out->assign(h_fnb, h_fnb + count);
     if (loss_out) loss_out->assign(h_fl, h_fl + count);
     return C2R_OK;
+}
+
+int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg, std::vector<int> *nbox_out,
+                std::vector<double> *loss_out, FusedIter *fz = nullptr)
+{
+    BatchSweep bs(ctx, first, count, first_of_pass, dbg, fz);
+    return bs.run(nbox_out, loss_out);
 }
 
 // +-x faces read (x,y)-transposed replicas so that their waves, which run along y, touch unit
@@ -1593,6 +1680,129 @@ int c2r_do_source(c2r_ctx *c, int32_t ns, double *cd_host, double *loss, int32_t
     return C2R_OK;
 }
 
+static int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum_xh1, double *stats_dst, size_t cell_off, size_t cell_cnt);
+
+// evolve0D(dt,rtpos,ns,niter) (evolve_point.F90:83-299) for ONE cell on the caller's arrays: the reference's per-cell call
+// surface (its sweep routines call it cell by cell, evolve_source.F90:227-591).  A launch and a few small copies per cell --
+// slow by construction; c2r_do_source / c2r_pass_sources are the product path.
+int c2r_evolve0d_host(c2r_ctx *c, int32_t ns, const int32_t rtpos[3], const int32_t last_l[3], const int32_t last_r[3],
+                      const float *ndens, const double *xh_av, double *coldensh_out, double *phih_grid, double *phiheat_grid,
+                      double *photon_loss_src)
+{
+    if (!c || !rtpos || !last_l || !last_r || !ndens || !xh_av || !coldensh_out || !phih_grid) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    if (ns < 1 || ns > ctx->nsrc) FAIL(C2R_EINVAL, "source number out of range");
+    if (ctx->thermal && !phiheat_grid) FAIL(C2R_EINVAL, "non-isothermal run: evolve0D needs phiheat_grid");
+    const c2r_params &p = ctx->prm;
+    // :122 pos = modulo(rtpos-1,mesh)+1; :125 only cells not yet done
+    int pos[3];
+    for (int d = 0; d < 3; ++d) { const int m = (rtpos[d] - 1) % p.mesh[d]; pos[d] = m < 0 ? m + p.mesh[d] : m; }
+    const size_t idx = (size_t)pos[0] + (size_t)p.mesh[0] * ((size_t)pos[1] + (size_t)p.mesh[1] * (size_t)pos[2]);
+    if (coldensh_out[idx] != 0.0) return C2R_OK;
+    if ((rc = ensure_sweep_scratch(ctx, 1))) return rc;
+    if ((rc = sync_step(ctx))) return rc;
+    ctx->sparse_valid = false;
+    hipStream_t st = ctx->stream;
+    // the source in slot 0 of the batch arrays; n_HI of the cell (evolve_point.F90:137-146) where the kernels read it
+    const int32_t *sp = &ctx->srcpos[3 * (size_t)(ns - 1)];
+    int spw[3], del[3];
+    for (int d = 0; d < 3; ++d) { const int m = (sp[d] - 1) % p.mesh[d]; spw[d] = m < 0 ? m + p.mesh[d] : m; del[d] = rtpos[d] - sp[d]; }
+    const double nflux = ctx->nflux[ns - 1];
+    HIP_TRY(hipMemcpyAsync(ctx->d_srcpos_b, sp, 3 * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->d_srcw_b, spw, 3 * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->d_nflux_b, &nflux, sizeof(double), hipMemcpyHostToDevice, st));
+    const double xav1 = std::max(xh_av[idx], p.epsilon), xav0 = std::max(1.0 - xav1, p.epsilon);
+    const double nhi = xav0 * (double)ndens[idx];
+    const size_t idt = (size_t)pos[1] + (size_t)p.mesh[1] * ((size_t)pos[0] + (size_t)p.mesh[0] * (size_t)pos[2]);
+    HIP_TRY(hipMemcpyAsync(ctx->d_nhi + idx, &nhi, sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->d_nhi_T + idt, &nhi, sizeof(double), hipMemcpyHostToDevice, st));
+    // cinterp's branch (column_density.f90:108,173,226: z over y over x) as face / plane coordinates / shell
+    const int ad[3] = {abs(del[0]), abs(del[1]), abs(del[2])};
+    const bool is_source = ad[0] == 0 && ad[1] == 0 && ad[2] == 0;
+    int axis, a, b;
+    if (ad[2] >= ad[1] && ad[2] >= ad[0]) { axis = 2; a = del[0]; b = del[1]; }
+    else if (ad[1] >= ad[0]) { axis = 1; a = del[0]; b = del[2]; }
+    else { axis = 0; a = del[1]; b = del[2]; }
+    const int pd = del[axis], q = abs(pd), face = (2 - axis) * 2 + (pd < 0 ? 1 : 0);
+    const int ua = axis == 0 ? 1 : 0, va = axis == 2 ? 1 : 2;
+    double cv[4] = {0.0, 0.0, 0.0, 0.0};
+    ShellArgs sa{};
+    if (!is_source) {
+        // the four upstream cells (column_density.f90:112-131 and the y / x counterparts): one step toward the source along
+        // the face's axis, 0 or 1 along the others; sign(1,0) = +1
+        const int sga = a < 0 ? -1 : 1, sgb = b < 0 ? -1 : 1, sgp = pd < 0 ? -1 : 1;
+        for (int k = 0; k < 4; ++k) {
+            int r[3];
+            r[axis] = rtpos[axis] - sgp;
+            r[ua] = rtpos[ua] - ((k & 1) ? 0 : sga);          // k = 0: (am,bm)  1: (a,bm)  2: (am,b)  3: (a,b)
+            r[va] = rtpos[va] - ((k & 2) ? 0 : sgb);
+            size_t id = 0, mul = 1;
+            for (int d = 0; d < 3; ++d) { int m = (r[d] - 1) % p.mesh[d]; if (m < 0) m += p.mesh[d]; id += mul * (size_t)m; mul *= (size_t)p.mesh[d]; }
+            cv[k] = coldensh_out[id];
+        }
+        sa.q = q;
+        sa.alam = (double)((float)(q - 1) + 0.5f) / (double)(float)q;
+        sa.dp2 = (double)q * (double)q; sa.inv_dp2 = 1.0 / sa.dp2; sa.inv_q = 1.0 / (double)q;
+        if (q > ctx->Qmax) FAIL(C2R_EINVAL, "evolve0D: the cell lies beyond the trace limit of its source");
+    }
+    // :288-293 the cell lies on the surface of the current sub-box
+    bool on_surface = false;
+    for (int d = 0; d < 3; ++d) on_surface = on_surface || rtpos[d] == last_l[d] || rtpos[d] == last_r[d];
+    KParams k = make_kparams(ctx);
+    if (!ctx->d_pair) FAIL(C2R_ESTATE, "context not initialised");
+    double *d_out = ctx->d_sum_out;                              // 4 doubles of device scratch
+#define C2R_LAUNCH_CELL(L) do { if (ctx->thermal) hipLaunchKernelGGL((k_evolve0d_cell<L, true>), dim3(1), dim3(64), 0, st, k, sa, face, a, b, is_source ? 1 : 0, on_surface ? 1 : 0, cv[0], cv[1], cv[2], cv[3], d_out); \
+                                else hipLaunchKernelGGL((k_evolve0d_cell<L, false>), dim3(1), dim3(64), 0, st, k, sa, face, a, b, is_source ? 1 : 0, on_surface ? 1 : 0, cv[0], cv[1], cv[2], cv[3], d_out); } while (0)
+    switch (ctx->lls_type) { case 1: C2R_LAUNCH_CELL(1); break; case 2: C2R_LAUNCH_CELL(2); break; default: C2R_LAUNCH_CELL(3); break; }
+#undef C2R_LAUNCH_CELL
+    HIP_TRY(hipGetLastError());
+    double out[4];
+    HIP_TRY(hipMemcpyAsync(out, d_out, sizeof out, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    coldensh_out[idx] = out[0];                                  // :247
+    phih_grid[idx] = phih_grid[idx] + out[1];                    // :283
+    if (ctx->thermal) phiheat_grid[idx] = phiheat_grid[idx] + out[2];     // :285-286
+    if (photon_loss_src && on_surface) *photon_loss_src = *photon_loss_src + out[3];    // :290-293
+    return C2R_OK;
+}
+
+// evolve0D_global(dt,pos,conv_flag) (evolve_point.F90:305-406) for ONE cell (pos 1-based) on the caller's arrays: the
+// same kernel as the mesh-wide pass on a one-cell slab.  Non-isothermal contexts: phiheat_grid / temperature_grid (3 x f32 per
+// cell) of the caller as well.  conv_flag is incremented when the cell has not converged.  Slow by construction.
+int c2r_global_pass_cell_host(c2r_ctx *c, double dt, const int32_t pos[3], const float *ndens, const double *xh, double *xh_av,
+                              double *xh_intermed, const double *phih_grid, const double *phiheat_grid, float *temperature_grid,
+                              int32_t *conv_flag)
+{
+    if (!c || !pos || !ndens || !xh || !xh_av || !xh_intermed || !phih_grid) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    const c2r_params &p = ctx->prm;
+    for (int d = 0; d < 3; ++d) if (pos[d] < 1 || pos[d] > p.mesh[d]) FAIL(C2R_EINVAL, "evolve0D_global: mesh position out of range");
+    if (ctx->thermal && (!phiheat_grid || !temperature_grid)) FAIL(C2R_EINVAL, "non-isothermal run: evolve0D_global needs phiheat_grid and temperature_grid");
+    const size_t idx = (size_t)(pos[0] - 1) + (size_t)p.mesh[0] * ((size_t)(pos[1] - 1) + (size_t)p.mesh[1] * (size_t)(pos[2] - 1));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync((float *)ctx->grid[0] + idx, ndens + idx, sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync((double *)ctx->grid[1] + idx, xh + idx, sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync((double *)ctx->grid[2] + idx, xh_av + idx, sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync((double *)ctx->grid[4] + idx, phih_grid + idx, sizeof(double), hipMemcpyHostToDevice, st));
+    if (ctx->thermal) {
+        HIP_TRY(hipMemcpyAsync((double *)ctx->grid[5] + idx, phiheat_grid + idx, sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((float *)ctx->grid[6] + 3 * idx, temperature_grid + 3 * idx, 3 * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    int64_t nonconv = 0;
+    if ((rc = global_pass_impl(ctx, dt, &nonconv, nullptr, nullptr, idx, 1))) return rc;
+    HIP_TRY(hipMemcpyAsync(xh_av + idx, (double *)ctx->grid[2] + idx, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(xh_intermed + idx, (double *)ctx->grid[3] + idx, sizeof(double), hipMemcpyDeviceToHost, st));
+    if (ctx->thermal)
+        HIP_TRY(hipMemcpyAsync(temperature_grid + 3 * idx, (float *)ctx->grid[6] + 3 * idx, 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (conv_flag) *conv_flag += (int32_t)nonconv;
+    return C2R_OK;
+}
+
 int c2r_do_source_host(c2r_ctx *c, int32_t ns, const float *ndens, const double *xh_av, double *phih_grid,
                        double *coldensh_out, double *photon_loss_src, int32_t *nbox)
 {
@@ -1740,8 +1950,7 @@ static int global_pass_enqueue(Ctx *ctx, double dt, double *stats_dst, size_t ce
 
 // global_pass (evolve.F90:499-573); stats_dst (device-visible, 4 doubles, or null): the photon-statistics sums of
 // (xh_intermed, xh_av) as the pass leaves them, from the same kernel
-static int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum_xh1, double *stats_dst,
-                            size_t cell_off = 0, size_t cell_cnt = (size_t)-1)
+static int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum_xh1, double *stats_dst, size_t cell_off, size_t cell_cnt)
 {
     if (cell_cnt == (size_t)-1) cell_cnt = ctx->ncell;        // (a slab [cell_off, cell_off+cell_cnt): slab chemistry)
     ctx->step_dt = dt;
@@ -1762,7 +1971,7 @@ int c2r_global_pass(c2r_ctx *c, double dt, int64_t *conv_flag, double *sum_xh1)
     Ctx *ctx = C(c);
     int rc = check_ready(ctx);
     if (rc) return rc;
-    return global_pass_impl(ctx, dt, conv_flag, sum_xh1, nullptr);
+    return global_pass_impl(ctx, dt, conv_flag, sum_xh1, nullptr, 0, (size_t)-1);
 }
 
 // One outer iteration on a single rank: set_rates_to_zero, pass_all_sources, global_pass (evolve.F90:243-269).  With few
@@ -1792,7 +2001,7 @@ static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, i
         // the three steps, with one wait behind the global pass instead of one behind each of the last two
         if ((rc = zero_rates())) return rc;
         if ((rc = pass_sources_impl(ctx, nullptr, nullptr, nullptr, vis, ctx->nranks == 1 && !ctx->balance))) return rc;
-        if ((rc = global_pass_impl(ctx, dt, conv, sum1, four))) return rc;
+        if ((rc = global_pass_impl(ctx, dt, conv, sum1, four, 0, (size_t)-1))) return rc;
         if (loss) *loss = ctx->h_sc->photon_loss;
         if (nb) *nb = ctx->h_sc->sum_nbox;
     } else {
@@ -1938,7 +2147,7 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
         // :269 global_pass; evolve.F90:570 calculate_photon_statistics(dt,xh_intermed,xh_av) + report (the conservation
         // line): the sums come out of the same kernel into this iteration's pinned slot
         if (!slab) {
-            rc = global_pass_impl(ctx, dt, &conv_flag, &sum1, niter <= C2R_MAX_ITER_LOG ? ctx->d_hit4 + 4 * (size_t)(niter - 1) : nullptr);
+            rc = global_pass_impl(ctx, dt, &conv_flag, &sum1, niter <= C2R_MAX_ITER_LOG ? ctx->d_hit4 + 4 * (size_t)(niter - 1) : nullptr, 0, (size_t)-1);
             if (rc) return rc;
         } else {
             // evolve0D_global on the own slab only (evolve.F90:548-555 visits every cell on every rank), the counts summed

@@ -1330,6 +1330,46 @@ __global__ __launch_bounds__(256) void k_transpose_xy(int n0, int n1, int n2, co
     }
 }
 
+// ---- evolve0D for ONE (cell, source): the reference's per-cell call surface (evolve_point.F90:83-299) ----------------
+// Slow by construction (a launch and a handful of copies per cell): for hosts that drive the sweep themselves and for tests.
+// The cell's geometry as the shell kernels see it (face, plane coordinates a, b, shell sa.q), the four upstream column
+// densities as VALUES (the caller reads them from its coldensh_out), n_HI from the context's arrays; the arithmetic is
+// cell_state's (bit-identical column densities) and rates_fast's, the source cell's is source_cell's.
+// out[0..3] = coldensh_out(pos), the rate to add to phih_grid(pos), to phiheat_grid(pos), the photon loss through the box surface
+template <int LLS, bool HEAT>
+__global__ __launch_bounds__(64) void k_evolve0d_cell(KParams p, ShellArgs sa, int face, int a, int b, int is_source, int on_surface,
+                                                      double c1, double c2, double c3, double c4, double *out)
+{
+    __shared__ v2f64 s_tab[kLogTab];
+    const v2f64 *ltab = wave_log_table(is_source ? p.logtab : p.odtab, s_tab);
+    if (threadIdx.x != 0) return;
+    const int s = 0;
+    const double nflux = p.normflux[s];
+    double cd_out, gamma = 0.0, heat = 0.0, loss = 0.0;
+    if (is_source) {                                             // evolve_point.F90:151-160
+        const unsigned i = wrap_pos(p.srcw[0], p.n[0], 0), j = wrap_pos(p.srcw[1], p.n[1], 0), k = wrap_pos(p.srcw[2], p.n[2], 0);
+        const double nhi = p.nhi[(size_t)i + (size_t)p.n[0] * ((size_t)j + (size_t)p.n[1] * (size_t)k)];
+        const double path = 0.5 * step_of(p).dr[0];
+        const double vol_ph = step_of(p).dr[0] * step_of(p).dr[1] * step_of(p).dr[2];
+        cd_out = 0.0 + nhi * path;
+        if (nflux > 0.0) {
+            double p_out = 0.0;
+            gamma = photoion<HEAT>(p, ltab, 0.0, cd_out, vol_ph, nflux, p_out, &heat) / nhi;
+            if (on_surface) loss = p_out * step_of(p).vol / vol_ph;
+        }
+    } else {
+        const CellState cs = cell_state<LLS, false>(p, sa, face, s, a, b, c1, c2, c3, c4, weight_rcp(p, c1), weight_rcp(p, c2),
+                                                    weight_rcp(p, c3), weight_rcp(p, c4));
+        cd_out = cs.cd_out;
+        if (!cs.stop_far && !(cs.cd_in > p.max_coldensh) && nflux > 0.0) {
+            double t_out;
+            gamma = rates_fast<HEAT>(p, ltab, p.thick, cs.cd_in, cd_out, nflux, cs.vol_ph * cs.nhi, cs.vol_ph, t_out, heat);
+            if (on_surface) loss = fdiv((nflux * t_out) * step_of(p).vol, cs.vol_ph);
+        }
+    }
+    out[0] = cd_out; out[1] = gamma; out[2] = heat; out[3] = loss;
+}
+
 // ---- sparse exchange of the rates (cold regime, big meshes) --------------------------------------------------------
 // evolve.F90:599 all-reduces the whole N^3 phih_grid after every pass, also while the rates are non-zero only inside a few
 // sub-boxes.  Every rank knows every source's final sub-box (one small all-reduce of the sub-box counts), so all ranks agree

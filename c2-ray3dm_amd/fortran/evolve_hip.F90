@@ -197,6 +197,31 @@ module c2ray_hip
        real(c_double), intent(out) :: photon_loss_src
        integer(c_int32_t), intent(out) :: nbox
      end function c2r_do_source_host
+     integer(c_int) function c2r_evolve0d_host(ctx, ns, rtpos, last_l, last_r, ndens, xh_av, coldensh_out, phih_grid, &
+          phiheat_grid, photon_loss_src) bind(C, name="c2r_evolve0d_host")
+       import :: c_int, c_ptr, c_double, c_float, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: ns           ! 1..NumSrc
+       integer(c_int32_t), intent(in) :: rtpos(3), last_l(3), last_r(3)
+       real(c_float), intent(in) :: ndens(*)
+       real(c_double), intent(in) :: xh_av(*)
+       real(c_double), intent(inout) :: coldensh_out(*), phih_grid(*)
+       type(c_ptr), value :: phiheat_grid        ! double* (non-isothermal builds) or NULL
+       real(c_double), intent(inout) :: photon_loss_src
+     end function c2r_evolve0d_host
+     integer(c_int) function c2r_global_pass_cell_host(ctx, dt, pos, ndens, xh, xh_av, xh_intermed, phih_grid, phiheat_grid, &
+          temperature_grid, conv_flag) bind(C, name="c2r_global_pass_cell_host")
+       import :: c_int, c_ptr, c_double, c_float, c_int32_t
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt
+       integer(c_int32_t), intent(in) :: pos(3)
+       real(c_float), intent(in) :: ndens(*)
+       real(c_double), intent(in) :: xh(*), phih_grid(*)
+       real(c_double), intent(inout) :: xh_av(*), xh_intermed(*)
+       type(c_ptr), value :: phiheat_grid        ! const double* or NULL
+       type(c_ptr), value :: temperature_grid    ! float* (3 per cell) or NULL
+       integer(c_int32_t), intent(inout) :: conv_flag
+     end function c2r_global_pass_cell_host
      integer(c_int) function c2r_do_grid_host(ctx, ndens, xh_av, phih_grid, phiheat_grid, photon_loss, sum_nbox) &
           bind(C, name="c2r_do_grid_host")
        import :: c_int, c_ptr, c_double, c_float, c_int64_t
@@ -548,21 +573,26 @@ end module master_slave_processing
 
 !> `evolve_point` of the reference (evolve_point.F90).  Its two public routines work on ONE cell: evolve0D(dt,rtpos,ns,niter)
 !! for one (cell, source) pair inside do_source's sweep, evolve0D_global(dt,pos,conv_flag) for one cell inside
-!! global_pass's triple loop.  A GPU has no use for a call per cell (a kernel launch costs what the reference spends on
-!! thirty cells): the per-(cell, source) work is inside do_source / do_grid above (kernels k_sweep_shell*), and the per-cell
-!! chemistry is exported for the WHOLE mesh at once -- the loop global_pass (evolve.F90:499-555) runs around
-!! evolve0D_global -- as evolve0D_global_all.  The module flag local_chemistry (evolve_point.F90:73) is kept: pass_all_sources
-!! resets it and nothing on this path sets it (the local variant of do_chemistry is not used by C2-Ray3Dm's evolve3D).
+!! global_pass's triple loop.  Both are exported with the reference's signatures and side effects on the module arrays
+!! (c2r_evolve0d_host, c2r_global_pass_cell_host: one kernel launch per call -- a launch costs what the reference spends on
+!! thirty cells, so they are slow by construction and meant for hosts that walk the cells themselves and for tests).  The
+!! product path is the same work in bulk: the per-(cell, source) work inside do_source / do_grid above (kernels
+!! k_sweep_shell*), the per-cell chemistry for the WHOLE mesh at once -- the loop global_pass (evolve.F90:499-555) runs
+!! around evolve0D_global -- as evolve0D_global_all.  The module flag local_chemistry (evolve_point.F90:73) is kept:
+!! pass_all_sources resets it and nothing on this path sets it (the local variant of do_chemistry is not used by
+!! C2-Ray3Dm's evolve3D).
 module evolve_point
 
   use, intrinsic :: iso_c_binding
   use precision, only: dp
   use density_module, only: ndens
   use ionfractions_module, only: xh
-  use temperature_module, only: temperature_grid
-  use evolve_data, only: phih_grid, phiheat_grid, xh_av, xh_intermed
+  use temperature_module, only: temperature_grid, temperature_states
+  use evolve_data, only: phih_grid, phiheat_grid, xh_av, xh_intermed, coldensh_out, last_l, last_r, &
+       photon_loss_src_thread, tn
   use c2ray_parameters, only: isothermal
-  use c2ray_hip, only: ctx, check, hip_step_state, c2r_global_pass_host, c2r_upload, c2r_download
+  use c2ray_hip, only: ctx, check, hip_step_state, c2r_global_pass_host, c2r_upload, c2r_download, &
+       c2r_evolve0d_host, c2r_global_pass_cell_host
 
   implicit none
 
@@ -573,9 +603,72 @@ module evolve_point
   !> Flag to know whether the do_chemistry routine was called with local option (evolve_point.F90:73)
   logical,public ::local_chemistry=.false.
 
-  public :: evolve0D_global_all
+  public :: evolve0D, evolve0D_global, evolve0D_global_all
 
 contains
+
+  !> evolve0D (evolve_point.F90:83-299): ray tracing for ONE cell at the unwrapped mesh position rtpos for source ns -- the
+  !! call the reference's sweep routines make cell by cell (evolve_source.F90:227-591).  Same contract: does nothing when
+  !! coldensh_out(pos) is set; otherwise sets it, adds the source's rate to phih_grid(pos) (and phiheat_grid(pos)) and, on
+  !! the surface of the current sub-box (evolve_data's last_l, last_r), the escaping photons to photon_loss_src_thread(tn).
+  !! One launch per cell on the GPU: slow by construction -- do_source and do_grid are the product path (they trace a whole
+  !! source, or all of them, per call); this entry is for hosts that walk the cells themselves and for tests.
+  subroutine evolve0D(dt,rtpos,ns,niter)
+
+    real(kind=dp),intent(in) :: dt !< time step (unused by the transfer, as in the reference)
+    integer,dimension(3),intent(in) :: rtpos !< cell position (for RT)
+    integer,intent(in) :: ns !< source number
+    integer,intent(in) :: niter !< global iteration number
+
+    integer(c_int32_t) :: rt(3), ll(3), lr(3)
+    type(c_ptr) :: heat
+
+    call hip_step_state()
+    rt = int(rtpos, c_int32_t); ll = int(last_l, c_int32_t); lr = int(last_r, c_int32_t)
+    heat = c_null_ptr
+    if (.not.isothermal) heat = heat_address0(phiheat_grid)
+    call check(c2r_evolve0d_host(ctx, int(ns, c_int32_t), rt, ll, lr, ndens, xh_av, coldensh_out, phih_grid, heat, &
+         photon_loss_src_thread(tn)), "c2r_evolve0d_host")
+
+  end subroutine evolve0D
+
+  !> evolve0D_global (evolve_point.F90:305-406) for ONE cell: do_chemistry with the collected rates and the global
+  !! convergence test; updates xh_av(pos), xh_intermed(pos) (temperature_grid(pos)) and increments conv_flag when the
+  !! cell has not converged.  One launch per cell: evolve0D_global_all (or evolve3D) is the product path.
+  subroutine evolve0D_global(dt,pos,conv_flag)
+
+    real(kind=dp),intent(in) :: dt !< time step
+    integer,dimension(3),intent(in) :: pos !< position on mesh
+    integer,intent(inout) :: conv_flag !< convergence counter
+
+    integer(c_int32_t) :: p3(3), cf
+    type(c_ptr) :: heat, temp
+
+    call hip_step_state()
+    p3 = int(pos, c_int32_t); cf = int(conv_flag, c_int32_t)
+    heat = c_null_ptr; temp = c_null_ptr
+    if (.not.isothermal) then
+       heat = heat_address0(phiheat_grid); temp = temper_address0(temperature_grid)
+    endif
+    call check(c2r_global_pass_cell_host(ctx, dt, p3, ndens, xh, xh_av, xh_intermed, phih_grid, heat, temp, cf), &
+         "c2r_global_pass_cell_host")
+    conv_flag = int(cf)
+
+  end subroutine evolve0D_global
+
+  function heat_address0(g) result(p)
+    real(kind=dp), dimension(:,:,:), allocatable, target, intent(in) :: g
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(g)) p = c_loc(g)
+  end function heat_address0
+
+  function temper_address0(g) result(p)
+    type(temperature_states), dimension(:,:,:), allocatable, target, intent(in) :: g
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(g)) p = c_loc(g)
+  end function temper_address0
 
   !> evolve0D_global (evolve_point.F90:305-406: do_chemistry with the collected rates, the global convergence test)
   !! for every cell of the mesh: reads xh, xh_av, phih_grid (phiheat_grid, temperature_grid), updates xh_av, xh_intermed

@@ -302,6 +302,22 @@ int  c2r_do_source_host(c2r_ctx *ctx, int32_t ns, const float *ndens, const doub
  * pass on the device for all of the rank's sources -- not NumSrc separate do_source calls. */
 int  c2r_do_grid_host(c2r_ctx *ctx, const float *ndens, const double *xh_av, double *phih_grid, double *phiheat_grid,
                       double *photon_loss, int64_t *sum_nbox);
+/* evolve0D(dt,rtpos,ns,niter) (evolve_point.F90:83-299) for ONE cell of source ns (1-based) on the caller's arrays -- the per-cell
+ * call the reference's sweep routines make (evolve_source.F90:227-591): rtpos is the unwrapped mesh position, last_l / last_r
+ * the current sub-box (evolve_data.F90:70-71); does nothing when coldensh_out(pos) is already set (:125); otherwise cinterp from
+ * the caller's coldensh_out (column_density.f90:29-271, bit-identical), the rate, coldensh_out(pos) = ..., phih_grid(pos) += ...,
+ * phiheat_grid(pos) += ... (non-isothermal; else may be null), *photon_loss_src += ... when the cell lies on the sub-box surface
+ * (:288-293).  A launch and a few small copies per cell: slow by construction, for hosts that walk the cells themselves and for
+ * tests; c2r_do_source / c2r_pass_sources are the product path. */
+int  c2r_evolve0d_host(c2r_ctx *ctx, int32_t ns, const int32_t rtpos[3], const int32_t last_l[3], const int32_t last_r[3],
+                       const float *ndens, const double *xh_av, double *coldensh_out, double *phih_grid, double *phiheat_grid,
+                       double *photon_loss_src);
+/* evolve0D_global(dt,pos,conv_flag) (evolve_point.F90:305-406) for ONE cell (pos 1-based): do_chemistry with the collected
+ * rates and the global convergence test, the same kernel as the mesh-wide pass on a one-cell slab; *conv_flag is incremented
+ * when the cell has not converged (:384-391).  phiheat_grid / temperature_grid (3 x f32 per cell): non-isothermal contexts. */
+int  c2r_global_pass_cell_host(c2r_ctx *ctx, double dt, const int32_t pos[3], const float *ndens, const double *xh, double *xh_av,
+                               double *xh_intermed, const double *phih_grid, const double *phiheat_grid, float *temperature_grid,
+                               int32_t *conv_flag);
 /* global_pass(conv_flag,dt) (evolve.F90:499): evolve0D_global over the mesh with the host arrays.  In a non-isothermal
  * context phiheat_grid and temperature_grid are used as they lie on the device (c2r_upload arrays 5 and 6 first, c2r_download
  * array 6 afterwards). */
