@@ -79,6 +79,16 @@ class Oracle:
         self.n = n
         self.ncell = n[0] * n[1] * n[2]
 
+    def clone(self):
+        """A second oracle with the same configuration and its own diagnostics (tests trace disjoint source sets in threads:
+        the C routines are serial and ctypes releases the GIL)."""
+        import copy
+        c = copy.copy(self)
+        c.cfg = type(self.cfg).from_buffer_copy(self.cfg)
+        c.tolw = None
+        c.cfg.tolw = None
+        return c
+
     def enable_thermal(self, heat_thick, heat_thin, cool_logT, cool_logL, zred, temper_grid=None):
         """Non-isothermal run (isothermal=.false.): heating tables, the cooling table as setup_cool (cooling.f90:64-87)
         holds it, the redshift of cosmo_cool, and the state arrays -- temper_grid (ncell x 3 f32: current, average,

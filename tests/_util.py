@@ -119,11 +119,37 @@ def assert_gamma(got, ref, w, what="", state_rtol=0.0):
 
 
 def oracle_pass(o, nd, xh, srcpos, normflux):
-    """One pass of the oracle over all sources with the tolerance weight: (loss, sum_nbox, visited, phih, W)."""
-    w = o.enable_tolerance_weight()
-    phih = np.zeros(o.ncell)
-    loss, nb, vis = o.pass_sources(nd, xh, phih, srcpos, normflux)
-    return loss, nb, vis, phih, w.copy()
+    """One pass of the oracle over all sources with the tolerance weight: (loss, sum_nbox, visited, phih, W).
+    On big meshes the sources are split into contiguous chunks traced by worker threads (the C oracle is serial: 0.15 us per
+    visited cell, 20 s per source at 504^3), each chunk into its own rate and weight arrays, added in chunk order afterwards:
+    integers are the serial pass's, rates / weight / loss re-associate at 1e-16 per add -- far inside every tolerance the
+    checker applies (and bit-identical to the serial pass for up to two sources)."""
+    srcpos = np.ascontiguousarray(srcpos, dtype=np.int32).reshape(-1, 3)
+    normflux = np.ascontiguousarray(normflux, dtype=np.float64)
+    nthr = min(len(normflux), os.cpu_count() or 1, 8)
+    if nthr <= 1 or o.ncell < 96 ** 3 or getattr(o, "heat_thick", None) is not None:
+        w = o.enable_tolerance_weight()
+        phih = np.zeros(o.ncell)
+        loss, nb, vis = o.pass_sources(nd, xh, phih, srcpos, normflux)
+        return loss, nb, vis, phih, w.copy()
+    import threading
+    bounds = np.linspace(0, len(normflux), nthr + 1).astype(int)
+    out = [None] * nthr
+
+    def work(t):
+        oc = o.clone()
+        w = oc.enable_tolerance_weight()
+        g = np.zeros(o.ncell)
+        lo, hi = bounds[t], bounds[t + 1]
+        out[t] = (oc.pass_sources(nd, xh, g, srcpos[lo:hi], normflux[lo:hi]), g, w, oc)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(nthr)]
+    for t in th: t.start()
+    for t in th: t.join()
+    (loss, nb, vis), phih, w, _ = out[0]
+    for (l, n_, v), g, wt, _ in out[1:]:
+        loss += l; nb += n_; vis += v
+        phih += g; w += wt
+    return loss, nb, vis, phih, w
 
 
 def oracle_step(o, dt, nd, xh0, srcpos, normflux):
