@@ -65,7 +65,6 @@ struct Ctx {
     long long captures = 0;                                      // launch sequences captured so far (c2r_info; tests: a new time step must not add one)
     bool use_graph = true;                                       // C2R_GRAPH=0: never (experiments)
     bool fused_iter = true;                                      // C2R_FUSED_ITER=0: c2r_iterate always runs its three steps in turn (experiments)
-    bool split_axes = false;                                     // C2R_SPLIT_AXES=1 (experiments)
     bool fold_source_cell = true;                                // C2R_FOLD_SOURCE_CELL=0: k_source_cells is always its own launch (experiments)
     bool pair_shells = true;                                     // C2R_PAIR_SHELLS=0: never two shells per launch (experiments)
     // cost-balanced distribution inside the library (c2r_set_balance): every rank learns every source's last
@@ -266,20 +265,6 @@ KParams make_kparams(const Ctx *ctx)
     for (int d = 0; d < 3; ++d) { k.n[d] = p.mesh[d]; k.hl[d] = ctx->hl[d]; k.hr[d] = ctx->hr[d]; }
     // dr, vol, coldensh_LLS, inv_dr0, dr2 stay zero here: the kernels read them from the device-resident step block
     // (load_step), so that captured launches do not depend on the time step
-#ifdef C2R_SQRT_TAB
-    {
-        static double *d_tab = nullptr; static int tab_n = 0;          // (experiment build: one context at a time)
-        const int nt = 3 * ctx->Qmax * ctx->Qmax + 1;
-        if (tab_n != nt) {
-            std::vector<double> h(nt);
-            for (int i = 0; i < nt; ++i) h[i] = sqrt((double)i);
-            hipFree(d_tab); hipMalloc(&d_tab, (size_t)nt * sizeof(double));
-            hipMemcpy(d_tab, h.data(), (size_t)nt * sizeof(double), hipMemcpyHostToDevice);
-            tab_n = nt;
-        }
-        k.sqrt_tab = d_tab;
-    }
-#endif
     k.step = reinterpret_cast<const StepBlock *>(ctx->d_step);
     k.shell_step = reinterpret_cast<const ShellStep *>(ctx->d_step + sizeof(StepBlock));
     k.sigma = p.sigma_HI; k.wfloor = p.weight_floor; k.sqrt2 = p.sqrt2; k.sqrt3 = p.sqrt3;
@@ -630,11 +615,8 @@ struct BatchSweep {
             pbuf = 1 - pbuf;
             ++in_box;
             if (ctx->prof == 1) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
-            // (experiment, C2R_SPLIT_AXES=1: the z, y and x faces of a shell as three launches -- one rate array and one n_HI
-            // array hot at a time instead of both pairs; measured in DESIGN s5, off by default)
-            for (int f0 = 0; f0 < (ctx->split_axes ? 6 : 2); f0 += 2) {
-                if (ctx->split_axes) sa.face0 = f0;
-                const dim3 grid(sa.tiles_max, ctx->split_axes ? 2 : 6, bound), blk(kBlock);
+            {
+                const dim3 grid(sa.tiles_max, 6, bound), blk(kBlock);
 #define C2R_LAUNCH_SWEEP_H(D, L, H) do { \
     if (ctx->fast) { if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_shell_fast<D, L, true, H>), grid, blk, 0, st, k, sa); \
                      else hipLaunchKernelGGL((k_sweep_shell_fast<D, L, false, H>), grid, blk, 0, st, k, sa); } \
@@ -1076,7 +1058,6 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     if (const char *e = getenv("C2R_PAIR_SHELLS")) ctx->pair_shells = atoi(e) != 0;
     if (const char *e = getenv("C2R_SPIN_WAIT")) ctx->spin_wait = atoi(e) != 0;
     if (const char *e = getenv("C2R_FOLD_SOURCE_CELL")) ctx->fold_source_cell = atoi(e) != 0;
-    if (const char *e = getenv("C2R_SPLIT_AXES")) ctx->split_axes = atoi(e) != 0;
     if (const char *e = getenv("C2R_SPARSE_EXCHANGE")) ctx->sparse_exchange = atoi(e) != 0;
     if (const char *e = getenv("C2R_SPARSE_FRACTION")) ctx->sparse_fraction = std::max(0.0, atof(e));
     if (p->sweep_mode != C2R_SWEEP_EXACT && p->sweep_mode != C2R_SWEEP_FAST) { delete ctx; return C2R_EINVAL; }

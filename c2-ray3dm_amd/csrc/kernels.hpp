@@ -43,9 +43,6 @@ struct KParams {
     int n[3];
     int hl[3], hr[3];          // trace limits around a source: -hl..+hr (evolve_source.F90:100-102)
     const StepBlock *step;         // dr, dr2, vol, coldensh_LLS, inv_dr0 (step_of)
-#ifdef C2R_SQRT_TAB
-    const double *sqrt_tab;        // [3 Qmax^2 + 1]
-#endif
     const ShellStep *shell_step;   // [Qmax + 1]
     double sigma, wfloor, sqrt2, sqrt3, fourpi;
     double max_coldensh, tau_limit, minlogtau, dlogtau, numtau_d, eps;
@@ -96,7 +93,6 @@ struct FaceRect {
 
 struct ShellArgs {
     int q;
-    int face0;                   // k_sweep_shell(_fast): blockIdx.y + face0 is the face (0 unless a shell is launched axis by axis)
     int has_boundary;
     int buf_prev, buf_cur;       // fast mode: which of a source's two plane sets holds the previous shell / receives this one
                                  // ((q-1)&1, q&1 while every launch is one shell; the look-ahead pairs advance two shells per set)
@@ -817,7 +813,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
 {
     __shared__ double sm[16];
     __shared__ v2f64 s_log[kBlock];                      // kBlock/64 waves x 64 entries
-    const int face = blockIdx.y + sa.face0;
+    const int face = blockIdx.y;
     const int tile = blockIdx.x;
     const int nact = *sa.n_active;
     if ((int)blockIdx.z >= nact) return;         // block-uniform: this source retired after the launch was sized
@@ -902,11 +898,7 @@ __device__ __forceinline__ CellCd cell_cd_fast(const KParams &p, const ShellArgs
     double cdi = num * rcp1(den);
     if (q == 1 && (abs(a) == 1 || abs(b) == 1))
         cdi = (abs(a) == 1 && abs(b) == 1) ? p.sqrt3 * cdi : p.sqrt2 * cdi;
-#ifdef C2R_SQRT_TAB      // experiment (DESIGN s5, round-4 levers): |delta| from an L2-resident table of square roots of integers
-    c.pq = p.sqrt_tab[q * q + a2 + b * b];
-#else
     c.pq = sqrt_pos((double)(q * q + a2 + b * b));                      // |delta| in cells
-#endif
     const C2R_AS4 ShellStep &ss = shell_step(p, q);
     c.path = c.pq * ss.path_scale;
     if (LLS == 3) c.cd_in = cdi;
@@ -1133,7 +1125,7 @@ __global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
 {
     __shared__ double sm[16];
     __shared__ v2f64 s_log[kBlock];                      // kBlock/64 waves x 64 entries
-    const int face = blockIdx.y + sa.face0;
+    const int face = blockIdx.y;
     const int tile = blockIdx.x;
     const int nact = *sa.n_active;
     if ((int)blockIdx.z >= nact) return;
