@@ -34,7 +34,7 @@ class Report(C.Structure):
                 ("conv_criterion", C.c_int64), ("sum_nbox_all", C.c_int64), ("visited", C.c_int64),
                 ("photon_loss_all", C.c_double), ("seconds_sweep", C.c_double),
                 ("seconds_chem", C.c_double), ("chem_not_converged", C.c_int32),
-                ("reserved0", C.c_int32),
+                ("timing_split", C.c_int32),
                 ("it_conv_flag", C.c_int64 * MAX_ITER_LOG), ("it_sum_nbox", C.c_int64 * MAX_ITER_LOG),
                 ("it_rel_change_xh1", C.c_double * MAX_ITER_LOG),
                 ("it_rel_change_xh0", C.c_double * MAX_ITER_LOG),

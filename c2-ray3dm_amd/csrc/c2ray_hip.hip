@@ -2062,6 +2062,7 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
     const int64_t c2 = (ctx->nsrc - 1) / 3;
     const int64_t conv_criterion = std::min(c1, c2);
     rep->conv_criterion = conv_criterion;
+    rep->timing_split = ctx->nranks > 1 ? 1 : 0;
     double before[4], after[4], totalsrc = 0.0;
     if ((rc = c2r_photon_sums(c, 1, 1, before))) return rc;                            // :136 state_before(xh)
     for (int i = 0; i < ctx->nsrc; ++i) totalsrc += ctx->nflux[i];                      // photonstatistics.F90:266

@@ -71,7 +71,7 @@ module c2ray_hip
      integer(c_int32_t) :: niter, converged
      integer(c_int64_t) :: conv_flag, conv_criterion, sum_nbox_all, visited
      real(c_double) :: photon_loss_all, seconds_sweep, seconds_chem
-     integer(c_int32_t) :: chem_not_converged, reserved0
+     integer(c_int32_t) :: chem_not_converged, timing_split
      integer(c_int64_t) :: it_conv_flag(C2R_MAX_ITER_LOG), it_sum_nbox(C2R_MAX_ITER_LOG)
      real(c_double) :: it_rel_change_xh1(C2R_MAX_ITER_LOG), it_rel_change_xh0(C2R_MAX_ITER_LOG), &
           it_sum_xh1(C2R_MAX_ITER_LOG)

@@ -104,7 +104,9 @@ typedef struct c2r_report {
     double  seconds_sweep;           /* wall time inside pass_all_sources, all iterations (one rank: the whole iteration, see c2r_iterate) */
     double  seconds_chem;            /* wall time inside global_pass, all iterations (one rank: 0, it is not waited for separately) */
     int32_t chem_not_converged;      /* cells that hit max_chem_iter in the last global pass */
-    int32_t reserved0;
+    int32_t timing_split;            /* 1: seconds_sweep and seconds_chem are separate waits (several ranks); 0: one rank -- the whole
+                                      * iteration is one wait and is booked under seconds_sweep, seconds_chem is 0.  With slab
+                                      * chemistry the pass's collectives are part of seconds_chem */
     int64_t it_conv_flag[C2R_MAX_ITER_LOG];        /* [k]: global pass of iteration k+1; after a restart from
                                                     * iteration r, [r-1] is the pass that follows the dump read */
     int64_t it_sum_nbox[C2R_MAX_ITER_LOG];
