@@ -30,11 +30,15 @@ def bubble_xfield(n, centres, radius, x_in=0.9995, x_out=2e-4, seed=7):
     rng = np.random.default_rng(seed)
     ax = np.arange(1, n + 1)
     x = np.full((n, n, n), x_out)
-    I, J, K = np.meshgrid(ax, ax, ax, indexing="ij")
     for (ci, cj, ck) in centres:
-        d = [np.minimum(np.abs(A - c), n - np.abs(A - c)) for A, c in ((I, ci), (J, cj), (K, ck))]
-        r2 = d[0] ** 2 + d[1] ** 2 + d[2] ** 2
-        x[r2 <= radius * radius] = x_in
+        # periodic distance per axis (integers), the sphere's bounding box only: the same mask as the full-mesh form
+        d = [np.minimum(np.abs(ax - c), n - np.abs(ax - c)) for c in (ci, cj, ck)]
+        idx = [np.nonzero(di <= radius)[0] for di in d]
+        r2 = (d[0][idx[0]] ** 2)[:, None, None] + (d[1][idx[1]] ** 2)[None, :, None] + (d[2][idx[2]] ** 2)[None, None, :]
+        box = np.ix_(*idx)
+        sub = x[box]
+        sub[r2 <= radius * radius] = x_in
+        x[box] = sub
     x = x * (1.0 + 1e-3 * rng.standard_normal(x.shape))
     return np.clip(x, 1e-6, 1.0 - 1e-6)
 
