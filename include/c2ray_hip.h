@@ -144,7 +144,9 @@ int  c2r_set_stream(c2r_ctx *ctx, void *hip_stream);
 int  c2r_set_tables(c2r_ctx *ctx, const double *thick, const double *thin, int32_t n);
 /* Per-time-step scalars the driver recomputes before every evolve3D call (C2Ray.F90:367-376):
  * dr(1:3), vol (grid.F90, cosmology.F90:161-193), coldensh_LLS (LLS.F90:178-182),
- * clumping (clumping_module.F90:74), temper_val (temperature_module.F90:34). */
+ * clumping (clumping_module.F90:74), temper_val (temperature_module.F90:34).  They (and dt, the redshift) reach the kernels
+ * through a small device-resident block refreshed when a value changes, never through captured kernel arguments: a new time
+ * step costs one small copy, not a re-capture of a replayed launch sequence. */
 int  c2r_set_step(c2r_ctx *ctx, const double dr[3], double vol, double coldensh_LLS,
                   float clumping, double temper);
 /* Non-default LLS treatment (c2ray_parameters.f90:80-99 type_of_LLS, evolve_point.F90:186-196):
@@ -193,7 +195,8 @@ int  c2r_set_redshift(c2r_ctx *ctx, double zred);
 int  c2r_set_final_temperature(c2r_ctx *ctx);
 
 /* srcpos(3,NumSrc) (1-based, may lie outside the mesh: wrapped at use) and
- * NormFlux_stellar(1:NumSrc) (sourceprops.F90:121-123,167-168). */
+ * NormFlux_stellar(1:NumSrc) (sourceprops.F90:121-123,167-168).  Also allocates the sweep scratch of this rank's share (shell
+ * planes, the pinned staging block: set-up, as evolve_ini's allocations are) if it is not large enough yet. */
 int  c2r_set_sources(c2r_ctx *ctx, const int32_t *srcpos, const double *normflux, int32_t nsrc);
 /* MPI rank / size of the static source distribution (master_slave.F90:85:
  * do ns1=1+rank,NumSrc,npr) and the collective that replaces MPI_ALLREDUCE. */
