@@ -98,7 +98,9 @@ struct Ctx {
     bool sched_hint = true;     // C2R_SCHED_HINT=0: always one sub-box ahead (experiments, see sweep_batch)
     double *d_planes = nullptr;
     // the time step's scalars as the kernels read them (kernels.hpp StepBlock + ShellStep[Qmax + 1]): device copy, the image last sent
-    char *d_step = nullptr; std::vector<char> step_image; double step_dt = 0.0;
+    char *d_step = nullptr, *h_step = nullptr; std::vector<char> step_image; double step_dt = 0.0;      // h_step: pinned staging of the copy
+    hipEvent_t ev_step = nullptr; bool ev_step_recorded = false;                                          // ... and 'the copy has read it'
+
     int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr;
     double *d_gbox = nullptr;   // deterministic mode: [batch_cap][2][ncell]
     double *d_gbox_h = nullptr; // ... and the per-source heating rates of a non-isothermal run
@@ -317,8 +319,12 @@ int sync_step(Ctx *ctx)
     c.zp = 1.0 + ctx->zred;
     c.dzdt = (ctx->thermal && ctx->tprm.cosmological) ? ctx->tprm.H0 * c.zp * sqrt(ctx->tprm.Omega0 * (c.zp * c.zp * c.zp) + 1.0 - ctx->tprm.Omega0) : 0.0;
     if (img == ctx->step_image) return C2R_OK;
-    // (from pageable memory: the runtime stages a copy this small before the call returns)
-    HIP_TRY(hipMemcpyAsync(ctx->d_step, img.data(), img.size(), hipMemcpyHostToDevice, ctx->stream));
+    // through the pinned staging block; the previous copy (a time step ago) has long read it, but say so
+    if (ctx->ev_step_recorded) HIP_TRY(hipEventSynchronize(ctx->ev_step));
+    memcpy(ctx->h_step, img.data(), img.size());
+    HIP_TRY(hipMemcpyAsync(ctx->d_step, ctx->h_step, img.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev_step, ctx->stream));
+    ctx->ev_step_recorded = true;
     ctx->step_image.swap(img);
     return C2R_OK;
 }
@@ -1152,6 +1158,8 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     ctx->R = ctx->Qmax; ctx->P = 2 * ctx->R + 1; ctx->PP = (size_t)ctx->P * ctx->P;
     ctx->tiles_cap = (int)((ctx->PP + kBlock - 1) / kBlock);
     HIP_TRY(hipMalloc(&ctx->d_step, sizeof(StepBlock) + (size_t)(ctx->Qmax + 1) * sizeof(ShellStep)));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_step, sizeof(StepBlock) + (size_t)(ctx->Qmax + 1) * sizeof(ShellStep)));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_step, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void **)&ctx->h_nactive, (size_t)(ctx->nbox_max + 2) * sizeof(int), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void **)&ctx->d_hnactive, ctx->h_nactive, 0));
     ctx->ev_box.resize(ctx->nbox_max + 2);
@@ -1175,6 +1183,8 @@ void c2r_destroy(c2r_ctx *c)
     hipFree(ctx->d_nhi); hipFree(ctx->d_nhi_T); hipFree(ctx->d_phih_T); hipFree(ctx->d_step); hipFree(ctx->d_pack); hipFree(ctx->d_boxdesc);
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
+    if (ctx->h_step) hipHostFree(ctx->h_step);
+    if (ctx->ev_step) hipEventDestroy(ctx->ev_step);
     hipFree(ctx->d_photon_loss); hipFree(ctx->d_sum_nbox); hipFree(ctx->d_sum_partial); hipFree(ctx->d_sum_out); hipFree(ctx->d_stat_partial);
     hipFree(ctx->d_conv); hipFree(ctx->d_chemfail); hipFree(ctx->d_dbg); hipFree(ctx->d_pair); hipFree(ctx->d_seq); hipFree(ctx->d_nbox_all);
     if (ctx->h_nbox_all) hipHostFree(ctx->h_nbox_all);
@@ -1578,7 +1588,7 @@ int c2r_allreduce_rates(c2r_ctx *c)
     // of boxes; while their volumes add up to a fraction of the mesh, only they travel -- packed box after box in source
     // order, reduced, written back (a cell of two overlapping boxes travels twice and comes back with the same sum).  The
     // rates are zero everywhere else on every rank (set_rates_to_zero, evolve.F90:430): the result is the all-reduce's.
-    if (ctx->sparse_exchange && ctx->nsrc > 0 && ctx->sparse_valid) {
+    if (ctx->sparse_exchange && ctx->nsrc > 0 && ctx->nsrc <= 65535 /* grid.y of k_pack_boxes */ && ctx->sparse_valid) {
         HIP_TRY(hipSetDevice(ctx->prm.device));
         int rc = gather_nbox_all(ctx);
         if (rc) return rc;
@@ -1751,7 +1761,6 @@ int c2r_evolve0d_host(c2r_ctx *c, int32_t ns, const int32_t rtpos[3], const int3
     bool on_surface = false;
     for (int d = 0; d < 3; ++d) on_surface = on_surface || rtpos[d] == last_l[d] || rtpos[d] == last_r[d];
     KParams k = make_kparams(ctx);
-    if (!ctx->d_pair) FAIL(C2R_ESTATE, "context not initialised");
     double *d_out = ctx->d_sum_out;                              // 4 doubles of device scratch
 #define C2R_LAUNCH_CELL(L) do { if (ctx->thermal) hipLaunchKernelGGL((k_evolve0d_cell<L, true>), dim3(1), dim3(64), 0, st, k, sa, face, a, b, is_source ? 1 : 0, on_surface ? 1 : 0, cv[0], cv[1], cv[2], cv[3], d_out); \
                                 else hipLaunchKernelGGL((k_evolve0d_cell<L, false>), dim3(1), dim3(64), 0, st, k, sa, face, a, b, is_source ? 1 : 0, on_surface ? 1 : 0, cv[0], cv[1], cv[2], cv[3], d_out); } while (0)
