@@ -26,7 +26,7 @@ for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
 tail = seq[-260:]
 print("--- last launches in order (kernel, ms)")
 for n, d in tail:
-    print("%s %.4f" % ("P" if "plane" in n else ("F" if "fused" in n else "S"), d))
+    print("%s %.4f" % ("P" if ("plane" in n or "tile" in n) else ("F" if "fused" in n else "S"), d))
 PY
 pmc () { local tag=$1; shift
   timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$W/$tag" -o p -- python3 bench.py $FL > /dev/null 2> "$OUT/pmc_$tag.err"
