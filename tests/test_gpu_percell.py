@@ -20,6 +20,60 @@ def _i3(v):
     return np.ascontiguousarray(v, dtype=np.int32)
 
 
+@pytest.mark.parametrize("lls,thermal", [(2, False), (3, False), (1, True)])
+def test_evolve0d_variants_equal_do_source(pkg, tables, lls, thermal):
+    """The per-cell entry with the non-default physics switches -- a position-dependent LLS column (type_of_LLS = 2), the hard
+    barrier (3), a non-isothermal context (heating rates into phiheat_grid) -- against the batch path on a 24^3 mesh, first
+    sub-box: column densities (bit for bit in the exact mode), rates and heating rates."""
+    from tests._util import load_thermal_tables
+    rng = np.random.default_rng(40 + lls)
+    n = 24
+    tp = pkg.TestProblem(32); s = tp.step(1)
+    nd = (s["ndens"] * np.exp(0.5 * rng.standard_normal(n ** 3))).astype(np.float32)
+    xh = np.clip(0.9995 * (1.0 - 1e-3 * rng.random(n ** 3)), 1e-6, 1 - 1e-9)
+    pos = np.array([[7, 9, 11]], dtype=np.int32); nf = np.array([3e8])
+    b = pkg.HipBackend(n, *tables, device=0)
+    b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], 1.0)
+    if lls == 2:
+        b.set_lls(2, (s["coldensh_LLS"] * np.exp(rng.standard_normal(n ** 3))).astype(np.float32), 0.0)
+    elif lls == 3:
+        b.set_lls(3, None, 6.0 * float(np.ravel(s["dr1"])[0]))
+    if thermal:
+        tt = load_thermal_tables()
+        b.set_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"])
+        b.set_redshift(9.0)
+    b.set_sources(pos, nf); b.set_rank(0, 1); b.load(ndens=nd, xh=xh)
+    if thermal:
+        b.load(temperature_grid=np.full(3 * n ** 3, 1e4, dtype=np.float32))
+    b.begin_step(); b.zero_rates()
+    nbox_ref, loss_ref, vis_ref, cd_ref = b.do_source(1, want_coldens=True)
+    phih_ref = b.fetch("phih_grid")
+    heat_ref = b.fetch("phiheat_grid") if thermal else None
+    cd = np.zeros(n ** 3); phih = np.zeros(n ** 3); heat = np.zeros(n ** 3)
+    src = pos[0].astype(np.int64)
+    hl, hr = n // 2, n // 2 - 1 + n % 2
+    for nbox in range(1, nbox_ref + 1):
+        ext_l, ext_r = min(5 * nbox, hl), min(5 * nbox, hr)
+        last_l, last_r = _i3(src - ext_l), _i3(src + ext_r)
+        loss = C.c_double(0.0)
+        cells = sorted((max(abs(i), abs(j), abs(k)), k, j, i) for k in range(-ext_l, ext_r + 1) for j in range(-ext_l, ext_r + 1)
+                       for i in range(-ext_l, ext_r + 1))
+        for q, k, j, i in cells:
+            rt = _i3(src + np.array([i, j, k]))
+            rc = b.lib.c2r_evolve0d_host(b.ctx, 1, rt.ctypes.data, last_l.ctypes.data, last_r.ctypes.data, nd.ctypes.data, xh.ctypes.data,
+                                         cd.ctypes.data, phih.ctypes.data, heat.ctypes.data if thermal else None, C.byref(loss))
+            assert rc == 0, b.lib.c2r_last_error(b.ctx)
+    assert np.array_equal(cd != 0, cd_ref != 0)
+    assert np.max(np.abs(cd - cd_ref) / np.maximum(cd_ref, 1e-300)) < tol("cd")
+    nz = phih_ref != 0
+    assert np.array_equal(phih != 0, nz) and np.max(np.abs(phih[nz] / phih_ref[nz] - 1)) < 1e-9
+    assert abs(loss.value - loss_ref) <= tol("loss") * abs(loss_ref) + 1e-300
+    if thermal:
+        hz = heat_ref != 0
+        assert np.array_equal(heat != 0, hz) and np.max(np.abs(heat[hz] / heat_ref[hz] - 1)) < 1e-9
+    b.close()
+
+
 def test_evolve0d_cell_by_cell_equals_do_source(pkg, tables):
     """One source of the 32^3 fixture traced by calling evolve0D for every cell of sub-boxes 1 and 2 in shell order (any order
     that visits a cell after its upstream neighbours is valid: evolve_source.F90:227-591), the sub-box limits moving as
