@@ -13,7 +13,7 @@
 !! Run in a scratch directory holding: results/ , test_sources.dat
 !! (sourceprops.F90:248), the answers file (inputs/input_example_test format)
 !! and driver.nml:
-!!   &ctl mode='evolve'|'sweep'|'grid'|'point'|'tables', nsteps=, x_init=, dens_file=,
+!!   &ctl mode='evolve'|'sweep'|'grid'|'cells'|'point'|'tables', nsteps=, x_init=, dens_file=,
 !!        x_file=, dump_first=, dump_last=, ns_dump=, nrep=, out_dir=, t_file= /
 !!   (mode 'sweep' also writes <tag>_nbox.txt: the sub-box count each source ended with; mode 'grid' calls
 !!    master_slave_processing::do_grid for all sources at once and then evolve_point::evolve0D_global for every cell --
@@ -49,14 +49,15 @@ program ref_driver
        NormFlux_stellar
   use photonstatistics, only: photon_loss, totrec, totcollisions, dh0, total_ion
   use evolve_data, only: evolve_ini, phih_grid, phiheat_grid, xh_av, xh_intermed, coldensh_out, &
-       photon_loss_all
+       photon_loss_all, last_l, last_r, photon_loss_src_thread
   use evolve_source, only: do_source, sum_nbox, sum_nbox_all
   use master_slave_processing, only: do_grid
 #ifdef C2RAY_HIP_SHIM
-  use evolve_point, only: local_chemistry, evolve0D_global_all
+  use evolve_point, only: local_chemistry, evolve0D_global_all, evolve0D, evolve0D_global
 #else
-  use evolve_point, only: local_chemistry, evolve0D_global
+  use evolve_point, only: local_chemistry, evolve0D, evolve0D_global
 #endif
+  use c2ray_parameters, only: subboxsize, max_subbox
   use evolve, only: evolve3D
   use column_density, only: cinterp
   use doric_module, only: doric
@@ -74,6 +75,7 @@ program ref_driver
   character(len=512) :: answers
   integer :: restart = 0, nz0 = 1, ierror = 0, nz, u, istep, ns, irep, gi, gj, gk, conv_flag
   integer :: nbox_before, nbox_src(4096) = 0
+  integer :: nbx, qq, ci, cj, ck, lastpos_l(3), lastpos_r(3), rt(3), ncall
   real(kind=dp) :: end_time, sim_time, output_time, dt, actual_dt
   real(kind=dp) :: t_sweep
   integer(kind=8) :: c0, c1, crate
@@ -217,6 +219,58 @@ program ref_driver
            do ns = 1, min(NumSrc, size(nbox_src))
               write(u,'(I8)') nbox_src(ns)
            enddo
+           close(u)
+           stop
+        endif
+
+        if (trim(mode) == 'cells') then
+           ! the per-cell call surface as such: source 1 traced through sub-boxes 1 and 2 by calling evolve0D cell by cell, shell
+           ! after shell (any order that visits a cell after its upstream neighbours is valid: evolve_source.F90:227-591), with the
+           ! sub-box limits moving as do_source moves them (:100-102, :128-136); then evolve0D_global for every cell of that box
+           call dump_inputs(tag)
+           xh_av = xh
+           xh_intermed = xh
+           phih_grid = 0.0
+           if (.not.isothermal) phiheat_grid = 0.0
+           coldensh_out(:,:,:) = 0.0
+           ns = 1
+           ncall = 0
+           lastpos_r(:) = srcpos(:,ns) + min(max_subbox, mesh(:)/2 - 1 + mod(mesh(:),2))
+           lastpos_l(:) = srcpos(:,ns) - min(max_subbox, mesh(:)/2)
+           do nbx = 1, 2
+              photon_loss_src_thread(:) = 0.0
+              last_r(:) = min(srcpos(:,ns) + subboxsize*nbx, lastpos_r(:))
+              last_l(:) = max(srcpos(:,ns) - subboxsize*nbx, lastpos_l(:))
+              do qq = 0, subboxsize*nbx
+                 do ck = -qq, qq
+                    do cj = -qq, qq
+                       do ci = -qq, qq
+                          if (max(abs(ci), abs(cj), abs(ck)) /= qq) cycle
+                          rt = srcpos(:,ns) + (/ ci, cj, ck /)
+                          if (any(rt < last_l) .or. any(rt > last_r)) cycle
+                          call evolve0D(actual_dt, rt, ns, 1)
+                          ncall = ncall + 1
+                       enddo
+                    enddo
+                 enddo
+              enddo
+           enddo
+           call dump_r8(trim(tag)//'_coldensh_out', coldensh_out)
+           call dump_r8(trim(tag)//'_phih_grid', phih_grid)
+           conv_flag = 0
+           do ck = last_l(3), last_r(3)
+              do cj = last_l(2), last_r(2)
+                 do ci = last_l(1), last_r(1)
+                    call evolve0D_global(actual_dt, (/ modulo(ci-1,mesh(1))+1, modulo(cj-1,mesh(2))+1, modulo(ck-1,mesh(3))+1 /), conv_flag)
+                 enddo
+              enddo
+           enddo
+           call dump_r8(trim(tag)//'_xh_av', xh_av)
+           call dump_r8(trim(tag)//'_xh_intermed', xh_intermed)
+           open(newunit=u, file=trim(out_dir)//trim(tag)//'_cells.txt', status='replace')
+           write(u,'(A,1X,ES26.17E3)') 'photon_loss_src', photon_loss_src_thread(1)
+           write(u,'(A,1X,I12)') 'evolve0D_calls', ncall
+           write(u,'(A,1X,I12)') 'conv_flag', conv_flag
            close(u)
            stop
         endif

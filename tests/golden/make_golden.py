@@ -254,6 +254,28 @@ def case_grid(name, n, sources, dens_seed, xfield, variant=None, tfield=None):
     print(name, "sum_nbox", kv["sum_nbox"], "conv_flag", kv["conv_flag"], "loss", kv["photon_loss"])
 
 
+def case_cells(name, n, sources, dens_seed, xfield):
+    """The per-cell call surface as such (driver mode 'cells'): source 1 traced through sub-boxes 1 and 2 by calling
+    evolve_point::evolve0D cell by cell in shell order, then evolve_point::evolve0D_global for every cell of that box."""
+    d = run_driver(n, sources, {"mode": "'cells'"}, dens=density_factor(n, dens_seed), xfield=xfield)
+    kv = read_kv(d + "/dump/step001_in.txt")
+    for line in open(d + "/dump/step001_cells.txt"):
+        k, v = line.split()
+        kv[k] = float(v) if "E" in v else int(v)
+    cd = rd(d, "step001_coldensh_out.f64", n)
+    nz = np.nonzero(cd)
+    lo, hi = [int(a.min()) for a in nz], [int(a.max()) + 1 for a in nz]
+    box = tuple(slice(l, h) for l, h in zip(lo, hi))          # the traced box does not wrap for this source: store it alone
+    assert np.count_nonzero(cd) == np.count_nonzero(cd[box])
+    arrays = {"xh": rd(d, "step001_xh_before.f64", n), "ndens": rd(d, "step001_ndens.f32", n, np.float32)}
+    for tag in ("coldensh_out", "phih_grid", "xh_av", "xh_intermed"):
+        arrays[tag + "_box"] = rd(d, "step001_%s.f64" % tag, n)[box]
+    kv["box_lo"], kv["box_hi"] = lo, hi
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    json.dump({"n": n, **kv}, open(os.path.join(HERE, name + ".json"), "w"), indent=1)
+    print(name, "calls", kv["evolve0D_calls"], "conv_flag", kv["conv_flag"], "loss", kv["photon_loss_src"])
+
+
 def read_sm3d(path, dtype):
     """Fortran sequential records: int32 12 | 3 x int32 | int32 12 | int32 nbytes | data | int32 nbytes"""
     raw = open(path, "rb").read()
@@ -437,6 +459,10 @@ def main():
     if want("grid32"):
         x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 7.0)
         case_grid("grid32_bubbles", 32, SRC_STD, 5, x)
+    # ... and its per-cell routines as the reference's own loops call them: evolve0D cell by cell, evolve0D_global cell by cell
+    if want("cells32"):
+        x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 7.0)
+        case_cells("cells32_bubbles", 32, SRC_STD, 5, x)
     if want("sweep64"):
         x = bubble_xfield(64, [(50, 50, 50), (20, 10, 10), (6, 8, 50), (20, 10, 26)], 14.0)
         srcs = SRC_STD[:8] + [(72, 72, 50, 1e58), (20, 10, 90, 1e54)]

@@ -6,6 +6,7 @@ oracle/ref_build.sh: ref_driver_hip).  Same inputs, same dumps, compared with th
     photon_loss(1), sum_nbox                                       (evolve_source.F90:58-221)
   * do_grid(dt,niter) for all sources at once and evolve0D_global over the mesh
                                                                    (master_slave.F90:53, evolve_point.F90:305)
+  * evolve0D(dt,rtpos,ns,niter) and evolve0D_global(dt,pos,conv_flag) cell by cell   (evolve_point.F90:83, :305)
   * evolve3D(time,dt,0) in builds with type_of_LLS=2,3 / type_of_clumping=5 (the shim forwards
     LLS_grid / R_max_LLS / clumping_grid)
   * evolve3D(time,dt,3): the shim's start_from_dump reads iterdump.bin (evolve.F90:328-426)
@@ -81,6 +82,33 @@ def test_fortran_do_grid_and_evolve0d_global_all_match_the_reference_modules(run
     assert np.array_equal(ph == 0.0, a["phih"] == 0.0) and relerr(ph, a["phih"]) < 1e-9
     assert np.max(np.abs(gi.rd(d, "step001_xh_av.f64", 32) - a["xh_av"])) < 1e-9
     assert np.max(np.abs(gi.rd(d, "step001_xh_intermed.f64", 32) - a["xh_intermed"])) < 1e-9
+
+
+def test_fortran_evolve0d_and_evolve0d_global_cell_by_cell_match_the_reference(rundir):
+    """The per-cell call surface as the reference's own loops use it (driver mode 'cells': the SAME driver code against the
+    reference's evolve_point and against the shim's): evolve0D(dt,rtpos,ns,niter) for every cell of sub-boxes 1 and 2 of source 1
+    in shell order (10 592 calls: the 1 331 cells of sub-box 1 are offered again and return at once, evolve_point.F90:125), then
+    evolve0D_global(dt,pos,conv_flag) for the 9 261 cells of the box.  coldensh_out bit for bit the Fortran's in BOTH sweep
+    modes of the context (the per-cell entry always takes cinterp in the reference's operation order)."""
+    need(32)
+    m = json.load(open(os.path.join(GOLDEN, "cells32_bubbles.json")))
+    a = np.load(os.path.join(GOLDEN, "cells32_bubbles.npz"))
+    d = gi.run_driver(32, gi.SRC_STD, {"mode": "'cells'"}, dens=gi.density_factor(32, 5), xfield=gi.bubble_xfield(32, BUBBLES, 7.0),
+                      hip=True, d=rundir)
+    assert np.array_equal(gi.rd(d, "step001_ndens.f32", 32, np.float32), a["ndens"])      # same inputs
+    assert np.array_equal(gi.rd(d, "step001_xh_before.f64", 32), a["xh"])
+    kv = dict(line.split() for line in open(d + "/dump/step001_cells.txt"))
+    assert int(kv["evolve0D_calls"]) == m["evolve0D_calls"] == 10592 and int(kv["conv_flag"]) == m["conv_flag"]
+    assert abs(float(kv["photon_loss_src"]) - m["photon_loss_src"]) <= 1e-10 * abs(m["photon_loss_src"])
+    box = tuple(slice(l, h) for l, h in zip(m["box_lo"], m["box_hi"]))
+    cd = gi.rd(d, "step001_coldensh_out.f64", 32)
+    assert np.count_nonzero(cd) == np.count_nonzero(cd[box]) == np.count_nonzero(a["coldensh_out_box"]) == 21 ** 3
+    assert np.array_equal(cd[box], a["coldensh_out_box"])                                 # bit for bit
+    ph = gi.rd(d, "step001_phih_grid.f64", 32)
+    assert np.count_nonzero(ph) == np.count_nonzero(ph[box])
+    assert np.array_equal(ph[box] == 0.0, a["phih_grid_box"] == 0.0) and relerr(ph[box], a["phih_grid_box"]) < 1e-9
+    assert np.max(np.abs(gi.rd(d, "step001_xh_av.f64", 32)[box] - a["xh_av_box"])) < 1e-9
+    assert np.max(np.abs(gi.rd(d, "step001_xh_intermed.f64", 32)[box] - a["xh_intermed_box"])) < 1e-9
 
 
 @pytest.mark.parametrize("variant,name", [("lls2", "evolve32_lls2"), ("lls3", "evolve32_lls3"),
