@@ -114,13 +114,12 @@ def parity_check(pkg, mesh, step, nd, xh_init, xfield, srcpos, normflux, tables,
     restatement of the reference, the checker).  Reports max |dxh| over the mesh, the worst rate error in units of the
     tolerance weight W (tests/_util.py: |dGamma| <= rtol Gamma + wtol W) and whether the integer results agree."""
     from oracle.oracle import Oracle
+    from tests._util import oracle_pass                       # (the oracle's pass with its source chunks in threads)
     thick, thin = tables
     o = Oracle(mesh, step["dr1"], step["vol"], step["coldensh_LLS"], thick, thin)
-    w = o.enable_tolerance_weight()
     pos, nf = srcpos[:nsub], normflux[:nsub]
     t0 = time.perf_counter()
-    phih_o = np.zeros(o.ncell)
-    oloss, onb, ovis = o.pass_sources(nd, xfield, phih_o, pos, nf)
+    oloss, onb, ovis, phih_o, w = oracle_pass(o, nd, xfield, pos, nf)
     xav, xint = xfield.copy(), xh_init.copy()
     oconv = o.global_pass(step["dt"], nd, xh_init, xav, xint, phih_o)
     sec = time.perf_counter() - t0
