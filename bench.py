@@ -248,9 +248,8 @@ def main():
     b.set_sources(srcpos, normflux)
     b.load(ndens=nd, xh=xh)
     if args.thermal:
-        from tests.golden.inputs import cooling_table
         hk, hn = pkg._capi.build_heat_tables()
-        _, lt, ll = cooling_table()
+        _, lt, ll = pkg.testproblem.synthetic_cooling_table()
         b.set_thermal(hk, hn, lt, ll)
         b.set_redshift(s["zred"])
         b.load(temperature_grid=np.full(n ** 3, 1e4, dtype=np.float32))

@@ -8,5 +8,6 @@ from ._capi import (load_library, default_params, build_tables, Params, Report, 
                     C2RayHipError, LIB_PATH)
 from .evolve import Evolve, HipBackend, static_source_share, balanced_source_shares, box_cost  # noqa: F401
 from .testproblem import TestProblem, seeded_sources  # noqa: F401
+from . import testproblem  # noqa: F401
 from . import fileio  # noqa: F401
 from . import _capi  # noqa: F401

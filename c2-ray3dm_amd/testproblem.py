@@ -102,3 +102,33 @@ def write_source_file(path, srcpos, normflux):
         f.write("%d\n" % len(normflux))
         for (i, j, k), nf in zip(srcpos, normflux):
             f.write("%d %d %d %.17e 0.0\n" % (i, j, k, nf * S_STAR))
+
+
+def synthetic_cooling_table(kind="primordial"):
+    """kind="steep": a SECOND synthetic curve, shaped like a collisional-ionization-equilibrium curve of enriched gas where it
+    matters to thermal.f90: negligible below 8e3 K, a rise of four orders of magnitude between 1e4 and 1e5 K (H, He and metal
+    lines), a slow decline beyond, free-free at the hot end -- and a cold-gas coolant below 100 K that DECLINES with
+    temperature, so that coolin's linear extrapolation below the first table row (cooling.f90:47-58: T < 10 K) stays
+    positive and large: dense cold cells are driven to minitemp, pinned there by thermal.f90:147-153 sub-step after
+    sub-step, and leave through the cap i_heating > 10000 (:163).
+    kind="primordial" (the default, the curve of the first fixtures):
+    A SYNTHETIC 61-point cooling curve in the format of the reference's tables/corocool.tab (cooling.f90:71-76:
+    rows of log10 T, log10 Lambda [erg cm^3 s^-1]).  The reference repository does not ship that file, so the
+    non-isothermal fixtures are generated with this one: hydrogen excitation + collisional ionization +
+    recombination + free-free cooling of a primordial gas (textbook fits), rounded to the 4 decimals written.
+    Returns (text of the file, log10 T values, log10 Lambda values as the Fortran list-directed read sees them)."""
+    lt = [float("%.2f" % (1.0 + 0.1 * i)) for i in range(61)]
+    T = 10.0 ** np.array(lt)
+    if kind == "steep":
+        lam = (3.0e-22 * (10.0 / T) ** 1.5 / (1.0 + (T / 100.0) ** 4)
+               + 6.6e-21 * np.exp(-118348.0 / T) * (1e4 / T) ** 0.2
+               + 1.2e-20 * np.exp(-473638.0 / T) / (1.0 + (T / 2e5) ** 1.8)
+               + 2.3e-27 * np.sqrt(T))
+    else:
+        lam = (7.5e-19 * np.exp(-118348.0 / T) / (1.0 + np.sqrt(T / 1e5))
+               + 1.27e-21 * np.sqrt(T) * np.exp(-157809.1 / T) / (1.0 + np.sqrt(T / 1e5))
+               + 8.7e-27 * np.sqrt(T) * (T / 1e3) ** -0.2 / (1.0 + (T / 1e6) ** 0.7)
+               + 1.42e-27 * 1.3 * np.sqrt(T))
+    ll = [float("%.4f" % v) for v in np.log10(lam)]
+    text = "".join("%5.2f %9.4f\n" % (a, b) for a, b in zip(lt, ll))
+    return text, np.array(lt), np.array(ll)
