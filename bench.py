@@ -107,6 +107,21 @@ def cpu_baseline(mesh, srcpos, normflux, xfield, gpu_nbox, box_cost, nd=None):
                       "relaxed xh_av field the timed GPU steps start from" % (nsamp, mesh)}
 
 
+def mix_ceiling_this_box(device):
+    """Visits per second the memory system of THIS box sustains for the sweep kernel's four streams with no arithmetic at
+    all (profiles/micro/trafficmix.hip as a library: one n_HI load from a pseudo-random run of a 134 MB grid, the previous
+    shell's plane rows, one plane store, one f64 atomic per visit; runs start anywhere, as the kernel's do).  Taken in the
+    bench process, after the timed region; None where the library is not built."""
+    import ctypes
+    path = os.path.join(ROOT, "profiles", "micro", "libtrafficmix.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    lib.c2r_micro_traffic_mix.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    v = ctypes.c_double(0.0)
+    return v.value if lib.c2r_micro_traffic_mix(int(device), 31, ctypes.byref(v)) == 0 else None
+
+
 def parity_check(pkg, mesh, step, nd, xh_init, xfield, srcpos, normflux, tables, device, fast, nsub=16):
     """The second half of BASELINE.json's metric -- "xh L-inf error vs Fortran ref" -- for THIS workload, outside the timed
     region: one pass over the first `nsub` sources of the bench's list plus one global pass (evolve0D_global over the mesh,
@@ -187,6 +202,8 @@ def main():
                          "instead of the synthetic field; scaled as scale_density does (density_unit grid, --n-box fine cells per side)")
     ap.add_argument("--n-box", type=int, default=13824, help="fine N-body cells per side of the density file's simulation (nbody_cubep3m.F90:9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mix-ceiling", action="store_true",
+                    help="skip the in-process run of the memory-only traffic mix (profiles/micro/libtrafficmix.so, 6.7 GB of HBM, ~1 s)")
     ap.add_argument("--no-other-mode", action="store_true",
                     help="skip the short leg that times the same steps in the OTHER sweep mode (reported as `other_sweep_mode`)")
     ap.add_argument("--no-small-leg", action="store_true",
@@ -348,7 +365,10 @@ def main():
             tj = json.load(open(tpath))
             traffic = (tj["fetch_corrected_bytes_per_visit"] + tj["write_bytes_per_visit"]) * vis_rank / launches
             traffic_note = "%s (profiled commit %s)" % (tj["source"], tj.get("commit", "?"))
-            mix_ceiling = tj.get("mix_ceiling_visits_per_s")
+        # the memory-only ceiling of the kernel's traffic mix, measured on THIS box, now (outside the timed region)
+        if timed and world == 1 and not args.thermal and not args.no_mix_ceiling:
+            torch.cuda.synchronize()
+            mix_ceiling = mix_ceiling_this_box(local_rank)
         out = {
             "metric": "cells-traced/sec (grid^3 x sources / wallclock) on 256^3",
             "value": value, "unit": "cells-traced/s", "n_gpus": world, "steps": args.steps,
@@ -376,7 +396,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if timed else None,
                          "traffic": traffic, "traffic_source": traffic_note,
                          # informational: the kernel's visits/s against what the memory system sustains for the same four
-                         # streams with no arithmetic at all (profiles/micro/trafficmix.hip, a committed measurement)
+                         # streams with no arithmetic at all, measured on THIS box after the timed region (mix_ceiling_this_box, profiles/micro/trafficmix.hip)
+                         "mix_ceiling_this_box": mix_ceiling,
                          "frac_of_memory_only_mix": (vis_rank / sweep_s / mix_ceiling) if (mix_ceiling and timed and not args.thermal) else None,
                          "algorithmic_bytes_per_launch": bytes_per_visit * vis_rank / launches if timed else None, "algorithmic_bytes_per_visit": bytes_per_visit,
                          "avg_launch_ms": prof["sweep_ms"] / launches if timed else None, "launches": prof["sweep_launches"],

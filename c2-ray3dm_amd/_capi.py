@@ -42,7 +42,8 @@ class Report(C.Structure):
                 ("h0_before", C.c_double), ("h1_before", C.c_double), ("h0_after", C.c_double),
                 ("h1_after", C.c_double), ("totrec", C.c_double), ("totcollisions", C.c_double),
                 ("dh0", C.c_double), ("total_ion", C.c_double), ("totalsrc", C.c_double),
-                ("photcons", C.c_double), ("it_photcons", C.c_double * MAX_ITER_LOG)]
+                ("photcons", C.c_double), ("it_photcons", C.c_double * MAX_ITER_LOG),
+                ("seconds_upload", C.c_double), ("seconds_download", C.c_double), ("seconds_total", C.c_double)]
 
 
 class SedParams(C.Structure):

@@ -79,8 +79,9 @@ struct Ctx {
     // units of the mesh, that still goes packed)
     bool sparse_exchange = true; double sparse_fraction = 0.5;
     long long pass_id = 0, nbox_all_pass = -1;                   // passes swept so far; the pass nbox_all was gathered for
-    bool sparse_valid = false;                                   // the rates in phih_grid are those of the last c2r_pass_sources over zeroed rates
-    double *d_pack = nullptr; size_t pack_cap = 0; BoxDesc *d_boxdesc = nullptr; int boxdesc_cap = 0;
+    bool sparse_valid = false;                                   // the rates in phih_grid are those of ONE c2r_pass_sources over rates the library had zeroed
+    bool rates_clean = false;                                    // phih_grid (phiheat_grid) zeroed by the library and not written since
+    double *d_pack = nullptr; size_t pack_cap = 0; BoxDesc *d_boxdesc = nullptr, *h_boxdesc = nullptr; int boxdesc_cap = 0;
     long long xchg_calls = 0, xchg_sparse = 0, xchg_bytes_last = 0, xchg_bytes_total = 0;
     // slab chemistry (c2r_set_slab_chemistry): reduce-scatter of the rates by z-slabs, the global pass on the own slab,
     // all-gather of its outputs -- instead of the all-reduce and a replicated global pass
@@ -120,7 +121,7 @@ struct Ctx {
     double *d_sum_partial = nullptr, *d_sum_out = nullptr, *d_stat_partial = nullptr;
     unsigned long long *d_conv = nullptr; unsigned int *d_chemfail = nullptr;
     struct HostScalars { double sum; double photon_loss; long long sum_nbox; unsigned long long conv; unsigned int chemfail; double pair[2]; double four[4];
-                         unsigned long long seq; } *h_sc = nullptr,  // pinned
+                         unsigned long long seq; double before[4], after[4]; } *h_sc = nullptr,  // pinned
       *d_hsc = nullptr;                       // ... and its device alias: kernels store results there directly
     double *d_dbg = nullptr, *d_pair = nullptr;
     unsigned long long *d_seq = nullptr, seq_seen = 0;           // passes completed by fused iterations (k_pass_final counts, the host polls h_sc->seq)
@@ -1181,6 +1182,7 @@ void c2r_destroy(c2r_ctx *c)
     hipFree(ctx->grid[5]); hipFree(ctx->grid[6]); hipFree(ctx->d_hthick); hipFree(ctx->d_hthin); hipFree(ctx->d_cool); hipFree(ctx->d_heat_T);
     hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_logtab); hipFree(ctx->d_odtab);
     hipFree(ctx->d_nhi); hipFree(ctx->d_nhi_T); hipFree(ctx->d_phih_T); hipFree(ctx->d_step); hipFree(ctx->d_pack); hipFree(ctx->d_boxdesc);
+    if (ctx->h_boxdesc) hipHostFree(ctx->h_boxdesc);
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
     if (ctx->h_step) hipHostFree(ctx->h_step);
@@ -1364,9 +1366,16 @@ int c2r_set_sources(c2r_ctx *c, const int32_t *srcpos, const double *normflux, i
 {
     if (!c || nsrc < 0 || (nsrc > 0 && (!srcpos || !normflux))) return C2R_EINVAL;
     Ctx *ctx = C(c);
+    // the same list again (the Fortran shim hands the driver's list over before every evolve3D; it changes once per redshift
+    // slice, sourceprops.F90:121-167): nothing to do -- and what the last pass learnt about it (where each source ended, the
+    // captured launch sequences of a small batch, the balanced shares) stays valid
+    if (nsrc == ctx->nsrc && nsrc > 0 && ctx->batch_cap > 0 && !(ctx->explicit_share && !ctx->auto_share) && memcmp(ctx->srcpos.data(), srcpos, 3 * (size_t)nsrc * sizeof(int32_t)) == 0 &&
+        memcmp(ctx->nflux.data(), normflux, (size_t)nsrc * sizeof(double)) == 0)
+        return C2R_OK;
     ctx->srcpos.assign(srcpos, srcpos + 3 * (size_t)nsrc);
     ctx->nflux.assign(normflux, normflux + nsrc);
     ctx->nsrc = nsrc;
+    ctx->sparse_valid = false;                    // (nbox_all / last_nbox no longer describe what is in phih_grid)
     ctx->explicit_share = false; ctx->auto_share = false; ctx->share.clear(); ctx->last_nbox.clear(); ctx->nbox_all.clear(); ctx->box_hint = 0;
     // set-up belongs here, not in the first evolve3D of a run (the reference allocates in evolve_ini, evolve_data.F90:75-90): the
     // sweep scratch of this rank's share -- device planes, the pinned staging block -- is a few milliseconds of allocation calls
@@ -1396,6 +1405,15 @@ int c2r_set_rank(c2r_ctx *c, int32_t rank, int32_t nranks, c2r_allreduce_fn fn, 
     }
     if (ctx->auto_share) { ctx->explicit_share = false; ctx->auto_share = false; ctx->share.clear(); }
     ctx->nbox_all.clear();
+    // c2r_set_sources sized the sweep scratch for the share it knew then (one rank: every source); a smaller share frees the
+    // difference -- in deterministic mode that is two N^3 grids per source (re-allocated at the next pass for the new share)
+    if (ctx->batch_want > 0 && n_local_sources(ctx) < ctx->batch_want) {
+        HIP_TRY(hipSetDevice(ctx->prm.device));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        free_sweep_scratch(ctx);
+        ++ctx->gen;
+        if (n_local_sources(ctx) > 0) { const int rc = ensure_sweep_scratch(ctx, n_local_sources(ctx)); if (rc) return rc; }
+    }
     return C2R_OK;
 }
 
@@ -1485,6 +1503,7 @@ int c2r_bind_device_buffers(c2r_ctx *c, void *ndens, void *xh, void *xh_av, void
         if (ctx->own[w]) { hipFree(ctx->grid[w]); ctx->own[w] = false; }
         ctx->grid[w] = in[w];
     }
+    if (phih) { ctx->rates_clean = false; ctx->sparse_valid = false; }
     ++ctx->gen;
     return C2R_OK;
 }
@@ -1504,6 +1523,7 @@ int c2r_upload(c2r_ctx *c, int32_t which, const void *host)
     if (which > 4 && !ctx->thermal) FAIL(C2R_ESTATE, "arrays 5 and 6 exist in non-isothermal runs only (c2r_set_thermal)");
     HIP_TRY(hipMemcpyAsync(ctx->grid[which], host, grid_bytes(ctx, which), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (which == 4 || which == 5) { ctx->rates_clean = false; ctx->sparse_valid = false; }     // the caller's rates: not a pass over zeroed ones
     return C2R_OK;
 }
 
@@ -1523,6 +1543,7 @@ int c2r_zero_rates(c2r_ctx *c)
     Ctx *ctx = C(c);
     HIP_TRY(hipMemsetAsync(ctx->grid[4], 0, grid_bytes(ctx, 4), ctx->stream));
     if (ctx->thermal) HIP_TRY(hipMemsetAsync(ctx->grid[5], 0, grid_bytes(ctx, 5), ctx->stream));     // evolve.F90:435
+    ctx->rates_clean = true; ctx->sparse_valid = false;
     return C2R_OK;
 }
 
@@ -1538,7 +1559,9 @@ static int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64
     balance_before_pass(ctx);
     const int nloc = n_local_sources(ctx);
     long long vis = 0;
-    ++ctx->pass_id; ctx->sparse_valid = true;
+    // the sparse exchange (c2r_allreduce_rates) is only right for ONE pass over rates the library itself had zeroed: everything
+    // outside this pass's sub-boxes is then zero on every rank.  fz: the fused iteration zeroes them itself (fz->pre)
+    ++ctx->pass_id; ctx->sparse_valid = ctx->rates_clean || fz != nullptr; ctx->rates_clean = false;
     ctx->last_nbox.clear();
     ctx->h_sc->photon_loss = 0.0; ctx->h_sc->sum_nbox = 0;      // (the stream is idle between calls)
     if (nloc > 0) {
@@ -1610,10 +1633,14 @@ int c2r_allreduce_rates(c2r_ctx *c)
                 }
                 if (ctx->nsrc > ctx->boxdesc_cap) {
                     hipFree(ctx->d_boxdesc); ctx->d_boxdesc = nullptr; ctx->boxdesc_cap = 0;
+                    if (ctx->h_boxdesc) { hipHostFree(ctx->h_boxdesc); ctx->h_boxdesc = nullptr; }
                     HIP_TRY(hipMalloc(&ctx->d_boxdesc, (size_t)ctx->nsrc * sizeof(BoxDesc)));
+                    HIP_TRY(hipHostMalloc((void **)&ctx->h_boxdesc, (size_t)ctx->nsrc * sizeof(BoxDesc)));
                     ctx->boxdesc_cap = ctx->nsrc;
                 }
-                HIP_TRY(hipMemcpyAsync(ctx->d_boxdesc, desc.data(), desc.size() * sizeof(BoxDesc), hipMemcpyHostToDevice, ctx->stream));
+                // through the pinned staging copy (gather_nbox_all above ended with a stream wait: the previous call's copy has read it)
+                memcpy(ctx->h_boxdesc, desc.data(), desc.size() * sizeof(BoxDesc));
+                HIP_TRY(hipMemcpyAsync(ctx->d_boxdesc, ctx->h_boxdesc, desc.size() * sizeof(BoxDesc), hipMemcpyHostToDevice, ctx->stream));
                 int nb_max = 0;
                 for (const BoxDesc &d : desc) nb_max = std::max(nb_max, d.nbox);
                 const long long vmax = visited_for_nbox(ctx, nb_max);
@@ -1662,7 +1689,7 @@ int c2r_do_source(c2r_ctx *c, int32_t ns, double *cd_host, double *loss, int32_t
     rc = ensure_sweep_scratch(ctx, 1);
     if (rc) return rc;
     if ((rc = sync_step(ctx))) return rc;
-    ctx->sparse_valid = false;                    // (one source, addressed directly: the per-rank sub-box list no longer describes phih_grid)
+    ctx->sparse_valid = false; ctx->rates_clean = false;     // (one source, addressed directly: the per-rank sub-box list no longer describes phih_grid)
     double *dbg = nullptr;
     if (cd_host) {
         if (!ctx->d_dbg) HIP_TRY(hipMalloc(&ctx->d_dbg, ctx->ncell * sizeof(double)));
@@ -1711,25 +1738,34 @@ int c2r_evolve0d_host(c2r_ctx *c, int32_t ns, const int32_t rtpos[3], const int3
     for (int d = 0; d < 3; ++d) { const int m = (rtpos[d] - 1) % p.mesh[d]; pos[d] = m < 0 ? m + p.mesh[d] : m; }
     const size_t idx = (size_t)pos[0] + (size_t)p.mesh[0] * ((size_t)pos[1] + (size_t)p.mesh[1] * (size_t)pos[2]);
     if (coldensh_out[idx] != 0.0) return C2R_OK;
-    if ((rc = ensure_sweep_scratch(ctx, 1))) return rc;
-    if ((rc = sync_step(ctx))) return rc;
-    ctx->sparse_valid = false;
-    hipStream_t st = ctx->stream;
-    // the source in slot 0 of the batch arrays; n_HI of the cell (evolve_point.F90:137-146) where the kernels read it
+    // the source, and the cell's place in its sweep: checked before anything is enqueued or overwritten
     const int32_t *sp = &ctx->srcpos[3 * (size_t)(ns - 1)];
     int spw[3], del[3];
     for (int d = 0; d < 3; ++d) { const int m = (sp[d] - 1) % p.mesh[d]; spw[d] = m < 0 ? m + p.mesh[d] : m; del[d] = rtpos[d] - sp[d]; }
+    // cinterp's branch (column_density.f90:108,173,226: z over y over x) as face / plane coordinates / shell
+    const int ad[3] = {abs(del[0]), abs(del[1]), abs(del[2])};
+    if (std::max(ad[0], std::max(ad[1], ad[2])) > ctx->Qmax) FAIL(C2R_EINVAL, "evolve0D: the cell lies beyond the trace limit of its source");
+    if ((rc = ensure_sweep_scratch(ctx, 1))) return rc;
+    if ((rc = sync_step(ctx))) return rc;
+    ctx->sparse_valid = false; ctx->rates_clean = false;
+    hipStream_t st = ctx->stream;
+    // the source in slot 0 of the batch arrays; n_HI of the cell (evolve_point.F90:137-146) where the kernels read it.  The
+    // small inputs travel through the context's pinned staging block (true async copies; the call ends with a stream wait)
     const double nflux = ctx->nflux[ns - 1];
-    HIP_TRY(hipMemcpyAsync(ctx->d_srcpos_b, sp, 3 * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ctx->d_srcw_b, spw, 3 * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ctx->d_nflux_b, &nflux, sizeof(double), hipMemcpyHostToDevice, st));
     const double xav1 = std::max(xh_av[idx], p.epsilon), xav0 = std::max(1.0 - xav1, p.epsilon);
     const double nhi = xav0 * (double)ndens[idx];
     const size_t idt = (size_t)pos[1] + (size_t)p.mesh[1] * ((size_t)pos[0] + (size_t)p.mesh[0] * (size_t)pos[2]);
-    HIP_TRY(hipMemcpyAsync(ctx->d_nhi + idx, &nhi, sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ctx->d_nhi_T + idt, &nhi, sizeof(double), hipMemcpyHostToDevice, st));
-    // cinterp's branch (column_density.f90:108,173,226: z over y over x) as face / plane coordinates / shell
-    const int ad[3] = {abs(del[0]), abs(del[1]), abs(del[2])};
+    {
+        double *hd = reinterpret_cast<double *>(ctx->h_batch);            // >= 3 doubles + 11 ints for a batch of one
+        int *hi = reinterpret_cast<int *>(hd + 3);
+        hd[0] = nflux; hd[1] = nhi;
+        for (int d = 0; d < 3; ++d) { hi[d] = sp[d]; hi[3 + d] = spw[d]; }
+        HIP_TRY(hipMemcpyAsync(ctx->d_srcpos_b, hi, 3 * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctx->d_srcw_b, hi + 3, 3 * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctx->d_nflux_b, hd, sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctx->d_nhi + idx, hd + 1, sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctx->d_nhi_T + idt, hd + 1, sizeof(double), hipMemcpyHostToDevice, st));
+    }
     const bool is_source = ad[0] == 0 && ad[1] == 0 && ad[2] == 0;
     int axis, a, b;
     if (ad[2] >= ad[1] && ad[2] >= ad[0]) { axis = 2; a = del[0]; b = del[1]; }
@@ -1755,7 +1791,6 @@ int c2r_evolve0d_host(c2r_ctx *c, int32_t ns, const int32_t rtpos[3], const int3
         sa.q = q;
         sa.alam = (double)((float)(q - 1) + 0.5f) / (double)(float)q;
         sa.dp2 = (double)q * (double)q; sa.inv_dp2 = 1.0 / sa.dp2; sa.inv_q = 1.0 / (double)q;
-        if (q > ctx->Qmax) FAIL(C2R_EINVAL, "evolve0D: the cell lies beyond the trace limit of its source");
     }
     // :288-293 the cell lies on the surface of the current sub-box
     bool on_surface = false;
@@ -1767,8 +1802,8 @@ int c2r_evolve0d_host(c2r_ctx *c, int32_t ns, const int32_t rtpos[3], const int3
     switch (ctx->lls_type) { case 1: C2R_LAUNCH_CELL(1); break; case 2: C2R_LAUNCH_CELL(2); break; default: C2R_LAUNCH_CELL(3); break; }
 #undef C2R_LAUNCH_CELL
     HIP_TRY(hipGetLastError());
-    double out[4];
-    HIP_TRY(hipMemcpyAsync(out, d_out, sizeof out, hipMemcpyDeviceToHost, st));
+    double *out = ctx->h_sc->four;                               // pinned
+    HIP_TRY(hipMemcpyAsync(out, d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     coldensh_out[idx] = out[0];                                  // :247
     phih_grid[idx] = phih_grid[idx] + out[1];                    // :283
@@ -2003,6 +2038,7 @@ static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, i
     auto zero_rates = [ctx]() -> int {
         HIP_TRY(hipMemsetAsync(ctx->grid[4], 0, grid_bytes(ctx, 4), ctx->stream));
         if (ctx->thermal) HIP_TRY(hipMemsetAsync(ctx->grid[5], 0, grid_bytes(ctx, 5), ctx->stream));     // evolve.F90:435
+        ctx->rates_clean = true; ctx->sparse_valid = false;
         return C2R_OK;
     };
     double *four = stats_host ? ctx->d_hsc->four : nullptr;
@@ -2047,7 +2083,10 @@ int c2r_iterate(c2r_ctx *c, double dt, double *photon_loss, int64_t *sum_nbox, i
     return iterate_impl(ctx, dt, nullptr, photon_loss, sum_nbox, visited, conv_flag, sum_xh1);
 }
 
-static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double restart_loss, c2r_report *rep)
+// tail (or null): enqueued on the context's stream once the step's last kernel has been -- the host-pointer entries put their
+// device-to-host copies there, so that the step ends with ONE host wait behind results and copies alike
+static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double restart_loss, c2r_report *rep,
+                           const std::function<int()> &tail = nullptr)
 {
     if (!c) return C2R_EINVAL;
     Ctx *ctx = C(c);
@@ -2072,8 +2111,9 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
     const int64_t conv_criterion = std::min(c1, c2);
     rep->conv_criterion = conv_criterion;
     rep->timing_split = ctx->nranks > 1 ? 1 : 0;
-    double before[4], after[4], totalsrc = 0.0;
-    if ((rc = c2r_photon_sums(c, 1, 1, before))) return rc;                            // :136 state_before(xh)
+    double totalsrc = 0.0;
+    // :136 state_before(xh): the four sums land in pinned memory; they are read when the step has ended (no host wait here)
+    if ((rc = photon_sums_launch(ctx, 1, 1, ctx->d_hsc->before))) return rc;
     for (int i = 0; i < ctx->nsrc; ++i) totalsrc += ctx->nflux[i];                      // photonstatistics.F90:266
     totalsrc = totalsrc * p.S_star * dt;
     double sum1 = 0.0;
@@ -2204,7 +2244,12 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
         if (ctx->ag(ctx->slab_user, ctx->grid[4], bo, bc, ctx->nranks, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-gather callback failed");
         if (ctx->thermal && ctx->ag(ctx->slab_user, ctx->grid[5], bo, bc, ctx->nranks, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-gather callback failed");
     }
+    // evolve.F90:277-279 calculate_photon_statistics(dt,xh,xh_av): enqueued, then whatever the caller wants behind the step
+    // (the host-pointer entries: their downloads), then the step's one final wait
+    if ((rc = photon_sums_launch(ctx, 1, 2, ctx->d_hsc->after))) return rc;
+    if (tail && (rc = tail())) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const double *before = ctx->h_sc->before, *after = ctx->h_sc->after;
     rep->niter = niter; rep->conv_flag = conv_flag;
     for (int k = (restart_niter > 0 ? restart_niter : 0); k < niter && k < C2R_MAX_ITER_LOG; ++k) {
         const double *a4 = ctx->h_it4 + 4 * (size_t)k;
@@ -2212,8 +2257,6 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
         const double tion = trec + (before[0] * ctx->vol - a4[0] * ctx->vol);
         rep->it_photcons[k] = totalsrc > 0.0 ? (tion - tcol) / totalsrc : 0.0;
     }
-    // evolve.F90:277-279 calculate_photon_statistics(dt,xh,xh_av)
-    if ((rc = c2r_photon_sums(c, 1, 2, after))) return rc;
     rep->h0_before = before[0] * ctx->vol; rep->h1_before = before[1] * ctx->vol;
     rep->h0_after = after[0] * ctx->vol;   rep->h1_after = after[1] * ctx->vol;
     rep->totrec = after[2] * ctx->vol * dt; rep->totcollisions = after[3] * ctx->vol * dt;
@@ -2253,24 +2296,60 @@ static void pin_host_array(Ctx *ctx, const void *ptr, size_t bytes)
     else (void)hipGetLastError();
 }
 
+// The host-pointer entries: every array the caller hands over is page-locked once (the driver allocates them once per run,
+// evolve_data.F90:75-90), the uploads are enqueued without a host wait in front of the step, the downloads behind its last
+// kernel (evolve3d_worker's tail), and the call waits ONCE, at the end.  The two groups of copies are timed with HIP events.
+namespace {
+struct HostCopies {
+    Ctx *ctx; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit HostCopies(Ctx *c) : ctx(c) { for (auto &e : ev) hipEventCreate(&e); }
+    ~HostCopies() { for (auto &e : ev) if (e) hipEventDestroy(e); }
+    int up(int which, const void *host)
+    {
+        pin_host_array(ctx, host, grid_bytes(ctx, which));
+        HIP_TRY(hipMemcpyAsync(ctx->grid[which], host, grid_bytes(ctx, which), hipMemcpyHostToDevice, ctx->stream));
+        if (which == 4 || which == 5) { ctx->rates_clean = false; ctx->sparse_valid = false; }
+        return C2R_OK;
+    }
+    int down(int which, void *host)
+    {
+        if (!host) return C2R_OK;
+        pin_host_array(ctx, host, grid_bytes(ctx, which));
+        HIP_TRY(hipMemcpyAsync(host, ctx->grid[which], grid_bytes(ctx, which), hipMemcpyDeviceToHost, ctx->stream));
+        return C2R_OK;
+    }
+    int mark(int i) { HIP_TRY(hipEventRecord(ev[i], ctx->stream)); return C2R_OK; }
+    void finish(c2r_report *rep)       // after the step's final wait
+    {
+        if (!rep) return;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) rep->seconds_upload = 1e-3 * ms;
+        if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) rep->seconds_download = 1e-3 * ms;
+        (void)hipGetLastError();
+        rep->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+}  // namespace
+
 int c2r_evolve3d(c2r_ctx *c, double dt, const float *ndens, double *xh, double *xh_av, double *xh_int,
                  double *phih, c2r_report *rep)
 {
     if (!c || !ndens || !xh) return C2R_EINVAL;
+    Ctx *ctx = C(c);
     int rc;
-    {
-        Ctx *ctx = C(c);
-        pin_host_array(ctx, ndens, grid_bytes(ctx, 0)); pin_host_array(ctx, xh, grid_bytes(ctx, 1));
-        pin_host_array(ctx, xh_av, grid_bytes(ctx, 2)); pin_host_array(ctx, xh_int, grid_bytes(ctx, 3));
-        pin_host_array(ctx, phih, grid_bytes(ctx, 4));
-    }
-    if ((rc = c2r_upload(c, 0, ndens))) return rc;
-    if ((rc = c2r_upload(c, 1, xh))) return rc;
-    if ((rc = c2r_evolve3d_dev(c, dt, rep))) return rc;
-    if ((rc = c2r_download(c, 1, xh))) return rc;
-    if (xh_av && (rc = c2r_download(c, 2, xh_av))) return rc;
-    if (xh_int && (rc = c2r_download(c, 3, xh_int))) return rc;
-    if (phih && (rc = c2r_download(c, 4, phih))) return rc;
+    HIP_TRY(hipSetDevice(ctx->prm.device));
+    c2r_report local;
+    if (!rep) rep = &local;
+    HostCopies hc(ctx);
+    if ((rc = hc.mark(0)) || (rc = hc.up(0, ndens)) || (rc = hc.up(1, xh)) || (rc = hc.mark(1))) return rc;
+    auto tail = [&]() -> int {
+        int r;
+        if ((r = hc.mark(2)) || (r = hc.down(1, xh)) || (r = hc.down(2, xh_av)) || (r = hc.down(3, xh_int)) || (r = hc.down(4, phih))) return r;
+        return hc.mark(3);
+    };
+    if ((rc = evolve3d_worker(c, dt, -1, 0.0, rep, tail))) return rc;
+    hc.finish(rep);
     return C2R_OK;
 }
 
@@ -2278,17 +2357,22 @@ int c2r_evolve3d_restart(c2r_ctx *c, double dt, int32_t niter, double photon_los
                          double *xh, double *xh_av, double *xh_int, double *phih, c2r_report *rep)
 {
     if (!c || !ndens || !xh || !xh_av || !xh_int || !phih || niter < 0) return C2R_EINVAL;
+    Ctx *ctx = C(c);
     int rc;
-    if ((rc = c2r_upload(c, 0, ndens))) return rc;
-    if ((rc = c2r_upload(c, 1, xh))) return rc;
-    if ((rc = c2r_upload(c, 2, xh_av))) return rc;
-    if ((rc = c2r_upload(c, 3, xh_int))) return rc;
-    if ((rc = c2r_upload(c, 4, phih))) return rc;
-    if ((rc = c2r_evolve3d_restart_dev(c, dt, niter, photon_loss_all, rep))) return rc;
-    if ((rc = c2r_download(c, 1, xh))) return rc;
-    if ((rc = c2r_download(c, 2, xh_av))) return rc;
-    if ((rc = c2r_download(c, 3, xh_int))) return rc;
-    return c2r_download(c, 4, phih);
+    HIP_TRY(hipSetDevice(ctx->prm.device));
+    c2r_report local;
+    if (!rep) rep = &local;
+    HostCopies hc(ctx);
+    if ((rc = hc.mark(0)) || (rc = hc.up(0, ndens)) || (rc = hc.up(1, xh)) || (rc = hc.up(2, xh_av)) || (rc = hc.up(3, xh_int)) ||
+        (rc = hc.up(4, phih)) || (rc = hc.mark(1))) return rc;
+    auto tail = [&]() -> int {
+        int r;
+        if ((r = hc.mark(2)) || (r = hc.down(1, xh)) || (r = hc.down(2, xh_av)) || (r = hc.down(3, xh_int)) || (r = hc.down(4, phih))) return r;
+        return hc.mark(3);
+    };
+    if ((rc = evolve3d_worker(c, dt, niter, photon_loss_all, rep, tail))) return rc;
+    hc.finish(rep);
+    return C2R_OK;
 }
 
 int c2r_evolve3d_thermal(c2r_ctx *c, double dt, int32_t restart_niter, double photon_loss_all, const float *ndens,
@@ -2301,26 +2385,24 @@ int c2r_evolve3d_thermal(c2r_ctx *c, double dt, int32_t restart_niter, double ph
     const bool restart = restart_niter >= 0;
     if (restart && (!xh_av || !xh_int || !phih || !phiheat)) return C2R_EINVAL;
     int rc;
-    pin_host_array(ctx, ndens, grid_bytes(ctx, 0)); pin_host_array(ctx, xh, grid_bytes(ctx, 1));
-    pin_host_array(ctx, xh_av, grid_bytes(ctx, 2)); pin_host_array(ctx, xh_int, grid_bytes(ctx, 3));
-    pin_host_array(ctx, phih, grid_bytes(ctx, 4)); pin_host_array(ctx, phiheat, grid_bytes(ctx, 5));
-    pin_host_array(ctx, temperature_grid, grid_bytes(ctx, 6));
-    if ((rc = c2r_upload(c, 0, ndens))) return rc;
-    if ((rc = c2r_upload(c, 1, xh))) return rc;
-    if ((rc = c2r_upload(c, 6, temperature_grid))) return rc;
+    HIP_TRY(hipSetDevice(ctx->prm.device));
+    c2r_report local;
+    if (!rep) rep = &local;
+    HostCopies hc(ctx);
+    if ((rc = hc.mark(0)) || (rc = hc.up(0, ndens)) || (rc = hc.up(1, xh)) || (rc = hc.up(6, temperature_grid))) return rc;
     if (restart) {       // start_from_dump (evolve.F90:328-426) read these, phiheat_grid and temperature_grid (:372-375)
-        if ((rc = c2r_upload(c, 2, xh_av))) return rc;
-        if ((rc = c2r_upload(c, 3, xh_int))) return rc;
-        if ((rc = c2r_upload(c, 4, phih))) return rc;
-        if ((rc = c2r_upload(c, 5, phiheat))) return rc;
+        if ((rc = hc.up(2, xh_av)) || (rc = hc.up(3, xh_int)) || (rc = hc.up(4, phih)) || (rc = hc.up(5, phiheat))) return rc;
     }
-    if ((rc = evolve3d_worker(c, dt, restart ? restart_niter : -1, photon_loss_all, rep))) return rc;
-    if ((rc = c2r_download(c, 1, xh))) return rc;
-    if (xh_av && (rc = c2r_download(c, 2, xh_av))) return rc;
-    if (xh_int && (rc = c2r_download(c, 3, xh_int))) return rc;
-    if (phih && (rc = c2r_download(c, 4, phih))) return rc;
-    if (phiheat && (rc = c2r_download(c, 5, phiheat))) return rc;
-    return c2r_download(c, 6, temperature_grid);
+    if ((rc = hc.mark(1))) return rc;
+    auto tail = [&]() -> int {
+        int r;
+        if ((r = hc.mark(2)) || (r = hc.down(1, xh)) || (r = hc.down(2, xh_av)) || (r = hc.down(3, xh_int)) || (r = hc.down(4, phih)) ||
+            (r = hc.down(5, phiheat)) || (r = hc.down(6, temperature_grid))) return r;
+        return hc.mark(3);
+    };
+    if ((rc = evolve3d_worker(c, dt, restart ? restart_niter : -1, photon_loss_all, rep, tail))) return rc;
+    hc.finish(rep);
+    return C2R_OK;
 }
 
 int c2r_selftest(c2r_ctx *c, int64_t *mismatches)

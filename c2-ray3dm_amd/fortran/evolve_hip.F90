@@ -6,12 +6,19 @@
 !!     EVOLVE = evolve_data.o column_density.o evolve_point.o evolve_source.o master_slave.o evolve.o
 !! by
 !!     EVOLVE = evolve_data.o evolve_hip.o            (and add  -L<dir> -lc2ray_hip  to the link line)
+!! and drop photonstatistics.o from the program's object list (makefile_core:40 and the other *_SET lines): this file
+!! brings its own module `photonstatistics` -- same public variables and routines, fed by the sums the device has
+!! already taken (c2r_report) instead of three serial N^3 host loops per time step.  (-DC2R_REFERENCE_PHOTONSTATISTICS
+!! keeps the reference's photonstatistics.o in the link and the host loops with it.)
 !! `evolve_data` (the arrays C2Ray.F90:61 and output.F90:31 use) stays the reference's own file.
 !!
-!! Three modules:
-!!   c2ray_hip      the bind(C) mirror of include/c2ray_hip.h, the context, per-step state transfer
-!!   evolve_source  `do_source(dt,ns1,niter)`, `sum_nbox`, `sum_nbox_all`   (evolve_source.F90:45-58)
-!!   evolve         `evolve3D(time,dt,restart)`                              (evolve.F90:83, C2Ray.F90:379)
+!! Modules:
+!!   c2ray_hip        the bind(C) mirror of include/c2ray_hip.h, the context, per-step state transfer
+!!   photonstatistics the reference's module surface (photonstatistics.F90:39-55, :71-293), device-fed
+!!   evolve_source    `do_source(dt,ns1,niter)`, `sum_nbox`, `sum_nbox_all`   (evolve_source.F90:45-58)
+!!   master_slave_processing `do_grid(dt,niter)`                              (master_slave.F90:53)
+!!   evolve_point     `evolve0D`, `evolve0D_global`, `evolve0D_global_all`    (evolve_point.F90:83, :305)
+!!   evolve           `evolve3D(time,dt,restart)`                              (evolve.F90:83, C2Ray.F90:379)
 !! All inputs are taken from the same module-global arrays the reference routines read, by `use`
 !! association; the HIP side never keeps a host pointer after a call returns.
 module c2ray_hip
@@ -77,6 +84,7 @@ module c2ray_hip
           it_sum_xh1(C2R_MAX_ITER_LOG)
      real(c_double) :: h0_before, h1_before, h0_after, h1_after, totrec, totcollisions, dh0, &
           total_ion, totalsrc, photcons, it_photcons(C2R_MAX_ITER_LOG)
+     real(c_double) :: seconds_upload, seconds_download, seconds_total
   end type c2r_report
 
   !> mirror of struct c2r_thermal_params (non-isothermal builds of the driver: c2ray_parameters.f90:28)
@@ -111,7 +119,8 @@ module c2ray_hip
        real(c_double), value :: dt, photon_loss_all
        integer(c_int32_t), value :: restart_niter
        real(c_float), intent(in) :: ndens(*)
-       real(c_double), intent(inout) :: xh(*), xh_av(*), xh_intermed(*), phih_grid(*), phiheat_grid(*)
+       real(c_double), intent(inout) :: xh(*), phih_grid(*), phiheat_grid(*)
+       type(c_ptr), value :: xh_av, xh_intermed              ! c_loc of the array (download; upload on restart) or c_null_ptr
        type(*), dimension(*), intent(inout) :: temperature_grid
        type(c2r_report), intent(out) :: rep
      end function c2r_evolve3d_thermal
@@ -154,13 +163,15 @@ module c2ray_hip
        real(c_double), intent(in) :: normflux(*)
        integer(c_int32_t), value :: nsrc
      end function c2r_set_sources
+     !> xh_av, xh_intermed, phih_grid: c_loc of the array to have it downloaded after the step, c_null_ptr to leave it alone
      integer(c_int) function c2r_evolve3d(ctx, dt, ndens, xh, xh_av, xh_intermed, phih_grid, rep) &
           bind(C, name="c2r_evolve3d")
        import :: c_int, c_ptr, c_double, c_float, c2r_report
        type(c_ptr), value :: ctx
        real(c_double), value :: dt
        real(c_float), intent(in) :: ndens(*)
-       real(c_double), intent(inout) :: xh(*), xh_av(*), xh_intermed(*), phih_grid(*)
+       real(c_double), intent(inout) :: xh(*)
+       type(c_ptr), value :: xh_av, xh_intermed, phih_grid
        type(c2r_report), intent(out) :: rep
      end function c2r_evolve3d
      integer(c_int) function c2r_evolve3d_restart(ctx, dt, niter, photon_loss_all, ndens, xh, xh_av, &
@@ -306,7 +317,20 @@ module c2ray_hip
 
   type(c_ptr) :: ctx = c_null_ptr
 
+  !> evolve3D also copies xh_av and xh_intermed back to the driver's arrays after every step.  Off by default: they are
+  !! work arrays of the replaced modules (nothing else in the reference reads them: output.F90 takes xh and phih_grid;
+  !! an iteration dump downloads them itself), 16 bytes per cell and step over PCIe.  Environment: C2R_SHIM_SYNC_WORK_ARRAYS=1
+  logical :: sync_work_arrays = .false.
+
 contains
+
+  !> address of one of the driver's f64 mesh arrays (for the C entries that take an optional array as a pointer)
+  function dp_address(g) result(p)
+    real(kind=dp), dimension(:,:,:), allocatable, target, intent(in) :: g
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(g)) p = c_loc(g)
+  end function dp_address
 
   subroutine check(rc, what)
     integer(c_int), intent(in) :: rc
@@ -363,6 +387,8 @@ contains
     ! 1: C2R_SWEEP_FAST).  The library reads no environment: what is set here is what runs, and it is logged below.
     call get_environment_variable("C2R_SWEEP_MODE", envval, status=envstat)
     if (envstat == 0 .and. len_trim(envval) > 0 .and. trim(envval) /= "0") p%sweep_mode = 1_c_int32_t
+    call get_environment_variable("C2R_SHIM_SYNC_WORK_ARRAYS", envval, status=envstat)
+    sync_work_arrays = envstat == 0 .and. len_trim(envval) > 0 .and. trim(envval) /= "0"
     call check(c2r_create(ctx, p), "c2r_create")
     call check(c2r_set_tables(ctx, stellar_photo_thick_table(:,1), stellar_photo_thin_table(:,1), &
          int(NumTau+1, c_int32_t)), "c2r_set_tables")
@@ -456,6 +482,162 @@ contains
   end function grid_address
 
 end module c2ray_hip
+
+#ifndef C2R_REFERENCE_PHOTONSTATISTICS
+! =============================================================================================
+
+!> `photonstatistics` of the reference (photonstatistics.F90) -- same module name, same public variables (output.F90:33-36
+!! reads totrec, totcollisions, dh0, total_ion, grtotal_ion, grtotal_src, LLS_loss, photon_loss) and the same public
+!! routines -- but the four mesh sums behind them (neutrals / ions before and after the step, recombinations and collisional
+!! ionizations during it: state_before :104, state_after :190, total_rates :137) are the ones the DEVICE has taken inside
+!! c2r_evolve3d (k_photon_sums; the chemistry kernel for the per-iteration ones) and returned in c2r_report:
+!! `photon_statistics_from_device`.  The reference walks the mesh three times per time step for them, serially, with a
+!! power and an exponential per cell -- of order 0.1 s at 128^3 where the whole step takes milliseconds on the GPU.
+!! The host-array routines remain for callers outside evolve3D; they run one fused loop over the mesh instead of three.
+module photonstatistics
+
+  use precision, only: dp
+  use my_mpi, only: rank
+  use file_admin, only: logf
+  use cgsconstants, only: albpow, bh00, colh0, temph0
+  use cgsphotoconstants, only: sigh => sigma_HI_at_ion_freq
+  use sizes, only: mesh
+  use grid, only: vol
+  use density_module, only: ndens
+  use temperature_module, only: temperature_states_dbl, get_temperature_point
+  use clumping_module, only: clumping, clumping_point
+  use abundances, only: abu_c
+  use sourceprops, only: NormFlux_stellar, NumSrc
+  use radiation_sed_parameters, only: S_star
+  use radiation_sizes, only: NumFreqBnd
+  use c2ray_parameters, only: type_of_clumping
+
+  implicit none
+
+  logical,parameter :: do_photonstatistics=.true.   !< photonstatistics.F90:39
+  real(kind=dp) :: totrec          !< recombinations during the step
+  real(kind=dp) :: totcollisions   !< collisional ionizations during the step
+  real(kind=dp) :: dh0             !< change in the number of neutral H atoms
+  real(kind=dp) :: total_ion       !< ionizing photons used
+  real(kind=dp) :: LLS_loss        !< photons lost in LLSs (identically zero on this path, see DESIGN.md)
+  real(kind=dp) :: grtotal_ion     !< grand total of ionizing photons used
+  real(kind=dp) :: grtotal_src     !< grand total of ionizing photons produced
+  real(kind=dp) :: photon_loss(NumFreqBnd)   !< photons leaving the grid (per cell after evolve3D)
+
+  real(kind=dp),private :: h0_before, h0_after, h1_before, h1_after
+
+contains
+
+  subroutine initialize_photonstatistics ()
+    grtotal_ion=0.0
+    grtotal_src=0.0
+  end subroutine initialize_photonstatistics
+
+  !> The step's statistics as c2r_report holds them (h0/h1 before and after, totrec, totcollisions: already times vol
+  !! and dt), followed by total_ionizations (photonstatistics.F90:222-228)
+  subroutine photon_statistics_from_device (h0b, h1b, h0a, h1a, rec, col)
+    real(kind=dp),intent(in) :: h0b, h1b, h0a, h1a, rec, col
+    h0_before = h0b; h1_before = h1b; h0_after = h0a; h1_after = h1a
+    totrec = rec; totcollisions = col
+    call total_ionizations ()
+  end subroutine photon_statistics_from_device
+
+  !> One walk over the mesh for any subset of the sums (host arrays; callers outside evolve3D).  Same expressions and the
+  !! same left-to-right order per sum as photonstatistics.F90:113-127, :153-180.
+  subroutine mesh_sums (x_state, x_rates, h0, h1, rec, col)
+    real(kind=dp),dimension(mesh(1),mesh(2),mesh(3)),intent(in),optional :: x_state, x_rates
+    real(kind=dp),intent(out) :: h0, h1, rec, col
+    integer :: i, j, k
+    real(kind=dp) :: nd, y0, y1, de
+    type(temperature_states_dbl) :: t
+    h0 = 0.0; h1 = 0.0; rec = 0.0; col = 0.0
+    do k = 1, mesh(3)
+       do j = 1, mesh(2)
+          do i = 1, mesh(1)
+             nd = ndens(i,j,k)
+             if (present(x_state)) then
+                h0 = h0 + ndens(i,j,k)*(1.0_dp - x_state(i,j,k))
+                h1 = h1 + ndens(i,j,k)*x_state(i,j,k)
+             endif
+             if (present(x_rates)) then
+                y1 = x_rates(i,j,k); y0 = 1.0_dp - y1
+                de = nd*(y1 + abu_c)                                   ! tped.f90:81
+                call get_temperature_point (i,j,k,t)
+                if (type_of_clumping >= 3 .and. type_of_clumping <= 5) call clumping_point (i,j,k)
+                rec = rec + nd*y1*de*clumping*bh00*(t%average/1e4)**albpow
+                col = col + nd*y0*de*colh0*sqrt(t%average)*exp(-temph0/t%average)
+             endif
+          enddo
+       enddo
+    enddo
+  end subroutine mesh_sums
+
+  subroutine state_before (xh_l)
+    real(kind=dp),dimension(mesh(1),mesh(2),mesh(3)),intent(in) :: xh_l
+    real(kind=dp) :: r, c
+    call mesh_sums (x_state=xh_l, h0=h0_before, h1=h1_before, rec=r, col=c)
+    h0_before = h0_before*vol; h1_before = h1_before*vol
+  end subroutine state_before
+
+  subroutine state_after (xh_l)
+    real(kind=dp),dimension(mesh(1),mesh(2),mesh(3)),intent(in) :: xh_l
+    real(kind=dp) :: r, c
+    call mesh_sums (x_state=xh_l, h0=h0_after, h1=h1_after, rec=r, col=c)
+    h0_after = h0_after*vol; h1_after = h1_after*vol
+  end subroutine state_after
+
+  subroutine total_rates (dt,xh_l)
+    real(kind=dp),intent(in) :: dt
+    real(kind=dp),dimension(mesh(1),mesh(2),mesh(3)),intent(in) :: xh_l
+    real(kind=dp) :: a, b
+    call mesh_sums (x_rates=xh_l, h0=a, h1=b, rec=totrec, col=totcollisions)
+    totrec = totrec*vol*dt; totcollisions = totcollisions*vol*dt
+  end subroutine total_rates
+
+  !> photonstatistics.F90:82-99 for host arrays: neutrals after the step from xh_l, rates from xh_r, one walk over the mesh
+  subroutine calculate_photon_statistics (dt,xh_l,xh_r)
+    real(kind=dp),intent(in) :: dt
+    real(kind=dp),dimension(mesh(1),mesh(2),mesh(3)),intent(in) :: xh_l, xh_r
+    call mesh_sums (xh_l, xh_r, h0_after, h1_after, totrec, totcollisions)
+    h0_after = h0_after*vol; h1_after = h1_after*vol
+    totrec = totrec*vol*dt; totcollisions = totcollisions*vol*dt
+    call total_ionizations ()
+  end subroutine calculate_photon_statistics
+
+  subroutine total_ionizations ()
+    dh0 = (h0_before - h0_after)
+    total_ion = totrec + dh0
+  end subroutine total_ionizations
+
+  !> photonstatistics.F90:233-249 (nothing on the HIP path calls it: LLS_loss stays zero, as in the reference, whose
+  !! evolve0D passes a photo_in_HI that nothing sets)
+  subroutine total_LLS_loss (phi_out,coldensh_LLS)
+    real(kind=dp),intent(in) :: phi_out, coldensh_LLS
+    LLS_loss = LLS_loss + phi_out*(1.0 - exp(-sigh*coldensh_LLS))
+  end subroutine total_LLS_loss
+
+  !> The conservation line of the log (photonstatistics.F90:254-281): same columns, same formats
+  subroutine report_photonstatistics (dt)
+    real(kind=dp),intent(in) :: dt
+    real(kind=dp) :: totalsrc, lost_cells, lost_lls
+    lost_cells = sum(photon_loss)*dt*real(mesh(1))*real(mesh(2))*real(mesh(3))
+    lost_lls = LLS_loss*dt
+    totalsrc = sum(NormFlux_stellar(1:NumSrc))*S_star*dt
+    if (rank == 0) then
+       write(logf,"(8(1pe10.3))") total_ion, totalsrc, (total_ion + LLS_loss - totcollisions)/totalsrc, dh0/total_ion, &
+            totrec/total_ion, lost_lls/totalsrc, lost_cells/totalsrc, totcollisions/total_ion
+       write(logf,*) h1_before,h1_after
+    endif
+  end subroutine report_photonstatistics
+
+  subroutine update_grandtotal_photonstatistics (dt)
+    real(kind=dp),intent(in) :: dt
+    grtotal_src = grtotal_src + sum(NormFlux_stellar(1:NumSrc))*S_star*dt
+    grtotal_ion = grtotal_ion + total_ion - totcollisions
+  end subroutine update_grandtotal_photonstatistics
+
+end module photonstatistics
+#endif
 
 ! =============================================================================================
 
@@ -708,8 +890,13 @@ module evolve
   use sourceprops, only: NumSrc
   use c2ray_parameters, only: convergence_fraction
   use temperature_module, only: temperature_grid
+#ifdef C2R_REFERENCE_PHOTONSTATISTICS
   use photonstatistics, only: photon_loss, LLS_loss, state_before, calculate_photon_statistics, &
        report_photonstatistics, update_grandtotal_photonstatistics
+#else
+  use photonstatistics, only: photon_loss, LLS_loss, photon_statistics_from_device, &
+       report_photonstatistics, update_grandtotal_photonstatistics
+#endif
   use evolve_data, only: phih_grid, phiheat_grid, xh_av, xh_intermed, photon_loss_all
   use evolve_source, only: sum_nbox, sum_nbox_all
   use c2ray_hip
@@ -736,8 +923,14 @@ contains
 
     integer :: k, niter0
     real(kind=dp) :: ncell
+    integer(kind=8) :: c_begin, c_state, c_call, c_end, c_rate
+    real(kind=dp) :: t_total, t_setup, t_call, t_iter
+    type(c_ptr) :: p_av, p_int
 
-    call state_before (xh)                                            ! evolve.F90:136
+    call system_clock(c_begin, c_rate)
+#ifdef C2R_REFERENCE_PHOTONSTATISTICS
+    call state_before (xh)                                            ! evolve.F90:136 (on the device otherwise: c2r_report%h0_before)
+#endif
 
     call hip_step_state()
     call check(c2r_set_iteration_hook(ctx, c_funloc(iteration_hook), c_null_ptr), &
@@ -745,22 +938,36 @@ contains
     wallclock_last_dump = timestamp_wallclock ()
 
     if (rank == 0) write(timefile,"(A,F8.1)") "Time before starting iteration: ", timestamp_wallclock ()
+    call system_clock(c_state)
+
+    ! what comes back after the step: xh and phih_grid (output.F90 writes them); the work arrays only on request
+    p_av = c_null_ptr; p_int = c_null_ptr
+    if (sync_work_arrays) then
+       p_av = dp_address(xh_av); p_int = dp_address(xh_intermed)
+    endif
+#ifdef C2R_REFERENCE_PHOTONSTATISTICS
+    p_av = dp_address(xh_av)                                          ! calculate_photon_statistics(dt,xh,xh_av) below reads it
+#endif
 
     niter0 = 0
     if (.not.isothermal) then
        ! heating and cooling: also phiheat_grid and temperature_grid (evolve_point.F90:285, :553; evolve.F90:220)
-       if (restart /= 0) call start_from_dump(restart, niter0)
+       if (restart /= 0) then
+          call start_from_dump(restart, niter0)
+          p_av = dp_address(xh_av); p_int = dp_address(xh_intermed)   ! (uploaded from the dump)
+       endif
        call check(c2r_evolve3d_thermal(ctx, dt, int(merge(niter0, -1, restart /= 0), c_int32_t), photon_loss_all(1), &
-            ndens, xh, xh_av, xh_intermed, phih_grid, phiheat_grid, temperature_grid, last_report), &
+            ndens, xh, p_av, p_int, phih_grid, phiheat_grid, temperature_grid, last_report), &
             "c2r_evolve3d_thermal")
     elseif (restart == 0) then
-       call check(c2r_evolve3d(ctx, dt, ndens, xh, xh_av, xh_intermed, phih_grid, last_report), &
+       call check(c2r_evolve3d(ctx, dt, ndens, xh, p_av, p_int, dp_address(phih_grid), last_report), &
             "c2r_evolve3d")
     else
        call start_from_dump(restart, niter0)                          ! evolve.F90:153-157
        call check(c2r_evolve3d_restart(ctx, dt, int(niter0, c_int32_t), photon_loss_all(1), ndens, &
             xh, xh_av, xh_intermed, phih_grid, last_report), "c2r_evolve3d_restart")
     endif
+    call system_clock(c_call)
 
     ! what the reference logs per outer iteration (evolve.F90:205-210, 249-251, 559-566)
     ncell = real(mesh(1),dp)*real(mesh(2),dp)*real(mesh(3),dp)
@@ -792,9 +999,28 @@ contains
     photon_loss(:) = photon_loss_all(:)/ncell                         ! evolve.F90:519
     LLS_loss = 0.0_dp                                                 ! identically zero, see DESIGN.md
 
-    call calculate_photon_statistics (dt,xh,xh_av)                    ! evolve.F90:277-279
+#ifdef C2R_REFERENCE_PHOTONSTATISTICS
+    call calculate_photon_statistics (dt,xh,xh_av)                    ! evolve.F90:277-279: three host loops over the mesh
+#else
+    ! evolve.F90:277-279: the same numbers, summed on the device while the step ran
+    call photon_statistics_from_device (last_report%h0_before, last_report%h1_before, last_report%h0_after, &
+         last_report%h1_after, last_report%totrec, last_report%totcollisions)
+#endif
     call report_photonstatistics (dt)
     call update_grandtotal_photonstatistics (dt)
+
+    ! where the wall time of this step went (seconds): the whole call; the shim's set-up before the library call (step
+    ! scalars, source list, grids of the non-default switches); host-to-device copies; the outer iterations; device-to-host
+    ! copies; the rest of the library call (sums, waits, page-locking on first use); logging and statistics after it
+    call system_clock(c_end)
+    t_total = real(c_end - c_begin, dp)/real(c_rate, dp)
+    t_setup = real(c_state - c_begin, dp)/real(c_rate, dp)
+    t_call = real(c_call - c_state, dp)/real(c_rate, dp)
+    t_iter = last_report%seconds_sweep + last_report%seconds_chem
+    if (rank == 0) write(logf,"(A,I4,7(1x,es10.3))") "c2ray_hip: evolve3D seconds [iterations|total set-up upload iterations download library-rest host-rest]:", &
+         last_report%niter, t_total, t_setup, last_report%seconds_upload, t_iter, last_report%seconds_download, &
+         t_call - last_report%seconds_upload - t_iter - last_report%seconds_download, &
+         real(c_end - c_call, dp)/real(c_rate, dp)
 
   end subroutine evolve3D
 

@@ -119,6 +119,12 @@ typedef struct c2r_report {
     double  h0_before, h1_before, h0_after, h1_after;
     double  totrec, totcollisions, dh0, total_ion, totalsrc, photcons;
     double  it_photcons[C2R_MAX_ITER_LOG];         /* conservation ratio logged after each global pass */
+    /* where the wall time of a host-pointer call (c2r_evolve3d, _restart, _thermal) went: the copies are timed with HIP
+     * events on the context's stream (they are enqueued without a host wait in between), the call as a whole with the host
+     * clock.  The device-resident entries (c2r_evolve3d_dev) leave the two copy times at zero. */
+    double  seconds_upload;          /* host -> device: ndens, xh (restart: xh_av, xh_intermed, phih_grid too) */
+    double  seconds_download;        /* device -> host: xh, phih_grid (+ whatever else the caller passed non-null) */
+    double  seconds_total;           /* the whole call */
 } c2r_report;
 
 /* Sum `count` doubles at device pointer `buf` over all ranks, in place, on `stream`

@@ -83,7 +83,8 @@ build_hip_dropin () {   # $1 = mesh[:variant]
   local S=$D/serial B=$D/hip PKG=$HERE/../c2-ray3dm_amd
   [ -f "$PKG/libc2ray_hip.so" ] || { echo "libc2ray_hip.so not built: skipping drop-in program" >&2; return 0; }
   mkdir -p "$B"
-  # the shim's evolve.mod / evolve_source.mod land in $B and shadow the reference's ($B before $S)
+  # the shim's evolve.mod / evolve_source.mod / photonstatistics.mod land in $B and shadow the reference's ($B before $S);
+  # output.o of the serial build is reused as it is: it refers to the module's public variables by name
   ( cd "$B" && $FC $FLAGS -I"$S" -c "$PKG/fortran/evolve_hip.F90" -o evolve_hip.o 2>>build.log \
       && $FC $FLAGS -I"$B" -I"$S" -c "$REF/C2Ray.F90" -o C2Ray.o 2>>build.log \
       && $FC $FLAGS -DC2RAY_HIP_SHIM -I"$B" -I"$S" -c "$HERE/ref_driver.F90" -o ref_driver.o 2>>build.log )
@@ -91,10 +92,19 @@ build_hip_dropin () {   # $1 = mesh[:variant]
   for o in "$S"/*.o; do
     case "$(basename "$o")" in
       evolve_point.o|evolve_source.o|master_slave.o|evolve.o|C2Ray.o|ref_driver.o) ;;
+      photonstatistics.o) ;;        # the shim brings its own module of that name (device-fed, evolve_hip.F90)
       *) objs="$objs $o" ;;
     esac
   done
   local LINK="-L$PKG -lc2ray_hip -Wl,-rpath,\$ORIGIN/../../../../c2-ray3dm_amd -Wl,-rpath,/opt/rocm/lib"
+  # (timing comparison only, profiles/dropin_timing.py leg "hip-hoststats": the shim as it was before round 5 -- the driver's
+  # own photonstatistics.o with its three serial mesh loops per step, xh_av copied back for them)
+  if [ -z "$V" ] && [ "$N" -ge 128 ]; then
+    mkdir -p "$D/hip_hoststats"
+    ( cd "$D/hip_hoststats" && $FC $FLAGS -DC2R_REFERENCE_PHOTONSTATISTICS -I"$S" -c "$PKG/fortran/evolve_hip.F90" -o evolve_hip.o 2>>build.log \
+        && $FC $FLAGS -I"$D/hip_hoststats" -I"$S" -c "$REF/C2Ray.F90" -o C2Ray.o 2>>build.log \
+        && $FC $FLAGS -o c2ray_test_hip $objs "$S/photonstatistics.o" evolve_hip.o C2Ray.o $LINK 2>>build.log )
+  fi
   # the reference's own program, and our fixture driver (ref_driver.F90: do_source / evolve3D / restart
   # modes), both with the HIP modules in place of the reference's evolve modules
   ( cd "$B" && $FC $FLAGS -o c2ray_test_hip $objs evolve_hip.o C2Ray.o $LINK 2>>build.log \

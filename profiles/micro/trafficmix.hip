@@ -117,6 +117,36 @@ double run(const double *nhi, double *gam, const double *pin, double *pout, unsi
     return (double)nthreads * 3 / (best * 1e-3);      // visits per second
 }
 
+#ifdef TRAFFICMIX_LIB
+// The same measurement as a function, for bench.py (ctypes): the memory-only ceiling of the sweep's traffic mix ON THE BOX
+// the bench runs on, taken in the bench process after the timed region -- so that `roofline.frac_of_memory_only_mix` does not
+// divide a number of this box by a constant measured on another one (boxes differ by +-5 %).
+//   mask: 31 = all four streams, runs starting anywhere (what the kernel does); 15 = 512-B aligned runs; see k_mix
+//   hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -DTRAFFICMIX_LIB -shared -fPIC trafficmix.hip -o libtrafficmix.so
+extern "C" int c2r_micro_traffic_mix(int device, int mask, double *visits_per_s)
+{
+    if (!visits_per_s) return -1;
+    CK(hipSetDevice(device));
+    const size_t n = (size_t)256 * 256 * 256;
+    const size_t nthreads = (size_t)1 << 27;
+    const size_t plane_elems = nthreads * 3 + 64;
+    double *nhi = nullptr, *gam = nullptr, *pin = nullptr, *pout = nullptr;
+    CK(hipMalloc(&nhi, n * 8)); CK(hipMalloc(&gam, n * 8)); CK(hipMalloc(&pin, plane_elems * 8)); CK(hipMalloc(&pout, plane_elems * 8));
+    CK(hipMemset(nhi, 0, n * 8)); CK(hipMemset(gam, 0, n * 8)); CK(hipMemset(pin, 0, plane_elems * 8)); CK(hipMemset(pout, 0, plane_elems * 8));
+    const unsigned nrows = (unsigned)(n / 64);
+    double v = 0.0;
+    switch (mask) {
+        case 31: v = run<31>(nhi, gam, pin, pout, nrows, plane_elems, nthreads); break;
+        case 15: v = run<15>(nhi, gam, pin, pout, nrows, plane_elems, nthreads); break;
+        case 24: v = run<24>(nhi, gam, pin, pout, nrows, plane_elems, nthreads); break;
+        case 6:  v = run<6>(nhi, gam, pin, pout, nrows, plane_elems, nthreads); break;
+        default: hipFree(nhi); hipFree(gam); hipFree(pin); hipFree(pout); return -2;
+    }
+    hipFree(nhi); hipFree(gam); hipFree(pin); hipFree(pout);
+    *visits_per_s = v;
+    return 0;
+}
+#else
 int main()
 {
     const size_t n = (size_t)256 * 256 * 256;                 // the 256^3 mesh
@@ -143,3 +173,4 @@ int main()
     printf("%-58s %.3e visits/s\n", "cell-major, 8 sources per cell", run_gather<8>(nhi, gam, pin, pout, nrows, plane_elems, nthreads));
     return 0;
 }
+#endif

@@ -103,6 +103,8 @@ def run_driver(n, sources, nml, dens=None, xfield=None, extra_files=None, omp=Fa
     sub, prog = ("hip", "ref_driver_hip") if hip else ("omp" if omp else "serial", "ref_driver")
     exe = os.path.join(REF, "N%d%s" % (n, "_" + variant if variant else ""), sub, prog)
     env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+    if hip:         # the fixture driver dumps xh_av / xh_intermed after evolve3D: have the shim copy the work arrays back too
+        env.setdefault("C2R_SHIM_SYNC_WORK_ARRAYS", "1")
     subprocess.check_call([exe, "answers"], cwd=d, env=env, stdout=subprocess.DEVNULL)
     return d
 
