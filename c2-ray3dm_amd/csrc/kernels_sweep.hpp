@@ -1,387 +1,11 @@
-// Device kernels of the C2-Ray evolve hot path for gfx950 (MI355X, CDNA4).
-//
-// Design:
-//  * The short-characteristics sweep of one source is causal only from one Chebyshev shell
-//    (cube surface |d|_inf = q) to the next: every upstream cell that cinterp gives a non-zero
-//    weight lies in shell q-1 (column_density.f90:108,173,226).  So shell q of ALL sources of a
-//    batch is one launch; its 24q^2+2 cells per source are independent.
-//  * A source's column densities live only in two "shell" buffers (planes of the 6 cube faces,
-//    ping-pong by q parity), not in an N^3 array per source (evolve_data.F90 coldensh_out).
-//  * f64 throughout, -ffp-contract=off: statement order follows the reference so that results
-//    agree with the Fortran to rounding of the transcendental functions only.
+// Device code, part 2 of 4: the short-characteristics sweep -- source cells, one Chebyshev shell of every active source
+// (exact and tolerance mode), look-ahead pairs, the fused first sub-boxes, the per-cell entry, the loss sums, the
+// sub-box decision, and the per-pass helpers (n_HI preparation, the (x,y) transposes, the ordered Gamma sum).
+// Included by sweep.hip ONLY (it defines non-template kernels).
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "kernels_common.hpp"
 
 namespace c2r {
-
-#ifndef C2R_BLOCK
-#define C2R_BLOCK 256
-#endif
-constexpr int kBlock = C2R_BLOCK;   // threads per block of the sweep; a face's owned rectangle is flattened into tiles of kBlock
-
-typedef double v2f64 __attribute__((ext_vector_type(2)));
-constexpr int kLogTab = 64;              // intervals of the log10 table (log10_tab)
-
-// The scalars of a time step live in DEVICE memory, not in the kernel arguments: the cell size and volume (cosmological
-// expansion: C2Ray.F90:360-376 changes them every step), the homogeneous LLS column, what a shell derives from them, and
-// the global pass's step constants (dt; doric.f90:73-78 at the step's temperature; cosmo_cool's redshift).  A replayed
-// hipGraph bakes its kernel arguments in; with these behind a pointer the captured launch sequence of a small batch stays
-// valid from time step to time step (no re-capture: 0.15 ms per step where an outer iteration takes 0.1 - 0.25 ms) and no
-// setter can leave a stale constant in a captured node.  The host refreshes the block when a value changes (sync_step).
-// Kernels read it through constant-address-space views (step_of, shell_step): scalar loads.
-struct ShellStep { double d2axis[3]; double path_scale, lls_scale; };      // per shell q: (dr_d q)^2, dr[0]/q, coldensh_LLS/q (1/q with an LLS grid)
-struct ChemStep { double dt, brech0, acolh0, recpow, clumping, sqrtt, expt, zp, dzdt; };
-struct StepBlock {
-    double dr[3], dr2[3], vol, coldensh_LLS, inv_dr0;
-    int exact_udiv_dr0, n_shell;
-    ChemStep chem;
-    // ShellStep shell[n_shell] follows (KParams::shell_step points at it)
-};
-
-struct KParams {
-    int n[3];
-    int hl[3], hr[3];          // trace limits around a source: -hl..+hr (evolve_source.F90:100-102)
-    const StepBlock *step;         // dr, dr2, vol, coldensh_LLS, inv_dr0 (step_of)
-    const ShellStep *shell_step;   // [Qmax + 1]
-    double sigma, wfloor, sqrt2, sqrt3, fourpi;
-    double max_coldensh, tau_limit, minlogtau, dlogtau, numtau_d, eps;
-    // correctly rounded reciprocals of launch-invariant divisors (exact division in 3 FMAs, see udiv)
-    double inv_dlogtau;
-    int exact_udiv;            // 0: dlogtau fails the precondition of udiv -> plain IEEE division (dr[0]: StepBlock::exact_udiv_dr0)
-    int numtau;
-    int R, P;                  // plane centre offset and pitch (P = 2R+1)
-    size_t PP;                 // P*P
-    // n_HI = max(1-max(xh_av,eps),eps)*ndens per cell (evolve_point.F90:137-146, doric.f90:153), the only
-    // way the sweep uses xh_av and ndens: evaluated once per cell and pass by k_prepare_nhi instead of
-    // once per (cell, source); nhi is [k][j][i] (i fastest), nhi_T [k][i][j] (j fastest) for the +-x
-    // faces, whose waves run along y
-    const double *nhi, *nhi_T;
-    double *phih;
-    double *phih_T;            // Gamma of the +-x faces, added back after the pass
-    // non-default physics switches (c2ray_parameters.f90:80-99)
-    int lls_type;              // 1 homogeneous, 2 per-cell grid, 3 hard barrier
-    double R_max2;             // R_max_LLS^2 (type 3)
-    const float *lls, *lls_T;  // LLS_grid and its (x,y)-transposed replica (type 2)
-    double *gbox_h;            // ... and per-source heating rates of a non-isothermal run, same layout (null: isothermal)
-    double *gbox;              // deterministic mode: [S_batch][2][ncell] per-source Gamma ([0] x-fastest cells of
-                               // z/y faces, [1] y-fastest cells of x faces); null: atomics into phih/phih_T
-    const double *thick, *thin;
-    // non-isothermal runs (c2ray_parameters.f90:28 isothermal=.false.; HEAT kernels only): heating tables
-    // stellar_heat_thick/thin_table (padded like thick/thin), phiheat_grid and its transposed accumulator
-    const double *hthick, *hthin;
-    double *heat, *heat_T;
-    double tau_heat_limit;    // radiation_photoionrates.F90:333
-    const v2f64 *logtab;      // [kLogTab] {r_i, -log10 r_i} for log10_tab
-    // tolerance ("fast") mode of the sweep (c2r_params.sweep_mode = 1, k_sweep_shell_fast)
-    const v2f64 *odtab;       // [kLogTab] {r_i, 1 + (-log10 r_i - minlogtau)/dlogtau}: table position of tau = 1/r_i
-    double od_per_e, od_per_ln; // log10(2)/dlogtau, log10(e)/dlogtau
-    const int    *srcpos;      // 3 x S_batch (unwrapped, 1-based: cinterp's real(i0) needs it)
-    const int    *srcw;        // 3 x S_batch wrapped to 0..N-1
-    const double *normflux;    // S_batch
-    double *planes;            // [S_batch][2][6][P][P]
-};
-
-// Cells of one cube face that this face OWNS in shell q, as a rectangle in plane coordinates
-// (a,b), already clipped to the trace limits; flattened row-major into tiles of 256 threads.
-struct FaceRect {
-    int a_lo, wa, b_lo, wb;
-    unsigned magic;            // t / wa == umulhi(t, magic) for t < wa*wb (0: wa == 1)
-    int ntiles;                // tiles of k_sweep_shell (groups of kRows rows); 0: face absent from this shell
-    int pp, npr;               // row groups of the rows b >= 0; row groups in all (k_sweep_shell walks wa x npr groups)
-};
-
-struct ShellArgs {
-    int q;
-    int has_boundary;
-    int buf_prev, buf_cur;       // fast mode: which of a source's two plane sets holds the previous shell / receives this one
-                                 // ((q-1)&1, q&1 while every launch is one shell; the look-ahead pairs advance two shells per set)
-    int tiles_max;               // grid.x; loss_partial is [n_active][6][tiles_max]
-    int boxR[3], boxL[3];        // limits of the current sub-box (last_r/last_l - srcpos)
-    double alam;                 // (q-0.5)/q, column_density.f90:112 (sign cancels)
-    double dp2, inv_dp2;         // q*q and its correctly rounded reciprocal
-    double inv_q;                // fast mode: 1/q  (what else a shell derives from the step's scalars: KParams::shell_step[q])
-    FaceRect face[6];
-    const int *active;           // compacted list of local source indices
-    const int *n_active;         // its length on the device: the grid may be sized by an older, larger count
-    double *loss_partial;
-    double *dbg_cdout;           // optional N^3 coldensh_out of the (single) source, else null
-};
-
-__device__ __forceinline__ int pmod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
-
-#define C2R_AS4 __attribute__((address_space(4)))
-// constant-address-space views of the step block: uniform addresses, so the loads are scalar (s_load) whatever else the kernel writes
-__device__ __forceinline__ const C2R_AS4 StepBlock &step_of(const KParams &p) { return *(const C2R_AS4 StepBlock *)p.step; }
-__device__ __forceinline__ const C2R_AS4 ShellStep &shell_step(const KParams &p, int q) { return ((const C2R_AS4 ShellStep *)p.shell_step)[q]; }
-
-// ---- IEEE-exact f64 division without the generic expansion ---------------------------------------
-// hipcc expands a/b into div_scale x2, rcp, 4 fma, mul, fma, div_fmas, div_fixup.  The scaling and
-// fix-up only matter for operands near the exponent limits; every quotient of this kernel is far
-// inside the normal range, so the bare Newton-Raphson core gives the same correctly rounded
-// result in 8 instructions.  c2r_selftest compares both forms bit for bit on the device.
-__device__ __forceinline__ double rcp_nr(double d)
-{
-    double r = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-d, r, 1.0);
-    return __builtin_fma(r, e, r);
-}
-__device__ __forceinline__ double fdiv(double n, double d)
-{
-    const double r = rcp_nr(d);
-    const double q = n * r;
-    const double rem = __builtin_fma(-d, q, n);
-    return __builtin_fma(rem, r, q);
-}
-__device__ __forceinline__ double frcp(double d)        // 1.0/d
-{
-    const double r = rcp_nr(d);
-    const double rem = __builtin_fma(-d, r, 1.0);
-    return __builtin_fma(rem, r, r);
-}
-// sqrt for arguments of order one (here 1 <= x <= 3: the path-length factor).  hipcc's expansion wraps the
-// same Goldschmidt/Newton core in exponent scaling and class fix-ups for tiny, huge and special inputs
-// (22 instructions); the bare core (10) returns the same correctly rounded root inside the normal range.
-__device__ __forceinline__ double fsqrt(double x)
-{
-#ifdef C2R_SQRT_GENERIC
-    return sqrt(x);
-#else
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y;
-    double h = y * 0.5;
-    const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    double d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, x);
-    return __builtin_fma(d, h, g);
-#endif
-}
-// n/d for a launch-invariant d with rd = RN(1/d) from the host (Markstein: q' = RN(q + r*rd) with
-// r = n - q*d exact is the correctly rounded quotient unless d's significand is all ones; the
-// host checks that and clears exact_udiv otherwise).
-__device__ __forceinline__ double udiv(double n, double d, double rd, int exact)
-{
-    if (!exact) return n / d;
-    const double q = n * rd;
-    const double r = __builtin_fma(-q, d, n);
-    return __builtin_fma(r, rd, q);
-}
-
-// log10 for the table position (radiation_photoionrates.F90:195).  The device library's log10
-// spends 105 VALU instructions on double-double arithmetic to stay under 1 ulp RELATIVE error;
-// the table position needs ABSOLUTE accuracy in log10(tau) (od = 1 + (lt+20)/0.012), which the
-// classic argument reduction x = 2^e * m, m in [sqrt(1/2), sqrt(2)), log(m) = 2 atanh(s) with
-// s = f/(2+f) and a degree-7 minimax polynomial in s^2 (the published fdlibm e_log.c / e_log10.c
-// scheme and coefficients) delivers in ~32 instructions: error <= ~1 ulp of the result, the same
-// class as glibc's log10 that the reference calls.  -DC2R_LOG10_OCML selects the library version.
-__device__ __forceinline__ double log10_pos(double x)      // x > 0, normal
-{
-#ifdef C2R_LOG10_OCML
-    return log10(x);
-#else
-    double m = __builtin_amdgcn_frexp_mant(x);              // [0.5, 1)
-    int e = __builtin_amdgcn_frexp_exp(x);
-    const bool lo = m < 0.70710678118654752440;
-    m = lo ? m + m : m;                                      // [sqrt(1/2), sqrt(2))
-    e = lo ? e - 1 : e;
-    const double dk = (double)e;
-    const double f = m - 1.0;
-    const double s = f * rcp_nr(2.0 + f);
-    const double z = s * s, w = z * z;
-    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
-                                        3.999999999940941908e-01);
-    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01,
-                                        1.818357216161805012e-01), 2.857142874366239149e-01),
-                                        6.666666666666735130e-01);
-    const double R = t2 + t1;
-    const double hfsq = 0.5 * f * f;
-    const double lm = f - (hfsq - s * (hfsq + R));           // log(m)
-    // dk*log10_2hi is exact (low 32 bits of the constant are zero)
-    const double hi = __builtin_fma(lm, 4.34294481903251816668e-01, dk * 3.01029995663611771306e-01);
-    return __builtin_fma(dk, 3.69423907715893078616e-13, hi);
-#endif
-}
-
-// The same log10 with a 64-interval table held in LDS (one private copy per wave, filled by
-// wave_log_table): x = 2^e * m, m in [0.5,1); interval i = top 6 fraction bits of m; with r_i ~ 1/c_i
-// (c_i the interval centre) z = m*r_i - 1 is exact to an fma rounding and |z| <= 2^-7, so
-// log(m) = -log(r_i) + log1p(z) needs a degree-7 series only: 17 VALU instructions and one 16-byte LDS
-// read instead of 32 VALU -- the LDS port is otherwise idle in this kernel, the VALU port is what binds it.
-// Entries: .x = r_i, .y = -log10(r_i) (host, long double).  Error <= ~1 ulp of the result like log10_pos.
-__device__ __forceinline__ double log10_tab(double x, const v2f64 *__restrict__ tab)   // x > 0, normal; tab in LDS
-{
-    const double m = __builtin_amdgcn_frexp_mant(x);        // [0.5, 1)
-    const int e = __builtin_amdgcn_frexp_exp(x);
-    const unsigned i = ((unsigned)__double2hiint(m) >> 14) & 63u;
-    const v2f64 rt = tab[i];
-    const double z = __builtin_fma(m, rt.x, -1.0);
-    // log1p(z) = z + z^2 * (-1/2 + z/3 - z^2/4 + z^3/5 - z^4/6 + z^5/7); next term z^8/8 < 2^-59
-    double P = __builtin_fma(z, 1.0 / 7.0, -1.0 / 6.0);
-    P = __builtin_fma(z, P, 0.2);
-    P = __builtin_fma(z, P, -0.25);
-    P = __builtin_fma(z, P, 1.0 / 3.0);
-    P = __builtin_fma(z, P, -0.5);
-    const double l1p = __builtin_fma(z * z, P, z);
-    return __builtin_fma((double)e, 3.01029995663981198017e-01, __builtin_fma(l1p, 4.34294481903251816668e-01, rt.y));
-}
-// Every wave keeps its own copy of the table in LDS: filled with all 64 lanes active at the top of the
-// kernel, read later by the same wave only, so no barrier is needed (same-wave LDS accesses are ordered).
-__device__ __forceinline__ const v2f64 *wave_log_table(const v2f64 *__restrict__ g, v2f64 *lds /* [waves][64] */)
-{
-    const unsigned tid = threadIdx.x, lane = tid & 63u;
-    v2f64 *mine = lds + (tid & ~63u);
-    mine[lane] = g[lane];
-    return mine;
-}
-
-// radiation_photoionrates.F90:184-208  set_tau_table_positions
-struct TauPos { int ip, ip1; double res; };
-__device__ __forceinline__ TauPos tau_pos(double tau, const KParams &p, const v2f64 *__restrict__ ltab)
-{
-#ifdef C2R_LOG10_NOTAB
-    const double lt = log10_pos(fmax(1.0e-20, tau));
-#else
-    const double lt = log10_tab(fmax(1.0e-20, tau), ltab);
-#endif
-    const double od = fmin(p.numtau_d, fmax(0.0, 1.0 + udiv(lt - p.minlogtau, p.dlogtau, p.inv_dlogtau, p.exact_udiv)));
-    TauPos t;
-    t.ip = (int)od;
-    t.res = od - (double)t.ip;
-    t.ip1 = min(p.numtau, t.ip + 1);
-    return t;
-}
-// radiation_photoionrates.F90:212-228  read_table
-__device__ __forceinline__ double read_table(const double *__restrict__ tab, const TauPos &t)
-{
-    // the device tables carry one extra element equal to the last (tab[numtau+1] = tab[numtau]), so the
-    // two neighbours tab(ip), tab(ip1 = min(numtau, ip+1)) are always tab[ip], tab[ip+1]: one 16-byte load
-    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-    const d2u v = *reinterpret_cast<const d2u *>(tab + t.ip);
-    return v.x + (v.y - v.x) * t.res;
-}
-
-// radiation_photoionrates.F90:71-179, :233-317 for NumFreqBnd=1, stellar table.
-// Returns photo_cell_HI (already divided by vol_ph); out = photo_out.
-// HEAT: also phi%heat of heat_lookuptable (:323-417) from the same two table positions.
-template <bool HEAT = false>
-__device__ __forceinline__ double photoion(const KParams &p, const v2f64 *__restrict__ ltab, double cd_in, double cd_out,
-                                           double vol_ph, double nflux, double &p_out, double *heat = nullptr)
-{
-    const double tau_in = cd_in * p.sigma, tau_out = cd_out * p.sigma;
-    const TauPos pin = tau_pos(tau_in, p, ltab);
-    const double p_in = nflux * read_table(p.thick, pin);
-    double p_cell;
-    TauPos pout = pin;
-    const bool thick_cell = fabs(tau_out - tau_in) > p.tau_limit;
-    if (thick_cell) {
-        pout = tau_pos(tau_out, p, ltab);
-        p_out = nflux * read_table(p.thick, pout);
-        p_cell = p_in - p_out;
-    } else {
-        p_cell = nflux * (tau_out - tau_in) * read_table(p.thin, pin);
-        p_out = p_in - p_cell;
-    }
-    if (HEAT) {
-        const double h_in = nflux * read_table(p.hthick, pin);                         // :384
-        if (fabs(tau_out - tau_in) > p.tau_heat_limit) {                               // :388
-            if (!thick_cell) pout = tau_pos(tau_out, p, ltab);                         // (only if tau_heat_limit < tau_photo_limit)
-            *heat = fdiv(h_in - nflux * read_table(p.hthick, pout), vol_ph);
-        } else {
-            const double tau_cell = (cd_out - cd_in) * p.sigma;                        // :104, :146
-            *heat = fdiv(nflux * tau_cell * read_table(p.hthin, pin), vol_ph);         // :396-400
-        }
-    }
-    return fdiv(p_cell, vol_ph);
-}
-
-// Deterministic block sum (fixed order): wave shuffles, then the 4 wave sums in order.
-__device__ __forceinline__ double block_sum_256(double v, double *sm /* >= 4 doubles */)
-{
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    if (lane == 0) sm[wave] = v;
-    __syncthreads();
-    double r = 0.0;
-    if (tid == 0) { const int nw = (blockDim.x * blockDim.y) >> 6; for (int w = 0; w < nw; ++w) r += sm[w]; }
-    return r;   // valid in thread 0
-}
-
-// ---- the rate arithmetic of one (cell, source), shared by both sweep modes -------------------------------------
-// radiation_photoionrates.F90:71-317 + evolve_point.F90:262 restated so that it costs ~60 instead of ~150 vector
-// instructions; what it gives up against the statement-by-statement form (photoion above, kept for the source cell) is
-// far inside the Gamma tolerance both modes state (tests/_util.TOL: the rounding of the table position dominates either):
-//  * the table position 1+(log10 tau-minlogtau)/dlogtau (:195-199) comes straight out of the log evaluation: the per-wave
-//    LDS table holds positions instead of logarithms, the two scale factors are folded into the last two FMAs;
-//  * reciprocals by v_rcp_f64 + one Newton step (2^-48) instead of the correctly rounded quotient;
-//  * Gamma = NormFlux (T_in - T_out) / (vol_ph n_HI) with ONE reciprocal (:262-263, evolve_point.F90:262).
-__device__ __forceinline__ double rcp1(double d)        // 1/d to 2^-48
-{
-    const double r = __builtin_amdgcn_rcp(d);
-    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-}
-// table position od = min(numtau, 1 + (log10(max(1e-20,tau)) - minlogtau)/dlogtau); tab = wave's LDS copy of p.odtab
-__device__ __forceinline__ double tau_od(double tau, const KParams &p, const v2f64 *__restrict__ tab)
-{
-    const double x = fmax(1.0e-20, tau);
-    const double m = __builtin_amdgcn_frexp_mant(x);        // [0.5, 1)
-    const int e = __builtin_amdgcn_frexp_exp(x);
-    const unsigned i = ((unsigned)__double2hiint(m) >> 14) & 63u;
-    const v2f64 rt = tab[i];
-    const double z = __builtin_fma(m, rt.x, -1.0);
-    double P = __builtin_fma(z, 1.0 / 7.0, -1.0 / 6.0);
-    P = __builtin_fma(z, P, 0.2);
-    P = __builtin_fma(z, P, -0.25);
-    P = __builtin_fma(z, P, 1.0 / 3.0);
-    P = __builtin_fma(z, P, -0.5);
-    const double l1p = __builtin_fma(z * z, P, z);
-    const double od = __builtin_fma((double)e, p.od_per_e, __builtin_fma(l1p, p.od_per_ln, rt.y));
-    return fmin(p.numtau_d, od);
-}
-// read_table at position od >= 1 (radiation_photoionrates.F90:212-228); tables padded by one element
-__device__ __forceinline__ double table_at(const double *__restrict__ tab, double od)
-{
-    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-    const d2u v = *reinterpret_cast<const d2u *>(tab + (int)od);
-    return __builtin_fma(v.y - v.x, __builtin_amdgcn_fract(od), v.x);
-}
-
-// photo-ionization (and heating) rate of a cell from its entry / exit columns; vol_ph = 4 pi dist2 path; volnhi = vol_ph n_HI.
-// t_out: the thick-table value at the exit column times 1 (photo_out / NormFlux), for the photon loss.
-template <bool HEAT>
-__device__ __forceinline__ double rates_fast(const KParams &p, const v2f64 *__restrict__ ltab, const double *__restrict__ thick,
-                                             const double cd_in, const double cd_out, const double nflux, const double volnhi,
-                                             const double vol_ph, double &t_out, double &heat)
-{
-    const double tau_in = cd_in * p.sigma, tau_out = cd_out * p.sigma;
-    const double od_in = tau_od(tau_in, p, ltab);
-    const double t_in = table_at(thick, od_in);
-    double dT, od_out = od_in;
-    const bool thick_cell = fabs(tau_out - tau_in) > p.tau_limit;
-    if (thick_cell) {
-        od_out = tau_od(tau_out, p, ltab);
-        t_out = table_at(thick, od_out);
-        dT = t_in - t_out;
-    } else {
-        dT = (tau_out - tau_in) * table_at(p.thin, od_in);
-        t_out = t_in - dT;
-    }
-    if (HEAT) {       // heat_lookuptable (radiation_photoionrates.F90:323-417) at the same table positions
-        const double h_in = table_at(p.hthick, od_in);
-        double dH;
-        if (fabs(tau_out - tau_in) > p.tau_heat_limit) {
-            if (!thick_cell) od_out = tau_od(tau_out, p, ltab);
-            dH = h_in - table_at(p.hthick, od_out);
-        } else dH = ((cd_out - cd_in) * p.sigma) * table_at(p.hthin, od_in);
-        heat = (nflux * dH) * rcp1(vol_ph);                                // phi%heat = .../vol_ph
-    }
-    return (nflux * dT) * rcp1(volnhi);                                    // photo_cell_HI / (n_HI vol_ph)
-}
 
 // ---- source cells (q = 0) ------------------------------------------------------------------
 // evolve_point.F90:151-160 (source cell) + the common tail of evolve0D, for source s; ltab: log10_tab's table (LDS or global).
@@ -429,47 +53,6 @@ __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0
                       loss_acc, dbg_cdout);
 }
 
-// ---- buffer addressing (SRSRC descriptor + 32-bit byte offset) ---------------------------------------
-// A descriptor built from block-uniform values lets every access use a 32-bit VGPR offset (no 64-bit
-// address arithmetic per lane) and gives a free range check: an offset beyond the buffer reads 0,
-// which is exactly the value of a zero-weight upstream corner.
-typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
-constexpr unsigned kOOB = 0x80000000u;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
-}
-template <int AUX = 0>      // AUX 1 = glc: read through to L2 (planes written by other waves of the same launch)
-__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
-{
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, AUX));
-}
-__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
-}
-// Cache policy of the sweep's streams (buffer instruction aux bits; 2 = nt, non-temporal): a source's shell
-// planes are written once and read once, one launch later, after every other source's shell has gone by; the
-// n_HI replica is read once per (cell, source).  Marking them non-temporal keeps the L2 for the Gamma
-// atomics and the rate tables: +2.8 % in a same-box A/B (stores only +1 %, stores + planes +1 %, all three).
-// Only in k_sweep_shell and only on large meshes (STREAM): at 128^3 the hint is neutral, at 64^3 -- everything
-// fits the L2s -- it costs 3 %; the fused first sub-boxes re-read their planes within the same workgroup a
-// shell later and never use it.
-#ifndef C2R_STORE_AUX
-#define C2R_STORE_AUX 2
-#endif
-#ifndef C2R_NHI_AUX
-#define C2R_NHI_AUX 2
-#endif
-#ifndef C2R_PLANE_AUX
-#define C2R_PLANE_AUX 2
-#endif
-template <int AUX = 0>
-__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double v)
-{
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, v), r, (int)byte_off, 0, AUX);
-}
-
 // ---- one Chebyshev shell of every active source ------------------------------------------------
 // evolve0D (evolve_point.F90:83-299) + cinterp (column_density.f90:29-271) + photoion_rates.
 // faces: 0:+z 1:-z 2:+y 3:-y 4:+x 5:-x.  Plane coordinates (a,b): z-face (x,y); y-face (x,z);
@@ -501,15 +84,6 @@ __device__ __forceinline__ Delta3 mesh_delta(int axis, int pd, int a, int b)
     d.d2 = (axis == 2) ? pd : b;
     return d;
 }
-// periodic wrap (evolve_point.F90:122): srcw + d + n lies in [n/2, 5n/2); min(c, c-n) as unsigned folds
-// [n, 2n) onto [0, n), twice
-__device__ __forceinline__ unsigned wrap_pos(int srcw, int n, int d)
-{
-    unsigned c = (unsigned)(srcw + n + d);
-    c = min(c, c - (unsigned)n);
-    return min(c, c - (unsigned)n);
-}
-
 // plane offset of (a,b) in bytes and the in-range test of a plane coordinate against shell q-1
 __device__ __forceinline__ unsigned plane_off8(const KParams &p, int a, int b)
 {
@@ -1370,65 +944,6 @@ __global__ __launch_bounds__(64) void k_evolve0d_cell(KParams p, ShellArgs sa, i
     out[0] = cd_out; out[1] = gamma; out[2] = heat; out[3] = loss;
 }
 
-// ---- sparse exchange of the rates (cold regime, big meshes) --------------------------------------------------------
-// evolve.F90:599 all-reduces the whole N^3 phih_grid after every pass, also while the rates are non-zero only inside a few
-// sub-boxes.  Every rank knows every source's final sub-box (one small all-reduce of the sub-box counts), so all ranks agree
-// on the same list of boxes: pack the rates of those boxes (box after box, in source order), all-reduce the packed
-// buffer, write it back.  A cell of overlapping boxes travels once per box; the collective may sum the copies in different
-// orders (RCCL's ring / tree order depends on the element's offset), so they can come back differing in the last bit.  The
-// write-back therefore takes the MAXIMUM of what the cell holds and every copy -- rates are non-negative, whose f64 bit
-// patterns order like unsigned integers, and a sum over the ranks is never below this rank's own addend (rounding is
-// monotone) -- one 64-bit atomic max per copy: the same value on every rank whichever copy lands last, and the all-reduce's
-// own sum wherever the copies agree.
-struct BoxDesc { int c[3]; int nbox; long long off; };      // wrapped source cell, final sub-box count, first packed element
-template <bool UNPACK>
-__global__ __launch_bounds__(256) void k_pack_boxes(int n0, int n1, int n2, int hl0, int hl1, int hl2, int hr0, int hr1, int hr2,
-                                                    int subbox, const BoxDesc *__restrict__ box, double *grid, double *packed)
-{
-    const BoxDesc b = box[blockIdx.y];
-    if (b.nbox <= 0) return;
-    const int ext = subbox * b.nbox;
-    const int l0 = min(ext, hl0), l1 = min(ext, hl1), l2 = min(ext, hl2);
-    const int e0 = l0 + min(ext, hr0) + 1, e1 = l1 + min(ext, hr1) + 1, e2 = l2 + min(ext, hr2) + 1;
-    const long long vol = (long long)e0 * e1 * e2;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < vol; t += (long long)gridDim.x * 256) {
-        const int i = (int)(t % e0), j = (int)((t / e0) % e1), k = (int)(t / ((long long)e0 * e1));
-        const unsigned c0 = wrap_pos(b.c[0], n0, i - l0), c1 = wrap_pos(b.c[1], n1, j - l1), c2 = wrap_pos(b.c[2], n2, k - l2);
-        const size_t id = (size_t)c0 + (size_t)n0 * ((size_t)c1 + (size_t)n1 * (size_t)c2);
-        if (UNPACK) atomicMax(reinterpret_cast<unsigned long long *>(grid) + id, (unsigned long long)__double_as_longlong(packed[b.off + t]));
-        else packed[b.off + t] = grid[id];
-    }
-}
-
-// c2r_create launches this once: the first launch of any kernel of the library makes the runtime load the whole code object
-// onto the device (milliseconds) -- set-up, not something the first evolve3D of a run should pay
-__global__ void k_load_code_object(int *out) { if (out) *out = 1; }
-
-// Device self-test of the division helpers against the compiler's IEEE division (c2r_selftest).
-__global__ void k_selftest_div(int n, double d_uniform, double rd_uniform, unsigned long long seed,
-                               unsigned int *mismatch)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    unsigned long long x = seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)(i + 1);
-    auto next = [&x]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
-    // operands spread over the magnitudes the kernels meet: 1e-40 .. 1e130
-    auto rnd = [&](double lo10, double hi10) {
-        const double u = (double)(next() >> 11) * (1.0 / 9007199254740992.0);
-        const double m = 1.0 + (double)(next() >> 11) * (1.0 / 9007199254740992.0);
-        return m * exp10(lo10 + (hi10 - lo10) * u);
-    };
-    const double num = rnd(-40, 130), den = rnd(-10, 80), w = rnd(-0.3, 7);
-    unsigned int bad = 0;
-    if (fdiv(num, den) != num / den) bad |= 1;
-    if (frcp(w) != 1.0 / w) bad |= 2;
-    const double nu = rnd(-30, 30);
-    if (udiv(nu, d_uniform, rd_uniform, 1) != nu / d_uniform) bad |= 4;
-    const double xs = 1.0 + 2.0 * (double)(next() >> 11) * (1.0 / 9007199254740992.0);     // path^2 lies in [1, 3]
-    if (fsqrt(xs) != sqrt(xs)) bad |= 8;
-    if (bad) atomicAdd(mismatch, 1u);
-}
-
 // Adds the block partials of one shell launch to loss_acc[source], in a fixed order.
 __global__ __launch_bounds__(256) void k_loss_reduce(const int *active, const int *n_active, const double *loss_partial,
                                                      int bps, double *loss_acc)
@@ -1575,287 +1090,6 @@ __global__ __launch_bounds__(1024) void k_batch_totals(int nsrc, const double *f
         for (int t = 0; t < used; ++t) { L = L + sl[t]; NB += sn[t]; }
         *photon_loss = L; *sum_nbox = NB;
         *host_loss = L; *host_nbox = NB;
-    }
-}
-
-// ---- global pass -------------------------------------------------------------------------------
-struct ChemParams {
-    const StepBlock *step;        // dt, brech0, acolh0, recpow, clumping, sqrtt, expt, zp, dzdt below are filled from step->chem at kernel entry
-    double dt, eps, min_frac_change, min_frac_atoms, abu_c, deltht_small;
-    double brech0, acolh0;        // doric.f90:73,78 evaluated on the host for the step's temperature
-    double bh00, recpow;          // brech0 = clumping*bh00*recpow when clumping comes from a grid
-    const float *clump;           // clumping_grid (clumping_module.F90:116) or null
-    int max_iter;
-    // STATS variant: the four mesh sums of photonstatistics.F90 over (xh_intermed, xh_av) as this pass leaves them
-    double clumping, colh0, sqrtt, expt;
-    double *stat_partial;         // [4][gridDim.x]
-    // THERMAL variant (c2ray_parameters.f90:28 isothermal=.false.): temperature_grid, phiheat_grid, the cooling curve
-    float *temper;                // temperature_module.F90:35: (current, average, intermed) f32 per cell
-    const double *phiheat;        // evolve_data.F90:42
-    const double *cool;           // cooling.f90:27 cie_cool(1:cool_points), linear
-    double cool_mintemp, cool_dtemp;
-    int cool_points, thermal_max_steps;
-    double k_B, gamma1, minitemp, rel_denergy, rate_floor, time_tol;   // tped.f90, atomic.f90:25, c2ray_parameters.f90:108-110, thermal.f90:117,160
-    double zp, dzdt;              // cosmology.F90:198-225 cosmo_cool = e*2/(1+zred)*dzdt (dzdt = 0: not cosmological)
-    double temph0, albpow;        // doric.f90:73-78 at the cell's own temperature
-    double tconv_rel, tconv_abs;  // evolve_point.F90:387-388
-};
-
-// cooling.f90:38-59 coolin
-__device__ __forceinline__ double coolin_dev(const ChemParams &c, double nucldens, double eldens, double temp0)
-{
-    const double tpos = (log10(temp0) - c.cool_mintemp) / c.cool_dtemp + 1.0;
-    const int itpos = min(c.cool_points - 1, max(1, (int)tpos));
-    const double dtpos = tpos - (double)itpos;
-    const int itpos1 = min(c.cool_points, itpos + 1);
-    const double c0 = c.cool[itpos - 1], c1 = c.cool[itpos1 - 1];
-    return nucldens * eldens * (c0 + (c1 - c0) * dtpos);
-}
-
-// thermal.f90:22-189: explicit sub-stepping of the internal energy, each sub-step limited to rel_denergy of the
-// thermal time scale.  t_final / t_average are left untouched when t_initial <= minitemp (:83).
-__device__ __forceinline__ void thermal_dev(const ChemParams &c, double t_initial, double &t_final, double &t_average,
-                                            double ndens_electron, double nd, double h_old1, double h_av1, double h1, double heating)
-{
-    const double ne_old = nd * (h_old1 + c.abu_c), ne_av = nd * (h_av1 + c.abu_c), ne_new = nd * (h1 + c.abu_c);   // tped.f90:81
-    double e_int = (nd + ne_old) * c.k_B * t_initial / c.gamma1;                    // :66 temper2pressr/(gamma1)
-    const double cosmo_cool_rate = e_int * 2.0 / c.zp * c.dzdt;                     // :73-76, cosmology.F90:223
-    if (!(t_initial > c.minitemp)) return;
-    double cumulative = 0.0, avg = 0.0, t_int = t_initial;
-    int i_heating = 0;
-    for (;;) {
-        i_heating++;
-        const double cooling = coolin_dev(c, nd, ndens_electron, t_int) + cosmo_cool_rate;        // :104
-        const double rate = fmax(c.rate_floor, fabs(cooling - heating));
-        const double timescale = e_int / fabs(rate);
-        const double dt_thermal = c.rel_denergy * timescale;
-        const double dt_ode = fmin(dt_thermal, c.dt - cumulative);                  // :127
-        e_int = e_int + dt_ode * (heating - cooling);
-        avg = avg + 0.5 * t_int * dt_ode;
-        t_int = e_int * c.gamma1 / (c.k_B * (nd + ne_av));                          // :137 pressr2temper
-        avg = avg + 0.5 * t_int * dt_ode;
-        if (t_int < c.minitemp) {                                                   // :147-153
-            e_int = (nd + ne_av) * c.k_B * c.minitemp;
-            t_int = c.minitemp;
-        }
-        cumulative = cumulative + dt_ode;
-        if (cumulative >= c.dt || fabs(cumulative - c.dt) < c.time_tol * c.dt) break;   // :160
-        if (i_heating > c.thermal_max_steps) break;                                 // :163
-    }
-    t_average = c.dt > 0.0 ? avg / c.dt : t_initial;                                // :168-172
-    t_final = e_int * c.gamma1 / (c.k_B * (nd + ne_new));                           // :175
-}
-
-// evolve0D_global (evolve_point.F90:305-406) + do_chemistry (:410-555) + doric (doric.f90:33-134).
-// Fixed grid, grid-stride: block partial sums of xh_intermed land in sum_partial[blockIdx.x].
-// STATS: also what k_photon_sums(xh_intermed, xh_av) would return after this pass -- the values are in registers here --
-// accumulated in the same order over the same grid, so the sums are bit-identical to the separate kernel's and the
-// 20 bytes per cell it reads are saved (evolve.F90:570 calculate_photon_statistics after every global pass).
-// THERMAL: the non-isothermal do_chemistry -- doric at the cell's own (time-averaged) temperature, thermal after every
-// doric call (evolve_point.F90:515-527), the temperature clause of the global convergence test (:387-388) and
-// set_temperature_point (:553; f32 stores of %intermed and %average).
-template <bool STATS, bool THERMAL>
-__global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell, const float *__restrict__ ndens,
-                                                     const double *__restrict__ xh, double *__restrict__ xh_av,
-                                                     double *__restrict__ xh_intermed,
-                                                     const double *__restrict__ phih, double *sum_partial,
-                                                     unsigned long long *conv_flag, unsigned int *chem_fail,
-                                                     const int *gate = nullptr)
-{
-    __shared__ double sm[4];
-    if (gate && *gate != 0) return;
-    {   // the step's constants (dt, doric's rate coefficients at the step's temperature, cosmo_cool's redshift): device-resident
-        const C2R_AS4 ChemStep &st = ((const C2R_AS4 StepBlock *)c.step)->chem;
-        c.dt = st.dt; c.brech0 = st.brech0; c.acolh0 = st.acolh0; c.recpow = st.recpow; c.clumping = st.clumping;
-        c.sqrtt = st.sqrtt; c.expt = st.expt; c.zp = st.zp; c.dzdt = st.dzdt;
-    }
-    double lsum = 0.0;
-    double st_h0 = 0.0, st_h1 = 0.0, st_tr = 0.0, st_tc = 0.0;
-    unsigned int nconv = 0, nfail = 0;
-    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < ncell; id += (size_t)gridDim.x * 256) {
-        const double h_old1 = fmax(c.eps, xh[id]);
-        const double xav_in = xh_av[id];
-        double hav1 = fmax(c.eps, xav_in);
-        const double h_old0 = 1.0 - h_old1;
-        double hav0 = 1.0 - hav1;
-        const double nd = (double)ndens[id];
-        const double gamma = phih[id];
-        double brech0 = c.clump ? (double)c.clump[id] * c.bh00 * c.recpow : c.brech0;   // evolve_point.F90:443-445
-        double acolh0 = c.acolh0;
-        // get_temperature_point (temperature_module.F90:133-151); temperature_end = temperature_start (:436)
-        double t_start_cur = 0.0, t_start_avg = 0.0, t_end_avg = 0.0, t_end_int = 0.0, heat = 0.0;
-        if (THERMAL) {
-            t_start_cur = (double)c.temper[3 * id]; t_start_avg = (double)c.temper[3 * id + 1]; t_end_int = (double)c.temper[3 * id + 2];
-            t_end_avg = t_start_avg;
-            heat = c.phiheat[id];                                    // evolve_point.F90:364
-        }
-        double h1 = h_old1, h0 = h_old0;
-        int nit = 0;
-        for (;;) {
-            nit++;
-            const double yh0_av_old = hav0;
-            const double de = nd * (hav1 + c.abu_c);                 // tped.f90:81
-            if (THERMAL) {                                           // doric.f90:73-78 at temperature_end%average
-                const double cl = c.clump ? (double)c.clump[id] : c.clumping;
-                brech0 = cl * c.bh00 * pow(t_end_avg / 1e4, c.albpow);
-                acolh0 = c.colh0 * sqrt(t_end_avg) * exp(-c.temph0 / t_end_avg);
-            }
-            const double aih0 = gamma + de * acolh0;
-            const double delth = aih0 + de * brech0;
-            const double eq1 = aih0 / delth;
-            const double eq0 = de * brech0 / delth;
-            const double deltht = delth * c.dt;
-            const double ee = exp(-deltht);
-            h1 = (h_old1 - eq1) * ee + eq1;
-            h0 = (h_old0 - eq0) * ee + eq0;
-            if (h0 < c.eps) { h0 = c.eps; h1 = 1.0 - c.eps; }
-            const double avg = deltht < c.deltht_small ? 1.0 : (1.0 - ee) / deltht;
-            hav1 = eq1 + (h_old1 - eq1) * avg;
-            hav0 = 1.0 - hav1;
-            if (hav0 < c.eps) hav0 = c.eps;
-            if (THERMAL)                                             // :518-527 (de from the new average)
-                thermal_dev(c, t_start_cur, t_end_int, t_end_avg, nd * (hav1 + c.abu_c), nd, h_old1, hav1, h1, heat);
-            // :531-538: the temperature clause compares temperature_end%current with its copy from the iteration
-            // before; thermal never writes %current, so it is |0/T| < 1e-3: true for every finite T > 0
-            if (fabs((hav0 - yh0_av_old) / hav0) < c.min_frac_change || hav0 < c.min_frac_atoms) break;
-            if (nit > c.max_iter) { nfail++; break; }
-        }
-        const double yh0_old = 1.0 - fmax(c.eps, xav_in);           // evolve_point.F90:378-379
-        bool notconv = fabs(hav0 - yh0_old) > c.min_frac_change && fabs((hav0 - yh0_old) / hav0) > c.min_frac_change &&
-                       hav0 > c.min_frac_atoms;
-        double t_stat = 0.0;
-        if (THERMAL) {
-            const float f_int = (float)t_end_int, f_avg = (float)t_end_avg;       // set_temperature_point, :553
-            c.temper[3 * id + 2] = f_int; c.temper[3 * id + 1] = f_avg;
-            t_stat = (double)f_avg;                                                // :381 get_temperature_point again
-            notconv = notconv || (fabs((t_start_avg - t_stat) / t_stat) > c.tconv_rel && fabs(t_start_avg - t_stat) > c.tconv_abs);
-        }
-        if (notconv) nconv++;
-        xh_intermed[id] = h1;
-        xh_av[id] = hav1;
-        lsum += h1;
-        if (STATS) {                                           // k_photon_sums with xl = xh_intermed, xr = xh_av, same expressions
-            st_h0 += nd * (1.0 - h1);
-            st_h1 += nd * h1;
-            const double y1 = hav1, y0 = 1.0 - y1;
-            const double de = nd * (y1 + c.abu_c);
-            const double cl = c.clump ? (double)c.clump[id] : c.clumping;
-            if (THERMAL) {                                         // photonstatistics.F90:167-177 at temperature%average
-                st_tr += nd * y1 * de * cl * c.bh00 * pow(t_stat / 1e4, c.albpow);
-                st_tc += nd * y0 * de * c.colh0 * sqrt(t_stat) * exp(-c.temph0 / t_stat);
-            } else {
-            st_tr += nd * y1 * de * cl * c.bh00 * c.recpow;
-            st_tc += nd * y0 * de * c.colh0 * c.sqrtt * c.expt;
-            }
-        }
-    }
-    const double tot = block_sum_256(lsum, sm);
-    if (threadIdx.x == 0) sum_partial[blockIdx.x] = tot;
-    if (STATS) {
-        double v[4] = {st_h0, st_h1, st_tr, st_tc};
-        for (int m = 0; m < 4; ++m) {
-            __syncthreads();
-            const double t4 = block_sum_256(v[m], sm);
-            if (threadIdx.x == 0) c.stat_partial[(size_t)m * gridDim.x + blockIdx.x] = t4;
-        }
-    }
-    // integer counts: order-independent
-    for (int off = 32; off > 0; off >>= 1) { nconv += __shfl_down(nconv, off, 64); nfail += __shfl_down(nfail, off, 64); }
-    if ((threadIdx.x & 63) == 0) {
-        if (nconv) atomicAdd(conv_flag, (unsigned long long)nconv);
-        if (nfail) atomicAdd(chem_fail, nfail);
-    }
-}
-
-// photonstatistics.F90:104-217: the four mesh sums of state_before/state_after/total_rates in one
-// pass (h0, h1 from xh_l; recombination and collisional-ionization sums from xh_r).
-// partial is [4][gridDim.x].
-__global__ __launch_bounds__(256) void k_photon_sums(size_t ncell, const float *__restrict__ ndens,
-                                                     const double *__restrict__ xl, const double *__restrict__ xr,
-                                                     double abu_c, double clumping, const float *__restrict__ clump,
-                                                     double bh00, double recpow, double colh0, double sqrtt, double expt,
-                                                     double *partial, const float *__restrict__ temper, double albpow,
-                                                     double temph0)
-{   // temper != null: non-isothermal run, the rate coefficients at every cell's temperature%average (:167)
-    __shared__ double sm[4];
-    double h0 = 0.0, h1 = 0.0, tr = 0.0, tc = 0.0;
-    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < ncell; id += (size_t)gridDim.x * 256) {
-        const double nd = (double)ndens[id];
-        const double x = xl[id];
-        h0 += nd * (1.0 - x);
-        h1 += nd * x;
-        const double y1 = xr[id], y0 = 1.0 - y1;
-        const double de = nd * (y1 + abu_c);
-        const double cl = clump ? (double)clump[id] : clumping;
-        if (temper) {
-            const double t = (double)temper[3 * id + 1];
-            tr += nd * y1 * de * cl * bh00 * pow(t / 1e4, albpow);
-            tc += nd * y0 * de * colh0 * sqrt(t) * exp(-temph0 / t);
-            continue;
-        }
-        tr += nd * y1 * de * cl * bh00 * recpow;              // photonstatistics.F90:166-168, left to right
-        tc += nd * y0 * de * colh0 * sqrtt * expt;            // :169-172
-    }
-    double v[4] = {h0, h1, tr, tc};
-    for (int m = 0; m < 4; ++m) {
-        const double tot = block_sum_256(v[m], sm);
-        if (threadIdx.x == 0) partial[(size_t)m * gridDim.x + blockIdx.x] = tot;
-        __syncthreads();
-    }
-}
-
-// set_final_temperature_point (temperature_module.F90:172-183): %current = %intermed on convergence (evolve.F90:220)
-__global__ __launch_bounds__(256) void k_final_temperature(size_t ncell, float *temper)
-{
-    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < ncell; id += (size_t)gridDim.x * 256)
-        temper[3 * id] = temper[3 * id + 2];
-}
-
-__global__ __launch_bounds__(256) void k_sum_partial(size_t n, const double *__restrict__ a, double *partial)
-{
-    __shared__ double sm[4];
-    double v = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) v += a[i];
-    const double tot = block_sum_256(v, sm);
-    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
-}
-
-// out[m] = sum of partial[m][0..n) in a fixed order, m = blockIdx.x; `out` may be mapped host memory.
-__global__ __launch_bounds__(256) void k_sum_final(int n, const double *partial, double *out, const int *gate = nullptr)
-{
-    __shared__ double sm[4];
-    if (gate && *gate != 0) return;
-    partial += (size_t)blockIdx.x * n;
-    double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
-    const double tot = block_sum_256(v, sm);
-    if (threadIdx.x == 0) out[blockIdx.x] = tot;
-}
-
-// End of a global pass: the sum of xh_intermed and the two counters go to the host's pinned scalars
-// (mapped pointers); the counters are left at zero for the next pass.
-__global__ __launch_bounds__(256) void k_pass_final(int n, const double *partial, unsigned long long *conv,
-                                                    unsigned int *chem_fail, double *host_sum,
-                                                    unsigned long long *host_conv, unsigned int *host_fail,
-                                                    const int *gate = nullptr, unsigned long long *dev_seq = nullptr,
-                                                    unsigned long long *host_seq = nullptr)
-{
-    // dev_seq / host_seq (fused iteration): a counter of completed passes, stored to the host LAST -- the host polls it
-    // instead of blocking in a stream synchronize (whose wake-up is a tenth of a 0.26 ms iteration)
-    __shared__ double sm[4];
-    if (gate && *gate != 0) return;
-    double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
-    const double tot = block_sum_256(v, sm);
-    if (threadIdx.x == 0) {
-        *host_sum = tot; *host_conv = *conv; *host_fail = *chem_fail;
-        *conv = 0ULL; *chem_fail = 0u;
-        if (host_seq) {
-            const unsigned long long sq = *dev_seq + 1ULL;
-            *dev_seq = sq;
-            __threadfence_system();
-            __hip_atomic_store(host_seq, sq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
     }
 }
 

@@ -26,6 +26,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly what this header declares is exported */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define C2R_OK            0
 #define C2R_EINVAL      (-1)   /* bad argument */
@@ -62,7 +66,7 @@ typedef struct c2r_params {
                                       *    (column_density.f90:29-271) in the reference's order, IEEE-exact division and
                                       *    sqrt: column densities bit-identical to the Fortran.  The RATE of a cell
                                       *    (photoion_rates, radiation_photoionrates.F90:71-317) is evaluated by the routine both
-                                      *    modes share (kernels.hpp rates_fast: table position straight out of the logarithm,
+                                      *    modes share (kernels_common.hpp rates_fast: table position straight out of the logarithm,
                                       *    one 2^-48 reciprocal): inside |dGamma| <= 1e-13 Gamma + 2e-14 W of the oracle, the
                                       *    bound this mode has always stated (the rounding of the table position dominates it
                                       *    in the reference's own libm too);
@@ -401,6 +405,9 @@ int  c2r_profile(c2r_ctx *ctx, int32_t mode);
 int  c2r_profile_read(c2r_ctx *ctx, double *sweep_ms, int64_t *sweep_launches,
                       double *chem_ms, int64_t *chem_launches);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

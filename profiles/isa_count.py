@@ -3,7 +3,7 @@
 
     python profiles/isa_count.py [substring-of-mangled-name ...]
 
-Compiles c2-ray3dm_amd/csrc/c2ray_hip.hip with the Makefile's flags to assembly (device only) and
+Compiles c2-ray3dm_amd/csrc/sweep.hip with the Makefile's flags to assembly (device only) and
 counts, per kernel, VALU / f64 VALU / SALU / vector-memory / LDS instructions in the kernel body.
 Static counts are an upper bound of what one wave executes (both sides of divergent branches are
 counted); the dynamic count per wave is in profiles/*/pmc_SQ.csv.
@@ -15,7 +15,7 @@ import sys
 from collections import Counter
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "c2-ray3dm_amd", "csrc", "c2ray_hip.hip")
+SRC = os.path.join(ROOT, "c2-ray3dm_amd", "csrc", "sweep.hip")
 FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics".split()
 
 
