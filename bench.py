@@ -311,6 +311,7 @@ def main():
     b.profile(prof_mode)
     visited_before = ev.visited
     ev.visited = 0
+    ev.phase_seconds = {"sweep": 0.0, "exchange": 0.0, "chem": 0.0}
     xchg0 = b.exchange_stats()
     nbox_hist = []
     t0 = time.perf_counter()
@@ -336,7 +337,15 @@ def main():
     stats = torch.tensor([dt_wall, float(ev.visited), prof["sweep_ms"], float(prof["sweep_launches"])],
                          dtype=torch.float64, device=b.device)
     shares = None
+    phases = None
     if world > 1:
+        # where each rank's wall time went (Evolve.iteration), min and max over the ranks: a rank that waits for a slower one
+        # shows a long exchange; and what the exchange would cost over xGMI as one ring (2 (N-1)/N x bytes at 153 GB/s per link)
+        ph = torch.tensor([ev.phase_seconds["sweep"], ev.phase_seconds["exchange"], ev.phase_seconds["chem"]], dtype=torch.float64, device=b.device)
+        pmin = ph.clone(); dist.all_reduce(pmin, op=dist.ReduceOp.MIN)
+        pmax = ph.clone(); dist.all_reduce(pmax, op=dist.ReduceOp.MAX)
+        phases = {k: {"min_s_per_step": float(pmin[i]) / max(1, args.steps), "max_s_per_step": float(pmax[i]) / max(1, args.steps)}
+                  for i, k in enumerate(("sweep", "exchange", "chem"))}
         # the source shares of the last pass (static stride or the library's LPT partition): they must partition the list
         mine = [int(i) for i in b.local_sources()]
         shares = [None] * world
@@ -383,9 +392,13 @@ def main():
                        # evolve.F90:599 through c2r_allreduce_rates: the whole grid, or the sources' packed sub-boxes while those are few
                        "gamma_exchange": {"calls": xchg1["calls"] - xchg0["calls"], "packed_calls": xchg1["sparse_calls"] - xchg0["sparse_calls"],
                                           "bytes_per_step": (xchg1["bytes_total"] - xchg0["bytes_total"]) / max(1, args.steps),
-                                          "full_grid_bytes": 8 * n ** 3} if world > 1 else None,
+                                          "full_grid_bytes": 8 * n ** 3,
+                                          # one ring over xGMI: 2 (N-1)/N x bytes per link at ~153 GB/s (MI355X_MICROARCH.md); RCCL may do better
+                                          "ring_over_xgmi_s_per_step": 2.0 * (world - 1) / world * (xchg1["bytes_total"] - xchg0["bytes_total"]) / max(1, args.steps) / 153e9}
+                       if world > 1 else None,
                        "source_share_sizes": [len(x) for x in shares] if shares else [S],
                        "shares_partition_sources": (sorted(i for x in shares for i in x) == list(range(S))) if shares else True,
+                       "rank_phases": phases,
                        "collective": None if world == 1 else ("gloo (C2R_BENCH_TEST_ONE_GPU)" if one_gpu_test else "nccl (RCCL)"),
                        "visited_cell_sources_per_step": visited_all / args.steps,
                        "visited_per_s": visited_all / dt_wall,

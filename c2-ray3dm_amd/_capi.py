@@ -51,7 +51,8 @@ class SedParams(C.Structure):
                 ("max_freq", C.c_double), ("pl_index_cross_section", C.c_double), ("hplanck", C.c_double),
                 ("k_B", C.c_double), ("two_pi_over_c_square", C.c_double), ("R_solar", C.c_double),
                 ("pi", C.c_double), ("minlogtau", C.c_double), ("maxlogtau", C.c_double),
-                ("numtau", C.c_int32), ("reserved0", C.c_int32)]
+                ("numtau", C.c_int32), ("sed_type", C.c_int32), ("pl_index", C.c_double),
+                ("grey", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class ThermalParams(C.Structure):
@@ -124,6 +125,7 @@ SYMBOLS = [
     ("c2r_evolve3d", C.c_int, [_P, _D, _P, _P, _P, _P, _P, C.POINTER(Report)]),
     ("c2r_evolve3d_thermal", C.c_int, [_P, _D, _I32, _D, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Report)]),
     ("c2r_default_sed", C.c_int, [C.POINTER(SedParams)]),
+    ("c2r_default_sed_power_law", C.c_int, [C.POINTER(SedParams)]),
     ("c2r_build_tables", C.c_int, [C.POINTER(SedParams), _P, _P, _I32, C.POINTER(_D)]),
     ("c2r_build_heat_tables", C.c_int, [C.POINTER(SedParams), _D, _P, _P, _I32]),
     ("c2r_selftest", C.c_int, [_P, C.POINTER(_I64)]),

@@ -152,10 +152,9 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipMalloc(&ctx->d_step, sizeof(StepBlock) + (size_t)(ctx->Qmax + 1) * sizeof(ShellStep)));
     HIP_TRY(hipHostMalloc((void **)&ctx->h_step, sizeof(StepBlock) + (size_t)(ctx->Qmax + 1) * sizeof(ShellStep)));
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_step, hipEventDisableTiming));
-    HIP_TRY(hipHostMalloc((void **)&ctx->h_nactive, (size_t)(ctx->nbox_max + 2) * sizeof(int), hipHostMallocMapped));
-    HIP_TRY(hipHostGetDevicePointer((void **)&ctx->d_hnactive, ctx->h_nactive, 0));
-    ctx->ev_box.resize(ctx->nbox_max + 2);
-    for (auto &e : ctx->ev_box) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_prepared, hipEventDisableTiming));
+    ctx->sc[0].stream = ctx->stream;                       // chain 0 of the sweep runs on the context's stream
+    if (const char *e = getenv("C2R_CHAINS")) ctx->chains_env = std::max(0, std::min(kMaxChains, atoi(e)));
     hipLaunchKernelGGL(k_load_code_object, dim3(1), dim3(1), 0, ctx->stream, (int *)nullptr);      // (loads the library's code object now)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return C2R_OK;
@@ -175,7 +174,8 @@ void c2r_destroy(c2r_ctx *c)
     hipFree(ctx->d_nhi); hipFree(ctx->d_nhi_T); hipFree(ctx->d_phih_T); hipFree(ctx->d_step); hipFree(ctx->d_pack); hipFree(ctx->d_boxdesc);
     if (ctx->h_boxdesc) hipHostFree(ctx->h_boxdesc);
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
-    if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
+    if (ctx->ev_prepared) hipEventDestroy(ctx->ev_prepared);
+    for (int c = 1; c < kMaxChains; ++c) if (ctx->sc[c].own_stream && ctx->sc[c].stream) hipStreamDestroy(ctx->sc[c].stream);
     if (ctx->h_step) hipHostFree(ctx->h_step);
     if (ctx->ev_step) hipEventDestroy(ctx->ev_step);
     hipFree(ctx->d_photon_loss); hipFree(ctx->d_sum_nbox); hipFree(ctx->d_sum_partial); hipFree(ctx->d_sum_out); hipFree(ctx->d_stat_partial);
@@ -183,7 +183,6 @@ void c2r_destroy(c2r_ctx *c)
     if (ctx->h_nbox_all) hipHostFree(ctx->h_nbox_all);
     if (ctx->h_sc) hipHostFree(ctx->h_sc);
     if (ctx->h_it4) hipHostFree(ctx->h_it4);
-    for (auto &e : ctx->ev_box) hipEventDestroy(e);
     for (auto &e : ctx->ev_sweep) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : ctx->ev_chem) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -215,6 +214,7 @@ int c2r_set_stream(c2r_ctx *c, void *s)
         if (ctx->own_stream) { hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
         ctx->stream = (hipStream_t)s;
     }
+    ctx->sc[0].stream = ctx->stream;
     ++ctx->gen;
     return C2R_OK;
 }

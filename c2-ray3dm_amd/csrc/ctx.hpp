@@ -29,6 +29,34 @@ constexpr int kFusedQmax = 10;        // sub-boxes ending at q <= this run in k_
 constexpr int kMaxSlabRanks = 64;     // slab chemistry keeps every rank's slab offsets in fixed arrays (evolve3d_worker)
 constexpr int kFewSources = 32;       // a batch of up to this many sources is nothing but launch latency (see sweep_batch)
 
+// What ONE batch of sources in flight reads and writes -- a "chain": its own stream, plane sets, staging block, active
+// lists, loss partials, counts read back per sub-box.  A rank's sources of a pass are normally ONE chain on the context's
+// stream.  With 64 - 512 sources a pass is split into several chains whose launches interleave on separate streams
+// (sweep.hip run_chains): shell q+1 of a source depends on shell q of the SAME source only, so while one chain's launch
+// drains (its last workgroups, the gap to the next launch) another chain's fills the GPU -- what one GPU's share of a
+// multi-GPU run looks like (125 sources: launches of 10 - 200 us).
+constexpr int kMaxChains = 4;
+struct SweepScratch {
+    hipStream_t stream = nullptr; bool own_stream = false;   // chain 0 runs on the context's stream
+    int cap = 0;                                             // sources this chain's arrays hold
+    double *d_planes = nullptr;                              // [cap][2][6][P][P]
+    double *d_gbox = nullptr;   // deterministic mode: [cap][2][ncell]
+    double *d_gbox_h = nullptr; // ... and the per-source heating rates of a non-isothermal run
+    int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr;
+    // one device block + one pinned staging block hold the small per-batch arrays (one copy per batch)
+    char *d_batch = nullptr, *h_batch = nullptr; size_t batch_bytes = 0;
+    char *d_batch_init = nullptr; std::vector<char> batch_image;   // fused iteration: the state block a small batch starts from, on the device / as last sent
+    char *d_hbatch = nullptr;                                // h_batch as the device sees it (k_box_decide_small writes results there)
+    int *d_active[2] = {nullptr, nullptr};
+    int *d_nactive = nullptr;                                // [2]: length of d_active[0/1]
+    int *h_nactive = nullptr;                                // pinned, one slot per sub-box
+    int *d_hnactive = nullptr;                               // the same slots as the device sees them
+    std::vector<hipEvent_t> ev_box;                          // 'slot written' events
+    hipEvent_t ev_done = nullptr;                            // 'this chain's launches of the pass have run'
+    double *d_loss_partial = nullptr, *d_loss_acc = nullptr, *d_final_loss = nullptr;
+    int *d_final_nbox = nullptr;
+};
+
 struct Ctx {
     c2r_params prm{};
     hipStream_t stream = nullptr;
@@ -97,30 +125,19 @@ struct Ctx {
     int hl[3], hr[3], nbox_max = 0, Qmax = 0, R = 0, P = 1;
     size_t PP = 1;
     int tiles_cap = 0;          // ceil(P*P/256): most tiles any face plane needs
-    // sweep scratch (one batch of sources)
+    // sweep scratch: `nchains` chains of `chain_cap` sources each are in flight at once (SweepScratch); batch_cap = their sum
     int batch_cap = 0, batch_want = 0;
+    SweepScratch sc[kMaxChains];
+    int nchains = 1, chain_cap = 0;
+    int chains_env = 0;         // C2R_CHAINS=n: force n chains (experiments; 0: the rule of choose_chains)
+    hipEvent_t ev_prepared = nullptr;      // 'the pass's inputs are ready' on the context's stream, for the other chains' streams
     bool stream_hint = false;   // non-temporal cache policy of k_sweep_shell: meshes whose n_HI array outgrows the L2s
     bool fuse_small = true;     // C2R_FUSE_SMALL=0 disables the fused first sub-boxes (experiments, A/B tests)
     bool sched_hint = true;     // C2R_SCHED_HINT=0: always one sub-box ahead (experiments, see sweep_batch)
-    double *d_planes = nullptr;
     // the time step's scalars as the kernels read them (kernels.hpp StepBlock + ShellStep[Qmax + 1]): device copy, the image last sent
     char *d_step = nullptr, *h_step = nullptr; std::vector<char> step_image; double step_dt = 0.0;      // h_step: pinned staging of the copy
     hipEvent_t ev_step = nullptr; bool ev_step_recorded = false;                                          // ... and 'the copy has read it'
 
-    int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr;
-    double *d_gbox = nullptr;   // deterministic mode: [batch_cap][2][ncell]
-    double *d_gbox_h = nullptr; // ... and the per-source heating rates of a non-isothermal run
-    // one device block + one pinned staging block hold the small per-batch arrays below (one copy per batch)
-    char *d_batch = nullptr, *h_batch = nullptr; size_t batch_bytes = 0;
-    char *d_batch_init = nullptr; std::vector<char> batch_image;   // fused iteration: the state block a small batch starts from, on the device / as last sent
-    char *d_hbatch = nullptr;                                // h_batch as the device sees it (k_box_decide_small writes results there)
-    int *d_active[2] = {nullptr, nullptr};
-    int *d_nactive = nullptr;                                // [2]: length of d_active[0/1]
-    int *h_nactive = nullptr;                                // pinned, one slot per sub-box
-    int *d_hnactive = nullptr;                               // the same slots as the device sees them
-    std::vector<hipEvent_t> ev_box;                          // 'slot written' events
-    double *d_loss_partial = nullptr, *d_loss_acc = nullptr, *d_final_loss = nullptr;
-    int *d_final_nbox = nullptr;
     double *d_photon_loss = nullptr; long long *d_sum_nbox = nullptr;
     // reductions
     double *d_sum_partial = nullptr, *d_sum_out = nullptr, *d_stat_partial = nullptr;

@@ -21,7 +21,7 @@ static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, i
                     !(ctx->thermal && ctx->tprm.cosmological && !ctx->have_zred);
     if (can_fuse) {
         if ((rc = ensure_sweep_scratch(ctx, nloc))) return rc;
-        can_fuse = nloc <= ctx->batch_cap;
+        can_fuse = nloc <= ctx->sc[0].cap;
     }
     auto zero_rates = [ctx]() -> int {
         HIP_TRY(hipMemsetAsync(ctx->grid[4], 0, grid_bytes(ctx, 4), ctx->stream));

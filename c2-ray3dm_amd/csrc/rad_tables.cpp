@@ -64,14 +64,31 @@ int c2r_default_sed(c2r_sed_params *p)
     p->pi = 3.14159274101257324;                       // mathconstants.f90:21
     p->minlogtau = -20.0; p->maxlogtau = 4.0;          // radiation_tables.F90:45-46
     p->numtau = 2000;
+    p->sed_type = C2R_SED_BLACK_BODY;                  // sed_parameters.f90:26 stellar_SED_type=1
+    p->pl_index = 3.0;                                 // sed_parameters.f90:40 (used by C2R_SED_POWER_LAW)
+    p->grey = 0;                                       // c2ray_parameters.f90:43
     return C2R_OK;
 }
 
-// rad_ini for the black-body source; hthick/hthin (optional): the heating tables of a non-isothermal run
+int c2r_default_sed_power_law(c2r_sed_params *p)
+{
+    const int rc = c2r_default_sed(p);
+    if (rc) return rc;
+    p->sed_type = C2R_SED_POWER_LAW;                   // stellar_SED_type=2
+    p->S_star = 1.00000000000000004e+48;               // sed_parameters.f90:42 pl_S_star
+    p->min_freq = 3.28851300169676800e+15;             // pl_MinFreq = ion_freq_HI
+    p->max_freq = 1.31598566206146560e+16;             // pl_MaxFreq = ion_freq_HeII
+    return C2R_OK;
+}
+
+// rad_ini for the black-body or the power-law source (sourcetype "B" / "P"), with the frequency-dependent or the grey cross
+// section; hthick/hthin (optional): the heating tables of a non-isothermal run
 static int build_all(const c2r_sed_params *sp, double ion_freq_HI, double *thick, double *thin, double *hthick, double *hthin,
                      int32_t n, double *R_star_out)
 {
     if (!sp || n != sp->numtau + 1 || sp->numtau < 1) return C2R_EINVAL;
+    if (sp->sed_type != 0 && sp->sed_type != C2R_SED_BLACK_BODY && sp->sed_type != C2R_SED_POWER_LAW) return C2R_EINVAL;
+    const bool power_law = sp->sed_type == C2R_SED_POWER_LAW;
     const int NF = kNumFreq, NT = sp->numtau;
     // radiation_sed_parameters.F90:82-163  spectrum_parms (black body)
     const double T_eff = std::fmax(std::fmin(sp->T_eff, (double)1e6f), (double)2000.f);
@@ -82,6 +99,19 @@ static int build_all(const c2r_sed_params *sp, double ion_freq_HI, double *thick
     const double delta_freq = (freq_max - freq_min) / (double)(float)NF;
     // romberg.f90:22
     const std::vector<double> romw = romberg_weights(NF);
+    double S_scaling = 1.0;                                   // radiation_sed_parameters.F90:72
+    if (power_law) {
+        // radiation_sed_parameters.F90:204-222 spec_diag "P" + :272-279 integrate_sed("P","S"): photon-number power law
+        const double freq_step = (freq_max - freq_min) / (double)(float)NF;
+        double integral = 0.0;
+        for (int i = 0; i <= NF; ++i) {
+            const double f = freq_min + freq_step * (double)(float)i;
+            const double integrand = std::pow(f, -sp->pl_index);                 // :276
+            integral = integral + integrand * freq_step * romw[i] * 1.0;        // romberg.f90:139-140
+        }
+        const double S_unscaled = S_scaling * integral;                         // :279 (S_scaling still 1)
+        S_scaling = sp->S_star / S_unscaled;                                    // :208
+    } else
     // radiation_sed_parameters.F90:172-224 spec_diag + :226-283 integrate_sed("B","S")
     {
         const double freq_step = (freq_max - freq_min) / (double)(float)NF;
@@ -109,8 +139,10 @@ static int build_all(const c2r_sed_params *sp, double ion_freq_HI, double *thick
     tau[0] = 0.0;
     for (int i = 0; i <= NF; ++i) {
         freq[i] = freq_min + delta_freq * (double)(float)i;                          // :330
-        cs[i] = std::pow(freq[i] / freq_min, -sp->pl_index_cross_section);           // :352
+        cs[i] = sp->grey ? 1.0 : std::pow(freq[i] / freq_min, -sp->pl_index_cross_section);   // :345 / :352
         const double f = freq[i];
+        if (power_law) sed[i] = S_scaling * std::pow(f, -sp->pl_index);              // PL_SED :455-466
+        else
         sed[i] = (f * h_over_kT < 700.0)                                             // BB_SED :434-452
                      ? 4.0 * sp->pi * R_star2 * sp->two_pi_over_c_square * f * f / (std::exp(f * h_over_kT) - 1.0)
                      : 0.0;

@@ -5,16 +5,24 @@
 
 namespace c2r {
 
+namespace {
+void free_chain(SweepScratch &sc)
+{
+    hipFree(sc.d_planes); hipFree(sc.d_gbox); hipFree(sc.d_gbox_h); hipFree(sc.d_batch); hipFree(sc.d_batch_init); hipFree(sc.d_loss_partial);
+    if (sc.h_batch) hipHostFree(sc.h_batch);
+    if (sc.h_nactive) hipHostFree(sc.h_nactive);
+    for (auto &e : sc.ev_box) hipEventDestroy(e);
+    if (sc.ev_done) hipEventDestroy(sc.ev_done);
+    const hipStream_t st = sc.stream; const bool own = sc.own_stream;     // the stream outlives the arrays
+    sc = SweepScratch();
+    sc.stream = st; sc.own_stream = own;
+}
+}  // namespace
+
 void free_sweep_scratch(Ctx *ctx)
 {
-    hipFree(ctx->d_planes); hipFree(ctx->d_gbox); hipFree(ctx->d_gbox_h); hipFree(ctx->d_batch); hipFree(ctx->d_batch_init); hipFree(ctx->d_loss_partial);
-    ctx->d_batch_init = nullptr; ctx->batch_image.clear();
-    if (ctx->h_batch) hipHostFree(ctx->h_batch);
-    ctx->d_batch = ctx->h_batch = nullptr; ctx->d_nactive = nullptr;
-    ctx->d_planes = nullptr; ctx->d_gbox = nullptr; ctx->d_gbox_h = nullptr; ctx->d_srcpos_b = nullptr; ctx->d_srcw_b = nullptr; ctx->d_nflux_b = nullptr;
-    ctx->d_active[0] = ctx->d_active[1] = nullptr;
-    ctx->d_loss_partial = ctx->d_loss_acc = ctx->d_final_loss = nullptr; ctx->d_final_nbox = nullptr;
-    ctx->batch_cap = 0; ctx->batch_want = 0;
+    for (int c = 0; c < kMaxChains; ++c) free_chain(ctx->sc[c]);
+    ctx->batch_cap = 0; ctx->batch_want = 0; ctx->chain_cap = 0; ctx->nchains = 1;
 }
 
 int n_local_sources(const Ctx *ctx)
@@ -22,6 +30,52 @@ int n_local_sources(const Ctx *ctx)
     if (ctx->explicit_share) return (int)ctx->share.size();
     return ctx->nsrc > ctx->rank ? (ctx->nsrc - ctx->rank + ctx->nranks - 1) / ctx->nranks : 0;
 }
+
+namespace {
+// How many chains a pass over `want` sources is split into (SweepScratch).  One, unless the pass is long enough to be
+// worth overlapping and short enough to need it: with 64 - 768 sources a shell launch takes 10 - 400 us, of which the
+// drain of its last workgroups and the gap to the next launch are a tenth (one GPU's share of the 8-GPU bench, 125 sources:
+// +13 % per source against 1000 at once); two or three interleaved chains hide both.  With more sources the launches are long
+// and one chain is best (and per-launch timing stays meaningful); with fewer, the few-source schedule (one hipGraph) applies.
+// Deterministic rates keep one chain: k_gamma_reduce sums a batch's per-source grids in source order.
+int choose_chains(const Ctx *ctx, int want)
+{
+    if (ctx->chains_env > 0) return std::min(ctx->chains_env, std::max(1, want));
+    if (ctx->prm.deterministic_rates || want < 64 || want > 768) return 1;
+    return (want >= 192 && want <= 384) ? 3 : 2;
+}
+
+int alloc_chain(Ctx *ctx, SweepScratch &sc, int cap)
+{
+    if (!sc.stream) { HIP_TRY(hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking)); sc.own_stream = true; }
+    HIP_TRY(hipMalloc(&sc.d_planes, (size_t)cap * 2 * 6 * ctx->PP * sizeof(double)));
+    if (ctx->prm.deterministic_rates) HIP_TRY(hipMalloc(&sc.d_gbox, (size_t)cap * 2 * ctx->ncell * sizeof(double)));
+    if (ctx->prm.deterministic_rates && ctx->thermal) HIP_TRY(hipMalloc(&sc.d_gbox_h, (size_t)cap * 2 * ctx->ncell * sizeof(double)));
+    HIP_TRY(hipMalloc(&sc.d_loss_partial, (size_t)cap * 6 * ctx->tiles_cap * sizeof(double)));
+    // small per-batch arrays: doubles first, then ints
+    //   nflux[cap] final_loss[cap] loss_acc[cap] | srcpos[3cap] srcw[3cap] active0[cap] active1[cap] final_nbox[cap] nactive[2]
+    sc.batch_bytes = (size_t)cap * 3 * sizeof(double) + ((size_t)cap * 9 + 2) * sizeof(int);
+    HIP_TRY(hipMalloc(&sc.d_batch, sc.batch_bytes));
+    HIP_TRY(hipMalloc(&sc.d_batch_init, sc.batch_bytes));
+    sc.batch_image.clear();
+    HIP_TRY(hipHostMalloc((void **)&sc.h_batch, sc.batch_bytes, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void **)&sc.d_hbatch, sc.h_batch, 0));
+    {
+        double *d = reinterpret_cast<double *>(sc.d_batch);
+        sc.d_nflux_b = d; sc.d_final_loss = d + cap; sc.d_loss_acc = d + 2 * (size_t)cap;
+        int *i = reinterpret_cast<int *>(d + 3 * (size_t)cap);
+        sc.d_srcpos_b = i; sc.d_srcw_b = i + 3 * (size_t)cap; sc.d_active[0] = i + 6 * (size_t)cap;
+        sc.d_active[1] = i + 7 * (size_t)cap; sc.d_final_nbox = i + 8 * (size_t)cap; sc.d_nactive = i + 9 * (size_t)cap;
+    }
+    HIP_TRY(hipHostMalloc((void **)&sc.h_nactive, (size_t)(ctx->nbox_max + 2) * sizeof(int), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void **)&sc.d_hnactive, sc.h_nactive, 0));
+    sc.ev_box.resize(ctx->nbox_max + 2);
+    for (auto &e : sc.ev_box) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sc.ev_done, hipEventDisableTiming));
+    sc.cap = cap;
+    return C2R_OK;
+}
+}  // namespace
 
 // Per-source scratch: two shells x six face planes of (2R+1)^2 f64.  Size the batch so that it
 // fits the budget; 288 GB of HBM normally holds every source of a rank at once.
@@ -41,25 +95,11 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
     int cap = (int)std::min<size_t>((size_t)want, std::max<size_t>(1, budget / per_src));
     if (const char *e = getenv("C2R_BATCH_CAP")) cap = std::max(1, std::min(cap, atoi(e)));      // experiments
     cap = std::min(cap, 65535);                 // grid.z of k_sweep_shell
-    HIP_TRY(hipMalloc(&ctx->d_planes, (size_t)cap * 2 * 6 * ctx->PP * sizeof(double)));
-    if (ctx->prm.deterministic_rates) HIP_TRY(hipMalloc(&ctx->d_gbox, (size_t)cap * 2 * ctx->ncell * sizeof(double)));
-    if (ctx->prm.deterministic_rates && ctx->thermal) HIP_TRY(hipMalloc(&ctx->d_gbox_h, (size_t)cap * 2 * ctx->ncell * sizeof(double)));
-    HIP_TRY(hipMalloc(&ctx->d_loss_partial, (size_t)cap * 6 * ctx->tiles_cap * sizeof(double)));
-    // small per-batch arrays: doubles first, then ints
-    //   nflux[cap] final_loss[cap] loss_acc[cap] | srcpos[3cap] srcw[3cap] active0[cap] active1[cap] final_nbox[cap] nactive[2]
-    ctx->batch_bytes = (size_t)cap * 3 * sizeof(double) + ((size_t)cap * 9 + 2) * sizeof(int);
-    HIP_TRY(hipMalloc(&ctx->d_batch, ctx->batch_bytes));
-    HIP_TRY(hipMalloc(&ctx->d_batch_init, ctx->batch_bytes));
-    ctx->batch_image.clear();
-    HIP_TRY(hipHostMalloc((void **)&ctx->h_batch, ctx->batch_bytes, hipHostMallocMapped));
-    HIP_TRY(hipHostGetDevicePointer((void **)&ctx->d_hbatch, ctx->h_batch, 0));
-    {
-        double *d = reinterpret_cast<double *>(ctx->d_batch);
-        ctx->d_nflux_b = d; ctx->d_final_loss = d + cap; ctx->d_loss_acc = d + 2 * (size_t)cap;
-        int *i = reinterpret_cast<int *>(d + 3 * (size_t)cap);
-        ctx->d_srcpos_b = i; ctx->d_srcw_b = i + 3 * (size_t)cap; ctx->d_active[0] = i + 6 * (size_t)cap;
-        ctx->d_active[1] = i + 7 * (size_t)cap; ctx->d_final_nbox = i + 8 * (size_t)cap; ctx->d_nactive = i + 9 * (size_t)cap;
-    }
+    // the sources of a round, split over the chains (each chain's arrays hold its share)
+    const int nch = choose_chains(ctx, cap);
+    const int per = (cap + nch - 1) / nch;
+    for (int c = 0; c < nch; ++c) { const int rc = alloc_chain(ctx, ctx->sc[c], per); if (rc) return rc; }
+    ctx->nchains = nch; ctx->chain_cap = per;
     ctx->batch_cap = cap;
     ctx->batch_want = want;
     ++ctx->gen;                                   // every captured launch points into the old scratch
@@ -95,7 +135,7 @@ FaceRect face_rect(const Ctx *ctx, int f, int q, int rows = kRows)
     return r;
 }
 
-KParams make_kparams(const Ctx *ctx)
+KParams make_kparams(const Ctx *ctx, const SweepScratch &sc)
 {
     KParams k{};
     const c2r_params &p = ctx->prm;
@@ -113,7 +153,7 @@ KParams make_kparams(const Ctx *ctx)
     k.exact_udiv = udiv_ok(p.dlogtau);               // (load_step adds udiv_ok(dr[0]))
     k.R = ctx->R; k.P = ctx->P; k.PP = ctx->PP;
     k.nhi = ctx->d_nhi; k.nhi_T = ctx->d_nhi_T; k.phih = (double *)ctx->grid[4]; k.phih_T = ctx->d_phih_T;
-    k.gbox = ctx->d_gbox; k.gbox_h = ctx->thermal ? ctx->d_gbox_h : nullptr;
+    k.gbox = sc.d_gbox; k.gbox_h = ctx->thermal ? sc.d_gbox_h : nullptr;
     k.lls_type = ctx->lls_type; k.R_max2 = ctx->R_max_LLS * ctx->R_max_LLS; k.lls = ctx->d_lls; k.lls_T = ctx->d_lls_T;
     k.thick = ctx->d_thick; k.thin = ctx->d_thin; k.logtab = ctx->d_logtab;
     k.hthick = ctx->d_hthick; k.hthin = ctx->d_hthin; k.heat = (double *)ctx->grid[5]; k.heat_T = ctx->d_heat_T;
@@ -121,7 +161,7 @@ KParams make_kparams(const Ctx *ctx)
     k.odtab = ctx->d_odtab;
     k.od_per_e = (double)(0.301029995663981195213738894724493027L / (long double)p.dlogtau);
     k.od_per_ln = (double)(0.434294481903251827651128918916605082L / (long double)p.dlogtau);
-    k.srcpos = ctx->d_srcpos_b; k.srcw = ctx->d_srcw_b; k.normflux = ctx->d_nflux_b; k.planes = ctx->d_planes;
+    k.srcpos = sc.d_srcpos_b; k.srcw = sc.d_srcw_b; k.normflux = sc.d_nflux_b; k.planes = sc.d_planes;
     return k;
 }
 
@@ -251,7 +291,7 @@ int plane_set_before(const Ctx *ctx, int nbox, int n_active, bool pair_ok)
 // captured launch sequence of a small batch and the wait behind a fused iteration, the run-ahead schedule.  sweep_batch()
 // below is its only user.  dbg: optional device N^3 array receiving coldensh_out (single-source test path).
 struct BatchSweep {
-    Ctx *ctx; const c2r_params &p;
+    Ctx *ctx; SweepScratch &sc; const c2r_params &p;
     const int first, count; const bool first_of_pass; double *const dbg; FusedIter *const fz;
     const size_t cap; hipStream_t st; KParams k;
     // the pinned staging block (layout of ensure_sweep_scratch)
@@ -260,11 +300,16 @@ struct BatchSweep {
     int cur = 0, last_bps = 0;     // which active list is current; size of the last shell's loss partials per source (0: none), for k_box_decide
     int totals_at_box = 0;         // fused iteration: the sub-box whose decision also writes the batch's totals (0: none)
 
-    BatchSweep(Ctx *c, int first_, int count_, bool first_of_pass_, double *dbg_, FusedIter *fz_)
-        : ctx(c), p(c->prm), first(first_), count(count_), first_of_pass(first_of_pass_), dbg(dbg_), fz(fz_),
-          cap((size_t)c->batch_cap), st(c->stream), k(make_kparams(c))
+    const int shape_count;         // sources of the whole pass (this rank): what the shape of the loss sums is chosen by
+    bool chained = false;          // one of several chains in flight (run_chains): no per-launch timing events, no host waits of its own
+    int launches = 0;              // shell launches enqueued so far (k_sweep_shell*, pairs)
+    int bound = 0, known = 0;      // run_chains: upper bound of the device's active count; sub-boxes whose count has been read back
+
+    BatchSweep(Ctx *c, SweepScratch &sc_, int first_, int count_, bool first_of_pass_, double *dbg_, FusedIter *fz_)
+        : ctx(c), sc(sc_), p(c->prm), first(first_), count(count_), first_of_pass(first_of_pass_), dbg(dbg_), fz(fz_),
+          cap((size_t)sc_.cap), st(sc_.stream), k(make_kparams(c, sc_)), shape_count(n_local_sources(c))
     {
-        h_nf = reinterpret_cast<double *>(ctx->h_batch); h_fl = h_nf + cap;
+        h_nf = reinterpret_cast<double *>(sc.h_batch); h_fl = h_nf + cap;
         h_pos = reinterpret_cast<int *>(h_nf + 3 * cap); h_posw = h_pos + 3 * cap; h_act = h_pos + 6 * cap; h_na = h_pos + 9 * cap;
         h_fnb = h_pos + 8 * cap;   // the batch's results travel back through the same block (same layout as the device block)
     }
@@ -274,7 +319,7 @@ struct BatchSweep {
     // node, by k_prepare_nhi from its device image, or directly)
     void stage()
     {
-        memset(ctx->h_batch, 0, ctx->batch_bytes);                     // loss_acc = 0, final_nbox = 0, active lists
+        memset(sc.h_batch, 0, sc.batch_bytes);                     // loss_acc = 0, final_nbox = 0, active lists
         const bool can_trace = ctx->hr[2] > 0 && ctx->hl[2] > 0;       // while condition, evolve_source.F90:130-131
         n_active = 0;
         for (int i = 0; i < count; ++i) {
@@ -319,8 +364,8 @@ struct BatchSweep {
         sa.alam = (double)((float)(q - 1) + 0.5f) / (double)(float)q;
         sa.dp2 = (double)q * (double)q; sa.inv_dp2 = 1.0 / sa.dp2;
         sa.inv_q = 1.0 / (double)q;                  // ((dr_d q)^2, dr[0]/q, coldensh_LLS/q: the step block, sync_step)
-        sa.active = ctx->d_active[cur]; sa.n_active = ctx->d_nactive + cur;
-        sa.loss_partial = ctx->d_loss_partial; sa.dbg_cdout = dbg;
+        sa.active = sc.d_active[cur]; sa.n_active = sc.d_nactive + cur;
+        sa.loss_partial = sc.d_loss_partial; sa.dbg_cdout = dbg;
         return sa;
     }
 
@@ -331,12 +376,12 @@ struct BatchSweep {
         {
             if (ctx->thermal)
                 hipLaunchKernelGGL(k_source_cells<true>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
-                                   ctx->d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
-                                   ctx->d_loss_acc, dbg);
+                                   sc.d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
+                                   sc.d_loss_acc, dbg);
             else
                 hipLaunchKernelGGL(k_source_cells<false>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
-                                   ctx->d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
-                                   ctx->d_loss_acc, dbg);
+                                   sc.d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
+                                   sc.d_loss_acc, dbg);
         }
     }
 
@@ -363,20 +408,21 @@ struct BatchSweep {
             if (ba.nshell > 0) ba.source_cell = 1;
             else {      // no shell at all to walk (degenerate limits): the plain kernel after all
                 if (ctx->thermal)
-                    hipLaunchKernelGGL(k_source_cells<true>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, ctx->d_active[cur],
-                                       boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], ctx->d_loss_acc, dbg);
+                    hipLaunchKernelGGL(k_source_cells<true>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, sc.d_active[cur],
+                                       boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], sc.d_loss_acc, dbg);
                 else
-                    hipLaunchKernelGGL(k_source_cells<false>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, ctx->d_active[cur],
-                                       boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], ctx->d_loss_acc, dbg);
+                    hipLaunchKernelGGL(k_source_cells<false>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, sc.d_active[cur],
+                                       boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], sc.d_loss_acc, dbg);
             }
         }
         if (ba.nshell > 0) {
-            ba.active = ctx->d_active[cur]; ba.n_active = ctx->d_nactive + cur; ba.loss_acc = ctx->d_loss_acc;
+            ba.active = sc.d_active[cur]; ba.n_active = sc.d_nactive + cur; ba.loss_acc = sc.d_loss_acc;
             // one workgroup per source: 256 / 512 / 1024 threads by the largest shell; with many sources 512 at most (two
             // workgroups per CU hide each other's shell-to-shell latency: cold 256^3 x 1000 0.973 -> 0.939 ms per
-            // iteration).  By the batch's INITIAL count: the block size shapes the loss sums, which must not depend on timing.
+            // iteration).  By the PASS's source count: the block size shapes the loss sums, which must depend neither on timing
+            // nor on how the pass was cut into batches and chains.
             int bt = most <= 256 ? 256 : (most <= 512 ? 512 : 1024);
-            if (n_active >= 256) bt = std::min(bt, 512);
+            if (shape_count >= 256) bt = std::min(bt, 512);
             const dim3 grid(bound), blk(bt);
             // (not in the k_sweep_shell launch timing of c2r_profile: a different kernel, 21^3 cells per source)
 #define C2R_LAUNCH_FUSED_H(D, L, H) do { if (ctx->fast) hipLaunchKernelGGL((k_sweep_box_fused<D, L, true, H>), grid, blk, 0, st, k, ba); \
@@ -403,7 +449,8 @@ struct BatchSweep {
         int &pbuf = bx.pbuf;
         int in_box = 0;                         // k_sweep_shell launches of this sub-box (coarse timing)
         last_bps = 0;
-        if (ctx->prof == 2) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
+        const int prof = chained ? 0 : ctx->prof;     // (chains in flight overlap: run_chains times the round as a whole)
+        if (prof == 2) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
         for (int q = q0; q <= q1; ++q) {
             ShellArgs sa = shell_args(bx, q);
             if (sa.tiles_max == 0) continue;
@@ -445,7 +492,7 @@ struct BatchSweep {
             }
             pbuf = 1 - pbuf;
             ++in_box;
-            if (ctx->prof == 1) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
+            if (prof == 1) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
             {
                 const dim3 grid(sa.tiles_max, 6, bound), blk(kBlock);
 #define C2R_LAUNCH_SWEEP_H(D, L, H) do { \
@@ -465,19 +512,21 @@ struct BatchSweep {
 #undef C2R_LAUNCH_SWEEP
 #undef C2R_LAUNCH_SWEEP_H
             }
-            if (ctx->prof == 1) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(1); }
+            if (prof == 1) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(1); }
             // the partials of the sub-box's last shell are summed by k_box_decide itself when few sources are active (one
             // launch less where launches are all there is); with many, its single workgroup would read 6 x tiles partials
             // for every source (2.5 MB through one CU: 89 us per sub-box, 1.6 % of the bench step) -- one block per source then
-            // (decided by the batch's INITIAL active count: `bound` depends on when the host happens to see a count arrive,
-            // and the two paths round differently -- the photon loss, which feeds the keep/retire decision, must not)
-            const bool fold = n_active <= kFoldLossMax;
+            // (decided by the PASS's source count: `bound` depends on when the host happens to see a count arrive, the batch's
+            // size on the scratch budget and the chains -- and the two paths round differently: the photon loss, which feeds
+            // the keep/retire decision, must not)
+            const bool fold = shape_count <= kFoldLossMax;
             if (sa.has_boundary && (q < q1 || !fold))
-                hipLaunchKernelGGL(k_loss_reduce, dim3(bound), dim3(256), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
-                                   ctx->d_loss_partial, 6 * sa.tiles_max, ctx->d_loss_acc);
+                hipLaunchKernelGGL(k_loss_reduce, dim3(bound), dim3(256), 0, st, sc.d_active[cur], sc.d_nactive + cur,
+                                   sc.d_loss_partial, 6 * sa.tiles_max, sc.d_loss_acc);
             if (q == q1 && sa.has_boundary && fold) last_bps = 6 * sa.tiles_max;
         }
-        if (ctx->prof == 2) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(in_box); }
+        if (prof == 2) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(in_box); }
+        launches += in_box;
     }
 
     // k_box_decide: which sources go on to the next sub-box (evolve_source.F90:128-131)
@@ -492,18 +541,18 @@ struct BatchSweep {
             if (nbox == totals_at_box) {
                 tot.on = 1; tot.nsrc = count; tot.photon_loss = ctx->d_photon_loss; tot.sum_nbox = ctx->d_sum_nbox;
                 tot.host_loss = &ctx->d_hsc->photon_loss; tot.host_nbox = &ctx->d_hsc->sum_nbox;
-                tot.host_final_loss = reinterpret_cast<double *>(ctx->d_hbatch) + cap;
-                tot.host_final_nbox = reinterpret_cast<int *>(reinterpret_cast<double *>(ctx->d_hbatch) + 3 * cap) + 8 * cap;
+                tot.host_final_loss = reinterpret_cast<double *>(sc.d_hbatch) + cap;
+                tot.host_final_nbox = reinterpret_cast<int *>(reinterpret_cast<double *>(sc.d_hbatch) + 3 * cap) + 8 * cap;
             }
-            hipLaunchKernelGGL(k_box_decide_small, dim3(1), dim3(64), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
-                               ctx->d_active[1 - cur], ctx->d_nactive + (1 - cur), ctx->d_hnactive + nbox, ctx->d_nflux_b,
-                               p.S_star, p.loss_fraction, can_grow, nbox, ctx->d_loss_acc, ctx->d_final_loss, ctx->d_final_nbox,
-                               (const double *)ctx->d_loss_partial, last_bps, tot);
+            hipLaunchKernelGGL(k_box_decide_small, dim3(1), dim3(64), 0, st, sc.d_active[cur], sc.d_nactive + cur,
+                               sc.d_active[1 - cur], sc.d_nactive + (1 - cur), sc.d_hnactive + nbox, sc.d_nflux_b,
+                               p.S_star, p.loss_fraction, can_grow, nbox, sc.d_loss_acc, sc.d_final_loss, sc.d_final_nbox,
+                               (const double *)sc.d_loss_partial, last_bps, tot);
         } else
-        hipLaunchKernelGGL(k_box_decide, dim3(1), dim3(1024), 0, st, ctx->d_active[cur], ctx->d_nactive + cur,
-                           ctx->d_active[1 - cur], ctx->d_nactive + (1 - cur), ctx->d_hnactive + nbox, ctx->d_nflux_b,
-                           p.S_star, p.loss_fraction, can_grow, nbox, ctx->d_loss_acc, ctx->d_final_loss, ctx->d_final_nbox,
-                           (const double *)ctx->d_loss_partial, last_bps);
+        hipLaunchKernelGGL(k_box_decide, dim3(1), dim3(1024), 0, st, sc.d_active[cur], sc.d_nactive + cur,
+                           sc.d_active[1 - cur], sc.d_nactive + (1 - cur), sc.d_hnactive + nbox, sc.d_nflux_b,
+                           p.S_star, p.loss_fraction, can_grow, nbox, sc.d_loss_acc, sc.d_final_loss, sc.d_final_nbox,
+                           (const double *)sc.d_loss_partial, last_bps);
     }
 
     // every launch of sub-box nbox for `bound` sources at most (no host wait, no event); flips `cur`
@@ -522,7 +571,7 @@ struct BatchSweep {
         bx.pbuf = plane_set_before(ctx, nbox, n_active, bx.pair_ok);
         bx.fused_box = box_is_fused(ctx, nbox, bx.pair_ok);
         bx.q0 = p.subboxsize * (nbox - 1) + 1; bx.q1 = std::min(p.subboxsize * nbox, ctx->Qmax);
-        bx.det = ctx->d_gbox != nullptr;
+        bx.det = sc.d_gbox != nullptr;
         // (the fused first sub-box does the source cells itself: one launch less)
         if (nbox == 1 && !(bx.fused_box && ctx->fold_source_cell)) launch_source_cells(bx);
         last_bps = 0;
@@ -532,22 +581,24 @@ struct BatchSweep {
         return C2R_OK;
     }
 
-    int enqueue_totals(std::vector<int> *nbox_out, std::vector<double> *loss_out)
+    // the batch's share of photon_loss / sum_nbox, added to the pass's running totals in source order -- on stream `on`: the
+    // chain's own, or the context's when several chains were in flight (run_chains: chain after chain, i.e. in source order)
+    int enqueue_totals(std::vector<int> *nbox_out, std::vector<double> *loss_out, hipStream_t on, bool first_batch)
     {
-        hipLaunchKernelGGL(k_batch_totals, dim3(1), dim3(1024), 0, st, count, ctx->d_final_loss, ctx->d_final_nbox,
-                           ctx->d_photon_loss, ctx->d_sum_nbox, first_of_pass ? 1 : 0, &ctx->d_hsc->photon_loss,
+        hipLaunchKernelGGL(k_batch_totals, dim3(1), dim3(1024), 0, on, count, sc.d_final_loss, sc.d_final_nbox,
+                           ctx->d_photon_loss, ctx->d_sum_nbox, first_batch ? 1 : 0, &ctx->d_hsc->photon_loss,
                            &ctx->d_hsc->sum_nbox);
         HIP_TRY(hipGetLastError());
-        if (nbox_out) HIP_TRY(hipMemcpyAsync(h_fnb, ctx->d_final_nbox, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, st));
-        if (loss_out) HIP_TRY(hipMemcpyAsync(h_fl, ctx->d_final_loss, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (nbox_out) HIP_TRY(hipMemcpyAsync(h_fnb, sc.d_final_nbox, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, on));
+        if (loss_out) HIP_TRY(hipMemcpyAsync(h_fl, sc.d_final_loss, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, on));
         return C2R_OK;
     }
     // deterministic rates: the per-source grids are summed in source order once every source has its final sub-box
     void gamma_reduce(const int *gate)
     {
-        if (ctx->d_gbox)
+        if (sc.d_gbox)
             hipLaunchKernelGGL(k_gamma_reduce, dim3((p.mesh[0] + 255) / 256, p.mesh[1], p.mesh[2]), dim3(256), 0, st, k, count,
-                               ctx->d_final_nbox, p.subboxsize, (double *)ctx->grid[4], ctx->thermal ? (double *)ctx->grid[5] : nullptr, gate);
+                               sc.d_final_nbox, p.subboxsize, (double *)ctx->grid[4], ctx->thermal ? (double *)ctx->grid[5] : nullptr, gate);
     }
 
     // ---- 3. a small batch's launch sequence up to sub-box `hint` as ONE hipGraph ---------------------------------------
@@ -564,14 +615,14 @@ struct BatchSweep {
             int rc = fuse_iter ? fz->pre() : C2R_OK;
             if (fuse_iter) fz->batch_in_prepare = false;
             totals_at_box = fuse_iter ? std::min(hint, ctx->nbox_max) : 0;
-            if (rc == C2R_OK && !fuse_iter) rc = (int)hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st);
+            if (rc == C2R_OK && !fuse_iter) rc = (int)hipMemcpyAsync(sc.d_batch, sc.h_batch, sc.batch_bytes, hipMemcpyHostToDevice, st);
             cur = 0;
             for (int nbox = 1; nbox <= hint && nbox <= ctx->nbox_max && rc == C2R_OK; ++nbox) rc = enqueue_box(nbox, n_active);
             if (fuse_iter && rc == C2R_OK) {
                 // the batch's totals and results, then the gated rest of the iteration: d_nactive[cur] is the count the
                 // last decision left (cur has been flipped by it)
-                gamma_reduce(ctx->d_nactive + cur);
-                rc = fz->post(ctx->d_nactive + cur);
+                gamma_reduce(sc.d_nactive + cur);
+                rc = fz->post(sc.d_nactive + cur);
             }
             totals_at_box = 0;
             const hipError_t e = hipStreamEndCapture(st, &bg.graph);
@@ -600,7 +651,7 @@ struct BatchSweep {
             const auto t0 = std::chrono::steady_clock::now();
             for (unsigned spins = 0;; ++spins) {
                 if (__atomic_load_n(&ctx->h_sc->seq, __ATOMIC_ACQUIRE) == want) { arrived = true; break; }
-                if (__atomic_load_n(&ctx->h_nactive[done], __ATOMIC_ACQUIRE) > 0) break;
+                if (__atomic_load_n(&sc.h_nactive[done], __ATOMIC_ACQUIRE) > 0) break;
                 if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
                 cpu_relax();
             }
@@ -656,12 +707,12 @@ int BatchSweep::run(std::vector<int> *nbox_out, std::vector<double> *loss_out)
         if (bg.exec) {
             const int done = std::min(hint, ctx->nbox_max);
             if (bg.fused) {
-                ctx->h_nactive[done] = -1;                        // (so that a stale zero is not taken for this launch's count)
+                sc.h_nactive[done] = -1;                        // (so that a stale zero is not taken for this launch's count)
                 // the device image of the state block: sent only when it differs from what was sent last (steady state: never)
-                if (ctx->batch_image.size() != ctx->batch_bytes || memcmp(ctx->batch_image.data(), ctx->h_batch, ctx->batch_bytes) != 0) {
-                    ctx->batch_image.assign(ctx->h_batch, ctx->h_batch + ctx->batch_bytes);
+                if (sc.batch_image.size() != sc.batch_bytes || memcmp(sc.batch_image.data(), sc.h_batch, sc.batch_bytes) != 0) {
+                    sc.batch_image.assign(sc.h_batch, sc.h_batch + sc.batch_bytes);
                     // (from the pinned block itself: it is not touched again before this iteration's kernels have run)
-                    HIP_TRY(hipMemcpyAsync(ctx->d_batch_init, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st));
+                    HIP_TRY(hipMemcpyAsync(sc.d_batch_init, sc.h_batch, sc.batch_bytes, hipMemcpyHostToDevice, st));
                 }
             }
             HIP_TRY(hipGraphLaunch(bg.exec, st));
@@ -670,29 +721,29 @@ int BatchSweep::run(std::vector<int> *nbox_out, std::vector<double> *loss_out)
             cur = done & 1;
             bool arrived = false;
             { const int rc = wait_fused(bg, done, arrived); if (rc) return rc; }
-            known = done; bound = ctx->h_nactive[done];
+            known = done; bound = sc.h_nactive[done];
             first_box = done + 1;
             if (bg.fused && arrived) { ctx->seq_seen += 1; bound = 0; fz->tail_done = true; }   // the gate was open: the whole iteration has run
         } else cur = 0;
     }
     if (fz && !pre_run) { const int rc = fz->pre(); if (rc) return rc; }
-    if (!uploaded) HIP_TRY(hipMemcpyAsync(ctx->d_batch, ctx->h_batch, ctx->batch_bytes, hipMemcpyHostToDevice, st));
+    if (!uploaded) HIP_TRY(hipMemcpyAsync(sc.d_batch, sc.h_batch, sc.batch_bytes, hipMemcpyHostToDevice, st));
     for (int nbox = first_box; nbox <= ctx->nbox_max && bound > 0; ++nbox) {
         { const int rc = enqueue_box(nbox, bound); if (rc) return rc; }
-        HIP_TRY(hipEventRecord(ctx->ev_box[nbox], st));
+        HIP_TRY(hipEventRecord(sc.ev_box[nbox], st));
         // counts that have already arrived (never blocks)
-        while (known < nbox && hipEventQuery(ctx->ev_box[known + 1]) == hipSuccess) bound = ctx->h_nactive[++known];
+        while (known < nbox && hipEventQuery(sc.ev_box[known + 1]) == hipSuccess) bound = sc.h_nactive[++known];
         // blocking read-back: the box's own count where the previous pass ended, the previous box's beyond
         // (many sources: always the previous box's -- one sub-box stays in flight from the first box on)
         const int need = !few ? nbox - 1 : (nbox == hint ? nbox : (nbox > hint ? nbox - 1 : 0));
         if (need > known) {
-            HIP_TRY(hipEventSynchronize(ctx->ev_box[need]));
-            known = need; bound = ctx->h_nactive[need];
+            HIP_TRY(hipEventSynchronize(sc.ev_box[need]));
+            known = need; bound = sc.h_nactive[need];
         }
     }
     if (!(fz && fz->tail_done)) {          // (the fused iteration's graph has done this already)
         gamma_reduce(nullptr);
-        { const int rc = enqueue_totals(nbox_out, loss_out); if (rc) return rc; }
+        { const int rc = enqueue_totals(nbox_out, loss_out, st, first_of_pass); if (rc) return rc; }
         HIP_TRY(hipStreamSynchronize(st));
     }
     if (nbox_out) nbox_out->assign(h_fnb, h_fnb + count);
@@ -703,10 +754,84 @@ int BatchSweep::run(std::vector<int> *nbox_out, std::vector<double> *loss_out)
 int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg, std::vector<int> *nbox_out,
                 std::vector<double> *loss_out, FusedIter *fz = nullptr)
 {
-    BatchSweep bs(ctx, first, count, first_of_pass, dbg, fz);
+    BatchSweep bs(ctx, ctx->sc[0], first, count, first_of_pass, dbg, fz);
     return bs.run(nbox_out, loss_out);
 }
 
+// One round of a pass as SEVERAL chains in flight: local sources [first, first + count) in nch contiguous shares, each with
+// its own scratch and stream (SweepScratch), driven in lock-step by this thread -- sub-box n of every chain is enqueued
+// before any count of sub-box n - 1 is waited for, so the streams always hold work of every chain and the GPU overlaps one
+// chain's launch with the tail of another's.  Same launches, same arguments, same per-source results as one chain after
+// the other; only the order in which the Gamma atomics of different sources land can differ (as it may within one launch).
+constexpr int kChainAhead = 2;
+int run_chains(Ctx *ctx, int first, int count, bool first_of_pass, std::vector<int> *nbox_out)
+{
+    const int nch = std::min(ctx->nchains, count);
+    const int per = (count + nch - 1) / nch;
+    std::vector<BatchSweep> ch;
+    ch.reserve(nch);
+    for (int c = 0, f = first; c < nch && f < first + count; ++c, f += per)
+        ch.emplace_back(ctx, ctx->sc[c], f, std::min(per, first + count - f), first_of_pass && c == 0, nullptr, nullptr);
+    // the pass's inputs (n_HI, the zeroed transposed accumulators: sweep_prepare on the context's stream) before any chain starts
+    HIP_TRY(hipEventRecord(ctx->ev_prepared, ctx->stream));
+    if (ctx->prof) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
+    for (auto &b : ch) {
+        b.chained = true;
+        b.stage();
+        if (b.st != ctx->stream) HIP_TRY(hipStreamWaitEvent(b.st, ctx->ev_prepared, 0));
+        HIP_TRY(hipMemcpyAsync(b.sc.d_batch, b.sc.h_batch, b.sc.batch_bytes, hipMemcpyHostToDevice, b.st));
+        b.bound = b.n_active; b.known = 0; b.cur = 0;
+    }
+    for (int nbox = 1; nbox <= ctx->nbox_max; ++nbox) {
+        bool any = false;
+        for (auto &b : ch) {
+            if (b.bound <= 0) continue;
+            any = true;
+            { const int rc = b.enqueue_box(nbox, b.bound); if (rc) return rc; }
+            HIP_TRY(hipEventRecord(b.sc.ev_box[nbox], b.st));
+        }
+        if (!any) break;
+        // kChainAhead sub-boxes stay in flight per chain: the count after sub-box nbox - kChainAhead sizes (and ends) the next
+        // round of launches.  (One ahead, as a single chain of many sources runs, leaves the streams empty while this thread
+        // enqueues the next sub-box of every chain -- near the source a sub-box is five launches of 10 - 20 us, about what
+        // enqueueing it costs; blocks of sources that retired in between return at once: at most 512 sources here.)
+        for (auto &b : ch) {
+            if (b.bound <= 0) continue;
+            while (b.known < nbox && hipEventQuery(b.sc.ev_box[b.known + 1]) == hipSuccess) b.bound = b.sc.h_nactive[++b.known];
+            const int need = nbox - kChainAhead;
+            if (need > b.known) {
+                // poll before blocking: the wake-up of an event wait is 20 - 50 us, a sub-box near the source lasts 100
+                const auto t0 = std::chrono::steady_clock::now();
+                for (unsigned spins = 0; hipEventQuery(b.sc.ev_box[need]) != hipSuccess; ++spins) {
+                    if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) {
+                        HIP_TRY(hipEventSynchronize(b.sc.ev_box[need]));
+                        break;
+                    }
+                    cpu_relax();
+                }
+                (void)hipGetLastError();                 // (hipErrorNotReady of the polls)
+                b.known = need; b.bound = b.sc.h_nactive[need];
+            }
+        }
+    }
+    // the chains join the context's stream; their totals follow in chain order = source order
+    int launches = 0;
+    for (auto &b : ch) {
+        launches += b.launches;
+        if (b.st != ctx->stream) {
+            HIP_TRY(hipEventRecord(b.sc.ev_done, b.st));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, b.sc.ev_done, 0));
+        }
+    }
+    if (ctx->prof) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(launches); }
+    for (auto &b : ch) { const int rc = b.enqueue_totals(nbox_out ? nbox_out : nullptr, nullptr, ctx->stream, b.first_of_pass); if (rc) return rc; }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (nbox_out) {
+        nbox_out->clear();
+        for (auto &b : ch) nbox_out->insert(nbox_out->end(), b.h_fnb, b.h_fnb + b.count);
+    }
+    return C2R_OK;
+}
 }  // namespace
 
 // +-x faces read (x,y)-transposed replicas so that their waves, which run along y, touch unit
@@ -724,7 +849,7 @@ int sweep_prepare(Ctx *ctx, bool zero_rates, bool copy_batch)
     }
     // copy_batch (fused iteration): the batch's pristine state block (d_batch_init, kept current by sweep_batch) over the working one
     WordCopy wc{};
-    if (copy_batch) { wc.src = (const unsigned *)ctx->d_batch_init; wc.dst = (unsigned *)ctx->d_batch; wc.n = (unsigned)(ctx->batch_bytes / 4); }
+    if (copy_batch) { const SweepScratch &sc = ctx->sc[0]; wc.src = (const unsigned *)sc.d_batch_init; wc.dst = (unsigned *)sc.d_batch; wc.n = (unsigned)(sc.batch_bytes / 4); }
     hipLaunchKernelGGL(k_prepare_nhi, g, dim3(256), 0, ctx->stream, p.mesh[0], p.mesh[1], p.mesh[2], p.epsilon,
                        (const float *)ctx->grid[0], (const double *)ctx->grid[2], ctx->d_nhi, ctx->d_nhi_T, z, wc);
     HIP_TRY(hipGetLastError());
@@ -795,9 +920,15 @@ int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64_t *sum
         if (fz && nloc > ctx->batch_cap) FAIL(C2R_ESTATE, "fused iteration needs the sources in one batch");
         if (!fz && (rc = sweep_prepare(ctx))) return rc;
         std::vector<int> nb;
-        for (int first = 0; first < nloc; first += ctx->batch_cap) {
-            const int count = std::min(ctx->batch_cap, nloc - first);
-            rc = sweep_batch(ctx, first, count, first == 0, nullptr, &nb, nullptr, fz);
+        for (int first = 0, count = 0; first < nloc; first += count) {
+            // several chains in flight where the scratch was laid out for it (ensure_sweep_scratch: 64 - 512 sources per round)
+            if (ctx->nchains > 1 && !fz && nloc - first >= 2 * kFewSources) {
+                count = std::min(ctx->batch_cap, nloc - first);
+                rc = run_chains(ctx, first, count, first == 0, &nb);
+            } else {
+                count = std::min(ctx->sc[0].cap, nloc - first);
+                rc = sweep_batch(ctx, first, count, first == 0, nullptr, &nb, nullptr, fz);
+            }
             if (rc) return rc;
             for (int v : nb) { vis += visited_for_nbox(ctx, v); ctx->last_nbox.push_back(v); }
         }
@@ -906,13 +1037,14 @@ int c2r_evolve0d_host(c2r_ctx *c, int32_t ns, const int32_t rtpos[3], const int3
     const double nhi = xav0 * (double)ndens[idx];
     const size_t idt = (size_t)pos[1] + (size_t)p.mesh[1] * ((size_t)pos[0] + (size_t)p.mesh[0] * (size_t)pos[2]);
     {
-        double *hd = reinterpret_cast<double *>(ctx->h_batch);            // >= 3 doubles + 11 ints for a batch of one
+        const SweepScratch &sc = ctx->sc[0];
+        double *hd = reinterpret_cast<double *>(sc.h_batch);            // >= 3 doubles + 11 ints for a batch of one
         int *hi = reinterpret_cast<int *>(hd + 3);
         hd[0] = nflux; hd[1] = nhi;
         for (int d = 0; d < 3; ++d) { hi[d] = sp[d]; hi[3 + d] = spw[d]; }
-        HIP_TRY(hipMemcpyAsync(ctx->d_srcpos_b, hi, 3 * sizeof(int), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(ctx->d_srcw_b, hi + 3, 3 * sizeof(int), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(ctx->d_nflux_b, hd, sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(sc.d_srcpos_b, hi, 3 * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(sc.d_srcw_b, hi + 3, 3 * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(sc.d_nflux_b, hd, sizeof(double), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(ctx->d_nhi + idx, hd + 1, sizeof(double), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(ctx->d_nhi_T + idt, hd + 1, sizeof(double), hipMemcpyHostToDevice, st));
     }
@@ -945,7 +1077,7 @@ int c2r_evolve0d_host(c2r_ctx *c, int32_t ns, const int32_t rtpos[3], const int3
     // :288-293 the cell lies on the surface of the current sub-box
     bool on_surface = false;
     for (int d = 0; d < 3; ++d) on_surface = on_surface || rtpos[d] == last_l[d] || rtpos[d] == last_r[d];
-    KParams k = make_kparams(ctx);
+    KParams k = make_kparams(ctx, ctx->sc[0]);
     double *d_out = ctx->d_sum_out;                              // 4 doubles of device scratch
 #define C2R_LAUNCH_CELL(L) do { if (ctx->thermal) hipLaunchKernelGGL((k_evolve0d_cell<L, true>), dim3(1), dim3(64), 0, st, k, sa, face, a, b, is_source ? 1 : 0, on_surface ? 1 : 0, cv[0], cv[1], cv[2], cv[3], d_out); \
                                 else hipLaunchKernelGGL((k_evolve0d_cell<L, false>), dim3(1), dim3(64), 0, st, k, sa, face, a, b, is_source ? 1 : 0, on_surface ? 1 : 0, cv[0], cv[1], cv[2], cv[3], d_out); } while (0)

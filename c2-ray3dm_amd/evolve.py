@@ -488,6 +488,9 @@ class Evolve:
         self.photon_loss = 0.0
         self.photon_loss_all = 0.0
         self.visited = 0
+        # wall time of this rank inside the three phases of `iteration` (several ranks): the sweep of its own sources, the
+        # exchange (all-reduce of the rates + the scalar pair: waiting for the slowest rank shows up here), the global pass
+        self.phase_seconds = {"sweep": 0.0, "exchange": 0.0, "chem": 0.0}
         self.log = []
         self.dump_dir = "./"               # file_admin.f90:23
         self.dump_interval_s = 15.0 * 60   # evolve.F90:260 (None: never)
@@ -574,9 +577,18 @@ class Evolve:
             self.visited += vis
             self.nbox_per_source = None
             return conv, s1
+        import time as _time
+        t0 = _time.perf_counter()
         self.set_rates_to_zero()
-        self.pass_all_sources(niter, dt)
-        return self.global_pass(dt)
+        self.sum_nbox = 0
+        self.do_grid(dt, niter)                       # (blocks until this rank's sweep has run)
+        t1 = _time.perf_counter()
+        self.mpi_accumulate_grid_quantities()         # (reads the reduced scalar pair back: blocks until the exchange has run)
+        t2 = _time.perf_counter()
+        out = self.global_pass(dt)
+        t3 = _time.perf_counter()
+        self.phase_seconds["sweep"] += t1 - t0; self.phase_seconds["exchange"] += t2 - t1; self.phase_seconds["chem"] += t3 - t2
+        return out
 
     # evolve.F90:285-324
     def write_iteration_dump(self, niter):

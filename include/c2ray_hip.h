@@ -373,17 +373,25 @@ int  c2r_set_iteration_hook(c2r_ctx *ctx, c2r_iteration_fn fn, void *user);
 /* ---- rate tables (one-time set-up; host code, needs no GPU and no context) ------------------ */
 /* SED and table parameters: compile-time `parameter`s of sed_parameters.f90, radiation_sizes.f90,
  * radiation_tables.F90:45-47 and the cgs constant modules. */
+#define C2R_SED_BLACK_BODY 1      /* sed_parameters.f90:26 stellar_SED_type: black body (the shipped value) */
+#define C2R_SED_POWER_LAW  2      /* ... power law in photon number, frequency**(-pl_index) (radiation_tables.F90:455-466) */
 typedef struct c2r_sed_params {
     double T_eff, S_star, min_freq, max_freq;   /* black body, sed_parameters.f90 */
     double pl_index_cross_section;              /* radiation_sizes.f90:85 */
     double hplanck, k_B, two_pi_over_c_square, R_solar, pi;
     double minlogtau, maxlogtau;
-    int32_t numtau, reserved0;
+    int32_t numtau;
+    int32_t sed_type;                           /* C2R_SED_BLACK_BODY (0 means the same) or C2R_SED_POWER_LAW */
+    double  pl_index;                           /* sed_parameters.f90:40: photon-number index of the power-law SED */
+    int32_t grey, reserved1;                    /* c2ray_parameters.f90:43 grey: frequency-independent cross section
+                                                 * (radiation_tables.F90:338-347) */
 } c2r_sed_params;
 int  c2r_default_sed(c2r_sed_params *p);
+/* the shipped power-law parameters (sed_parameters.f90:38-45: index 3, 1e48 photons/s between the HI and HeII edges) */
+int  c2r_default_sed_power_law(c2r_sed_params *p);
 /* rad_ini (radiation_tables.F90:95-126): spectrum_parms, setup_scalingfactors,
- * romberg_initialisation, spec_diag, spec_integration for the black-body source with
- * NumFreqBnd=1.  Fills stellar_photo_thick_table / _thin_table(0:numtau); n = numtau+1.
+ * romberg_initialisation, spec_diag, spec_integration for the black-body or the power-law source
+ * (sed_type) with NumFreqBnd=1, frequency-dependent or grey opacity.  Fills stellar_photo_thick_table / _thin_table(0:numtau); n = numtau+1.
  * R_star (optional) returns the rescaled black-body radius the reference logs. */
 int  c2r_build_tables(const c2r_sed_params *sed, double *thick, double *thin, int32_t n, double *R_star);
 /* The heating tables of a non-isothermal run (fill_heating_integrands_HI + make_heat_tables_HI,

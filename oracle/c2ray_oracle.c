@@ -56,6 +56,13 @@ typedef struct {
     float  *temper_grid;      /* temperature_module.F90:35 temperature_grid: (current, average, intermed) f32 per cell */
     double *phiheat;          /* evolve_data.F90:42 phiheat_grid                                */
     double *tolw_heat;        /* checker diagnostic like tolw, for the heating rate: sum_s (1+tau_in) heat_in / vol_ph */
+    /* Second ("P") source type of photoion_rates (radiation_photoionrates.F90:133-137; builds with use_xray_SED=.true.,
+     * sed_parameters.f90:56).  xray_thick == NULL: the shipped build.  Pinned against the reference rebuilt with that one
+     * parameter (oracle/ref_build.sh 32:xray) whose X-ray tables the fixture driver sets (the reference integrates them
+     * over an array it never fills, radiation_tables.F90:367): the tables are inputs of this path, like the stellar ones. */
+    const double *xray_thick; /* xray_photo_thick_table(0:NumTau,1) */
+    const double *xray_thin;  /* xray_photo_thin_table(0:NumTau,1)  */
+    const double *xray_flux;  /* NormFlux_xray(1:NumSrc): column 5 of the source list / S_star_xray (sourceprops.F90:381, 631) */
     long   *thermal_stats;    /* checker diagnostic (NULL = off): [0] thermal() calls, [1] of them left untouched because T_initial <=
                                * minitemp (thermal.f90:83), [2] of them ended by the sub-step cap i_heating > 10000 (:163), [3] sub-steps
                                * in all -- what the fixtures exercise; the reference has no such counters */
@@ -275,6 +282,7 @@ typedef struct {
     double *cdout;             /* coldensh_out scratch, N^3 */
     const int *src;            /* unwrapped source position */
     double normflux;
+    double normflux_x;         /* NormFlux_xray(ns) (0: none) */
     int last_l[3], last_r[3];
     double loss;               /* photon_loss_src_thread(1) */
     long   visited;
@@ -320,6 +328,11 @@ static void evolve0d(sweep_t *s, const int rt[3])
     double phi[3] = {0.0, 0.0, 0.0}, heat = 0.0;
     if (!stop) {
         oracle_photoion_rates(c->thick, c->thin, cd_in, cd_out, vol_ph, s->normflux, phi);
+        if (c->xray_thick && s->normflux_x > 0.0) {                             /* radiation_photoionrates.F90:133-137: phi = phi + "P" */
+            double px[3];
+            oracle_photoion_rates(c->xray_thick, c->xray_thin, cd_in, cd_out, vol_ph, s->normflux_x, px);
+            phi[0] = phi[0] + px[0]; phi[1] = phi[1] + px[1]; phi[2] = phi[2] + px[2];
+        }
         if (c->heat_thick) heat = oracle_heat_rate(c->heat_thick, c->heat_thin, cd_in, cd_out, vol_ph, s->normflux);   /* radiation_photoionrates.F90:142-172 */
         if (c->heat_thick && c->tolw_heat && s->normflux > 0.0)
             c->tolw_heat[id] += (1.0 + cd_in * C2R_SIGMA_HI) * s->normflux * table_lookup(c->heat_thick, cd_in * C2R_SIGMA_HI) / vol_ph;
@@ -352,13 +365,13 @@ static void evolve2d(sweep_t *s, int k)
 /* evolve_source.F90:58-221  do_source, serial branch (:188-208).
  * Adds this source's rates into phih; returns nbox; *loss_out = final photon_loss_src.
  * cdout (N^3 scratch) holds coldensh_out of this source on return. */
-int oracle_do_source(const oracle_cfg *c, const float *ndens, const double *xh_av, double *phih,
-                     double *cdout, const int src[3], double normflux,
-                     double *loss_out, long *visited_out)
+int oracle_do_source_x(const oracle_cfg *c, const float *ndens, const double *xh_av, double *phih,
+                       double *cdout, const int src[3], double normflux, double normflux_xray,
+                       double *loss_out, long *visited_out)
 {
     const size_t ncell = (size_t)c->n[0] * c->n[1] * c->n[2];
     memset(cdout, 0, ncell * sizeof(double));                                  /* :91 */
-    sweep_t s = { c, ndens, xh_av, phih, cdout, src, normflux, {0,0,0}, {0,0,0}, 0.0, 0 };
+    sweep_t s = { c, ndens, xh_av, phih, cdout, src, normflux, normflux_xray, {0,0,0}, {0,0,0}, 0.0, 0 };
     int lastpos_l[3], lastpos_r[3];
     for (int d = 0; d < 3; ++d) {                                              /* :100-102 */
         const int hr = c->n[d] / 2 - 1 + c->n[d] % 2, hl = c->n[d] / 2;
@@ -387,6 +400,13 @@ int oracle_do_source(const oracle_cfg *c, const float *ndens, const double *xh_a
     return nbox;
 }
 
+int oracle_do_source(const oracle_cfg *c, const float *ndens, const double *xh_av, double *phih,
+                     double *cdout, const int src[3], double normflux,
+                     double *loss_out, long *visited_out)
+{
+    return oracle_do_source_x(c, ndens, xh_av, phih, cdout, src, normflux, 0.0, loss_out, visited_out);
+}
+
 /* evolve.F90:444-495 pass_all_sources + master_slave.F90:74-96 do_grid_static for one rank:
  * sources rank+1, rank+1+npr, ... (1-based).  phih must be zeroed by the caller
  * (set_rates_to_zero, evolve.F90:430).  srcpos is 3 x S (column-major, 1-based positions). */
@@ -399,7 +419,8 @@ void oracle_pass_sources(const oracle_cfg *c, const float *ndens, const double *
     double loss_total = 0.0; long nb = 0, vis = 0;
     for (int ns = rank; ns < nsrc; ns += npr) {
         double loss; long v;
-        nb += oracle_do_source(c, ndens, xh_av, phih, cdout, srcpos + 3 * ns, normflux[ns], &loss, &v);
+        nb += oracle_do_source_x(c, ndens, xh_av, phih, cdout, srcpos + 3 * ns, normflux[ns],
+                                 c->xray_flux ? c->xray_flux[ns] : 0.0, &loss, &v);
         loss_total = loss_total + loss;                                        /* evolve_source.F90:216 */
         vis += v;
     }

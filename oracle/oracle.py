@@ -27,6 +27,7 @@ class Cfg(C.Structure):
                 ("heat_thick", C.c_void_p), ("heat_thin", C.c_void_p), ("cie_cool", C.c_void_p),
                 ("cool_mintemp", C.c_double), ("cool_dtemp", C.c_double), ("zred", C.c_double),
                 ("temper_grid", C.c_void_p), ("phiheat", C.c_void_p), ("tolw_heat", C.c_void_p),
+                ("xray_thick", C.c_void_p), ("xray_thin", C.c_void_p), ("xray_flux", C.c_void_p),
                 ("thermal_stats", C.c_void_p)]
 
 
@@ -50,6 +51,7 @@ def lib():
         _LIB.oracle_sum.restype = C.c_double
         _LIB.oracle_global_pass.restype = C.c_long
         _LIB.oracle_do_source.restype = C.c_int
+        _LIB.oracle_do_source_x.restype = C.c_int
         _LIB.oracle_heat_rate.restype = C.c_double
         _LIB.oracle_coolin.restype = C.c_double
     return _LIB
@@ -88,6 +90,16 @@ class Oracle:
         c.tolw = None
         c.cfg.tolw = None
         return c
+
+    def enable_xray(self, xray_thick, xray_thin, xray_flux):
+        """The second source type of photoion_rates (use_xray_SED=.true.): its two tables and NormFlux_xray per source, in the
+        order of the source lists later passed to pass_sources / evolve3d (do_source: source number ns -> xray_flux[ns-1])."""
+        self.xray_thick = np.ascontiguousarray(xray_thick, dtype=np.float64)
+        self.xray_thin = np.ascontiguousarray(xray_thin, dtype=np.float64)
+        self.xray_flux = np.ascontiguousarray(xray_flux, dtype=np.float64)
+        assert self.xray_thick.size == 2001 and self.xray_thin.size == 2001
+        self.cfg.xray_thick, self.cfg.xray_thin = self.xray_thick.ctypes.data, self.xray_thin.ctypes.data
+        self.cfg.xray_flux = self.xray_flux.ctypes.data
 
     def enable_thermal(self, heat_thick, heat_thin, cool_logT, cool_logL, zred, temper_grid=None):
         """Non-isothermal run (isothermal=.false.): heating tables, the cooling table as setup_cool (cooling.f90:64-87)
@@ -169,13 +181,13 @@ class Oracle:
         return xf[0], xf[1], xa[0], xa[1]
 
     # -- sweep ----------------------------------------------------------------------------
-    def do_source(self, ndens, xh_av, phih, src, normflux):
+    def do_source(self, ndens, xh_av, phih, src, normflux, normflux_xray=0.0):
         """One source; adds into phih (in place).  Returns (nbox, loss, visited, coldensh_out)."""
         cdout = np.zeros(self.ncell, dtype=np.float64)
         loss, vis = C.c_double(), C.c_long()
-        nbox = lib().oracle_do_source(C.byref(self.cfg), _p(ndens), _p(xh_av), _p(phih), _p(cdout),
-                                      (C.c_int * 3)(*[int(v) for v in src]), C.c_double(normflux),
-                                      C.byref(loss), C.byref(vis))
+        nbox = lib().oracle_do_source_x(C.byref(self.cfg), _p(ndens), _p(xh_av), _p(phih), _p(cdout),
+                                        (C.c_int * 3)(*[int(v) for v in src]), C.c_double(normflux), C.c_double(normflux_xray),
+                                        C.byref(loss), C.byref(vis))
         return nbox, loss.value, vis.value, cdout
 
     def pass_sources(self, ndens, xh_av, phih, srcpos, normflux, rank=0, npr=1):

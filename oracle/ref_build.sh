@@ -38,12 +38,28 @@ SRCS="precision.f90 mathconstants.f90 cgsconstants.f90 cgsastroconstants.f90 c2r
 #   lls3   type_of_LLS=3       hard barrier at R_max_cMpc
 #   clump5 type_of_clumping=5  pre-computed clumping grid (clumping_grid)
 #   thermal isothermal=.false.  heating and cooling (thermal.f90); the run directory needs tables/corocool.tab
+# Further compile-time switches of the path that the shipped parameters leave off (round 5):
+#   pl     sed_parameters.f90 stellar_SED_type=2   power-law stellar SED (radiation_tables.F90:371-379 PL_SED): table fixtures
+#   grey   c2ray_parameters.f90 grey=.true.         grey opacities (radiation_tables.F90:338-357): table fixtures
+#   xray   sed_parameters.f90 use_xray_SED=.true.   the second ("P") source type of photoion_rates (radiation_photoionrates.F90:
+#          133-137, 167-171).  The reference fills its X-ray tables from an UNINITIALISED local array (radiation_tables.F90:367,
+#          :405-425: xray_SED is never set; sed_parameters.f90:55 "not yet implemented"), so ref_driver overwrites
+#          xray_photo_thick/thin_table with tables it is handed (namelist xray_tables=) before any rate is evaluated.
+variant_file () {   # $1 = variant -> the reference file the variant rewrites
+  case "$1" in
+    pl|xray) echo sed_parameters.f90 ;;
+    *) echo c2ray_parameters.f90 ;;
+  esac
+}
 params_for_variant () {   # $1 = variant, $2 = output file
   case "$1" in
     lls2)   sed 's|^\( *integer,parameter :: type_of_LLS=\)1|\12|' "$REF/c2ray_parameters.f90" > "$2"; grep -q "type_of_LLS=2" "$2" ;;
     lls3)   sed 's|^\( *integer,parameter :: type_of_LLS=\)1|\13|' "$REF/c2ray_parameters.f90" > "$2"; grep -q "type_of_LLS=3" "$2" ;;
     thermal) sed 's|^\( *logical,parameter :: isothermal=\).true.|\1.false.|' "$REF/c2ray_parameters.f90" > "$2"; grep -q "isothermal=.false." "$2" ;;
     clump5) sed 's|^\( *integer,parameter :: type_of_clumping=\)1|\15|' "$REF/c2ray_parameters.f90" > "$2"; grep -q "type_of_clumping=5" "$2" ;;
+    grey)   sed 's|^\( *logical,parameter :: grey = \).false.|\1.true.|' "$REF/c2ray_parameters.f90" > "$2"; grep -q "grey = .true." "$2" ;;
+    pl)     sed 's|^\( *integer,parameter :: stellar_SED_type=\)1|\12|' "$REF/sed_parameters.f90" > "$2"; grep -q "stellar_SED_type=2" "$2" ;;
+    xray)   sed 's|^\( *logical,parameter :: use_xray_SED=\).false.|\1.true.|' "$REF/sed_parameters.f90" > "$2"; grep -q "use_xray_SED=.true." "$2" ;;
     *) echo "unknown variant $1" >&2; exit 1 ;;
   esac
 }
@@ -56,12 +72,13 @@ build_variant () {   # $1 = mesh[:variant], $2 = subdir, $3 = extra flags
   sed "s|^\( *integer,dimension(Ndim),parameter,public :: mesh=\)(/ 300, 300, 300 /)|\1(/ $N, $N, $N /)|" \
       "$REF/sizes.f90" > "$B/sizes.f90"
   grep -q "mesh=(/ $N, $N, $N /)" "$B/sizes.f90"
-  [ -n "$V" ] && params_for_variant "$V" "$B/c2ray_parameters.f90"
+  local VF=""
+  [ -n "$V" ] && VF=$(variant_file "$V") && params_for_variant "$V" "$B/$VF"
   local objs=""
   for s in $SRCS; do
     local src o
     if [ "${s#@}" != "$s" ]; then src="$B/${s#@}"; else src="$REF/$s"; fi
-    [ -n "$V" ] && [ "$s" = "c2ray_parameters.f90" ] && src="$B/c2ray_parameters.f90"
+    [ -n "$V" ] && [ "$s" = "$VF" ] && src="$B/$VF"
     o="$B/$(basename "${s#@}" | sed 's/\.[fF]90$/.o/')"
     if [ ! -f "$o" ] || [ "$src" -nt "$o" ]; then
       ( cd "$B" && $FC $FLAGS -c "$src" -o "$o" 2>>"$B/build.log" )

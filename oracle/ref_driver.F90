@@ -30,7 +30,8 @@ program ref_driver
   use sizes, only: mesh
   use grid, only: grid_ini, dr, vol
   use radiation_tables, only: rad_ini, stellar_photo_thick_table, stellar_photo_thin_table, &
-       stellar_heat_thick_table, stellar_heat_thin_table
+       stellar_heat_thick_table, stellar_heat_thin_table, xray_photo_thick_table, xray_photo_thin_table
+  use sed_parameters, only: use_xray_SED
   use radiative_cooling, only: setup_cool, coolin
   use thermalevolution, only: thermal
   use temperature_module, only: temperature_grid
@@ -46,7 +47,7 @@ program ref_driver
   use lls_module, only: set_LLS, coldensh_LLS, LLS_grid, R_max_LLS
   use times, only: time_ini, set_timesteps
   use sourceprops, only: source_properties_ini, source_properties, NumSrc, srcpos, &
-       NormFlux_stellar
+       NormFlux_stellar, NormFlux_xray
   use photonstatistics, only: photon_loss, totrec, totcollisions, dh0, total_ion
   use evolve_data, only: evolve_ini, phih_grid, phiheat_grid, xh_av, xh_intermed, coldensh_out, &
        photon_loss_all, last_l, last_r, photon_loss_src_thread
@@ -68,9 +69,9 @@ program ref_driver
   integer            :: nsteps = 1, dump_first = 1, dump_last = 1, ns_dump = 1, nrep = 1
   real(kind=dp)      :: x_init = -1.0_dp
   character(len=512) :: dens_file = 'none', x_file = 'none', out_dir = './dump/'
-  character(len=512) :: lls_file = 'none', clump_file = 'none', t_file = 'none'
+  character(len=512) :: lls_file = 'none', clump_file = 'none', t_file = 'none', xray_tables = 'none'
   namelist /ctl/ mode, nsteps, x_init, dens_file, x_file, dump_first, dump_last, &
-       ns_dump, nrep, out_dir, lls_file, clump_file, t_file
+       ns_dump, nrep, out_dir, lls_file, clump_file, t_file, xray_tables
 
   character(len=512) :: answers
   integer :: restart = 0, nz0 = 1, ierror = 0, nz, u, istep, ns, irep, gi, gj, gk, conv_flag
@@ -95,6 +96,15 @@ program ref_driver
   call setup_output()
   call grid_ini()
   call rad_ini()
+  ! Builds with use_xray_SED=.true. (sed_parameters.f90:56): rad_ini integrates the X-ray tables over a local array it never
+  ! fills (radiation_tables.F90:367 xray_SED; "not yet implemented", sed_parameters.f90:55).  The tables are INPUTS of the rate
+  ! path (radiation_photoionrates.F90:268-270), so the fixture runs hand them in: thick(0:NumTau) then thin(0:NumTau), raw f64.
+  if (use_xray_SED .and. trim(xray_tables) /= 'none') then
+     open(newunit=u, file=trim(xray_tables), access='stream', form='unformatted', status='old')
+     read(u) xray_photo_thick_table(:,1)
+     read(u) xray_photo_thin_table(:,1)
+     close(u)
+  endif
   if (.not.isothermal) call setup_cool()          ! C2Ray.F90:143 (reads ./tables/corocool.tab)
   call material_ini(restart, nz0, ierror)
   call nbody_ini(ierror)
@@ -413,6 +423,11 @@ contains
        write(uu,'(A,1X,3(I8,1X),ES26.17E3)') 'src', srcpos(1,is), srcpos(2,is), srcpos(3,is), &
             NormFlux_stellar(is)
     enddo
+    if (use_xray_SED) then                      ! NormFlux_xray (sourceprops.F90:381, :631), source by source
+       do is = 1, NumSrc
+          write(uu,'(A,1X,ES26.17E3)') 'xsrc', NormFlux_xray(is)
+       enddo
+    endif
     close(uu)
   end subroutine dump_inputs
 

@@ -84,8 +84,8 @@ def run_driver(n, sources, nml, dens=None, xfield=None, extra_files=None, omp=Fa
         f.write(ANSWERS)
     with open(d + "/test_sources.dat", "w") as f:
         f.write("%d\n" % len(sources))
-        for (i, j, k, flux) in sources:
-            f.write("%d %d %d %.17e 0.0\n" % (i, j, k, flux))
+        for src in sources:           # (i, j, k, photon rate[, X-ray photon rate: column 5, sourceprops.F90:381])
+            f.write("%d %d %d %.17e %.17e\n" % (tuple(src[:4]) + ((src[4],) if len(src) > 4 else (0.0,))))
     nml = dict(nml)
     if dens is not None:
         dens.T.tofile(d + "/dens.f32")         # Fortran order on disk
@@ -115,6 +115,8 @@ def read_kv(path):
         t = line.split()
         if t[0] == "src":
             srcs.append((int(t[1]), int(t[2]), int(t[3]), float(t[4])))
+        elif t[0] == "xsrc":
+            out.setdefault("normflux_xray", []).append(float(t[1]))
         else:
             out[t[0]] = float(t[1]) if ("E" in t[1] or "." in t[1]) else int(t[1])
     if srcs:

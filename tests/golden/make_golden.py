@@ -36,6 +36,28 @@ def case_tables():
     print("tables: thick[0]=%.17g thin[0]=%.17g" % (thick[0], thin[0]))
 
 
+def case_tables_variant(name, variant):
+    """The rate tables of the reference rebuilt with another SED / opacity switch (ref_build.sh 32:pl, 32:grey):
+    stellar_SED_type=2 (power law, radiation_tables.F90:455-466 PL_SED) and grey=.true. (:338-357)."""
+    d = run_driver(32, SRC_ONE, {"mode": "'tables'"}, variant=variant)
+    thick = np.fromfile(d + "/dump/thick_table.f64")
+    thin = np.fromfile(d + "/dump/thin_table.f64")
+    assert thick.size == 2001 and thin.size == 2001
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), thick=thick, thin=thin)
+    print("%s: thick[0]=%.17g thin[0]=%.17g" % (name, thick[0], thin[0]))
+
+
+def xray_files(xray):
+    """run_driver arguments that hand the fixture driver the X-ray tables (ref_driver.F90: namelist xray_tables)."""
+    if xray is None:
+        return {}, {}
+    thick, thin = xray
+    def w(p):
+        with open(p, "wb") as f:
+            np.ascontiguousarray(thick, dtype=np.float64).tofile(f); np.ascontiguousarray(thin, dtype=np.float64).tofile(f)
+    return {"xray.f64": w}, {"xray_tables": "'xray.f64'"}
+
+
 def case_point():
     n = 32
     rng = np.random.default_rng(20261003)
@@ -169,10 +191,11 @@ def case_thermal_points_steep():
 
 
 def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, keep=("xh_after", "phih_grid", "xh_av"),
-                variant=None, lls_grid=None, clump_grid=None, tfield=None, cooling="primordial", dens_sigma=0.6):
+                variant=None, lls_grid=None, clump_grid=None, tfield=None, cooling="primordial", dens_sigma=0.6, xray=None):
     dens = density_factor(n, dens_seed, dens_sigma) if dens_seed is not None else None
     nml = {"mode": "'evolve'", "nsteps": nsteps, "dump_first": dump[0], "dump_last": dump[-1]}
-    extra = {}
+    extra, xn = xray_files(xray)
+    nml.update(xn)
     if lls_grid is not None:
         extra["lls.f32"] = lambda p: lls_grid.astype(np.float32).T.tofile(p); nml["lls_file"] = "'lls.f32'"
     if clump_grid is not None:
@@ -197,17 +220,20 @@ def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, kee
             arrays[tag + "_phiheat_grid"] = rd(d, tag + "_phiheat_grid.f64", n)
     if lls_grid is not None: arrays["lls_grid"] = lls_grid.astype(np.float32)
     if clump_grid is not None: arrays["clump_grid"] = clump_grid.astype(np.float32)
+    if xray is not None: arrays["xray_thick"], arrays["xray_thin"] = xray
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
     json.dump(meta, open(os.path.join(HERE, name + ".json"), "w"), indent=1)
     print(name, {t: m["niter"] for t, m in meta["steps"].items()})
 
 
-def case_sweep(name, n, sources, x_init=None, dens_seed=None, xfield=None, ns_dump=1, full=True, variant=None):
+def case_sweep(name, n, sources, x_init=None, dens_seed=None, xfield=None, ns_dump=1, full=True, variant=None, xray=None):
     dens = density_factor(n, dens_seed) if dens_seed is not None else None
     nml = {"mode": "'sweep'", "ns_dump": ns_dump}
     if x_init is not None:
         nml["x_init"] = "%.17g" % x_init
-    d = run_driver(n, sources, nml, dens=dens, xfield=xfield, variant=variant)
+    extra, xn = xray_files(xray)
+    nml.update(xn)
+    d = run_driver(n, sources, nml, dens=dens, xfield=xfield, variant=variant, extra_files=extra)
     tag = "step001"
     kv = read_kv("%s/dump/%s_in.txt" % (d, tag))
     kv.update(read_kv("%s/dump/%s_sweep.txt" % (d, tag)))
@@ -218,6 +244,8 @@ def case_sweep(name, n, sources, x_init=None, dens_seed=None, xfield=None, ns_du
     arrays = {"xh": rd(d, tag + "_xh_before.f64", n), "ndens": rd(d, tag + "_ndens.f32", n, np.float32)}
     if variant == "thermal":
         arrays["phiheat"] = rd(d, tag + "_phiheat_grid.f64", n)
+    if xray is not None:
+        arrays["xray_thick"], arrays["xray_thin"] = xray
     if full:
         arrays.update(phih=phih, coldensh_out=cdo)
     else:   # large grids: three orthogonal planes through source ns_dump + checksums
@@ -438,6 +466,23 @@ def main():
         case_evolve("evolve32_lls3", 32, SRC_STD, 1, [1], dens_seed=11, xfield=x, variant="lls3")
         clump = 1.0 + 9.0 * rng.random((32, 32, 32)) ** 3
         case_evolve("evolve32_clump5", 32, SRC_STD, 1, [1], dens_seed=11, xfield=x, variant="clump5", clump_grid=clump)
+    # other SEDs / opacities of the table builder, and the second source type of photoion_rates (round 5)
+    if want("seds"):
+        case_tables_variant("tables_pl", "pl")
+        case_tables_variant("tables_grey", "grey")
+    if want("xray"):
+        # The X-ray tables are inputs of the rate path (the reference's own fill integrates an array it never sets): the
+        # fixture runs use the reference's POWER-LAW tables (tables_pl: photon index 3 between the HI and HeII edges).
+        pl = np.load(os.path.join(HERE, "tables_pl.npz"))
+        xr = (pl["thick"], pl["thin"])
+        # column 5 of the list = X-ray photon rate / S_star_xray (= 1): four sources with an X-ray component of the order
+        # of their stellar one (NormFlux ~ 1e7), one dominated by it, five without
+        src = [SRC_STD[0] + (3e6,), SRC_STD[1] + (0.0,), SRC_STD[2] + (2e7,), SRC_STD[3] + (0.0,), SRC_STD[4] + (5e8,),
+               SRC_STD[5] + (0.0,), SRC_STD[6] + (1e6,), SRC_STD[7] + (0.0,), SRC_STD[8] + (4e8,), SRC_STD[9] + (0.0,)]
+        x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 7.0)
+        case_sweep("sweep32_xray", 32, src, dens_seed=5, xfield=x, ns_dump=5, variant="xray", xray=xr)
+        x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 6.0)
+        case_evolve("evolve32_xray", 32, src, 1, [1], dens_seed=11, xfield=x, variant="xray", xray=xr)
     # non-isothermal run (isothermal=.false.), with the synthetic cooling table of inputs.cooling_table()
     if want("thermal"):
         case_thermal_tables_and_points()

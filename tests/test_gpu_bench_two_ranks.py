@@ -90,6 +90,13 @@ def test_bench_eight_ranks_equal_one_rank(form, balance):
     assert len(b["config"]["source_share_sizes"]) == 8
     if not balance:
         assert b["config"]["source_share_sizes"] == [8] * 8
+    # the diagnostic fields a first real multi-GPU run will be read by: where each rank's time went (min / max over the
+    # ranks) and what the exchange moves against one ring over xGMI
+    ph = b["config"]["rank_phases"]
+    for k in ("sweep", "exchange", "chem"):
+        assert 0.0 < ph[k]["min_s_per_step"] <= ph[k]["max_s_per_step"]
+    assert sum(ph[k]["max_s_per_step"] for k in ph) >= 0.5 * b["ms_per_step"] * 1e-3
+    assert b["config"]["gamma_exchange"]["ring_over_xgmi_s_per_step"] > 0.0 and a["config"]["rank_phases"] is None
 
 
 def test_bench_a_failing_rank_fails_the_run():

@@ -1,0 +1,88 @@
+"""A pass of 64 - 512 sources runs as several chains in flight (csrc/sweep.hip run_chains: the sources in contiguous shares,
+each with its own stream and scratch, driven in lock-step) -- what one GPU's share of a multi-GPU run looks like.  The chains
+change WHEN launches run, not what they compute: per-source sub-box counts, visited cells, the photon loss (bit for bit: the
+shape of its sums is chosen by the pass's source count, not by the batch's) are those of one chain; Gamma differs only by the
+order in which the f64 atomics of different sources land.  C2R_CHAINS=n forces n chains (read by c2r_create)."""
+import numpy as np
+import pytest
+from tests._util import F, tol, assert_gamma, oracle_pass
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("sweep_mode")]
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+def _case(pkg, n, S, seed):
+    from tests.golden.inputs import bubble_xfield, density_factor
+    tp = pkg.TestProblem(n); s = tp.step(1)
+    nd = (tp.fields(1)[0].reshape((n, n, n), order="F") * density_factor(n, 21)).astype(np.float32)
+    pos, nf = pkg.seeded_sources(n, S, seed=seed)
+    xh = bubble_xfield(n, [tuple(int(v) for v in q) for q in pos[:40]], 9.0)
+    return s, F(nd), F(xh), pos, nf
+
+
+def _pass(pkg, tables, monkeypatch, chains, n, s, nd, xh, pos, nf, thermal=False):
+    if chains is None:
+        monkeypatch.delenv("C2R_CHAINS", raising=False)
+    else:
+        monkeypatch.setenv("C2R_CHAINS", str(chains))
+    b = pkg.HipBackend(n, *tables, device=0)
+    b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], 1.0)
+    b.set_sources(pos, nf); b.set_rank(0, 1); b.load(ndens=nd, xh=xh); b.begin_step(); b.zero_rates()
+    loss, nbox, vis = b.pass_sources()
+    out = (loss, nbox, vis, b.last_nbox().copy(), b.fetch("phih_grid"))
+    b.close()
+    return out
+
+
+@pytest.mark.parametrize("S", [96, 130, 200])
+def test_chains_give_one_chains_results(pkg, tables, monkeypatch, S):
+    n = 64
+    s, nd, xh, pos, nf = _case(pkg, n, S, 77)
+    one = _pass(pkg, tables, monkeypatch, 1, n, s, nd, xh, pos, nf)
+    assert len(set(int(v) for v in one[3])) > 2                     # sources retire at different sub-boxes
+    for chains in (None, 2, 3, 4):                                  # None: the library's own rule (2 below 192 sources, 3 from there)
+        r = _pass(pkg, tables, monkeypatch, chains, n, s, nd, xh, pos, nf)
+        assert r[0] == one[0], (chains, r[0], one[0])               # photon loss: the same bits
+        assert r[1:3] == one[1:3] and np.array_equal(r[3], one[3])  # sum of sub-boxes, visited pairs, per-source sub-box counts
+        live = one[4] > 0
+        assert np.array_equal(r[4] > 0, live)
+        assert np.max(np.abs(r[4][live] - one[4][live]) / one[4][live]) < 1e-13      # atomics in another order
+
+
+def test_chained_pass_against_the_oracle(pkg, tables, monkeypatch, sweep_mode):
+    """The default rule's chains at 100 sources on 48^3 against the pinned oracle: integers equal, Gamma inside the mode's tolerance."""
+    n, S = 48, 100
+    s, nd, xh, pos, nf = _case(pkg, n, S, 5)
+    r = _pass(pkg, tables, monkeypatch, None, n, s, nd, xh, pos, nf)
+    from oracle.oracle import Oracle
+    o = Oracle(n, s["dr1"], s["vol"], s["coldensh_LLS"], *tables)
+    oloss, onb, ovis, phih, w = oracle_pass(o, nd, xh, pos, nf)
+    assert (r[1], r[2]) == (onb, ovis)
+    assert abs(r[0] - oloss) <= tol("loss") * abs(oloss)
+    assert_gamma(r[4], phih, w, "chained pass")
+
+
+def test_whole_steps_with_and_without_chains(pkg, tables, monkeypatch):
+    """evolve3D over a cold start with 80 sources: iteration count, non-converged-cell history, sub-box history and xh equal."""
+    n, S = 32, 80
+    tp = pkg.TestProblem(n); s = tp.step(1)
+    nd, xh = tp.fields(1)
+    pos, nf = pkg.seeded_sources(n, S, seed=3)
+    reps = []
+    for chains in (1, 2, 3):
+        monkeypatch.setenv("C2R_CHAINS", str(chains))
+        b = pkg.HipBackend(n, *tables, device=0)
+        b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], 1.0)
+        b.set_sources(pos, nf); b.load(ndens=nd, xh=xh)
+        rep = b.evolve3d_native(s["dt"])
+        reps.append((rep.niter, list(rep.it_conv_flag[:rep.niter]), list(rep.it_sum_nbox[:rep.niter]), rep.photon_loss_all, b.fetch("xh")))
+        b.close()
+    for r in reps[1:]:
+        assert r[0] == reps[0][0] and r[1] == reps[0][1] and r[2] == reps[0][2]
+        assert abs(r[3] - reps[0][3]) <= 1e-12 * abs(reps[0][3])
+        assert np.max(np.abs(r[4] - reps[0][4])) < 1e-11

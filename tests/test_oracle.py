@@ -93,6 +93,41 @@ def test_sweep_full_grid(tables, name):
     assert np.array_equal(cdo, F(a["coldensh_out"]))
 
 
+def test_xray_source_type_equals_reference(tables):
+    """The second ("P") source type of photoion_rates (radiation_photoionrates.F90:133-137: phi = phi + the lookup in the
+    X-ray tables with NormFlux_xray(ns), column 5 of the source list) against the reference rebuilt with
+    use_xray_SED=.true. (ref_build.sh 32:xray).  The fixture driver hands the reference its X-ray tables -- the reference's
+    own fill integrates an array it never sets (radiation_tables.F90:367) -- here: the reference's power-law tables."""
+    m, a = load_case("sweep32_xray")
+    n = m["n"]
+    assert sum(1 for v in m["normflux_xray"] if v > 0) == 5 and len(m["normflux_xray"]) == len(m["normflux"])
+    o = oracle_for(m, tables, n)
+    o.enable_xray(a["xray_thick"], a["xray_thin"], m["normflux_xray"])
+    nd, xh = F(expand(a["ndens"], n)), F(expand(a["xh"], n))
+    phih = np.zeros(o.ncell)
+    loss, nb, vis = o.pass_sources(nd, xh, phih, m["srcpos"], m["normflux"])
+    assert nb == m["sum_nbox"] and loss == m["photon_loss"]
+    assert np.array_equal(phih, F(a["phih"])) and np.count_nonzero(phih) == m["phih_nonzero"]
+    ns = m["ns_dump"] - 1
+    _, _, _, cdo = o.do_source(nd, xh, np.zeros(o.ncell), m["srcpos"][ns], m["normflux"][ns], m["normflux_xray"][ns])
+    assert np.array_equal(cdo, F(a["coldensh_out"]))
+    # ... and the X-ray component matters: without it the rates differ (the stellar-only oracle is NOT the fixture)
+    o2 = oracle_for(m, tables, n)
+    p2 = np.zeros(o2.ncell)
+    o2.pass_sources(nd, xh, p2, m["srcpos"], m["normflux"])
+    assert np.max(np.abs(p2 - phih) / np.maximum(phih, 1e-300)) > 0.1
+    # a whole evolve3D step with both source types
+    m, a = load_case("evolve32_xray")
+    s = m["steps"]["step001"]
+    o = oracle_for(s, tables, n)
+    o.enable_xray(a["xray_thick"], a["xray_thin"], s["normflux_xray"])
+    xh = F(a["step001_xh_before"]); nd = F(a["step001_ndens"])
+    rep, xav, xint, phih = o.evolve3d(s["dt"], nd, xh, s["srcpos"], s["normflux"])
+    assert rep.niter == s["niter"] and list(rep.it_conv_flag[:rep.niter]) == s["log"]["nonconv"]
+    assert np.array_equal(xh, F(a["step001_xh_after"])) and np.array_equal(phih, F(a["step001_phih_grid"]))
+    assert rep.sum_nbox_all == s["sum_nbox_all"] and rep.photon_loss_all == s["photon_loss_all"]
+
+
 def test_sweep32_known_answers(tables):
     """The numbers SURVEY.md s8a records for this case (independent of our fixture files)."""
     m, _ = load_case("sweep32_std_x999")

@@ -22,6 +22,30 @@ def test_tables_equal_reference_bit_for_bit(pkg, tables):
     assert 1e11 < r_star < 1.2e11          # rescaled black-body radius (1.62 R_solar)
 
 
+def test_power_law_and_grey_tables_equal_reference_bit_for_bit(pkg):
+    """The other two switches of the table builder, each against the reference rebuilt with that one parameter
+    (oracle/ref_build.sh 32:pl, 32:grey; tests/golden/make_golden.py seds): stellar_SED_type=2 -- a power law in photon
+    number between the HI and HeII edges (sed_parameters.f90:38-45, radiation_tables.F90:455-466) -- and grey=.true.
+    (c2ray_parameters.f90:43, radiation_tables.F90:338-347)."""
+    import os
+    from tests._util import GOLDEN
+    lib = pkg.load_library()
+    sed = pkg.SedParams()
+    assert lib.c2r_default_sed_power_law(C.byref(sed)) == 0 and sed.sed_type == 2 and sed.pl_index == 3.0
+    thick, thin, _ = pkg.build_tables(sed)
+    ref = np.load(os.path.join(GOLDEN, "tables_pl.npz"))
+    assert np.array_equal(thick, ref["thick"]) and np.array_equal(thin, ref["thin"])
+    assert abs(thick[0] / 1e48 - 1) < 1e-14                       # normalised to S_star photons per second
+    sed = pkg.SedParams()
+    lib.c2r_default_sed(C.byref(sed)); sed.grey = 1
+    thick, thin, _ = pkg.build_tables(sed)
+    ref = np.load(os.path.join(GOLDEN, "tables_grey.npz"))
+    assert np.array_equal(thick, ref["thick"]) and np.array_equal(thin, ref["thin"])
+    assert np.array_equal(thick, thin)                            # sigma(nu) = sigma_0: both integrands are SED exp(-tau)
+    bad = pkg.SedParams(); lib.c2r_default_sed(C.byref(bad)); bad.sed_type = 3
+    assert lib.c2r_build_tables(C.byref(bad), thick.ctypes.data, thin.ctypes.data, 2001, None) != 0
+
+
 def test_table_properties(pkg):
     thick, thin, _ = pkg.build_tables()
     # tau=0 entry integrates the bare SED to S_star; thick decreases monotonically with tau
