@@ -202,6 +202,8 @@ def main():
                          "instead of the synthetic field; scaled as scale_density does (density_unit grid, --n-box fine cells per side)")
     ap.add_argument("--n-box", type=int, default=13824, help="fine N-body cells per side of the density file's simulation (nbody_cubep3m.F90:9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin-leg", action="store_true",
+                    help="skip the informational run of the reference driver linked with the Fortran drop-in (128^3, one source, 14 steps)")
     ap.add_argument("--no-mix-ceiling", action="store_true",
                     help="skip the in-process run of the memory-only traffic mix (profiles/micro/libtrafficmix.so, 6.7 GB of HBM, ~1 s)")
     ap.add_argument("--no-other-mode", action="store_true",
@@ -472,6 +474,26 @@ def main():
                 out["configs1_128_1src"][mode] = {"steps": k3, "ms_per_step": 1e3 * dt3 / k3, "value": float(n3) ** 3 * k3 / dt3,
                                                   "unit": "cells-traced/s", "sum_nbox_last_step": int(ev3.sum_nbox_all)}
                 b3.close()
+        if world == 1 and not args.no_dropin_leg and (n, S) == (256, 1000) and not args.thermal and not args.density_file:
+            # The boundary north_star names, end to end: the reference's OWN program (C2Ray.F90 and every set-up module,
+            # unmodified) with its evolve modules replaced by the Fortran shim + this library, on its own test problem
+            # (128^3, the one-source list, 14 time steps) -- wall clock per evolve3D call as the shim logs it.  Informational,
+            # outside the timed region; needs the drop-in program (oracle/_ref, built where the reference is present).
+            b.close()
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("dropin_timing", os.path.join(ROOT, "profiles", "dropin_timing.py"))
+                dt_mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(dt_mod)
+                leg = dt_mod.run_leg(128, dt_mod.SRC_ONE, 1, "hip-fast" if args.sweep_mode == "fast" else "hip-exact", 600)
+                keep = ("skipped", "exit", "process_wall_s", "outer_iterations", "steps", "evolve3d_s", "split_total",
+                        "split_total_without_first_step", "fraction_inside_evolve3d_dev_without_first_step", "sweep_mode")
+                out["dropin_128_1src"] = dict({k: leg[k] for k in keep if k in leg},
+                                              what="oracle/_ref/N128/hip/c2ray_test_hip: reference driver + evolve_hip.F90 + libc2ray_hip.so, "
+                                                   "14 evolve3D calls; seconds summed over the calls (split: shim set-up, upload, outer "
+                                                   "iterations, download, rest of the library call, logging/statistics after it); the "
+                                                   "compiled reference takes 134 s for the same 14 calls (INTEGRATION.md)")
+            except Exception as exc:
+                out["dropin_128_1src"] = {"skipped": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, srcpos, normflux, xh_state, nbox_first, pkg.box_cost, nd=nd)
             # ... and, in the same CPU leg, the oracle as the CHECKER of this workload's results (never timed as the product)

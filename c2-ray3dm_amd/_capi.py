@@ -89,6 +89,8 @@ SYMBOLS = [
     ("c2r_set_redshift", C.c_int, [_P, _D]),
     ("c2r_set_final_temperature", C.c_int, [_P]),
     ("c2r_set_sources", C.c_int, [_P, _P, _P, _I32]),
+    ("c2r_set_xray_tables", C.c_int, [_P, _P, _P, _I32]),
+    ("c2r_set_xray_sources", C.c_int, [_P, _P, _I32]),
     ("c2r_set_rank", C.c_int, [_P, _I32, _I32, ALLREDUCE_FN, _P]),
     ("c2r_set_slab_chemistry", C.c_int, [_P, _P, _P, _P]),
     ("c2r_slab", C.c_int, [_P, _I32, _I32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -170,7 +170,7 @@ void c2r_destroy(c2r_ctx *c)
     free_sweep_scratch(ctx);
     for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
     hipFree(ctx->grid[5]); hipFree(ctx->grid[6]); hipFree(ctx->d_hthick); hipFree(ctx->d_hthin); hipFree(ctx->d_cool); hipFree(ctx->d_heat_T);
-    hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_logtab); hipFree(ctx->d_odtab);
+    hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_xthick); hipFree(ctx->d_xthin); hipFree(ctx->d_logtab); hipFree(ctx->d_odtab);
     hipFree(ctx->d_nhi); hipFree(ctx->d_nhi_T); hipFree(ctx->d_phih_T); hipFree(ctx->d_step); hipFree(ctx->d_pack); hipFree(ctx->d_boxdesc);
     if (ctx->h_boxdesc) hipHostFree(ctx->h_boxdesc);
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
@@ -229,6 +229,36 @@ int c2r_set_tables(c2r_ctx *c, const double *thick, const double *thin, int32_t 
     HIP_TRY(hipMemcpy(ctx->d_thick + n, thick + n - 1, sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_thin + n, thin + n - 1, sizeof(double), hipMemcpyHostToDevice));
     ctx->have_tables = true; ++ctx->gen;
+    return C2R_OK;
+}
+
+int c2r_set_xray_tables(c2r_ctx *c, const double *thick, const double *thin, int32_t n)
+{
+    if (!c || ((thick == nullptr) != (thin == nullptr))) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    HIP_TRY(hipSetDevice(ctx->prm.device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ++ctx->gen;                                   // (captured launch sequences hold the choice of kernel)
+    if (!thick) { ctx->xray = false; return C2R_OK; }
+    if (n != ctx->prm.numtau + 1) FAIL(C2R_EINVAL, "table length must be numtau+1");
+    if (ctx->thermal) FAIL(C2R_ESTATE, "the X-ray source type is built for isothermal runs only (heat_lookuptable's \"P\" tables are not)");
+    if (!ctx->d_xthick) HIP_TRY(hipMalloc(&ctx->d_xthick, (size_t)(n + 1) * sizeof(double)));
+    if (!ctx->d_xthin) HIP_TRY(hipMalloc(&ctx->d_xthin, (size_t)(n + 1) * sizeof(double)));
+    // padded like the stellar tables: tab[numtau+1] = tab[numtau]
+    HIP_TRY(hipMemcpy(ctx->d_xthick, thick, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_xthin, thin, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_xthick + n, thick + n - 1, sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_xthin + n, thin + n - 1, sizeof(double), hipMemcpyHostToDevice));
+    ctx->xray = true;
+    return C2R_OK;
+}
+
+int c2r_set_xray_sources(c2r_ctx *c, const double *normflux_xray, int32_t nsrc)
+{
+    if (!c || nsrc < 0 || (nsrc > 0 && !normflux_xray)) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (nsrc != ctx->nsrc) FAIL(C2R_EINVAL, "c2r_set_xray_sources: one value per source of the list c2r_set_sources was given");
+    ctx->nflux_x.assign(normflux_xray, normflux_xray + nsrc);
     return C2R_OK;
 }
 
@@ -296,6 +326,7 @@ int c2r_set_thermal(c2r_ctx *c, const c2r_thermal_params *t, const double *heat_
     ++ctx->gen;
     if (ctx->prm.deterministic_rates && (t != nullptr) != ctx->thermal) free_sweep_scratch(ctx);   // per-source heating grids come and go
     if (!t) { ctx->thermal = false; return C2R_OK; }     // back to the isothermal path (the arrays stay allocated)
+    if (ctx->xray) FAIL(C2R_ESTATE, "the X-ray source type is built for isothermal runs only: c2r_set_xray_tables(ctx, NULL, NULL, 0) first");
     if (!heat_thick || !heat_thin || !cie_cool) FAIL(C2R_EINVAL, "non-isothermal run needs the heating tables and the cooling curve");
     if (n != ctx->prm.numtau + 1) FAIL(C2R_EINVAL, "table length must be numtau+1");
     if (t->cool_points < 2 || !(t->cool_dtemp > 0.0) || !(t->gamma1 > 0.0) || !(t->k_B > 0.0) || t->thermal_max_steps < 1)
@@ -348,6 +379,7 @@ int c2r_set_sources(c2r_ctx *c, const int32_t *srcpos, const double *normflux, i
     ctx->nflux.assign(normflux, normflux + nsrc);
     ctx->nsrc = nsrc;
     ctx->sparse_valid = false;                    // (nbox_all / last_nbox no longer describe what is in phih_grid)
+    ctx->nflux_x.clear();                         // (NormFlux_xray belongs to the list: c2r_set_xray_sources follows a new one)
     ctx->explicit_share = false; ctx->auto_share = false; ctx->share.clear(); ctx->last_nbox.clear(); ctx->nbox_all.clear(); ctx->box_hint = 0;
     // set-up belongs here, not in the first evolve3D of a run (the reference allocates in evolve_ini, evolve_data.F90:75-90): the
     // sweep scratch of this rank's share -- device planes, the pinned staging block -- is a few milliseconds of allocation calls

@@ -42,7 +42,7 @@ struct SweepScratch {
     double *d_planes = nullptr;                              // [cap][2][6][P][P]
     double *d_gbox = nullptr;   // deterministic mode: [cap][2][ncell]
     double *d_gbox_h = nullptr; // ... and the per-source heating rates of a non-isothermal run
-    int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr;
+    int *d_srcpos_b = nullptr, *d_srcw_b = nullptr; double *d_nflux_b = nullptr, *d_nflux_x = nullptr;
     // one device block + one pinned staging block hold the small per-batch arrays (one copy per batch)
     char *d_batch = nullptr, *h_batch = nullptr; size_t batch_bytes = 0;
     char *d_batch_init = nullptr; std::vector<char> batch_image;   // fused iteration: the state block a small batch starts from, on the device / as last sent
@@ -85,6 +85,8 @@ struct Ctx {
     float clumping = 1.0f;
     std::vector<int32_t> srcpos;   // 3 x nsrc
     std::vector<double>  nflux;
+    // the second source type of photoion_rates (builds with use_xray_SED=.true.): c2r_set_xray
+    bool xray = false; std::vector<double> nflux_x; double *d_xthick = nullptr, *d_xthin = nullptr;
     int nsrc = 0, rank = 0, nranks = 1;
     bool explicit_share = false; std::vector<int32_t> share;   // c2r_set_source_share: this rank's sources
     std::vector<int32_t> last_nbox;                              // final sub-box count per local source, last pass

@@ -70,7 +70,7 @@ struct KParams {
     double *gbox;              // deterministic mode: [S_batch][2][ncell] per-source Gamma ([0] x-fastest cells of
                                // z/y faces, [1] y-fastest cells of x faces); null: atomics into phih/phih_T
     const double *thick, *thin;
-    // non-isothermal runs (c2ray_parameters.f90:28 isothermal=.false.; HEAT kernels only): heating tables
+    // non-isothermal runs (c2ray_parameters.f90:28 isothermal=.false.; HEAT kernels only, EXT & 1): heating tables
     // stellar_heat_thick/thin_table (padded like thick/thin), phiheat_grid and its transposed accumulator
     const double *hthick, *hthin;
     double *heat, *heat_T;
@@ -82,6 +82,10 @@ struct KParams {
     const int    *srcpos;      // 3 x S_batch (unwrapped, 1-based: cinterp's real(i0) needs it)
     const int    *srcw;        // 3 x S_batch wrapped to 0..N-1
     const double *normflux;    // S_batch
+    // builds with use_xray_SED=.true. (sed_parameters.f90:56; XRAY kernels only, EXT & 2): the second source type of
+    // photoion_rates (radiation_photoionrates.F90:133-137) -- its tables (padded like thick/thin) and NormFlux_xray per source
+    const double *xthick, *xthin;
+    const double *normflux_x;  // S_batch
     double *planes;            // [S_batch][2][6][P][P]
 };
 
@@ -270,10 +274,10 @@ __device__ __forceinline__ double read_table(const double *__restrict__ tab, con
 
 // radiation_photoionrates.F90:71-179, :233-317 for NumFreqBnd=1, stellar table.
 // Returns photo_cell_HI (already divided by vol_ph); out = photo_out.
-// HEAT: also phi%heat of heat_lookuptable (:323-417) from the same two table positions.
-template <bool HEAT = false>
+// EXT & 1 (HEAT): also phi%heat of heat_lookuptable (:323-417) from the same two table positions.
+template <int EXT = 0>
 __device__ __forceinline__ double photoion(const KParams &p, const v2f64 *__restrict__ ltab, double cd_in, double cd_out,
-                                           double vol_ph, double nflux, double &p_out, double *heat = nullptr)
+                                           double vol_ph, double nflux, double &p_out, double *heat = nullptr, double nflux_x = 0.0)
 {
     const double tau_in = cd_in * p.sigma, tau_out = cd_out * p.sigma;
     const TauPos pin = tau_pos(tau_in, p, ltab);
@@ -289,7 +293,7 @@ __device__ __forceinline__ double photoion(const KParams &p, const v2f64 *__rest
         p_cell = nflux * (tau_out - tau_in) * read_table(p.thin, pin);
         p_out = p_in - p_cell;
     }
-    if (HEAT) {
+    if (EXT & 1) {
         const double h_in = nflux * read_table(p.hthick, pin);                         // :384
         if (fabs(tau_out - tau_in) > p.tau_heat_limit) {                               // :388
             if (!thick_cell) pout = tau_pos(tau_out, p, ltab);                         // (only if tau_heat_limit < tau_photo_limit)
@@ -299,7 +303,21 @@ __device__ __forceinline__ double photoion(const KParams &p, const v2f64 *__rest
             *heat = fdiv(nflux * tau_cell * read_table(p.hthin, pin), vol_ph);         // :396-400
         }
     }
-    return fdiv(p_cell, vol_ph);
+    double rate = fdiv(p_cell, vol_ph);
+    if ((EXT & 2) && nflux_x > 0.0) {             // :133-137  phi = phi + photo_lookuptable(..., NormFlux_xray(nsrc), "P", vol)
+        const double x_in = nflux_x * read_table(p.xthick, pin);
+        double x_cell, x_out;
+        if (thick_cell) {
+            x_out = nflux_x * read_table(p.xthick, pout);
+            x_cell = x_in - x_out;
+        } else {
+            x_cell = nflux_x * (tau_out - tau_in) * read_table(p.xthin, pin);
+            x_out = x_in - x_cell;
+        }
+        p_out = p_out + x_out;
+        rate = rate + fdiv(x_cell, vol_ph);
+    }
+    return rate;
 }
 
 // Deterministic block sum (fixed order): wave shuffles, then the 4 wave sums in order.
@@ -355,16 +373,17 @@ __device__ __forceinline__ double table_at(const double *__restrict__ tab, doubl
 }
 
 // photo-ionization (and heating) rate of a cell from its entry / exit columns; vol_ph = 4 pi dist2 path; volnhi = vol_ph n_HI.
-// t_out: the thick-table value at the exit column times 1 (photo_out / NormFlux), for the photon loss.
-template <bool HEAT>
+// p_out: photo_out, the photons leaving the cell (NormFlux x the thick-table value at the exit column, both source types), for
+// the photon loss.
+template <int EXT>
 __device__ __forceinline__ double rates_fast(const KParams &p, const v2f64 *__restrict__ ltab, const double *__restrict__ thick,
-                                             const double cd_in, const double cd_out, const double nflux, const double volnhi,
-                                             const double vol_ph, double &t_out, double &heat)
+                                             const double cd_in, const double cd_out, const double nflux, const double nflux_x,
+                                             const double volnhi, const double vol_ph, double &p_out, double &heat)
 {
     const double tau_in = cd_in * p.sigma, tau_out = cd_out * p.sigma;
     const double od_in = tau_od(tau_in, p, ltab);
     const double t_in = table_at(thick, od_in);
-    double dT, od_out = od_in;
+    double dT, t_out, od_out = od_in;
     const bool thick_cell = fabs(tau_out - tau_in) > p.tau_limit;
     if (thick_cell) {
         od_out = tau_od(tau_out, p, ltab);
@@ -374,7 +393,8 @@ __device__ __forceinline__ double rates_fast(const KParams &p, const v2f64 *__re
         dT = (tau_out - tau_in) * table_at(p.thin, od_in);
         t_out = t_in - dT;
     }
-    if (HEAT) {       // heat_lookuptable (radiation_photoionrates.F90:323-417) at the same table positions
+    p_out = nflux * t_out;                                                 // photo_out (radiation_photoionrates.F90:292, :302)
+    if (EXT & 1) {       // heat_lookuptable (radiation_photoionrates.F90:323-417) at the same table positions
         const double h_in = table_at(p.hthick, od_in);
         double dH;
         if (fabs(tau_out - tau_in) > p.tau_heat_limit) {
@@ -383,7 +403,17 @@ __device__ __forceinline__ double rates_fast(const KParams &p, const v2f64 *__re
         } else dH = ((cd_out - cd_in) * p.sigma) * table_at(p.hthin, od_in);
         heat = (nflux * dH) * rcp1(vol_ph);                                // phi%heat = .../vol_ph
     }
-    return (nflux * dT) * rcp1(volnhi);                                    // photo_cell_HI / (n_HI vol_ph)
+    const double r = rcp1(volnhi);
+    double gamma = (nflux * dT) * r;                                       // photo_cell_HI / (n_HI vol_ph)
+    if ((EXT & 2) && nflux_x > 0.0) {      // :133-137 the "P" source type: the same table positions, its own two tables and flux
+        const double x_in = table_at(p.xthick, od_in);
+        double dX, x_out;
+        if (thick_cell) { x_out = table_at(p.xthick, od_out); dX = x_in - x_out; }
+        else { dX = (tau_out - tau_in) * table_at(p.xthin, od_in); x_out = x_in - dX; }
+        p_out = p_out + nflux_x * x_out;
+        gamma = gamma + (nflux_x * dX) * r;
+    }
+    return gamma;
 }
 
 // ---- buffer addressing (SRSRC descriptor + 32-bit byte offset) ---------------------------------------

@@ -10,7 +10,7 @@ namespace c2r {
 // ---- source cells (q = 0) ------------------------------------------------------------------
 // evolve_point.F90:151-160 (source cell) + the common tail of evolve0D, for source s; ltab: log10_tab's table (LDS or global).
 // on_surface: degenerate meshes only, the source cell itself sits on the sub-box surface
-template <bool HEAT>
+template <int EXT>
 __device__ __forceinline__ void source_cell(const KParams &p, const v2f64 *__restrict__ ltab, const int s, const bool on_surface,
                                             double *loss_acc, double *dbg_cdout)
 {
@@ -31,17 +31,17 @@ __device__ __forceinline__ void source_cell(const KParams &p, const v2f64 *__res
     double p_out = 0.0, gamma = 0.0;
     if (nflux > 0.0) {      // cd_in = 0 is never above max_coldensh
         double heat = 0.0;
-        gamma = photoion<HEAT>(p, ltab, cd_in, cd_out, vol_ph, nflux, p_out, &heat) / nhi;
+        gamma = photoion<EXT>(p, ltab, cd_in, cd_out, vol_ph, nflux, p_out, &heat, (EXT & 2) ? p.normflux_x[s] : 0.0) / nhi;
         if (!p.gbox) atomicAdd(&p.phih[id], gamma);
-        if (HEAT && !p.gbox && heat != 0.0) atomicAdd(&p.heat[id], heat);       // evolve_point.F90:285-286
-        if (HEAT && p.gbox) p.gbox_h[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = heat;
-    } else if (HEAT && p.gbox) p.gbox_h[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = 0.0;
+        if ((EXT & 1) && !p.gbox && heat != 0.0) atomicAdd(&p.heat[id], heat);       // evolve_point.F90:285-286
+        if ((EXT & 1) && p.gbox) p.gbox_h[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = heat;
+    } else if ((EXT & 1) && p.gbox) p.gbox_h[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = 0.0;
     if (p.gbox) p.gbox[(size_t)s * 2 * ((size_t)p.n[0] * p.n[1] * p.n[2]) + id] = gamma;
     if (on_surface) loss_acc[s] += p_out * step_of(p).vol / vol_ph;
 }
 
 // One thread per source (the fused first sub-box does the same itself: BoxArgs::source_cell).
-template <bool HEAT>
+template <int EXT>
 __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0, int boxR1, int boxR2,
                                int boxL0, int boxL1, int boxL2, double *loss_acc, double *dbg_cdout)
 {
@@ -49,7 +49,7 @@ __global__ void k_source_cells(KParams p, int nsrc, const int *active, int boxR0
     const v2f64 *ltab = wave_log_table(p.logtab, s_log);
     const int sl = blockIdx.x * blockDim.x + threadIdx.x;
     if (sl >= nsrc) return;
-    source_cell<HEAT>(p, ltab, active[sl], boxR0 == 0 || boxR1 == 0 || boxR2 == 0 || boxL0 == 0 || boxL1 == 0 || boxL2 == 0,
+    source_cell<EXT>(p, ltab, active[sl], boxR0 == 0 || boxR1 == 0 || boxR2 == 0 || boxL0 == 0 || boxL1 == 0 || boxL2 == 0,
                       loss_acc, dbg_cdout);
 }
 
@@ -168,7 +168,7 @@ __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArg
 }
 
 // Returns the cell's photon-loss contribution (0 unless it lies on the sub-box surface).
-template <bool DET, int LLS, bool STREAM, bool HEAT, bool STORE = true>
+template <bool DET, int LLS, bool STREAM, int EXT, bool STORE = true>
 __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                               const int face, const int s, const int a, const int b, const CellState &cs)
 {
@@ -205,19 +205,19 @@ __device__ __forceinline__ double cell_commit(const KParams &p, const ShellArgs 
     const double nflux = p.normflux[s];
     double gamma = 0.0, heat = 0.0;
     if (!cs.stop_far && !(cs.cd_in > p.max_coldensh) && nflux > 0.0) {
-        double t_out;
-        gamma = rates_fast<HEAT>(p, ltab, p.thick, cs.cd_in, cd_out, nflux, cs.vol_ph * cs.nhi, cs.vol_ph, t_out, heat);
+        double p_out;
+        gamma = rates_fast<EXT>(p, ltab, p.thick, cs.cd_in, cd_out, nflux, (EXT & 2) ? p.normflux_x[s] : 0.0, cs.vol_ph * cs.nhi, cs.vol_ph, p_out, heat);
         if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[cs.id], gamma);
-        if (HEAT && !DET && heat != 0.0) atomicAdd(&(xf ? p.heat_T : p.heat)[cs.id], heat);      // evolve_point.F90:285-286
+        if ((EXT & 1) && !DET && heat != 0.0) atomicAdd(&(xf ? p.heat_T : p.heat)[cs.id], heat);      // evolve_point.F90:285-286
         if (sa.has_boundary) {
             const bool bnd = dl.d0 == sa.boxR[0] || dl.d1 == sa.boxR[1] || dl.d2 == sa.boxR[2] ||
                              dl.d0 == -sa.boxL[0] || dl.d1 == -sa.boxL[1] || dl.d2 == -sa.boxL[2];
-            if (bnd) loss = fdiv((nflux * t_out) * step_of(p).vol, cs.vol_ph);
+            if (bnd) loss = fdiv(p_out * step_of(p).vol, cs.vol_ph);
         }
     }
     // deterministic mode: every visited cell records its rate (zero included) for k_gamma_reduce
     if (DET) p.gbox[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + cs.id] = gamma;
-    if (DET && HEAT) p.gbox_h[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + cs.id] = heat;
+    if (DET && (EXT & 1)) p.gbox_h[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + cs.id] = heat;
     return loss;
 }
 
@@ -225,7 +225,7 @@ __device__ __forceinline__ double weight_rcp(const KParams &p, double c) { retur
 
 // One cell (a,b): four upstream corners of plane q-1 (zero weight and value outside |.| <= q-1: an
 // out-of-range offset reads 0), state, commit.  Used by the fused first-sub-box kernel.
-template <bool DET, int LLS, int GLC, bool HEAT>
+template <bool DET, int LLS, int GLC, int EXT>
 __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                              const int face, const int s, const int a, const int b)
 {
@@ -244,7 +244,7 @@ __device__ __forceinline__ double shell_cell(const KParams &p, const ShellArgs &
     const double c4v = buf_load_f64<GLC>(r_prev, (ina && inb) ? o8 : kOOB);
     const CellState cs = cell_state<LLS, false>(p, sa, face, s, a, b, c1v, c2v, c3v, c4v, weight_rcp(p, c1v), weight_rcp(p, c2v),
                                          weight_rcp(p, c3v), weight_rcp(p, c4v));
-    return cell_commit<DET, LLS, false, HEAT>(p, sa, ltab, face, s, a, b, cs);
+    return cell_commit<DET, LLS, false, EXT>(p, sa, ltab, face, s, a, b, cs);
 }
 
 // kRows cells of one column: (a,b0), (a,b0+sgb), ... with sgb the sign class of all their rows (rows are
@@ -262,7 +262,7 @@ constexpr int kRows = C2R_ROWS;
 #define C2R_PAIR_LDS_TABLE 0        // 1: the pair kernels fill the per-wave LDS table like the single-shell kernels (experiments)
 #endif
 constexpr int kPairRows = 1;        // rows per thread of the second shell of a look-ahead pair (k_sweep_pair, k_sweep_pair_fast)
-template <bool DET, int LLS, bool STREAM, bool HEAT, bool STORE = true>
+template <bool DET, int LLS, bool STREAM, int EXT, bool STORE = true>
 __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                              const int face, const int s, const int a, const int b0, const int sgb,
                                              const int nvalid)
@@ -295,13 +295,13 @@ __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &
 #if C2R_ROWS >= 4
     const CellState c3 = cell_state<LLS, STREAM>(p, sa, face, s, a, b0 + 3 * sgb, vm[3], va[3], vm[4], va[4], rm[3], ra[3], rm[4], ra[4]);
 #endif
-    double loss = cell_commit<DET, LLS, STREAM, HEAT, STORE>(p, sa, ltab, face, s, a, b0, c0);
-    if (nvalid > 1) loss = loss + cell_commit<DET, LLS, STREAM, HEAT, STORE>(p, sa, ltab, face, s, a, b0 + sgb, c1);
+    double loss = cell_commit<DET, LLS, STREAM, EXT, STORE>(p, sa, ltab, face, s, a, b0, c0);
+    if (nvalid > 1) loss = loss + cell_commit<DET, LLS, STREAM, EXT, STORE>(p, sa, ltab, face, s, a, b0 + sgb, c1);
 #if C2R_ROWS >= 3
-    if (nvalid > 2) loss = loss + cell_commit<DET, LLS, STREAM, HEAT, STORE>(p, sa, ltab, face, s, a, b0 + 2 * sgb, c2);
+    if (nvalid > 2) loss = loss + cell_commit<DET, LLS, STREAM, EXT, STORE>(p, sa, ltab, face, s, a, b0 + 2 * sgb, c2);
 #endif
 #if C2R_ROWS >= 4
-    if (nvalid > 3) loss = loss + cell_commit<DET, LLS, STREAM, HEAT, STORE>(p, sa, ltab, face, s, a, b0 + 3 * sgb, c3);
+    if (nvalid > 3) loss = loss + cell_commit<DET, LLS, STREAM, EXT, STORE>(p, sa, ltab, face, s, a, b0 + 3 * sgb, c3);
 #endif
     return loss;
 }
@@ -339,7 +339,7 @@ __device__ __forceinline__ double lookahead_cd_out_exact(const KParams &p, const
     return inside ? cs.cd_out : 0.0;
 }
 // one cell of the second shell of a pair: its four upstream corners recomputed
-template <bool DET, int LLS, bool STREAM, bool HEAT>
+template <bool DET, int LLS, bool STREAM, int EXT>
 __device__ __forceinline__ double shell_cell_look(const KParams &p, const ShellArgs &sa, const ShellArgs &sq,
                                                   const v2f64 *__restrict__ ltab, const int face, const int s, const int a, const int b)
 {
@@ -351,12 +351,12 @@ __device__ __forceinline__ double shell_cell_look(const KParams &p, const ShellA
     const double c4v = lookahead_cd_out_exact<LLS, STREAM>(p, sq, face, s, a, b);
     const CellState cs = cell_state<LLS, STREAM>(p, sa, face, s, a, b, c1v, c2v, c3v, c4v, weight_rcp(p, c1v), weight_rcp(p, c2v),
                                                  weight_rcp(p, c3v), weight_rcp(p, c4v));
-    return cell_commit<DET, LLS, STREAM, HEAT>(p, sa, ltab, face, s, a, b, cs);
+    return cell_commit<DET, LLS, STREAM, EXT>(p, sa, ltab, face, s, a, b, cs);
 }
 
 // STREAM: the non-temporal cache policy above (the host turns it on for meshes whose n_HI array outgrows the L2s)
 // LOOK (sq = the previous shell's arguments): one row per thread (FaceRect built for kPairRows), corners recomputed
-template <bool DET, int LLS, bool STREAM, bool HEAT, int LOOK = 0, bool STORE = true>
+template <bool DET, int LLS, bool STREAM, int EXT, int LOOK = 0, bool STORE = true>
 __device__ __forceinline__ void sweep_tile(const KParams &p, const ShellArgs &sa, const FaceRect &fr, const v2f64 *ltab,
                                            double *sm, const int face, const int tile, const int sl, const ShellArgs &sq)
 {
@@ -372,8 +372,8 @@ __device__ __forceinline__ void sweep_tile(const KParams &p, const ShellArgs &sa
         const int sgb = pos ? 1 : -1;
         const int b0 = pos ? k0 : -1 - k0;
         const int left = pos ? (fr.b_lo + fr.wb - b0) : (b0 - fr.b_lo + 1);     // rows from b0 to the end of the class
-        if (LOOK) loss = shell_cell_look<DET, LLS, STREAM, HEAT>(p, sa, sq, ltab, face, sa.active[sl], a, b0);
-        else loss = shell_rows<DET, LLS, STREAM, HEAT, STORE>(p, sa, ltab, face, sa.active[sl], a, b0, sgb, min(left, kRows));
+        if (LOOK) loss = shell_cell_look<DET, LLS, STREAM, EXT>(p, sa, sq, ltab, face, sa.active[sl], a, b0);
+        else loss = shell_rows<DET, LLS, STREAM, EXT, STORE>(p, sa, ltab, face, sa.active[sl], a, b0, sgb, min(left, kRows));
     }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
@@ -382,7 +382,7 @@ __device__ __forceinline__ void sweep_tile(const KParams &p, const ShellArgs &sa
     }
 }
 
-template <bool DET, int LLS, bool STREAM, bool HEAT>
+template <bool DET, int LLS, bool STREAM, int EXT>
 __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
 {
     __shared__ double sm[16];
@@ -394,12 +394,12 @@ __global__ __launch_bounds__(kBlock) void k_sweep_shell(KParams p, ShellArgs sa)
     const FaceRect fr = sa.face[face];
     if (tile >= fr.ntiles && !sa.has_boundary) return;   // block-uniform: nothing to do and no partial to write
     const v2f64 *ltab = wave_log_table(p.odtab, s_log);      // (table positions: rates_fast)
-    sweep_tile<DET, LLS, STREAM, HEAT>(p, sa, fr, ltab, sm, face, tile, (int)blockIdx.z, sa);
+    sweep_tile<DET, LLS, STREAM, EXT>(p, sa, fr, ltab, sm, face, tile, (int)blockIdx.z, sa);
 }
 
 // The look-ahead pair of the exact mode (see k_sweep_pair_fast below): shell sa.q in blockIdx.y 0..5 (planes not stored),
 // shell sb.q = sa.q + 1 in 6..11 (corners recomputed, one row per thread).
-template <bool DET, int LLS, bool STREAM, bool HEAT>
+template <bool DET, int LLS, bool STREAM, int EXT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 4)))
 void k_sweep_pair(KParams p, ShellArgs sa, ShellArgs sb)
 {
@@ -414,11 +414,11 @@ void k_sweep_pair(KParams p, ShellArgs sa, ShellArgs sb)
     if (second) {
         const FaceRect fr = sb.face[face];
         if (tile >= fr.ntiles) return;
-        sweep_tile<DET, LLS, STREAM, HEAT, 1, true>(p, sb, fr, ltab, sm, face, tile, (int)blockIdx.z, sa);
+        sweep_tile<DET, LLS, STREAM, EXT, 1, true>(p, sb, fr, ltab, sm, face, tile, (int)blockIdx.z, sa);
     } else {
         const FaceRect fr = sa.face[face];
         if (tile >= fr.ntiles) return;
-        sweep_tile<DET, LLS, STREAM, HEAT, 0, false>(p, sa, fr, ltab, sm, face, tile, (int)blockIdx.z, sa);
+        sweep_tile<DET, LLS, STREAM, EXT, 0, false>(p, sa, fr, ltab, sm, face, tile, (int)blockIdx.z, sa);
     }
 }
 
@@ -534,7 +534,7 @@ __device__ __forceinline__ double lookahead_cd_out(const KParams &p, const Shell
 // Everything a thread does for its NR rows once the upstream values are known: vm[r], va_[r] = the previous shell's
 // column densities at columns am = a - sga and a of rows b0 - sgb, b0, ..., b0 + (NR-1) sgb.
 // STORE: write the column densities into the planes (off for the first shell of a look-ahead pair: nothing reads them)
-template <bool DET, int LLS, bool STREAM, int NR, bool HEAT, bool STORE = true>
+template <bool DET, int LLS, bool STREAM, int NR, int EXT, bool STORE = true>
 __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                                        const double *__restrict__ thick, const int face, const int s, const int a,
                                                        const int b0, const int sgb, const int nvalid,
@@ -574,6 +574,7 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
 #pragma unroll
     for (int r = 0; r <= NR; ++r) row_sum_fast(p, omu, ddu, vm[r], va_[r], R[r], T[r]);
     const double nflux = p.normflux[s];
+    const double nflux_x = (EXT & 2) ? p.normflux_x[s] : 0.0;
     const __amdgpu_buffer_rsrc_t r_cur = make_rsrc(p.planes + ((size_t)s * 2 + sa.buf_cur) * 6 * p.PP, 6u * plane_bytes);
     constexpr int SA = STREAM ? C2R_STORE_AUX : 0;
     const bool bnd_col = sa.has_boundary && (a == sa.boxR[ua] || a == -sa.boxL[ua] || pd == sa.boxR[axis] || pd == -sa.boxL[axis]);
@@ -610,15 +611,15 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
             double gamma = 0.0, heat = 0.0;
             if (!stop && !(cd_in > p.max_coldensh) && nflux > 0.0) {
                 const double area = p.fourpi * dist2;                             // vol_ph = area path
-                double t_out;
-                gamma = rates_fast<HEAT>(p, ltab, thick, cd_in, cd_out, nflux, area * np, area * path, t_out, heat);
+                double p_out;
+                gamma = rates_fast<EXT>(p, ltab, thick, cd_in, cd_out, nflux, nflux_x, area * np, area * path, p_out, heat);
                 if (!DET && gamma != 0.0) atomicAdd(&(xf ? p.phih_T : p.phih)[id[k]], gamma);
-                if (HEAT && !DET && heat != 0.0) atomicAdd(&(xf ? p.heat_T : p.heat)[id[k]], heat);
+                if ((EXT & 1) && !DET && heat != 0.0) atomicAdd(&(xf ? p.heat_T : p.heat)[id[k]], heat);
                 if (sa.has_boundary && (bnd_col || b == sa.boxR[va] || b == -sa.boxL[va]))
-                    loss = loss + fdiv((nflux * t_out) * step_of(p).vol, area * path);
+                    loss = loss + fdiv(p_out * step_of(p).vol, area * path);
             }
             if (DET) p.gbox[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + id[k]] = gamma;
-            if (DET && HEAT) p.gbox_h[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + id[k]] = heat;
+            if (DET && (EXT & 1)) p.gbox_h[((size_t)s * 2 + (xf ? 1 : 0)) * ncell + id[k]] = heat;
         }
         o8 += db8;
     }
@@ -628,7 +629,7 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
 // LOOK = 0: the upstream values are read from the previous shell's planes (sq unused: pass sa).  LOOK = 1 (sq = the previous
 // shell's arguments, by reference -- a pointer to a kernel argument would force it into scratch): they are recomputed from
 // the planes of the shell before it (lookahead_cd_out).
-template <bool DET, int LLS, bool STREAM, int NR, bool HEAT, int LOOK = 0, bool STORE = true>
+template <bool DET, int LLS, bool STREAM, int NR, int EXT, int LOOK = 0, bool STORE = true>
 __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                                   const double *__restrict__ thick,   // p.thick, or the block's LDS copy of it
                                                   const int face, const int s, const int a, const int b0, const int sgb,
@@ -662,14 +663,14 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
             o += db8;
         }
     }
-    return shell_rows_fast_core<DET, LLS, STREAM, NR, HEAT, STORE>(p, sa, ltab, thick, face, s, a, b0, sgb, nvalid, vm, va_);
+    return shell_rows_fast_core<DET, LLS, STREAM, NR, EXT, STORE>(p, sa, ltab, thick, face, s, a, b0, sgb, nvalid, vm, va_);
 }
 
 #ifndef C2R_FAST_ATTR
 #define C2R_FAST_ATTR __launch_bounds__(kBlock)
 #endif
 // one (source, face, tile) block of work of k_sweep_shell_fast; sl = position in the active list
-template <bool DET, int LLS, bool STREAM, bool HEAT, int LOOK = 0, bool STORE = true, int NR = kRows>
+template <bool DET, int LLS, bool STREAM, int EXT, int LOOK = 0, bool STORE = true, int NR = kRows>
 __device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArgs &sa, const FaceRect &fr, const v2f64 *ltab,
                                                 const double *thick, double *sm, const int face, const int tile, const int sl,
                                                 const ShellArgs &sq)
@@ -684,7 +685,7 @@ __device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArg
         const int sgb = pos ? 1 : -1;
         const int b0 = pos ? k0 : -1 - k0;
         const int left = pos ? (fr.b_lo + fr.wb - b0) : (b0 - fr.b_lo + 1);
-        loss = shell_rows_fast<DET, LLS, STREAM, NR, HEAT, LOOK, STORE>(p, sa, ltab, thick, face, sa.active[sl], a, b0, sgb,
+        loss = shell_rows_fast<DET, LLS, STREAM, NR, EXT, LOOK, STORE>(p, sa, ltab, thick, face, sa.active[sl], a, b0, sgb,
                                                                         min(left, NR), sq);
     }
     if (sa.has_boundary) {
@@ -694,7 +695,7 @@ __device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArg
     }
 }
 
-template <bool DET, int LLS, bool STREAM, bool HEAT>
+template <bool DET, int LLS, bool STREAM, int EXT>
 __global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
 {
     __shared__ double sm[16];
@@ -706,14 +707,14 @@ __global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
     const FaceRect fr = sa.face[face];
     if (tile >= fr.ntiles && !sa.has_boundary) return;
     const v2f64 *ltab = wave_log_table(p.odtab, s_log);
-    sweep_tile_fast<DET, LLS, STREAM, HEAT>(p, sa, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z, sa);
+    sweep_tile_fast<DET, LLS, STREAM, EXT>(p, sa, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z, sa);
 }
 
 // Look-ahead pair (few sources, no cell of either shell on the sub-box surface): shell sa.q (blockIdx.y 0..5) and shell
 // sb.q = sa.q + 1 (blockIdx.y 6..11) in ONE launch, both from the planes of shell sa.q - 1 -- the second shell recomputes
 // the first shell's column densities where it needs them (lookahead_cd_out).  The first shell's planes are not stored
 // (nobody reads them); the second shell's go to the other plane set, which the next launch reads.
-template <bool DET, int LLS, bool STREAM, bool HEAT>
+template <bool DET, int LLS, bool STREAM, int EXT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 4)))     // latency-bound by design: registers before occupancy
 void k_sweep_pair_fast(KParams p, ShellArgs sa, ShellArgs sb)
 {
@@ -730,11 +731,11 @@ void k_sweep_pair_fast(KParams p, ShellArgs sa, ShellArgs sb)
     if (second) {
         const FaceRect fr = sb.face[face];
         if (tile >= fr.ntiles) return;
-        sweep_tile_fast<DET, LLS, STREAM, HEAT, 1, true, kPairRows>(p, sb, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z, sa);
+        sweep_tile_fast<DET, LLS, STREAM, EXT, 1, true, kPairRows>(p, sb, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z, sa);
     } else {
         const FaceRect fr = sa.face[face];
         if (tile >= fr.ntiles) return;
-        sweep_tile_fast<DET, LLS, STREAM, HEAT, 0, false>(p, sa, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z, sa);
+        sweep_tile_fast<DET, LLS, STREAM, EXT, 0, false>(p, sa, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z, sa);
     }
 }
 
@@ -756,7 +757,7 @@ struct BoxArgs {
     double *loss_acc;
 };
 
-template <bool DET, int LLS, bool FAST, bool HEAT>
+template <bool DET, int LLS, bool FAST, int EXT>
 __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
 {
     __shared__ double sm[16];
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
     if (ba.source_cell) {
         if (threadIdx.x == 0) {
             const ShellArgs &s0 = ba.sh[0];
-            source_cell<HEAT>(p, p.logtab, s, s0.boxR[0] == 0 || s0.boxR[1] == 0 || s0.boxR[2] == 0 || s0.boxL[0] == 0 ||
+            source_cell<EXT>(p, p.logtab, s, s0.boxR[0] == 0 || s0.boxR[1] == 0 || s0.boxR[2] == 0 || s0.boxL[0] == 0 ||
                               s0.boxL[1] == 0 || s0.boxL[2] == 0, ba.loss_acc, s0.dbg_cdout);
         }
         __syncthreads();             // shell 0's plane entries are visible to the waves that read them in shell 1
@@ -785,8 +786,8 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
             const unsigned bi = fr.magic ? __umulhi(lt, fr.magic) : lt;
             const int a = fr.a_lo + (int)(lt - __umul24(bi, (unsigned)fr.wa));
             const int b = fr.b_lo + (int)bi;
-            if (FAST) loss = loss + shell_rows_fast<DET, LLS, false, 1, HEAT>(p, sa, ltab, p.thick, f, s, a, b, b < 0 ? -1 : 1, 1, sa);
-            else loss = loss + shell_cell<DET, LLS, 0, HEAT>(p, sa, ltab, f, s, a, b);
+            if (FAST) loss = loss + shell_rows_fast<DET, LLS, false, 1, EXT>(p, sa, ltab, p.thick, f, s, a, b, b < 0 ? -1 : 1, 1, sa);
+            else loss = loss + shell_cell<DET, LLS, 0, EXT>(p, sa, ltab, f, s, a, b);
         }
         if (sa.has_boundary) {
             const double tot = block_sum_256(loss, sm);       // contains a barrier
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(256) void k_transpose_xy(int n0, int n1, int n2, co
 // densities as VALUES (the caller reads them from its coldensh_out), n_HI from the context's arrays; the arithmetic is
 // cell_state's (bit-identical column densities) and rates_fast's, the source cell's is source_cell's.
 // out[0..3] = coldensh_out(pos), the rate to add to phih_grid(pos), to phiheat_grid(pos), the photon loss through the box surface
-template <int LLS, bool HEAT>
+template <int LLS, int EXT>
 __global__ __launch_bounds__(64) void k_evolve0d_cell(KParams p, ShellArgs sa, int face, int a, int b, int is_source, int on_surface,
                                                       double c1, double c2, double c3, double c4, double *out)
 {
@@ -928,7 +929,7 @@ __global__ __launch_bounds__(64) void k_evolve0d_cell(KParams p, ShellArgs sa, i
         cd_out = 0.0 + nhi * path;
         if (nflux > 0.0) {
             double p_out = 0.0;
-            gamma = photoion<HEAT>(p, ltab, 0.0, cd_out, vol_ph, nflux, p_out, &heat) / nhi;
+            gamma = photoion<EXT>(p, ltab, 0.0, cd_out, vol_ph, nflux, p_out, &heat, (EXT & 2) ? p.normflux_x[s] : 0.0) / nhi;
             if (on_surface) loss = p_out * step_of(p).vol / vol_ph;
         }
     } else {
@@ -936,9 +937,9 @@ __global__ __launch_bounds__(64) void k_evolve0d_cell(KParams p, ShellArgs sa, i
                                                     weight_rcp(p, c3), weight_rcp(p, c4));
         cd_out = cs.cd_out;
         if (!cs.stop_far && !(cs.cd_in > p.max_coldensh) && nflux > 0.0) {
-            double t_out;
-            gamma = rates_fast<HEAT>(p, ltab, p.thick, cs.cd_in, cd_out, nflux, cs.vol_ph * cs.nhi, cs.vol_ph, t_out, heat);
-            if (on_surface) loss = fdiv((nflux * t_out) * step_of(p).vol, cs.vol_ph);
+            double p_out;
+            gamma = rates_fast<EXT>(p, ltab, p.thick, cs.cd_in, cd_out, nflux, (EXT & 2) ? p.normflux_x[s] : 0.0, cs.vol_ph * cs.nhi, cs.vol_ph, p_out, heat);
+            if (on_surface) loss = fdiv(p_out * step_of(p).vol, cs.vol_ph);
         }
     }
     out[0] = cd_out; out[1] = gamma; out[2] = heat; out[3] = loss;

@@ -53,8 +53,8 @@ int alloc_chain(Ctx *ctx, SweepScratch &sc, int cap)
     if (ctx->prm.deterministic_rates && ctx->thermal) HIP_TRY(hipMalloc(&sc.d_gbox_h, (size_t)cap * 2 * ctx->ncell * sizeof(double)));
     HIP_TRY(hipMalloc(&sc.d_loss_partial, (size_t)cap * 6 * ctx->tiles_cap * sizeof(double)));
     // small per-batch arrays: doubles first, then ints
-    //   nflux[cap] final_loss[cap] loss_acc[cap] | srcpos[3cap] srcw[3cap] active0[cap] active1[cap] final_nbox[cap] nactive[2]
-    sc.batch_bytes = (size_t)cap * 3 * sizeof(double) + ((size_t)cap * 9 + 2) * sizeof(int);
+    //   nflux[cap] final_loss[cap] loss_acc[cap] nflux_xray[cap] | srcpos[3cap] srcw[3cap] active0[cap] active1[cap] final_nbox[cap] nactive[2]
+    sc.batch_bytes = (size_t)cap * 4 * sizeof(double) + ((size_t)cap * 9 + 2) * sizeof(int);
     HIP_TRY(hipMalloc(&sc.d_batch, sc.batch_bytes));
     HIP_TRY(hipMalloc(&sc.d_batch_init, sc.batch_bytes));
     sc.batch_image.clear();
@@ -62,8 +62,8 @@ int alloc_chain(Ctx *ctx, SweepScratch &sc, int cap)
     HIP_TRY(hipHostGetDevicePointer((void **)&sc.d_hbatch, sc.h_batch, 0));
     {
         double *d = reinterpret_cast<double *>(sc.d_batch);
-        sc.d_nflux_b = d; sc.d_final_loss = d + cap; sc.d_loss_acc = d + 2 * (size_t)cap;
-        int *i = reinterpret_cast<int *>(d + 3 * (size_t)cap);
+        sc.d_nflux_b = d; sc.d_final_loss = d + cap; sc.d_loss_acc = d + 2 * (size_t)cap; sc.d_nflux_x = d + 3 * (size_t)cap;
+        int *i = reinterpret_cast<int *>(d + 4 * (size_t)cap);
         sc.d_srcpos_b = i; sc.d_srcw_b = i + 3 * (size_t)cap; sc.d_active[0] = i + 6 * (size_t)cap;
         sc.d_active[1] = i + 7 * (size_t)cap; sc.d_final_nbox = i + 8 * (size_t)cap; sc.d_nactive = i + 9 * (size_t)cap;
     }
@@ -162,6 +162,7 @@ KParams make_kparams(const Ctx *ctx, const SweepScratch &sc)
     k.od_per_e = (double)(0.301029995663981195213738894724493027L / (long double)p.dlogtau);
     k.od_per_ln = (double)(0.434294481903251827651128918916605082L / (long double)p.dlogtau);
     k.srcpos = sc.d_srcpos_b; k.srcw = sc.d_srcw_b; k.normflux = sc.d_nflux_b; k.planes = sc.d_planes;
+    k.xthick = ctx->d_xthick; k.xthin = ctx->d_xthin; k.normflux_x = sc.d_nflux_x;
     return k;
 }
 
@@ -295,7 +296,7 @@ struct BatchSweep {
     const int first, count; const bool first_of_pass; double *const dbg; FusedIter *const fz;
     const size_t cap; hipStream_t st; KParams k;
     // the pinned staging block (layout of ensure_sweep_scratch)
-    double *h_nf, *h_fl; int *h_pos, *h_posw, *h_act, *h_na, *h_fnb;
+    double *h_nf, *h_fl, *h_nfx; int *h_pos, *h_posw, *h_act, *h_na, *h_fnb;
     int n_active = 0;
     int cur = 0, last_bps = 0;     // which active list is current; size of the last shell's loss partials per source (0: none), for k_box_decide
     int totals_at_box = 0;         // fused iteration: the sub-box whose decision also writes the batch's totals (0: none)
@@ -309,8 +310,8 @@ struct BatchSweep {
         : ctx(c), sc(sc_), p(c->prm), first(first_), count(count_), first_of_pass(first_of_pass_), dbg(dbg_), fz(fz_),
           cap((size_t)sc_.cap), st(sc_.stream), k(make_kparams(c, sc_)), shape_count(n_local_sources(c))
     {
-        h_nf = reinterpret_cast<double *>(sc.h_batch); h_fl = h_nf + cap;
-        h_pos = reinterpret_cast<int *>(h_nf + 3 * cap); h_posw = h_pos + 3 * cap; h_act = h_pos + 6 * cap; h_na = h_pos + 9 * cap;
+        h_nf = reinterpret_cast<double *>(sc.h_batch); h_fl = h_nf + cap; h_nfx = h_nf + 3 * cap;
+        h_pos = reinterpret_cast<int *>(h_nf + 4 * cap); h_posw = h_pos + 3 * cap; h_act = h_pos + 6 * cap; h_na = h_pos + 9 * cap;
         h_fnb = h_pos + 8 * cap;   // the batch's results travel back through the same block (same layout as the device block)
     }
 
@@ -331,6 +332,7 @@ struct BatchSweep {
                 h_posw[3 * i + d] = m < 0 ? m + p.mesh[d] : m;         // evolve_point.F90:122 for the source cell
             }
             h_nf[i] = ctx->nflux[g];
+            h_nfx[i] = (ctx->xray && g < (int)ctx->nflux_x.size()) ? ctx->nflux_x[g] : 0.0;       // NormFlux_xray(ns), sourceprops.F90:381
             const double flux = h_nf[i] * p.S_star;
             if (flux > p.loss_fraction * flux && can_trace) h_act[n_active++] = i;
             else h_fl[i] = flux;                                       // loop never entered: loss = initial value
@@ -375,11 +377,15 @@ struct BatchSweep {
         const int bound = bx.bound;
         {
             if (ctx->thermal)
-                hipLaunchKernelGGL(k_source_cells<true>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
+                hipLaunchKernelGGL(k_source_cells<1>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
+                                   sc.d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
+                                   sc.d_loss_acc, dbg);
+            else if (ctx->xray)
+                hipLaunchKernelGGL(k_source_cells<2>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
                                    sc.d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
                                    sc.d_loss_acc, dbg);
             else
-                hipLaunchKernelGGL(k_source_cells<false>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
+                hipLaunchKernelGGL(k_source_cells<0>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
                                    sc.d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
                                    sc.d_loss_acc, dbg);
         }
@@ -408,10 +414,13 @@ struct BatchSweep {
             if (ba.nshell > 0) ba.source_cell = 1;
             else {      // no shell at all to walk (degenerate limits): the plain kernel after all
                 if (ctx->thermal)
-                    hipLaunchKernelGGL(k_source_cells<true>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, sc.d_active[cur],
+                    hipLaunchKernelGGL(k_source_cells<1>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, sc.d_active[cur],
+                                       boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], sc.d_loss_acc, dbg);
+                else if (ctx->xray)
+                    hipLaunchKernelGGL(k_source_cells<2>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, sc.d_active[cur],
                                        boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], sc.d_loss_acc, dbg);
                 else
-                    hipLaunchKernelGGL(k_source_cells<false>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, sc.d_active[cur],
+                    hipLaunchKernelGGL(k_source_cells<0>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, sc.d_active[cur],
                                        boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], sc.d_loss_acc, dbg);
             }
         }
@@ -427,7 +436,7 @@ struct BatchSweep {
             // (not in the k_sweep_shell launch timing of c2r_profile: a different kernel, 21^3 cells per source)
 #define C2R_LAUNCH_FUSED_H(D, L, H) do { if (ctx->fast) hipLaunchKernelGGL((k_sweep_box_fused<D, L, true, H>), grid, blk, 0, st, k, ba); \
                                 else hipLaunchKernelGGL((k_sweep_box_fused<D, L, false, H>), grid, blk, 0, st, k, ba); } while (0)
-#define C2R_LAUNCH_FUSED(D, L) do { if (ctx->thermal) C2R_LAUNCH_FUSED_H(D, L, true); else C2R_LAUNCH_FUSED_H(D, L, false); } while (0)
+#define C2R_LAUNCH_FUSED(D, L) do { if (ctx->thermal) C2R_LAUNCH_FUSED_H(D, L, 1); else if (ctx->xray) C2R_LAUNCH_FUSED_H(D, L, 2); else C2R_LAUNCH_FUSED_H(D, L, 0); } while (0)
             switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
                 case 2: C2R_LAUNCH_FUSED(false, 1); break;
                 case 3: C2R_LAUNCH_FUSED(true, 1); break;
@@ -474,7 +483,7 @@ struct BatchSweep {
                      else hipLaunchKernelGGL((k_sweep_pair_fast<D, L, false, H>), grid, blk, 0, st, k, sa, sb); } \
     else if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_pair<D, L, true, H>), grid, blk, 0, st, k, sa, sb); \
     else hipLaunchKernelGGL((k_sweep_pair<D, L, false, H>), grid, blk, 0, st, k, sa, sb); } while (0)
-#define C2R_LAUNCH_PAIR(D, L) do { if (ctx->thermal) C2R_LAUNCH_PAIR_H(D, L, true); else C2R_LAUNCH_PAIR_H(D, L, false); } while (0)
+#define C2R_LAUNCH_PAIR(D, L) do { if (ctx->thermal) C2R_LAUNCH_PAIR_H(D, L, 1); else if (ctx->xray) C2R_LAUNCH_PAIR_H(D, L, 2); else C2R_LAUNCH_PAIR_H(D, L, 0); } while (0)
                     switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
                         case 2: C2R_LAUNCH_PAIR(false, 1); break;
                         case 3: C2R_LAUNCH_PAIR(true, 1); break;
@@ -500,7 +509,7 @@ struct BatchSweep {
                      else hipLaunchKernelGGL((k_sweep_shell_fast<D, L, false, H>), grid, blk, 0, st, k, sa); } \
     else if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_shell<D, L, true, H>), grid, blk, 0, st, k, sa); \
     else hipLaunchKernelGGL((k_sweep_shell<D, L, false, H>), grid, blk, 0, st, k, sa); } while (0)
-#define C2R_LAUNCH_SWEEP(D, L) do { if (ctx->thermal) C2R_LAUNCH_SWEEP_H(D, L, true); else C2R_LAUNCH_SWEEP_H(D, L, false); } while (0)
+#define C2R_LAUNCH_SWEEP(D, L) do { if (ctx->thermal) C2R_LAUNCH_SWEEP_H(D, L, 1); else if (ctx->xray) C2R_LAUNCH_SWEEP_H(D, L, 2); else C2R_LAUNCH_SWEEP_H(D, L, 0); } while (0)
                 switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
                     case 2: C2R_LAUNCH_SWEEP(false, 1); break;
                     case 3: C2R_LAUNCH_SWEEP(true, 1); break;
@@ -542,7 +551,7 @@ struct BatchSweep {
                 tot.on = 1; tot.nsrc = count; tot.photon_loss = ctx->d_photon_loss; tot.sum_nbox = ctx->d_sum_nbox;
                 tot.host_loss = &ctx->d_hsc->photon_loss; tot.host_nbox = &ctx->d_hsc->sum_nbox;
                 tot.host_final_loss = reinterpret_cast<double *>(sc.d_hbatch) + cap;
-                tot.host_final_nbox = reinterpret_cast<int *>(reinterpret_cast<double *>(sc.d_hbatch) + 3 * cap) + 8 * cap;
+                tot.host_final_nbox = reinterpret_cast<int *>(reinterpret_cast<double *>(sc.d_hbatch) + 4 * cap) + 8 * cap;
             }
             hipLaunchKernelGGL(k_box_decide_small, dim3(1), dim3(64), 0, st, sc.d_active[cur], sc.d_nactive + cur,
                                sc.d_active[1 - cur], sc.d_nactive + (1 - cur), sc.d_hnactive + nbox, sc.d_nflux_b,
@@ -1038,13 +1047,14 @@ int c2r_evolve0d_host(c2r_ctx *c, int32_t ns, const int32_t rtpos[3], const int3
     const size_t idt = (size_t)pos[1] + (size_t)p.mesh[1] * ((size_t)pos[0] + (size_t)p.mesh[0] * (size_t)pos[2]);
     {
         const SweepScratch &sc = ctx->sc[0];
-        double *hd = reinterpret_cast<double *>(sc.h_batch);            // >= 3 doubles + 11 ints for a batch of one
-        int *hi = reinterpret_cast<int *>(hd + 3);
-        hd[0] = nflux; hd[1] = nhi;
+        double *hd = reinterpret_cast<double *>(sc.h_batch);            // >= 4 doubles + 11 ints for a batch of one
+        int *hi = reinterpret_cast<int *>(hd + 4);
+        hd[0] = nflux; hd[1] = nhi; hd[2] = (ctx->xray && ns - 1 < (int)ctx->nflux_x.size()) ? ctx->nflux_x[ns - 1] : 0.0;
         for (int d = 0; d < 3; ++d) { hi[d] = sp[d]; hi[3 + d] = spw[d]; }
         HIP_TRY(hipMemcpyAsync(sc.d_srcpos_b, hi, 3 * sizeof(int), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(sc.d_srcw_b, hi + 3, 3 * sizeof(int), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(sc.d_nflux_b, hd, sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(sc.d_nflux_x, hd + 2, sizeof(double), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(ctx->d_nhi + idx, hd + 1, sizeof(double), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(ctx->d_nhi_T + idt, hd + 1, sizeof(double), hipMemcpyHostToDevice, st));
     }
@@ -1079,10 +1089,11 @@ int c2r_evolve0d_host(c2r_ctx *c, int32_t ns, const int32_t rtpos[3], const int3
     for (int d = 0; d < 3; ++d) on_surface = on_surface || rtpos[d] == last_l[d] || rtpos[d] == last_r[d];
     KParams k = make_kparams(ctx, ctx->sc[0]);
     double *d_out = ctx->d_sum_out;                              // 4 doubles of device scratch
-#define C2R_LAUNCH_CELL(L) do { if (ctx->thermal) hipLaunchKernelGGL((k_evolve0d_cell<L, true>), dim3(1), dim3(64), 0, st, k, sa, face, a, b, is_source ? 1 : 0, on_surface ? 1 : 0, cv[0], cv[1], cv[2], cv[3], d_out); \
-                                else hipLaunchKernelGGL((k_evolve0d_cell<L, false>), dim3(1), dim3(64), 0, st, k, sa, face, a, b, is_source ? 1 : 0, on_surface ? 1 : 0, cv[0], cv[1], cv[2], cv[3], d_out); } while (0)
+#define C2R_LAUNCH_CELL_H(L, H) hipLaunchKernelGGL((k_evolve0d_cell<L, H>), dim3(1), dim3(64), 0, st, k, sa, face, a, b, is_source ? 1 : 0, on_surface ? 1 : 0, cv[0], cv[1], cv[2], cv[3], d_out)
+#define C2R_LAUNCH_CELL(L) do { if (ctx->thermal) C2R_LAUNCH_CELL_H(L, 1); else if (ctx->xray) C2R_LAUNCH_CELL_H(L, 2); else C2R_LAUNCH_CELL_H(L, 0); } while (0)
     switch (ctx->lls_type) { case 1: C2R_LAUNCH_CELL(1); break; case 2: C2R_LAUNCH_CELL(2); break; default: C2R_LAUNCH_CELL(3); break; }
 #undef C2R_LAUNCH_CELL
+#undef C2R_LAUNCH_CELL_H
     HIP_TRY(hipGetLastError());
     double *out = ctx->h_sc->four;                               // pinned
     HIP_TRY(hipMemcpyAsync(out, d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, st));

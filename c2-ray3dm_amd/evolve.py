@@ -181,6 +181,19 @@ class HipBackend:
         self._check(self.lib.c2r_set_sources(self.ctx, srcpos.ctypes.data, normflux.ctypes.data, self.nsrc),
                     "c2r_set_sources")
 
+    def set_xray(self, xray_thick=None, xray_thin=None, normflux_xray=None):
+        """The second source type of photoion_rates (use_xray_SED=.true.): its two tables (None: off) and NormFlux_xray per
+        source of the current list (after set_sources; None: leave as it is).  Isothermal runs only."""
+        if xray_thick is None:
+            self._check(self.lib.c2r_set_xray_tables(self.ctx, None, None, 0), "c2r_set_xray_tables")
+            return
+        if xray_thin is not None:
+            k = np.ascontiguousarray(xray_thick, dtype=np.float64); t = np.ascontiguousarray(xray_thin, dtype=np.float64)
+            self._check(self.lib.c2r_set_xray_tables(self.ctx, k.ctypes.data, t.ctypes.data, len(k)), "c2r_set_xray_tables")
+        if normflux_xray is not None:
+            f = np.ascontiguousarray(normflux_xray, dtype=np.float64)
+            self._check(self.lib.c2r_set_xray_sources(self.ctx, f.ctypes.data, len(f)), "c2r_set_xray_sources")
+
     def set_source_share(self, indices=None):
         """Explicit list of this rank's sources (0-based) instead of the static stride; None resets."""
         if indices is None:

@@ -31,10 +31,11 @@ module c2ray_hip
   use temperature_module, only: temper_val, temperature_grid
   use clumping_module, only: clumping, clumping_grid
   use lls_module, only: coldensh_LLS, LLS_grid, R_max_LLS
-  use sourceprops, only: NumSrc, srcpos, NormFlux_stellar
+  use sourceprops, only: NumSrc, srcpos, NormFlux_stellar, NormFlux_xray
   use radiation_sizes, only: NumTau
   use radiation_tables, only: stellar_photo_thick_table, stellar_photo_thin_table, minlogtau, dlogtau, &
-       stellar_heat_thick_table, stellar_heat_thin_table
+       stellar_heat_thick_table, stellar_heat_thin_table, xray_photo_thick_table, xray_photo_thin_table
+  use sed_parameters, only: use_xray_SED
   use radiation_sed_parameters, only: S_star
   use cgsphotoconstants, only: sigma_HI_at_ion_freq
   use cgsconstants, only: bh00, albpow, colh0, temph0, k_B
@@ -164,6 +165,18 @@ module c2ray_hip
        integer(c_int32_t), value :: nsrc
      end function c2r_set_sources
      !> xh_av, xh_intermed, phih_grid: c_loc of the array to have it downloaded after the step, c_null_ptr to leave it alone
+     integer(c_int) function c2r_set_xray_tables(ctx, thick, thin, n) bind(C, name="c2r_set_xray_tables")
+       import :: c_int, c_ptr, c_double, c_int32_t
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: thick(*), thin(*)
+       integer(c_int32_t), value :: n
+     end function c2r_set_xray_tables
+     integer(c_int) function c2r_set_xray_sources(ctx, normflux_xray, nsrc) bind(C, name="c2r_set_xray_sources")
+       import :: c_int, c_ptr, c_double, c_int32_t
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: normflux_xray(*)
+       integer(c_int32_t), value :: nsrc
+     end function c2r_set_xray_sources
      integer(c_int) function c2r_evolve3d(ctx, dt, ndens, xh, xh_av, xh_intermed, phih_grid, rep) &
           bind(C, name="c2r_evolve3d")
        import :: c_int, c_ptr, c_double, c_float, c2r_report
@@ -396,6 +409,13 @@ contains
     write(logf,*) "c2ray_hip: evolve hot path on HIP device ", dev
     write(logf,*) "c2ray_hip: sweep mode ", merge("fast (C2R_SWEEP_FAST)  ", "exact (C2R_SWEEP_EXACT)", p%sweep_mode == 1)
     if (.not.isothermal) call thermal_hip_ini()
+    ! builds with use_xray_SED=.true. (sed_parameters.f90:56): the second source type of photoion_rates
+    ! (radiation_photoionrates.F90:133-137) -- its two tables now, NormFlux_xray with every source list (hip_step_state)
+    if (use_xray_SED) then
+       call check(c2r_set_xray_tables(ctx, xray_photo_thick_table(:,1), xray_photo_thin_table(:,1), &
+            int(NumTau+1, c_int32_t)), "c2r_set_xray_tables")
+       write(logf,*) "c2ray_hip: X-ray source type on the device (photo_lookuptable 'P')"
+    endif
 #ifdef MPI
     ! Join the RCCL communicator: rank 0 makes the 128-byte token, one broadcast next to those of mpi.F90 hands it
     ! out, every rank attaches on its own device.  From here on c2r_evolve3d sweeps this rank's share of the sources
@@ -471,6 +491,8 @@ contains
     endif
     call check(c2r_set_sources(ctx, srcpos, NormFlux_stellar(1:NumSrc), int(NumSrc, c_int32_t)), &
          "c2r_set_sources")
+    if (use_xray_SED .and. allocated(NormFlux_xray)) &
+         call check(c2r_set_xray_sources(ctx, NormFlux_xray, int(NumSrc, c_int32_t)), "c2r_set_xray_sources")
     if (.not.isothermal) call check(c2r_set_redshift(ctx, zred), "c2r_set_redshift")   ! cosmo_cool, cosmology.F90:198
   end subroutine hip_step_state
 

@@ -152,6 +152,19 @@ int  c2r_set_stream(c2r_ctx *ctx, void *hip_stream);
 /* stellar_photo_thick_table / _thin_table (0:NumTau,1), built once by rad_ini
  * (radiation_tables.F90:95-126). n = numtau+1. */
 int  c2r_set_tables(c2r_ctx *ctx, const double *thick, const double *thin, int32_t n);
+/* The second source type of photoion_rates -- builds of the driver with use_xray_SED=.true. (sed_parameters.f90:56):
+ * `phi = phi + photo_lookuptable(..., NormFlux_xray(nsrc), "P", vol)` (radiation_photoionrates.F90:133-137): the same table
+ * positions, its own thick / thin tables (xray_photo_thick_table / _thin_table(0:NumTau,1), radiation_tables.F90:80-81) and a
+ * second normalised flux per source (NormFlux_xray: column 5 of the source list / S_star_xray, sourceprops.F90:63, :381, :631).
+ * A source is traced while its STELLAR flux leaves its sub-box (evolve_source.F90:119: total_source_flux counts that alone);
+ * where NormFlux_xray > 0 the X-ray rate is added cell by cell and its photons count in photo_out.
+ * c2r_set_xray_tables(ctx, thick, thin, numtau+1): switch it on (NULL, NULL: off); isothermal contexts only.
+ * c2r_set_xray_sources(ctx, normflux_xray, nsrc): after every c2r_set_sources with a new list; sources without a value: 0.
+ * (The reference fills these tables from an array it never sets, radiation_tables.F90:367: they are inputs here -- e.g.
+ * c2r_build_tables with C2R_SED_POWER_LAW.) */
+int  c2r_set_xray_tables(c2r_ctx *ctx, const double *thick, const double *thin, int32_t n);
+int  c2r_set_xray_sources(c2r_ctx *ctx, const double *normflux_xray, int32_t nsrc);
+
 /* Per-time-step scalars the driver recomputes before every evolve3D call (C2Ray.F90:367-376):
  * dr(1:3), vol (grid.F90, cosmology.F90:161-193), coldensh_LLS (LLS.F90:178-182),
  * clumping (clumping_module.F90:74), temper_val (temperature_module.F90:34).  They (and dt, the redshift) reach the kernels

@@ -6,7 +6,7 @@ out=${1:-gpurun_out/ab_chains.txt}
 mkdir -p "$(dirname "$out")"; : > "$out"
 run () {   # $1 = sources, $2 = chains ("" = the library's rule), $3 = steps
   local line
-  line=$(C2R_CHAINS=$2 python bench.py --sources $1 --steps $3 --warmup 2 --no-cpu-baseline --no-other-mode --no-small-leg --no-mix-ceiling 2>/dev/null | tail -1)
+  line=$(C2R_CHAINS=$2 python bench.py --sources $1 --steps $3 --warmup 2 --no-cpu-baseline --no-other-mode --no-small-leg --no-mix-ceiling --no-dropin-leg 2>/dev/null | tail -1)
   echo "S=$1 chains=${2:-rule} $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("ms_per_step=%.3f sum_nbox=%s phih_sum=%.12e" % (d["ms_per_step"], d["check"]["sum_nbox_last_step"], d["check"]["phih_grid_sum"]))')" | tee -a "$out"
 }
 for rep in 1 2; do

@@ -113,7 +113,7 @@ def test_bench_cold_two_ranks_exchange_packed_sub_boxes():
     sub-boxes, at most a tenth of the N^3 x 8 bytes the plain all-reduce of evolve.F90:599 moves per iteration; same checksums
     as one rank."""
     args = ["--steps", "2", "--warmup", "1", "--mesh", "256", "--sources", "1000", "--x-init", "2e-4", "--no-cpu-baseline", "--no-other-mode",
-            "--no-small-leg"]
+            "--no-small-leg", "--no-dropin-leg", "--no-mix-ceiling"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, capture_output=True, text=True,
                          timeout=900, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
