@@ -154,6 +154,7 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_step, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_prepared, hipEventDisableTiming));
     ctx->sc[0].stream = ctx->stream;                       // chain 0 of the sweep runs on the context's stream
+    if (const char *e = getenv("C2R_EXCHANGE_OVERLAP")) ctx->exchange_overlap = atoi(e) != 0;
     if (const char *e = getenv("C2R_CHAINS")) ctx->chains_env = std::max(0, std::min(kMaxChains, atoi(e)));
     hipLaunchKernelGGL(k_load_code_object, dim3(1), dim3(1), 0, ctx->stream, (int *)nullptr);      // (loads the library's code object now)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -175,6 +176,10 @@ void c2r_destroy(c2r_ctx *c)
     if (ctx->h_boxdesc) hipHostFree(ctx->h_boxdesc);
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
     if (ctx->ev_prepared) hipEventDestroy(ctx->ev_prepared);
+    hipFree(ctx->d_phih2); hipFree(ctx->d_phih2_T);
+    if (ctx->ev_half) hipEventDestroy(ctx->ev_half);
+    if (ctx->ev_xdone) hipEventDestroy(ctx->ev_xdone);
+    if (ctx->xstream) hipStreamDestroy(ctx->xstream);
     for (int c = 1; c < kMaxChains; ++c) if (ctx->sc[c].own_stream && ctx->sc[c].stream) hipStreamDestroy(ctx->sc[c].stream);
     if (ctx->h_step) hipHostFree(ctx->h_step);
     if (ctx->ev_step) hipEventDestroy(ctx->ev_step);
@@ -198,6 +203,8 @@ const char *c2r_info(c2r_ctx *c)
     ctx->info = ctx->info_device + "; sweep_mode " + (ctx->fast ? "fast (C2R_SWEEP_FAST)" : "exact (C2R_SWEEP_EXACT)") +
                 "; rates " + (ctx->prm.deterministic_rates ? "ordered per-source sums" : "f64 atomics") +
                 "; rank " + std::to_string(ctx->rank) + " of " + std::to_string(ctx->nranks) +
+                "; chains " + std::to_string(ctx->nchains) +
+                "; exchanges overlapped with the sweep " + std::to_string(ctx->xchg_overlapped) +
                 "; graph captures " + std::to_string(ctx->captures);
     if (!ctx->info_warn.empty()) ctx->info += "; " + ctx->info_warn;
     return ctx->info.c_str();

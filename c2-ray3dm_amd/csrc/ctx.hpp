@@ -117,7 +117,13 @@ struct Ctx {
     bool sparse_valid = false;                                   // the rates in phih_grid are those of ONE c2r_pass_sources over rates the library had zeroed
     bool rates_clean = false;                                    // phih_grid (phiheat_grid) zeroed by the library and not written since
     double *d_pack = nullptr; size_t pack_cap = 0; BoxDesc *d_boxdesc = nullptr, *h_boxdesc = nullptr; int boxdesc_cap = 0;
-    long long xchg_calls = 0, xchg_sparse = 0, xchg_bytes_last = 0, xchg_bytes_total = 0;
+    long long xchg_calls = 0, xchg_sparse = 0, xchg_bytes_last = 0, xchg_bytes_total = 0, xchg_overlapped = 0;
+    // the exchange overlapped with the sweep (c2r_set_exchange_overlap; sweep.hip pass_sources_impl): a pass as two halves of the
+    // rank's sources into two pairs of accumulators, the first half's all-reduce on a second stream while the second is swept
+    bool exchange_overlap = false;
+    double *d_phih2 = nullptr, *d_phih2_T = nullptr, *acc_phih = nullptr, *acc_phih_T = nullptr;   // acc_*: what the launches being enqueued add into (null: phih_grid / d_phih_T)
+    hipStream_t xstream = nullptr; hipEvent_t ev_half = nullptr, ev_xdone = nullptr;
+    long long rates_reduced_pass = -1;                           // the pass whose rates in phih_grid are already summed over the ranks
     // slab chemistry (c2r_set_slab_chemistry): reduce-scatter of the rates by z-slabs, the global pass on the own slab,
     // all-gather of its outputs -- instead of the all-reduce and a replicated global pass
     c2r_reduce_scatter_fn rs = nullptr; c2r_allgather_fn ag = nullptr; void *slab_user = nullptr;

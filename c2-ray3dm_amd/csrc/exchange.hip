@@ -210,6 +210,13 @@ int c2r_allreduce_rates(c2r_ctx *c)
     Ctx *ctx = C(c);
     if (ctx->nranks <= 1 || !ctx->ar) return C2R_OK;
     const c2r_params &p = ctx->prm;
+    if (ctx->rates_reduced_pass == ctx->pass_id) {
+        // the pass exchanged its rates itself, overlapped with its second half (c2r_set_exchange_overlap); what remains is the
+        // list of sub-boxes every rank learns per pass (it decides whether the NEXT pass travels packed, and the LPT shares)
+        ctx->rates_reduced_pass = -1;
+        HIP_TRY(hipSetDevice(ctx->prm.device));
+        return ctx->sparse_exchange ? gather_nbox_all(ctx) : C2R_OK;
+    }
     ++ctx->xchg_calls;
     // Sparse form: every rank learns every source's final sub-box (one small all-reduce), so all ranks agree on the same list
     // of boxes; while their volumes add up to a fraction of the mesh, only they travel -- packed box after box in source
@@ -269,6 +276,13 @@ int c2r_allreduce_rates(c2r_ctx *c)
         FAIL(C2R_ECALLBACK, "all-reduce callback failed");
     ctx->xchg_bytes_last = ((long long)ctx->ncell * (ctx->thermal ? 2 : 1) + (ctx->sparse_exchange ? ctx->nsrc : 0)) * (long long)sizeof(double);
     ctx->xchg_bytes_total += ctx->xchg_bytes_last;
+    return C2R_OK;
+}
+
+int c2r_set_exchange_overlap(c2r_ctx *c, int32_t on)
+{
+    if (!c) return C2R_EINVAL;
+    C(c)->exchange_overlap = on != 0;
     return C2R_OK;
 }
 

@@ -905,6 +905,12 @@ __global__ __launch_bounds__(256) void k_transpose_xy(int n0, int n1, int n2, co
     }
 }
 
+// dst += src over the mesh (the two reduced halves of an overlapped pass: sweep.hip overlap_end)
+__global__ __launch_bounds__(256) void k_add_grid(size_t n, const double *__restrict__ src, double *__restrict__ dst)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = dst[i] + src[i];
+}
+
 // ---- evolve0D for ONE (cell, source): the reference's per-cell call surface (evolve_point.F90:83-299) ----------------
 // Slow by construction (a launch and a handful of copies per cell): for hosts that drive the sweep themselves and for tests.
 // The cell's geometry as the shell kernels see it (face, plane coordinates a, b, shell sa.q), the four upstream column

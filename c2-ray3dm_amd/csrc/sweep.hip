@@ -152,7 +152,10 @@ KParams make_kparams(const Ctx *ctx, const SweepScratch &sc)
     k.inv_dlogtau = 1.0 / p.dlogtau;
     k.exact_udiv = udiv_ok(p.dlogtau);               // (load_step adds udiv_ok(dr[0]))
     k.R = ctx->R; k.P = ctx->P; k.PP = ctx->PP;
-    k.nhi = ctx->d_nhi; k.nhi_T = ctx->d_nhi_T; k.phih = (double *)ctx->grid[4]; k.phih_T = ctx->d_phih_T;
+    k.nhi = ctx->d_nhi; k.nhi_T = ctx->d_nhi_T;
+    // the accumulators of the rates: phih_grid and its transposed companion -- or, for the second half of an overlapped
+    // pass (pass_sources_impl), the second pair
+    k.phih = ctx->acc_phih ? ctx->acc_phih : (double *)ctx->grid[4]; k.phih_T = ctx->acc_phih_T ? ctx->acc_phih_T : ctx->d_phih_T;
     k.gbox = sc.d_gbox; k.gbox_h = ctx->thermal ? sc.d_gbox_h : nullptr;
     k.lls_type = ctx->lls_type; k.R_max2 = ctx->R_max_LLS * ctx->R_max_LLS; k.lls = ctx->d_lls; k.lls_T = ctx->d_lls_T;
     k.thick = ctx->d_thick; k.thin = ctx->d_thin; k.logtab = ctx->d_logtab;
@@ -875,7 +878,8 @@ int sweep_finish(Ctx *ctx, const int *gate)
     // phih_T is [k][i][j]: transposing it back swaps the roles of the two mesh extents
     const dim3 g((p.mesh[1] + 31) / 32, (p.mesh[0] + 31) / 32, p.mesh[2]);
     hipLaunchKernelGGL((k_transpose_xy<double, true>), g, dim3(256), 0, ctx->stream, p.mesh[1], p.mesh[0], p.mesh[2],
-                       (const double *)ctx->d_phih_T, (double *)ctx->grid[4], gate);
+                       (const double *)(ctx->acc_phih_T ? ctx->acc_phih_T : ctx->d_phih_T),
+                       ctx->acc_phih ? ctx->acc_phih : (double *)ctx->grid[4], gate);
     if (ctx->thermal)
         hipLaunchKernelGGL((k_transpose_xy<double, true>), g, dim3(256), 0, ctx->stream, p.mesh[1], p.mesh[0], p.mesh[2],
                            (const double *)ctx->d_heat_T, (double *)ctx->grid[5], gate);
@@ -911,6 +915,61 @@ int upload_lls_grid(Ctx *ctx, const float *lls_grid)
 // follows the pass (sweep_batch); sweep_prepare / sweep_finish are then fz->pre / fz->post, not called here.
 // no_wait (iterate_impl): return with sweep_finish enqueued and not waited for -- the caller enqueues the global pass behind
 // it, waits once and reads the totals itself (they are in h_sc after that wait).
+namespace {
+// ---- the all-reduce of the rates overlapped with the sweep (c2r_set_exchange_overlap) ------------------------------------
+// (every rank must come to the same answer: nothing below depends on the rank's own share)
+bool exchange_overlap_applies(Ctx *ctx, const FusedIter *fz)
+{
+    if (!ctx->exchange_overlap || ctx->nranks <= 1 || !ctx->ar || (ctx->rs && ctx->ag) || fz || ctx->prm.deterministic_rates ||
+        ctx->thermal || ctx->nsrc / ctx->nranks < 2 * kFewSources || !ctx->sparse_valid /* = over rates the library zeroed */) return false;
+    // the previous pass's sub-boxes (every rank knows them: gather_nbox_all) say whether this pass's rates will travel packed
+    if (ctx->sparse_exchange && (int)ctx->nbox_all.size() == ctx->nsrc) {
+        double total = 0.0;
+        for (int i = 0; i < ctx->nsrc; ++i) total += (double)visited_for_nbox(ctx, ctx->nbox_all[i]);
+        if (total <= ctx->sparse_fraction * (double)ctx->ncell) return false;
+    } else if (ctx->sparse_exchange) return false;          // nothing known yet (first pass of a list): the plain path learns it
+    return true;
+}
+
+int overlap_begin(Ctx *ctx)
+{
+    if (!ctx->d_phih2) {
+        HIP_TRY(hipMalloc(&ctx->d_phih2, grid_bytes(ctx, 4)));
+        HIP_TRY(hipMalloc(&ctx->d_phih2_T, grid_bytes(ctx, 4)));
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->xstream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_half, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_xdone, hipEventDisableTiming));
+    }
+    HIP_TRY(hipMemsetAsync(ctx->d_phih2, 0, grid_bytes(ctx, 4), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_phih2_T, 0, grid_bytes(ctx, 4), ctx->stream));
+    return C2R_OK;
+}
+
+// the half's rates are complete in their accumulator (sweep_finish has folded the transposed part back, on the context's
+// stream): their all-reduce goes to the exchange stream -- behind the other half's, in rank-independent order
+int overlap_exchange_half(Ctx *ctx, int half)
+{
+    HIP_TRY(hipEventRecord(ctx->ev_half, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->xstream, ctx->ev_half, 0));
+    double *buf = half == 0 ? (double *)ctx->grid[4] : ctx->d_phih2;
+    if (ctx->ar(ctx->ar_user, buf, ctx->ncell, (void *)ctx->xstream) != 0) FAIL(C2R_ECALLBACK, "all-reduce callback failed");
+    return C2R_OK;
+}
+
+int overlap_end(Ctx *ctx)
+{
+    HIP_TRY(hipEventRecord(ctx->ev_xdone, ctx->xstream));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_xdone, 0));
+    hipLaunchKernelGGL(k_add_grid, dim3(kSumBlocks), dim3(256), 0, ctx->stream, ctx->ncell, (const double *)ctx->d_phih2, (double *)ctx->grid[4]);
+    HIP_TRY(hipGetLastError());
+    ctx->rates_reduced_pass = ctx->pass_id;
+    ++ctx->xchg_calls; ++ctx->xchg_overlapped;
+    ctx->xchg_bytes_last = 2 * (long long)ctx->ncell * (long long)sizeof(double);
+    ctx->xchg_bytes_total += ctx->xchg_bytes_last;
+    return C2R_OK;
+}
+}  // namespace
+
 int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64_t *sum_nbox, int64_t *visited, bool no_wait)
 {
     int rc;
@@ -923,25 +982,45 @@ int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64_t *sum
     ++ctx->pass_id; ctx->sparse_valid = ctx->rates_clean || fz != nullptr; ctx->rates_clean = false;
     ctx->last_nbox.clear();
     ctx->h_sc->photon_loss = 0.0; ctx->h_sc->sum_nbox = 0;      // (the stream is idle between calls)
+    const bool overlap = exchange_overlap_applies(ctx, fz);
+    if (nloc == 0 && overlap) {
+        // a rank without sources (more ranks than sources in its share) still takes part in both exchanges
+        if ((rc = overlap_begin(ctx)) || (rc = overlap_exchange_half(ctx, 0)) || (rc = overlap_exchange_half(ctx, 1)) || (rc = overlap_end(ctx))) return rc;
+    }
     if (nloc > 0) {
         rc = ensure_sweep_scratch(ctx, nloc);
         if (rc) return rc;
         if (fz && nloc > ctx->batch_cap) FAIL(C2R_ESTATE, "fused iteration needs the sources in one batch");
         if (!fz && (rc = sweep_prepare(ctx))) return rc;
+        // Several ranks, the whole grid to exchange (evolve.F90:599): the pass runs as TWO halves of this rank's sources, each
+        // into its own pair of accumulators, and the all-reduce of the first half's rates travels (on a second stream) while
+        // the second half is swept; the sum of the two reduced halves is what the plain pass + c2r_allreduce_rates leave
+        // (re-associated: (a1+a2+..) + (b1+b2+..) over ranks and halves, 1e-16 relative).  c2r_allreduce_rates then has
+        // nothing left to do for this pass (rates_reduced).  Not where the rates travel packed (cold steps: far fewer bytes
+        // than half a grid), with slab chemistry, ordered rates, heating rates, or few sources.
+        const int n_first = overlap ? (nloc + 1) / 2 : nloc;
+        if (overlap && (rc = overlap_begin(ctx))) return rc;
         std::vector<int> nb;
-        for (int first = 0, count = 0; first < nloc; first += count) {
-            // several chains in flight where the scratch was laid out for it (ensure_sweep_scratch: 64 - 512 sources per round)
-            if (ctx->nchains > 1 && !fz && nloc - first >= 2 * kFewSources) {
-                count = std::min(ctx->batch_cap, nloc - first);
-                rc = run_chains(ctx, first, count, first == 0, &nb);
-            } else {
-                count = std::min(ctx->sc[0].cap, nloc - first);
-                rc = sweep_batch(ctx, first, count, first == 0, nullptr, &nb, nullptr, fz);
+        for (int half = 0; half < (overlap ? 2 : 1); ++half) {
+            const int h0 = half == 0 ? 0 : n_first, h1 = half == 0 ? n_first : nloc;
+            if (half == 1) { ctx->acc_phih = ctx->d_phih2; ctx->acc_phih_T = ctx->d_phih2_T; }
+            for (int first = h0, count = 0; first < h1; first += count) {
+                // several chains in flight where the scratch was laid out for it (ensure_sweep_scratch: 64 - 768 sources per round)
+                if (ctx->nchains > 1 && !fz && h1 - first >= 2 * kFewSources) {
+                    count = std::min(ctx->batch_cap, h1 - first);
+                    rc = run_chains(ctx, first, count, first == 0, &nb);
+                } else {
+                    count = std::min(ctx->sc[0].cap, h1 - first);
+                    rc = sweep_batch(ctx, first, count, first == 0, nullptr, &nb, nullptr, fz);
+                }
+                if (rc) { ctx->acc_phih = ctx->acc_phih_T = nullptr; return rc; }
+                for (int v : nb) { vis += visited_for_nbox(ctx, v); ctx->last_nbox.push_back(v); }
             }
-            if (rc) return rc;
-            for (int v : nb) { vis += visited_for_nbox(ctx, v); ctx->last_nbox.push_back(v); }
+            if (!fz && (rc = sweep_finish(ctx))) { ctx->acc_phih = ctx->acc_phih_T = nullptr; return rc; }
+            if (overlap && (rc = overlap_exchange_half(ctx, half))) { ctx->acc_phih = ctx->acc_phih_T = nullptr; return rc; }
         }
-        if (!fz && (rc = sweep_finish(ctx))) return rc;
+        ctx->acc_phih = ctx->acc_phih_T = nullptr;
+        if (overlap && (rc = overlap_end(ctx))) return rc;
         ctx->box_hint = 0;
         for (int v : ctx->last_nbox) ctx->box_hint = std::max(ctx->box_hint, v);
     } else if (fz && (rc = fz->pre())) return rc;

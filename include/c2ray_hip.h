@@ -286,6 +286,16 @@ int  c2r_zero_rates(c2r_ctx *ctx);
  * (radiation_photoionrates.F90:71).  Reads ndens, xh_av; accumulates into phih_grid.
  * Does NOT reduce across ranks (c2r_allreduce_rates does). */
 int  c2r_pass_sources(c2r_ctx *ctx, double *photon_loss, int64_t *sum_nbox, int64_t *visited);
+/* The all-reduce of the rates overlapped with the sweep.  on = 1: where a pass would be followed by an all-reduce of the WHOLE
+ * grid (several ranks, no slab chemistry, f64 atomics, isothermal, at least 64 sources on this rank, rates not sparse by the
+ * previous pass's sub-boxes), c2r_pass_sources sweeps this rank's sources as two halves into two pairs of accumulators and
+ * hands the first half's rates to the all-reduce callback -- on a second stream -- while the second half is swept; both
+ * reduced halves are then added.  c2r_allreduce_rates after such a pass only refreshes the per-source sub-box list.  The
+ * result is the plain path's up to the association of the sums (1e-16 relative).  Every rank must make the same choice, and
+ * the callback must honour its stream argument (the RCCL binding and the torch.distributed host do).  Off by default; the
+ * environment variable C2R_EXCHANGE_OVERLAP=1 (read by c2r_create) switches it on as well. */
+int  c2r_set_exchange_overlap(c2r_ctx *ctx, int32_t on);
+
 /* mpi_accumulate_grid_quantities (evolve.F90:577-616) through the callback; no-op for 1 rank.
  * Sparse form (on by default): the rates of a pass are non-zero only inside the sources' final sub-boxes, which every rank
  * learns through one small all-reduce of the sub-box counts; while the boxes' volumes add up to at most half the mesh only
