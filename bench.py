@@ -213,6 +213,9 @@ def main():
                          "as `configs1_128_1src`; only the default workload runs it)")
     ap.add_argument("--balance", action="store_true",
                     help="cost-balanced source shares (by the previous pass) instead of the static stride")
+    ap.add_argument("--overlap-exchange", action="store_true",
+                    help="several ranks: the all-reduce of the first half of a rank's sources travels while the second half is swept "
+                         "(c2r_set_exchange_overlap; off by default until an N > 1 RCCL run has measured it)")
     ap.add_argument("--deterministic", action="store_true",
                     help="per-source Gamma grids reduced in source order instead of f64 atomics")
     ap.add_argument("--thermal", action="store_true",
@@ -275,6 +278,8 @@ def main():
         args.no_cpu_baseline = True
     bytes_per_visit = SWEEP_BYTES_PER_VISIT + (16 if args.thermal else 0)      # + phiheat_grid read-modify-write
     ev = pkg.Evolve(b, comm=dist if world > 1 else None, balance=args.balance)
+    if args.overlap_exchange and world > 1:
+        b.set_exchange_overlap(True)
     b.begin_step()
 
     def one_step(k):
@@ -400,7 +405,7 @@ def main():
                        if world > 1 else None,
                        "source_share_sizes": [len(x) for x in shares] if shares else [S],
                        "shares_partition_sources": (sorted(i for x in shares for i in x) == list(range(S))) if shares else True,
-                       "rank_phases": phases,
+                       "rank_phases": phases, "exchange_overlapped_with_sweep": bool(args.overlap_exchange and world > 1),
                        "collective": None if world == 1 else ("gloo (C2R_BENCH_TEST_ONE_GPU)" if one_gpu_test else "nccl (RCCL)"),
                        "visited_cell_sources_per_step": visited_all / args.steps,
                        "visited_per_s": visited_all / dt_wall,

@@ -89,6 +89,7 @@ SYMBOLS = [
     ("c2r_set_redshift", C.c_int, [_P, _D]),
     ("c2r_set_final_temperature", C.c_int, [_P]),
     ("c2r_set_sources", C.c_int, [_P, _P, _P, _I32]),
+    ("c2r_set_exchange_overlap", C.c_int, [_P, _I32]),
     ("c2r_set_xray_tables", C.c_int, [_P, _P, _P, _I32]),
     ("c2r_set_xray_sources", C.c_int, [_P, _P, _I32]),
     ("c2r_set_rank", C.c_int, [_P, _I32, _I32, ALLREDUCE_FN, _P]),

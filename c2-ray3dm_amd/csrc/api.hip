@@ -155,6 +155,7 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_prepared, hipEventDisableTiming));
     ctx->sc[0].stream = ctx->stream;                       // chain 0 of the sweep runs on the context's stream
     if (const char *e = getenv("C2R_EXCHANGE_OVERLAP")) ctx->exchange_overlap = atoi(e) != 0;
+    if (const char *e = getenv("C2R_EXCHANGE_OVERLAP_MIN")) ctx->overlap_min_sources = std::max(1, atoi(e));
     if (const char *e = getenv("C2R_CHAINS")) ctx->chains_env = std::max(0, std::min(kMaxChains, atoi(e)));
     hipLaunchKernelGGL(k_load_code_object, dim3(1), dim3(1), 0, ctx->stream, (int *)nullptr);      // (loads the library's code object now)
     HIP_TRY(hipStreamSynchronize(ctx->stream));

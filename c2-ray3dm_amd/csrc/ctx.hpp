@@ -94,7 +94,8 @@ struct Ctx {
     // hipGraph of a small batch's launch sequence up to box_hint (see sweep_batch); gen counts everything that
     // the captured kernel arguments depend on (tables, buffers, stream, scratch, physics switches; NOT the step's scalars: sync_step)
     struct BatchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long long gen = 0; int count = 0, n_active = 0, hint = 0;
-                        bool fused = false; bool stats = false; };
+                        bool fused = false; bool stats = false; const void *acc = nullptr;   // acc: the accumulator the captured launches add into
+    };
     std::map<int, BatchGraph> graphs;                            // key: 2 x (first source of the batch) + (fused iteration ? 1 : 0)
     unsigned long long gen = 1;
     long long captures = 0;                                      // launch sequences captured so far (c2r_info; tests: a new time step must not add one)
@@ -120,7 +121,7 @@ struct Ctx {
     long long xchg_calls = 0, xchg_sparse = 0, xchg_bytes_last = 0, xchg_bytes_total = 0, xchg_overlapped = 0;
     // the exchange overlapped with the sweep (c2r_set_exchange_overlap; sweep.hip pass_sources_impl): a pass as two halves of the
     // rank's sources into two pairs of accumulators, the first half's all-reduce on a second stream while the second is swept
-    bool exchange_overlap = false;
+    bool exchange_overlap = false; int overlap_min_sources = 2 * kFewSources;    // (C2R_EXCHANGE_OVERLAP_MIN: experiments, tests)
     double *d_phih2 = nullptr, *d_phih2_T = nullptr, *acc_phih = nullptr, *acc_phih_T = nullptr;   // acc_*: what the launches being enqueued add into (null: phih_grid / d_phih_T)
     hipStream_t xstream = nullptr; hipEvent_t ev_half = nullptr, ev_xdone = nullptr;
     long long rates_reduced_pass = -1;                           // the pass whose rates in phih_grid are already summed over the ranks

@@ -639,7 +639,7 @@ struct BatchSweep {
             totals_at_box = 0;
             const hipError_t e = hipStreamEndCapture(st, &bg.graph);
             if (rc == C2R_OK && e == hipSuccess && hipGraphInstantiate(&bg.exec, bg.graph, nullptr, nullptr, 0) == hipSuccess) {
-                bg.gen = ctx->gen; bg.count = count; bg.n_active = n_active; bg.hint = hint;
+                bg.gen = ctx->gen; bg.count = count; bg.n_active = n_active; bg.hint = hint; bg.acc = (const void *)k.phih;
                 bg.fused = fuse_iter; bg.stats = fuse_iter && fz->stats;
             } else {
                 if (bg.graph) { hipGraphDestroy(bg.graph); bg.graph = nullptr; }
@@ -714,7 +714,7 @@ int BatchSweep::run(std::vector<int> *nbox_out, std::vector<double> *loss_out)
         // c2r_pass_sources and c2r_iterate does not re-capture every time)
         Ctx::BatchGraph &bg = ctx->graphs[2 * first + (fuse_iter ? 1 : 0)];
         if (!(bg.exec && bg.gen == ctx->gen && bg.count == count && bg.n_active == n_active && bg.hint == hint &&
-              bg.fused == fuse_iter && (!fuse_iter || bg.stats == fz->stats)))
+              bg.fused == fuse_iter && (!fuse_iter || bg.stats == fz->stats) && bg.acc == (const void *)k.phih))
             capture(bg, fuse_iter, hint);
         if (bg.exec) {
             const int done = std::min(hint, ctx->nbox_max);
@@ -921,7 +921,7 @@ namespace {
 bool exchange_overlap_applies(Ctx *ctx, const FusedIter *fz)
 {
     if (!ctx->exchange_overlap || ctx->nranks <= 1 || !ctx->ar || (ctx->rs && ctx->ag) || fz || ctx->prm.deterministic_rates ||
-        ctx->thermal || ctx->nsrc / ctx->nranks < 2 * kFewSources || !ctx->sparse_valid /* = over rates the library zeroed */) return false;
+        ctx->thermal || ctx->nsrc / ctx->nranks < ctx->overlap_min_sources || !ctx->sparse_valid /* = over rates the library zeroed */) return false;
     // the previous pass's sub-boxes (every rank knows them: gather_nbox_all) say whether this pass's rates will travel packed
     if (ctx->sparse_exchange && (int)ctx->nbox_all.size() == ctx->nsrc) {
         double total = 0.0;

@@ -250,6 +250,11 @@ class HipBackend:
             self._cb = _capi.ALLREDUCE_FN(0)
         self._check(self.lib.c2r_set_rank(self.ctx, rank, npr, self._cb, None), "c2r_set_rank")
 
+    def set_exchange_overlap(self, on=True):
+        """c2r_set_exchange_overlap: passes that are followed by an all-reduce of the whole grid run as two halves, the first
+        half's all-reduce travelling while the second is swept (allreduce_rates afterwards only refreshes the sub-box list)."""
+        self._check(self.lib.c2r_set_exchange_overlap(self.ctx, 1 if on else 0), "c2r_set_exchange_overlap")
+
     def set_slab_chemistry(self, reduce_scatter=None, allgather=None):
         """Slab chemistry of the native loop (c2r_set_slab_chemistry, include/c2ray_hip.h): the rates are reduce-scattered
         by z-slabs, every rank runs the global pass on its slab, the pass's outputs are all-gathered.

@@ -33,6 +33,9 @@ struct Shared {
     std::vector<int> rc; std::vector<std::string> err;
     c2r_report rep0; std::vector<double> xh0, phih0;
     int64_t xchg[4] = {0, 0, 0, 0};                               // rank 0's c2r_exchange_stats: calls, packed calls, bytes of the last call, bytes in all
+    bool rotate = false;                                          // C2R_HARNESS_ROTATE_SUM=1: the host all-reduce sums element i starting at rank i mod nranks
+    std::vector<unsigned long long> hash;                         // per rank: a hash of the bits of xh and phih_grid the step left (replicas must agree)
+    std::string info0;
 };
 struct RankArg { Shared *sh; int rank; };
 
@@ -51,8 +54,15 @@ static int host_allreduce(void *user, void *dev_buf, size_t count, void *stream)
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;
     pthread_barrier_wait(&sh->bar);
     for (size_t i = 0; i < count; ++i) sum[i] = 0.0;
-    for (int r = 0; r < sh->nranks; ++r)
-        for (size_t i = 0; i < count; ++i) sum[i] = sum[i] + sh->stage[r][i];
+    if (!sh->rotate) {
+        for (int r = 0; r < sh->nranks; ++r)
+            for (size_t i = 0; i < count; ++i) sum[i] = sum[i] + sh->stage[r][i];
+    } else {
+        // an OFFSET-dependent order, as a ring / tree collective has (RCCL's order depends on where in the buffer an element
+        // lies): element i is summed starting at rank i mod nranks -- the same on every rank, different from element to element
+        for (size_t i = 0; i < count; ++i)
+            for (int k = 0; k < sh->nranks; ++k) sum[i] = sum[i] + sh->stage[(k + (int)(i % (size_t)sh->nranks)) % sh->nranks][i];
+    }
     pthread_barrier_wait(&sh->bar);                  // everyone has read every staging buffer
     if (hipMemcpyAsync(dev_buf, sum, count * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return 1;
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : 1;
@@ -149,7 +159,15 @@ static void *rank_main(void *p)
             }
         }
         TRY(c2r_evolve3d(ctx, pb.dt, ndens.data(), xh.data(), xh_av.data(), xh_int.data(), phih.data(), &rep));
+        {   // FNV-1a over the bits of the replicated results
+            unsigned long long h = 1469598103934665603ULL;
+            auto mix = [&h](const std::vector<double> &v) { const unsigned char *b = reinterpret_cast<const unsigned char *>(v.data());
+                                                           for (size_t i = 0; i < v.size() * sizeof(double); ++i) { h ^= b[i]; h *= 1099511628211ULL; } };
+            mix(xh); mix(phih);
+            sh->hash[rank] = h;
+        }
         if (rank == 0) {
+            sh->info0 = c2r_info(ctx);
             sh->rep0 = rep; sh->xh0 = xh; sh->phih0 = phih;
             (void)c2r_exchange_stats(ctx, &sh->xchg[0], &sh->xchg[1], &sh->xchg[2], &sh->xchg[3]);
         }
@@ -180,6 +198,8 @@ int main(int argc, char **argv)
     Shared sh;
     sh.nranks = atoi(argv[3]); sh.rccl = strcmp(argv[4], "rccl") == 0; sh.balance = atoi(argv[5]) != 0; sh.pb = &pb;
     sh.slab = argc > 6 && atoi(argv[6]) != 0;
+    if (const char *e = getenv("C2R_HARNESS_ROTATE_SUM")) sh.rotate = atoi(e) != 0;
+    sh.hash.assign(sh.nranks, 0ULL);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { fprintf(stderr, "no HIP device\n"); return 1; }
     if (sh.rccl && ndev < sh.nranks) { printf("SKIP: %d ranks over RCCL need %d devices, %d visible\n", sh.nranks, sh.nranks, ndev); return 77; }
@@ -203,6 +223,11 @@ int main(int argc, char **argv)
     printf("ok: %d rank(s) on %d device(s), %s %s, balance %d: niter %d sum_nbox %lld\n", sh.nranks, ndev < sh.nranks ? ndev : sh.nranks,
            sh.rccl ? "rccl" : "host", sh.slab ? "reduce-scatter + slab chemistry + all-gather" : "all-reduce", (int)sh.balance, sh.rep0.niter,
            (long long)sh.rep0.sum_nbox_all);
+    bool same = true;
+    for (int r = 1; r < sh.nranks; ++r) same = same && sh.hash[r] == sh.hash[0];
+    printf("replicas identical: %s\n", same ? "yes" : "NO");
+    printf("info: %s\n", sh.info0.c_str());
+    if (!same) return 1;
     printf("exchange: calls %lld packed %lld bytes_last %lld bytes_total %lld\n", (long long)sh.xchg[0], (long long)sh.xchg[1],
            (long long)sh.xchg[2], (long long)sh.xchg[3]);
     return 0;

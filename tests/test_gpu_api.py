@@ -80,10 +80,21 @@ def test_host_pointer_evolve3d_is_what_the_shim_calls(pkg, tables):
     assert np.array_equal(xint, xh)                 # evolve.F90:218 xh = xh_intermed on convergence
     ref = F(a["step001_phih_grid"])
     assert np.max(np.abs(phih - ref) / np.maximum(ref, 1e-60)) < 1e-8
-    # optional outputs may be NULL
+    # where the call's wall time went: the two groups of copies (HIP events), the whole call (host clock)
+    assert 0.0 < rep.seconds_upload < rep.seconds_total and 0.0 < rep.seconds_download < rep.seconds_total
+    assert rep.seconds_sweep + rep.seconds_chem < rep.seconds_total
+    # optional outputs may be NULL -- then they are neither copied back nor touched (what the Fortran shim does with the work
+    # arrays xh_av / xh_intermed); the same list of sources again keeps what the last pass learnt (no second scratch allocation)
+    assert lib.c2r_set_sources(ctx, pos.ctypes.data, nf.ctypes.data, len(nf)) == 0
     xh2 = F(a["step001_xh_before"])
-    assert lib.c2r_evolve3d(ctx, s["dt"], nd.ctypes.data, xh2.ctypes.data, None, None, None, None) == 0
+    rep2 = pkg.Report()
+    assert lib.c2r_evolve3d(ctx, s["dt"], nd.ctypes.data, xh2.ctypes.data, None, None, None, C.byref(rep2)) == 0
     assert np.max(np.abs(xh2 - xh)) < 1e-13
+    assert rep2.niter == rep.niter and list(rep2.it_conv_flag[:rep.niter]) == list(rep.it_conv_flag[:rep.niter])
+    assert rep2.seconds_download < rep.seconds_download            # 8 B per cell instead of 32
+    # the photon statistics the shim's photonstatistics module is fed with (c2r_report) = the reference's module variables
+    for k in ("totrec", "totcollisions", "dh0", "total_ion"):
+        assert abs(getattr(rep2, k) / s[k] - 1) < 1e-9, k
     lib.c2r_destroy(ctx)
 
 

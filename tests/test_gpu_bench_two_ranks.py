@@ -99,6 +99,27 @@ def test_bench_eight_ranks_equal_one_rank(form, balance):
     assert b["config"]["gamma_exchange"]["ring_over_xgmi_s_per_step"] > 0.0 and a["config"]["rank_phases"] is None
 
 
+def test_bench_two_ranks_with_the_exchange_overlapped():
+    """bench.py --gpus 2 --overlap-exchange (two ranks on the one GPU, gloo): 128 sources, i.e. 64 per rank -- the pass runs as
+    two halves with the first half's all-reduce in flight during the second; same checksums as one rank."""
+    args = ["--steps", "2", "--warmup", "1", "--mesh", "64", "--sources", "128", "--no-cpu-baseline", "--no-other-mode"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(C2R_BENCH_TEST_ONE_GPU="1", C2R_SPARSE_EXCHANGE="0")
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--overlap-exchange"] + args, capture_output=True,
+                         text=True, timeout=900, cwd=ROOT, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b = line(one.stdout), line(two.stdout)
+    assert b["config"]["exchange_overlapped_with_sweep"] is True
+    x = b["config"]["gamma_exchange"]
+    assert x["bytes_per_step"] == 2 * x["full_grid_bytes"]          # two halves of a grid per pass: the overlapped path ran
+    assert a["check"]["sum_nbox_last_step"] == b["check"]["sum_nbox_last_step"]
+    for k in ("phih_grid_sum", "xh_intermed_sum", "xh_av_sum"):
+        assert abs(a["check"][k] / b["check"][k] - 1) < 1e-11, k
+
+
 def test_bench_a_failing_rank_fails_the_run():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(C2R_BENCH_TEST_ONE_GPU="1", C2R_BENCH_TEST_FAIL_RANK="3")

@@ -122,6 +122,58 @@ def test_sparse_exchange_equals_the_full_all_reduce(tmp_path, case, fraction, mo
         assert st_sp["packed"] >= 1 and (fraction != "0.5" or st_sp["bytes_total"] < 0.1 * st_full["bytes_total"])
 
 
+def test_sparse_unpack_agrees_on_every_rank_when_the_collective_sums_in_an_offset_dependent_order(tmp_path, monkeypatch):
+    """A cell of several overlapping sub-boxes travels once per box; a ring / tree all-reduce (RCCL) sums each copy in an order
+    that depends on where in the buffer it lies, so the copies can come back differing in the last bit.  The write-back takes
+    the maximum of the copies with a 64-bit atomic (k_pack_boxes), whichever lands last: phih_grid -- and with it conv_flag
+    and the moment a rank leaves the evolve3D loop -- stays the same on every rank.  Harness collective: element i summed
+    starting at rank i mod nranks (C2R_HARNESS_ROTATE_SUM); three and four ranks, ten sources whose boxes overlap and are
+    packed although they add up to more than the mesh; the harness itself fails when the ranks' xh / phih_grid bits differ."""
+    assert os.path.exists(HARNESS)
+    m, a = load_case("evolve64_std_bubbles")
+    n, s = m["n"], m["steps"]["step001"]
+    write_input(str(tmp_path / "in.bin"), n, s, F(a["step001_ndens"]), F(a["step001_xh_before"]))
+    monkeypatch.setenv("C2R_HARNESS_ROTATE_SUM", "1")
+    monkeypatch.setenv("C2R_SPARSE_FRACTION", "50")
+    for nranks in (3, 4):
+        st = {}
+        r = read_output(run(tmp_path, "rot%d" % nranks, nranks, "host", 1, 0, st), n)     # (returns non-zero unless the replicas are identical)
+        assert st["packed"] >= 1
+        assert r["converged"] and r["niter"] == s["niter"] and r["conv"] == s["log"]["nonconv"]
+        assert np.max(np.abs(r["xh"] - F(a["step001_xh_after"]))) < tol("x")
+
+
+@pytest.mark.parametrize("case", ["evolve32_std_bubbles", "evolve64_std_bubbles"])
+def test_exchange_overlapped_with_the_sweep_equals_the_plain_exchange(tmp_path, case, monkeypatch):
+    """c2r_set_exchange_overlap (here through C2R_EXCHANGE_OVERLAP=1, and the 64-sources-per-rank threshold lowered for the
+    ten-source fixtures): every pass as two halves of a rank's sources into two pairs of accumulators, the first half's
+    all-reduce handed to the callback on a second stream before the second half is swept, the two reduced halves added.
+    Against the plain pass + all-reduce of the whole grid (C2R_SPARSE_EXCHANGE=0 in both): same iteration history, sub-box
+    counts, photon loss; xh and phih_grid to the re-association of the sums."""
+    assert os.path.exists(HARNESS)
+    m, a = load_case(case)
+    n, s = m["n"], m["steps"]["step001"]
+    write_input(str(tmp_path / "in.bin"), n, s, F(a["step001_ndens"]), F(a["step001_xh_before"]))
+    monkeypatch.setenv("C2R_SPARSE_EXCHANGE", "0")
+    monkeypatch.setenv("C2R_EXCHANGE_OVERLAP_MIN", "1")
+    for nranks, bal in ((2, 0), (3, 1), (4, 0)):
+        monkeypatch.setenv("C2R_EXCHANGE_OVERLAP", "0")
+        st0, st1 = {}, {}
+        plain = read_output(run(tmp_path, "plain%d" % nranks, nranks, "host", bal, 0, st0), n)
+        monkeypatch.setenv("C2R_EXCHANGE_OVERLAP", "1")
+        out = run(tmp_path, "ovl%d" % nranks, nranks, "host", bal, 0, st1)
+        ov = read_output(out, n)
+        assert ov["converged"] and ov["niter"] == plain["niter"] == s["niter"]
+        assert ov["conv"] == plain["conv"] == s["log"]["nonconv"]
+        assert ov["sum_nbox"] == plain["sum_nbox"]
+        assert abs(ov["loss"] - plain["loss"]) <= 1e-13 * abs(plain["loss"])
+        assert np.max(np.abs(ov["xh"] - plain["xh"])) < 1e-12
+        nz = plain["phih"] != 0
+        assert np.array_equal(ov["phih"] != 0, nz) and np.max(np.abs(ov["phih"][nz] / plain["phih"][nz] - 1)) < 1e-10     # (the last pass starts from an xh_av that differs by 1e-13: n_HI = (1 - x) n amplifies it)
+        # every pass exchanged two halves of a grid instead of one grid
+        assert st1["calls"] == st0["calls"] == s["niter"] and st1["bytes_total"] == 2 * st0["bytes_total"]
+
+
 def test_two_ranks_over_rccl(tmp_path):
     """ncclAllReduce of phih_grid between two devices of the node (libc2ray_rccl.so); skipped on a one-GPU box."""
     assert os.path.exists(HARNESS)
