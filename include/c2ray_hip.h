@@ -69,7 +69,11 @@ typedef struct c2r_params {
                                       *    modes share (kernels_common.hpp rates_fast: table position straight out of the logarithm,
                                       *    one 2^-48 reciprocal): inside |dGamma| <= 1e-13 Gamma + 2e-14 W of the oracle, the
                                       *    bound this mode has always stated (the rounding of the table position dominates it
-                                      *    in the reference's own libm too);
+                                      *    in the reference's own libm too).  The photon loss through a sub-box surface is taken
+                                      *    from the same routine, so the keep / retire decision of evolve_source.F90:128-131
+                                      *    compares a loss good to ~1e-13 with loss_fraction x flux: the integer results (sub-box
+                                      *    counts, visited cells) are tolerance-bound in BOTH modes -- equal to the reference's on
+                                      *    every fixture and in every fuzz run so far, not equal by construction;
                                       * C2R_SWEEP_FAST (1): the interpolation and the geometry re-associated as well (factored
                                       *    weights, 2^-48 reciprocals): same integer results, column densities within 1e-11 and
                                       *    rates within |dGamma| <= 1e-12 Gamma + 2e-14 W of the oracle (W = sum_s (1+tau_in)
