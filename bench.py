@@ -479,6 +479,30 @@ def main():
                 out["configs1_128_1src"][mode] = {"steps": k3, "ms_per_step": 1e3 * dt3 / k3, "value": float(n3) ** 3 * k3 / dt3,
                                                   "unit": "cells-traced/s", "sum_nbox_last_step": int(ev3.sum_nbox_all)}
                 b3.close()
+        if world == 1 and not args.no_small_leg and (n, S) == (256, 1000) and not args.thermal and not args.density_file:
+            # What one GPU's share of the 8-GPU strong-scaling run costs, on THIS box: 125 of the 1000 sources (the static share of
+            # rank 0), same field, next to an eighth of the headline step -- the ratio bounds the 8-GPU speed-up before the exchange
+            # (DESIGN.md s3d, s6).  Informational, outside the timed region.
+            b.close()
+            share = pkg.static_source_share(S, 0, 8)
+            b4 = pkg.HipBackend(n, thick, thin, device=local_rank, fast=args.sweep_mode == "fast")
+            b4.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], s["clumping"], s["temper"])
+            b4.set_sources(srcpos[share], normflux[share])
+            b4.load(ndens=nd, xh=xh)
+            ev4 = pkg.Evolve(b4)
+            b4.begin_step()
+            k4 = 6
+            for k in range(-2, k4):
+                if k == 0:
+                    torch.cuda.synchronize(); t4 = time.perf_counter()
+                ev4.iteration(k, s["dt"])
+            torch.cuda.synchronize()
+            ms4 = 1e3 * (time.perf_counter() - t4) / k4
+            out["one_gpu_share_of_8"] = {"sources": int(len(share)), "ms_per_step": ms4, "eighth_of_headline_ms": 1e3 * dt_wall / args.steps / 8.0,
+                                         "ratio": ms4 / (1e3 * dt_wall / args.steps / 8.0), "chains": b4.info().split("chains ")[1].split(";")[0],
+                                         "note": "its own field relaxes from x = %.3f with 125 sources only: sub-box counts as in the headline" % args.x_init,
+                                         "sum_nbox_last_step": int(ev4.sum_nbox_all)}
+            b4.close()
         if world == 1 and not args.no_dropin_leg and (n, S) == (256, 1000) and not args.thermal and not args.density_file:
             # The boundary north_star names, end to end: the reference's OWN program (C2Ray.F90 and every set-up module,
             # unmodified) with its evolve modules replaced by the Fortran shim + this library, on its own test problem

@@ -5,7 +5,8 @@ both fully and barely ionized gas, so that sub-boxes end anywhere between the fi
 row-group tiling of k_sweep_shell (three rows per thread, groups per sign class) meets every remainder; one case in
 two also draws a non-default switch: type_of_LLS 2 or 3, source-ordered (deterministic) Gamma accumulation, one
 source per batch; three in ten run in a non-isothermal context and compare the heating rates too (asserted here, within
-the Gamma tolerance with the heating weight W_heat)."""
+the Gamma tolerance with the heating weight W_heat); a quarter of the isothermal ones carry the second (X-ray) source type with
+the reference's power-law tables and a random NormFlux_xray per source (round 5)."""
 import numpy as np
 
 
@@ -40,7 +41,10 @@ def make_case(seed, pkg):
     deterministic = bool(rng.random() < 0.25)
     scratch = int(rng.choice([0, 0, 1]))     # 1 byte: one source per batch
     heating = bool(rng.random() < 0.3)       # a non-isothermal context: the sweep also accumulates the heating rates
-    return dict(heating=heating, mesh=mesh, dr=dr, vol=dr[0] * dr[1] * dr[2], nd=nd, xh=xh, pos=pos, nf=nf, lls=lls, k=k,
+    # (drawn last again, round 5) the second source type of photoion_rates: NormFlux_xray per source, some of them zero
+    xray = bool(rng.random() < 0.25) and not heating
+    nfx = 10.0 ** rng.uniform(3, 9, nsrc) * (rng.random(nsrc) < 0.7)
+    return dict(xray=xray, nfx=nfx, heating=heating, mesh=mesh, dr=dr, vol=dr[0] * dr[1] * dr[2], nd=nd, xh=xh, pos=pos, nf=nf, lls=lls, k=k,
                 lls_type=lls_type, lls_grid=lls_grid, r_max=r_max, deterministic=deterministic, scratch=scratch)
 
 
@@ -58,6 +62,11 @@ def run_case(seed, pkg, tables, fast):
         tt = load_thermal_tables()
         o.enable_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"], 9.0, np.zeros((ncell, 3), dtype=np.float32))
         wh = o.enable_heat_tolerance_weight()
+    if c["xray"]:
+        import os
+        from tests._util import GOLDEN
+        pl = np.load(os.path.join(GOLDEN, "tables_pl.npz"))
+        o.enable_xray(pl["thick"], pl["thin"], c["nfx"])
     phih_o = np.zeros(ncell)
     oloss, onb, ovis = o.pass_sources(c["nd"], c["xh"], phih_o, c["pos"], c["nf"])
     w = w.copy()
@@ -70,6 +79,8 @@ def run_case(seed, pkg, tables, fast):
     b.set_sources(c["pos"], c["nf"]); b.set_rank(0, 1); b.load(ndens=c["nd"], xh=c["xh"])
     if c["heating"]:
         b.set_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"])
+    if c["xray"]:
+        b.set_xray(pl["thick"], pl["thin"], c["nfx"])
     b.begin_step(); b.zero_rates()
     loss, nbox, vis = b.pass_sources()
     phih = b.fetch("phih_grid")
@@ -87,13 +98,13 @@ def run_case(seed, pkg, tables, fast):
     assert np.array_equal(phih == 0, phih_o == 0), (seed, mesh)
     k = c["k"]
     nb1, l1, v1, cd = b.do_source(k + 1, want_coldens=True)
-    nbo, lo1, vo, cdo = o.do_source(c["nd"], c["xh"], np.zeros(ncell), c["pos"][k], c["nf"][k])
+    nbo, lo1, vo, cdo = o.do_source(c["nd"], c["xh"], np.zeros(ncell), c["pos"][k], c["nf"][k], c["nfx"][k] if c["xray"] else 0.0)
     b.close()
     assert nb1 == nbo and v1 == vo, (seed, mesh, k)
     assert np.array_equal(cd == 0, cdo == 0), (seed, mesh, k)
     d = np.abs(phih - phih_o)
     nz = phih_o != 0
-    return dict(mesh=mesh, nsrc=len(c["nf"]), nbox=nbox, visited=vis, variant="lls%d%s%s%s" % (c["lls_type"], " det" if c["deterministic"] else "", " batches" if c["scratch"] else "", " heat" if c["heating"] else ""), heat_w=heat_w,
+    return dict(mesh=mesh, nsrc=len(c["nf"]), nbox=nbox, visited=vis, variant="lls%d%s%s%s" % (c["lls_type"], " det" if c["deterministic"] else "", " batches" if c["scratch"] else "", " heat" if c["heating"] else "") + (" xray" if c["xray"] else ""), heat_w=heat_w,
                 loss=abs(loss - oloss) / max(abs(oloss), 1e-300),
                 cd=float(np.max(np.abs(cd - cdo) / np.maximum(cdo, 1e-300))),
                 gamma_rel=float(np.max(d[nz] / phih_o[nz])) if nz.any() else 0.0,
