@@ -43,7 +43,15 @@ def sources_for(mesh, nsrc):
     return [(int(p[0]), int(p[1]), int(p[2]), float(f) * pkg.testproblem.S_STAR) for p, f in zip(pos, nf)]
 
 
-def run_leg(mesh, srcs, first_slice, leg, timeout):
+def read_sm3d(path, dtype):
+    """xfrac3D / IonRates3D files (read_sm3d.f90:63-103): int32 12 | n1 n2 n3 | 12 | nbytes | data | nbytes."""
+    import numpy as np
+    raw = open(path, "rb").read()
+    nb = int(np.frombuffer(raw, dtype=np.int32, count=1, offset=20)[0])
+    return np.frombuffer(raw, dtype=dtype, count=nb // np.dtype(dtype).itemsize, offset=24)
+
+
+def run_leg(mesh, srcs, first_slice, leg, timeout, keep_outputs=None):
     sub, prog = {"serial": ("serial", "c2ray_test"), "omp": ("omp", "c2ray_test"),
                  "hip-hoststats": ("hip_hoststats", "c2ray_test_hip")}.get(leg, ("hip", "c2ray_test_hip"))
     exe = os.path.join(ROOT, "oracle", "_ref", "N%d" % mesh, sub, prog)
@@ -102,6 +110,11 @@ def run_leg(mesh, srcs, first_slice, leg, timeout):
             out["sweep_mode"] = m.group(1) if m else None
         else:
             out["evolve3d_s"] = sum(steps)
+        if keep_outputs is not None:        # the ionized-fraction outputs of the run, for --compare
+            import numpy as np
+            for f in sorted(os.listdir(d + "/results")):
+                if f.startswith("xfrac3D_"):
+                    keep_outputs[f] = np.array(read_sm3d(d + "/results/" + f, np.float64))
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -113,6 +126,8 @@ def main():
     ap.add_argument("--legs", default="hip-exact,hip-fast")
     ap.add_argument("--timeout", type=int, default=1800)
     ap.add_argument("--out", default=None, help="also write the JSON there")
+    ap.add_argument("--compare", action="store_true",
+                    help="keep every leg's xfrac3D outputs and report, per leg, the largest |difference| from the FIRST leg's over all of them")
     a = ap.parse_args()
     res = {"host_cores": os.cpu_count(), "cases": []}
     for case in a.cases.split(","):
@@ -120,8 +135,18 @@ def main():
         mesh, nsrc, first = int(m.group(1)), int(m.group(2)), int(m.group(3) or 1)
         srcs = sources_for(mesh, nsrc)
         row = {"case": case, "mesh": mesh, "sources": nsrc, "first_slice": first, "steps_expected": 15 - first, "legs": []}
+        ref_out = None
         for leg in a.legs.split(","):
-            r = run_leg(mesh, srcs, first, leg, a.timeout)
+            outs = {} if a.compare else None
+            r = run_leg(mesh, srcs, first, leg, a.timeout, outs)
+            if a.compare:
+                if ref_out is None:
+                    ref_out = outs
+                    r["outputs"] = sorted(outs)
+                else:
+                    import numpy as np
+                    r["same_output_files_as_first_leg"] = sorted(outs) == sorted(ref_out)
+                    r["xfrac_max_abs_diff_vs_first_leg"] = max([float(np.max(np.abs(outs[k] - ref_out[k]))) for k in outs if k in ref_out] or [None])
             row["legs"].append(r)
             sys.stderr.write("%s %s: %s\n" % (case, leg, json.dumps({k: v for k, v in r.items() if k not in ("split_per_step", "evolve3d_s_per_step_timings_log")})))
         res["cases"].append(row)

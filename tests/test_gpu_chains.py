@@ -54,6 +54,19 @@ def test_chains_give_one_chains_results(pkg, tables, monkeypatch, S):
         assert np.max(np.abs(r[4][live] - one[4][live]) / one[4][live]) < 1e-13      # atomics in another order
 
 
+def test_chains_over_several_rounds_of_a_small_scratch(pkg, tables, monkeypatch):
+    """200 sources through a scratch that holds 90 at a time (C2R_BATCH_CAP): rounds of 90 (two chains of 45), 90 and 20 (below
+    64: one chain) -- the same results as everything at once on one chain."""
+    n, S = 64, 200
+    s, nd, xh, pos, nf = _case(pkg, n, S, 77)
+    one = _pass(pkg, tables, monkeypatch, 1, n, s, nd, xh, pos, nf)
+    monkeypatch.setenv("C2R_BATCH_CAP", "90")
+    r = _pass(pkg, tables, monkeypatch, None, n, s, nd, xh, pos, nf)
+    assert r[0] == one[0] and r[1:3] == one[1:3] and np.array_equal(r[3], one[3])
+    live = one[4] > 0
+    assert np.array_equal(r[4] > 0, live) and np.max(np.abs(r[4][live] - one[4][live]) / one[4][live]) < 1e-13
+
+
 def test_chained_pass_against_the_oracle(pkg, tables, monkeypatch, sweep_mode):
     """The default rule's chains at 100 sources on 48^3 against the pinned oracle: integers equal, Gamma inside the mode's tolerance."""
     n, S = 48, 100
