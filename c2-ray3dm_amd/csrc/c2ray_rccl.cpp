@@ -73,9 +73,11 @@ int c2r_rccl_attach(c2r_ctx *ctx, const void *id, int32_t rank, int32_t nranks)
 {
     if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return C2R_EINVAL;
     if (find(ctx)) return C2R_ESTATE;                       // already attached
+    int32_t dev = 0;
+    if (c2r_get_device(ctx, &dev) != C2R_OK || hipSetDevice(dev) != hipSuccess) return C2R_ESTATE;   // the communicator lives on the context's device
     Link *l = new Link();
     ncclUniqueId uid = *static_cast<const ncclUniqueId *>(id);
-    ncclResult_t r = ncclCommInitRank(&l->comm, nranks, uid, rank);   // on the device current in c2r_create
+    ncclResult_t r = ncclCommInitRank(&l->comm, nranks, uid, rank);
     if (r != ncclSuccess) { delete l; return (int)r; }
     // a single rank keeps the callback too: c2r_rccl_allreduce stays usable, the library skips it
     int rc = c2r_set_rank(ctx, rank, nranks, rccl_cb, l);

@@ -100,9 +100,10 @@ def test_bench_eight_ranks_equal_one_rank(form, balance):
 
 
 def test_bench_two_ranks_with_the_exchange_overlapped():
-    """bench.py --gpus 2 --overlap-exchange (two ranks on the one GPU, gloo): 128 sources, i.e. 64 per rank -- the pass runs as
-    two halves with the first half's all-reduce in flight during the second; same checksums as one rank."""
-    args = ["--steps", "2", "--warmup", "1", "--mesh", "64", "--sources", "128", "--no-cpu-baseline", "--no-other-mode"]
+    """bench.py --gpus 2 --overlap-exchange (two ranks on the one GPU, gloo): 256 sources, i.e. 128 per rank -- the pass runs as
+    two halves of 64 (each as two chains in flight) with the first half's all-reduce issued before the second is swept; same
+    checksums as one rank."""
+    args = ["--steps", "2", "--warmup", "1", "--mesh", "64", "--sources", "256", "--no-cpu-baseline", "--no-other-mode"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, capture_output=True, text=True,
                          timeout=900, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]

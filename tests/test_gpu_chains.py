@@ -67,6 +67,32 @@ def test_chains_over_several_rounds_of_a_small_scratch(pkg, tables, monkeypatch)
     assert np.array_equal(r[4] > 0, live) and np.max(np.abs(r[4][live] - one[4][live]) / one[4][live]) < 1e-13
 
 
+def test_chains_in_a_non_isothermal_context(pkg, tables, monkeypatch):
+    """The HEAT kernels under chains: 90 sources, the rates AND the heating rates (a second accumulator pair all chains add
+    into) as one chain leaves them, to the order of the atomics."""
+    from tests._util import load_thermal_tables
+    n, S = 48, 90
+    s, nd, xh, pos, nf = _case(pkg, n, S, 11)
+    tt = load_thermal_tables()
+    res = []
+    for chains in (1, 3):
+        monkeypatch.setenv("C2R_CHAINS", str(chains))
+        b = pkg.HipBackend(n, *tables, device=0)
+        b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], 1.0)
+        b.set_sources(pos, nf); b.set_rank(0, 1); b.load(ndens=nd, xh=xh)
+        b.set_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"])
+        b.begin_step(); b.zero_rates()
+        loss, nbox, vis = b.pass_sources()
+        res.append((loss, nbox, vis, b.fetch("phih_grid"), b.fetch("phiheat_grid")))
+        b.close()
+    a, c = res
+    assert a[:3] == c[:3]
+    for k in (3, 4):
+        live = a[k] > 0
+        assert live.any() and np.array_equal(c[k] > 0, live)
+        assert np.max(np.abs(c[k][live] - a[k][live]) / a[k][live]) < 1e-13
+
+
 def test_chained_pass_against_the_oracle(pkg, tables, monkeypatch, sweep_mode):
     """The default rule's chains at 100 sources on 48^3 against the pinned oracle: integers equal, Gamma inside the mode's tolerance."""
     n, S = 48, 100
