@@ -91,6 +91,7 @@ SYMBOLS = [
     ("c2r_set_sources", C.c_int, [_P, _P, _P, _I32]),
     ("c2r_set_exchange_overlap", C.c_int, [_P, _I32]),
     ("c2r_set_xray_tables", C.c_int, [_P, _P, _P, _I32]),
+    ("c2r_set_xray_heat_tables", C.c_int, [_P, _P, _P, _I32]),
     ("c2r_set_xray_sources", C.c_int, [_P, _P, _I32]),
     ("c2r_set_rank", C.c_int, [_P, _I32, _I32, ALLREDUCE_FN, _P]),
     ("c2r_set_slab_chemistry", C.c_int, [_P, _P, _P, _P]),

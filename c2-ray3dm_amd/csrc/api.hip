@@ -11,6 +11,8 @@ int check_ready(Ctx *ctx)
     HIP_TRY(hipSetDevice(ctx->prm.device));
     if (!ctx->have_tables) FAIL(C2R_ESTATE, "c2r_set_tables has not been called");
     if (!ctx->have_step) FAIL(C2R_ESTATE, "c2r_set_step has not been called");
+    if (ctx->thermal && ctx->xray && !ctx->have_xheat)
+        FAIL(C2R_ESTATE, "non-isothermal run with the X-ray source type: c2r_set_xray_heat_tables has not been called (heat_lookuptable's \"P\" tables)");
     return C2R_OK;
 }
 
@@ -172,7 +174,7 @@ void c2r_destroy(c2r_ctx *c)
     free_sweep_scratch(ctx);
     for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
     hipFree(ctx->grid[5]); hipFree(ctx->grid[6]); hipFree(ctx->d_hthick); hipFree(ctx->d_hthin); hipFree(ctx->d_cool); hipFree(ctx->d_heat_T);
-    hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_xthick); hipFree(ctx->d_xthin); hipFree(ctx->d_logtab); hipFree(ctx->d_odtab);
+    hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_xthick); hipFree(ctx->d_xthin); hipFree(ctx->d_xhthick); hipFree(ctx->d_xhthin); hipFree(ctx->d_logtab); hipFree(ctx->d_odtab);
     hipFree(ctx->d_nhi); hipFree(ctx->d_nhi_T); hipFree(ctx->d_phih_T); hipFree(ctx->d_step); hipFree(ctx->d_pack); hipFree(ctx->d_boxdesc);
     if (ctx->h_boxdesc) hipHostFree(ctx->h_boxdesc);
     hipFree(ctx->d_lls); hipFree(ctx->d_lls_T); hipFree(ctx->d_clump);
@@ -249,7 +251,6 @@ int c2r_set_xray_tables(c2r_ctx *c, const double *thick, const double *thin, int
     ++ctx->gen;                                   // (captured launch sequences hold the choice of kernel)
     if (!thick) { ctx->xray = false; return C2R_OK; }
     if (n != ctx->prm.numtau + 1) FAIL(C2R_EINVAL, "table length must be numtau+1");
-    if (ctx->thermal) FAIL(C2R_ESTATE, "the X-ray source type is built for isothermal runs only (heat_lookuptable's \"P\" tables are not)");
     if (!ctx->d_xthick) HIP_TRY(hipMalloc(&ctx->d_xthick, (size_t)(n + 1) * sizeof(double)));
     if (!ctx->d_xthin) HIP_TRY(hipMalloc(&ctx->d_xthin, (size_t)(n + 1) * sizeof(double)));
     // padded like the stellar tables: tab[numtau+1] = tab[numtau]
@@ -258,6 +259,23 @@ int c2r_set_xray_tables(c2r_ctx *c, const double *thick, const double *thin, int
     HIP_TRY(hipMemcpy(ctx->d_xthick + n, thick + n - 1, sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_xthin + n, thin + n - 1, sizeof(double), hipMemcpyHostToDevice));
     ctx->xray = true;
+    return C2R_OK;
+}
+
+int c2r_set_xray_heat_tables(c2r_ctx *c, const double *heat_thick, const double *heat_thin, int32_t n)
+{
+    if (!c || !heat_thick || !heat_thin) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (n != ctx->prm.numtau + 1) FAIL(C2R_EINVAL, "table length must be numtau+1");
+    HIP_TRY(hipSetDevice(ctx->prm.device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (!ctx->d_xhthick) HIP_TRY(hipMalloc(&ctx->d_xhthick, (size_t)(n + 1) * sizeof(double)));
+    if (!ctx->d_xhthin) HIP_TRY(hipMalloc(&ctx->d_xhthin, (size_t)(n + 1) * sizeof(double)));
+    HIP_TRY(hipMemcpy(ctx->d_xhthick, heat_thick, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_xhthin, heat_thin, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_xhthick + n, heat_thick + n - 1, sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_xhthin + n, heat_thin + n - 1, sizeof(double), hipMemcpyHostToDevice));
+    ctx->have_xheat = true; ++ctx->gen;
     return C2R_OK;
 }
 
@@ -334,7 +352,6 @@ int c2r_set_thermal(c2r_ctx *c, const c2r_thermal_params *t, const double *heat_
     ++ctx->gen;
     if (ctx->prm.deterministic_rates && (t != nullptr) != ctx->thermal) free_sweep_scratch(ctx);   // per-source heating grids come and go
     if (!t) { ctx->thermal = false; return C2R_OK; }     // back to the isothermal path (the arrays stay allocated)
-    if (ctx->xray) FAIL(C2R_ESTATE, "the X-ray source type is built for isothermal runs only: c2r_set_xray_tables(ctx, NULL, NULL, 0) first");
     if (!heat_thick || !heat_thin || !cie_cool) FAIL(C2R_EINVAL, "non-isothermal run needs the heating tables and the cooling curve");
     if (n != ctx->prm.numtau + 1) FAIL(C2R_EINVAL, "table length must be numtau+1");
     if (t->cool_points < 2 || !(t->cool_dtemp > 0.0) || !(t->gamma1 > 0.0) || !(t->k_B > 0.0) || t->thermal_max_steps < 1)

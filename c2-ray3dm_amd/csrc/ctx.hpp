@@ -87,6 +87,7 @@ struct Ctx {
     std::vector<double>  nflux;
     // the second source type of photoion_rates (builds with use_xray_SED=.true.): c2r_set_xray
     bool xray = false; std::vector<double> nflux_x; double *d_xthick = nullptr, *d_xthin = nullptr;
+    bool have_xheat = false; double *d_xhthick = nullptr, *d_xhthin = nullptr;          // its heating tables (c2r_set_xray_heat_tables: non-isothermal runs)
     int nsrc = 0, rank = 0, nranks = 1;
     bool explicit_share = false; std::vector<int32_t> share;   // c2r_set_source_share: this rank's sources
     std::vector<int32_t> last_nbox;                              // final sub-box count per local source, last pass

@@ -85,6 +85,7 @@ struct KParams {
     // builds with use_xray_SED=.true. (sed_parameters.f90:56; XRAY kernels only, EXT & 2): the second source type of
     // photoion_rates (radiation_photoionrates.F90:133-137) -- its tables (padded like thick/thin) and NormFlux_xray per source
     const double *xthick, *xthin;
+    const double *xhthick, *xhthin;   // ... and its heating tables (xray_heat_thick/thin_table; HEAT and XRAY together, EXT == 3)
     const double *normflux_x;  // S_batch
     double *planes;            // [S_batch][2][6][P][P]
 };
@@ -316,6 +317,11 @@ __device__ __forceinline__ double photoion(const KParams &p, const v2f64 *__rest
         }
         p_out = p_out + x_out;
         rate = rate + fdiv(x_cell, vol_ph);
+        if (EXT & 1) {                            // :165-171  phi = phi + heat_lookuptable(..., NormFlux_xray(nsrc), "P", ...)
+            const double hx_in = nflux_x * read_table(p.xhthick, pin);
+            if (fabs(tau_out - tau_in) > p.tau_heat_limit) *heat = *heat + fdiv(hx_in - nflux_x * read_table(p.xhthick, pout), vol_ph);
+            else *heat = *heat + fdiv(nflux_x * ((cd_out - cd_in) * p.sigma) * read_table(p.xhthin, pin), vol_ph);
+        }
     }
     return rate;
 }
@@ -412,6 +418,12 @@ __device__ __forceinline__ double rates_fast(const KParams &p, const v2f64 *__re
         else { dX = (tau_out - tau_in) * table_at(p.xthin, od_in); x_out = x_in - dX; }
         p_out = p_out + nflux_x * x_out;
         gamma = gamma + (nflux_x * dX) * r;
+        if (EXT & 1) {                     // :165-171 its heating rate, from the X-ray heating tables at the same positions
+            double dHx;
+            if (fabs(tau_out - tau_in) > p.tau_heat_limit) dHx = table_at(p.xhthick, od_in) - table_at(p.xhthick, od_out);
+            else dHx = ((cd_out - cd_in) * p.sigma) * table_at(p.xhthin, od_in);
+            heat = heat + (nflux_x * dHx) * rcp1(vol_ph);
+        }
     }
     return gamma;
 }

@@ -165,7 +165,7 @@ KParams make_kparams(const Ctx *ctx, const SweepScratch &sc)
     k.od_per_e = (double)(0.301029995663981195213738894724493027L / (long double)p.dlogtau);
     k.od_per_ln = (double)(0.434294481903251827651128918916605082L / (long double)p.dlogtau);
     k.srcpos = sc.d_srcpos_b; k.srcw = sc.d_srcw_b; k.normflux = sc.d_nflux_b; k.planes = sc.d_planes;
-    k.xthick = ctx->d_xthick; k.xthin = ctx->d_xthin; k.normflux_x = sc.d_nflux_x;
+    k.xthick = ctx->d_xthick; k.xthin = ctx->d_xthin; k.xhthick = ctx->d_xhthick; k.xhthin = ctx->d_xhthin; k.normflux_x = sc.d_nflux_x;
     return k;
 }
 
@@ -379,7 +379,11 @@ struct BatchSweep {
         const int (&boxR)[3] = bx.boxR, (&boxL)[3] = bx.boxL;
         const int bound = bx.bound;
         {
-            if (ctx->thermal)
+            if (ctx->thermal && ctx->xray)
+                hipLaunchKernelGGL(k_source_cells<3>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
+                                   sc.d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
+                                   sc.d_loss_acc, dbg);
+            else if (ctx->thermal)
                 hipLaunchKernelGGL(k_source_cells<1>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound,
                                    sc.d_active[cur], boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2],
                                    sc.d_loss_acc, dbg);
@@ -416,7 +420,10 @@ struct BatchSweep {
         if (nbox == 1 && ctx->fold_source_cell) {
             if (ba.nshell > 0) ba.source_cell = 1;
             else {      // no shell at all to walk (degenerate limits): the plain kernel after all
-                if (ctx->thermal)
+                if (ctx->thermal && ctx->xray)
+                    hipLaunchKernelGGL(k_source_cells<3>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, sc.d_active[cur],
+                                       boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], sc.d_loss_acc, dbg);
+                else if (ctx->thermal)
                     hipLaunchKernelGGL(k_source_cells<1>, dim3((bound + 63) / 64), dim3(64), 0, st, k, bound, sc.d_active[cur],
                                        boxR[0], boxR[1], boxR[2], boxL[0], boxL[1], boxL[2], sc.d_loss_acc, dbg);
                 else if (ctx->xray)
@@ -439,7 +446,7 @@ struct BatchSweep {
             // (not in the k_sweep_shell launch timing of c2r_profile: a different kernel, 21^3 cells per source)
 #define C2R_LAUNCH_FUSED_H(D, L, H) do { if (ctx->fast) hipLaunchKernelGGL((k_sweep_box_fused<D, L, true, H>), grid, blk, 0, st, k, ba); \
                                 else hipLaunchKernelGGL((k_sweep_box_fused<D, L, false, H>), grid, blk, 0, st, k, ba); } while (0)
-#define C2R_LAUNCH_FUSED(D, L) do { if (ctx->thermal) C2R_LAUNCH_FUSED_H(D, L, 1); else if (ctx->xray) C2R_LAUNCH_FUSED_H(D, L, 2); else C2R_LAUNCH_FUSED_H(D, L, 0); } while (0)
+#define C2R_LAUNCH_FUSED(D, L) do { if (ctx->thermal && ctx->xray) C2R_LAUNCH_FUSED_H(D, L, 3); else if (ctx->thermal) C2R_LAUNCH_FUSED_H(D, L, 1); else if (ctx->xray) C2R_LAUNCH_FUSED_H(D, L, 2); else C2R_LAUNCH_FUSED_H(D, L, 0); } while (0)
             switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
                 case 2: C2R_LAUNCH_FUSED(false, 1); break;
                 case 3: C2R_LAUNCH_FUSED(true, 1); break;
@@ -486,7 +493,7 @@ struct BatchSweep {
                      else hipLaunchKernelGGL((k_sweep_pair_fast<D, L, false, H>), grid, blk, 0, st, k, sa, sb); } \
     else if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_pair<D, L, true, H>), grid, blk, 0, st, k, sa, sb); \
     else hipLaunchKernelGGL((k_sweep_pair<D, L, false, H>), grid, blk, 0, st, k, sa, sb); } while (0)
-#define C2R_LAUNCH_PAIR(D, L) do { if (ctx->thermal) C2R_LAUNCH_PAIR_H(D, L, 1); else if (ctx->xray) C2R_LAUNCH_PAIR_H(D, L, 2); else C2R_LAUNCH_PAIR_H(D, L, 0); } while (0)
+#define C2R_LAUNCH_PAIR(D, L) do { if (ctx->thermal && ctx->xray) C2R_LAUNCH_PAIR_H(D, L, 3); else if (ctx->thermal) C2R_LAUNCH_PAIR_H(D, L, 1); else if (ctx->xray) C2R_LAUNCH_PAIR_H(D, L, 2); else C2R_LAUNCH_PAIR_H(D, L, 0); } while (0)
                     switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
                         case 2: C2R_LAUNCH_PAIR(false, 1); break;
                         case 3: C2R_LAUNCH_PAIR(true, 1); break;
@@ -512,7 +519,7 @@ struct BatchSweep {
                      else hipLaunchKernelGGL((k_sweep_shell_fast<D, L, false, H>), grid, blk, 0, st, k, sa); } \
     else if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_shell<D, L, true, H>), grid, blk, 0, st, k, sa); \
     else hipLaunchKernelGGL((k_sweep_shell<D, L, false, H>), grid, blk, 0, st, k, sa); } while (0)
-#define C2R_LAUNCH_SWEEP(D, L) do { if (ctx->thermal) C2R_LAUNCH_SWEEP_H(D, L, 1); else if (ctx->xray) C2R_LAUNCH_SWEEP_H(D, L, 2); else C2R_LAUNCH_SWEEP_H(D, L, 0); } while (0)
+#define C2R_LAUNCH_SWEEP(D, L) do { if (ctx->thermal && ctx->xray) C2R_LAUNCH_SWEEP_H(D, L, 3); else if (ctx->thermal) C2R_LAUNCH_SWEEP_H(D, L, 1); else if (ctx->xray) C2R_LAUNCH_SWEEP_H(D, L, 2); else C2R_LAUNCH_SWEEP_H(D, L, 0); } while (0)
                 switch (ctx->lls_type * 2 + (det ? 1 : 0)) {
                     case 2: C2R_LAUNCH_SWEEP(false, 1); break;
                     case 3: C2R_LAUNCH_SWEEP(true, 1); break;
@@ -1169,7 +1176,7 @@ int c2r_evolve0d_host(c2r_ctx *c, int32_t ns, const int32_t rtpos[3], const int3
     KParams k = make_kparams(ctx, ctx->sc[0]);
     double *d_out = ctx->d_sum_out;                              // 4 doubles of device scratch
 #define C2R_LAUNCH_CELL_H(L, H) hipLaunchKernelGGL((k_evolve0d_cell<L, H>), dim3(1), dim3(64), 0, st, k, sa, face, a, b, is_source ? 1 : 0, on_surface ? 1 : 0, cv[0], cv[1], cv[2], cv[3], d_out)
-#define C2R_LAUNCH_CELL(L) do { if (ctx->thermal) C2R_LAUNCH_CELL_H(L, 1); else if (ctx->xray) C2R_LAUNCH_CELL_H(L, 2); else C2R_LAUNCH_CELL_H(L, 0); } while (0)
+#define C2R_LAUNCH_CELL(L) do { if (ctx->thermal && ctx->xray) C2R_LAUNCH_CELL_H(L, 3); else if (ctx->thermal) C2R_LAUNCH_CELL_H(L, 1); else if (ctx->xray) C2R_LAUNCH_CELL_H(L, 2); else C2R_LAUNCH_CELL_H(L, 0); } while (0)
     switch (ctx->lls_type) { case 1: C2R_LAUNCH_CELL(1); break; case 2: C2R_LAUNCH_CELL(2); break; default: C2R_LAUNCH_CELL(3); break; }
 #undef C2R_LAUNCH_CELL
 #undef C2R_LAUNCH_CELL_H

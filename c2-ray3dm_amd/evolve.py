@@ -194,6 +194,11 @@ class HipBackend:
             f = np.ascontiguousarray(normflux_xray, dtype=np.float64)
             self._check(self.lib.c2r_set_xray_sources(self.ctx, f.ctypes.data, len(f)), "c2r_set_xray_sources")
 
+    def set_xray_heat(self, heat_thick, heat_thin):
+        """The X-ray source type's heating tables (c2r_set_xray_heat_tables): non-isothermal contexts need them before a pass."""
+        k = np.ascontiguousarray(heat_thick, dtype=np.float64); t = np.ascontiguousarray(heat_thin, dtype=np.float64)
+        self._check(self.lib.c2r_set_xray_heat_tables(self.ctx, k.ctypes.data, t.ctypes.data, len(k)), "c2r_set_xray_heat_tables")
+
     def set_source_share(self, indices=None):
         """Explicit list of this rank's sources (0-based) instead of the static stride; None resets."""
         if indices is None:

@@ -34,7 +34,8 @@ module c2ray_hip
   use sourceprops, only: NumSrc, srcpos, NormFlux_stellar, NormFlux_xray
   use radiation_sizes, only: NumTau
   use radiation_tables, only: stellar_photo_thick_table, stellar_photo_thin_table, minlogtau, dlogtau, &
-       stellar_heat_thick_table, stellar_heat_thin_table, xray_photo_thick_table, xray_photo_thin_table
+       stellar_heat_thick_table, stellar_heat_thin_table, xray_photo_thick_table, xray_photo_thin_table, &
+       xray_heat_thick_table, xray_heat_thin_table
   use sed_parameters, only: use_xray_SED
   use radiation_sed_parameters, only: S_star
   use cgsphotoconstants, only: sigma_HI_at_ion_freq
@@ -171,6 +172,12 @@ module c2ray_hip
        real(c_double), intent(in) :: thick(*), thin(*)
        integer(c_int32_t), value :: n
      end function c2r_set_xray_tables
+     integer(c_int) function c2r_set_xray_heat_tables(ctx, heat_thick, heat_thin, n) bind(C, name="c2r_set_xray_heat_tables")
+       import :: c_int, c_ptr, c_double, c_int32_t
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: heat_thick(*), heat_thin(*)
+       integer(c_int32_t), value :: n
+     end function c2r_set_xray_heat_tables
      integer(c_int) function c2r_set_xray_sources(ctx, normflux_xray, nsrc) bind(C, name="c2r_set_xray_sources")
        import :: c_int, c_ptr, c_double, c_int32_t
        type(c_ptr), value :: ctx
@@ -414,6 +421,8 @@ contains
     if (use_xray_SED) then
        call check(c2r_set_xray_tables(ctx, xray_photo_thick_table(:,1), xray_photo_thin_table(:,1), &
             int(NumTau+1, c_int32_t)), "c2r_set_xray_tables")
+       if (.not.isothermal) call check(c2r_set_xray_heat_tables(ctx, xray_heat_thick_table(:,1), xray_heat_thin_table(:,1), &
+            int(NumTau+1, c_int32_t)), "c2r_set_xray_heat_tables")
        write(logf,*) "c2ray_hip: X-ray source type on the device (photo_lookuptable 'P')"
     endif
 #ifdef MPI

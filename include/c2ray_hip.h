@@ -162,11 +162,14 @@ int  c2r_set_tables(c2r_ctx *ctx, const double *thick, const double *thin, int32
  * second normalised flux per source (NormFlux_xray: column 5 of the source list / S_star_xray, sourceprops.F90:63, :381, :631).
  * A source is traced while its STELLAR flux leaves its sub-box (evolve_source.F90:119: total_source_flux counts that alone);
  * where NormFlux_xray > 0 the X-ray rate is added cell by cell and its photons count in photo_out.
- * c2r_set_xray_tables(ctx, thick, thin, numtau+1): switch it on (NULL, NULL: off); isothermal contexts only.
+ * c2r_set_xray_tables(ctx, thick, thin, numtau+1): switch it on (NULL, NULL: off).
+ * c2r_set_xray_heat_tables(ctx, heat_thick, heat_thin, numtau+1): non-isothermal contexts (c2r_set_thermal) need the type's
+ *   heating tables too (xray_heat_thick/thin_table, radiation_tables.F90:84-85; heat_lookuptable "P", :165-171) before a pass.
  * c2r_set_xray_sources(ctx, normflux_xray, nsrc): after every c2r_set_sources with a new list; sources without a value: 0.
  * (The reference fills these tables from an array it never sets, radiation_tables.F90:367: they are inputs here -- e.g.
  * c2r_build_tables with C2R_SED_POWER_LAW.) */
 int  c2r_set_xray_tables(c2r_ctx *ctx, const double *thick, const double *thin, int32_t n);
+int  c2r_set_xray_heat_tables(c2r_ctx *ctx, const double *heat_thick, const double *heat_thin, int32_t n);
 int  c2r_set_xray_sources(c2r_ctx *ctx, const double *normflux_xray, int32_t nsrc);
 
 /* Per-time-step scalars the driver recomputes before every evolve3D call (C2Ray.F90:367-376):

@@ -63,6 +63,7 @@ typedef struct {
     const double *xray_thick; /* xray_photo_thick_table(0:NumTau,1) */
     const double *xray_thin;  /* xray_photo_thin_table(0:NumTau,1)  */
     const double *xray_flux;  /* NormFlux_xray(1:NumSrc): column 5 of the source list / S_star_xray (sourceprops.F90:381, 631) */
+    const double *xray_heat_thick, *xray_heat_thin;   /* xray_heat_thick/thin_table(0:NumTau,1): non-isothermal runs (heat_lookuptable "P", :165-171) */
     long   *thermal_stats;    /* checker diagnostic (NULL = off): [0] thermal() calls, [1] of them left untouched because T_initial <=
                                * minitemp (thermal.f90:83), [2] of them ended by the sub-step cap i_heating > 10000 (:163), [3] sub-steps
                                * in all -- what the fixtures exercise; the reference has no such counters */
@@ -334,6 +335,10 @@ static void evolve0d(sweep_t *s, const int rt[3])
             phi[0] = phi[0] + px[0]; phi[1] = phi[1] + px[1]; phi[2] = phi[2] + px[2];
         }
         if (c->heat_thick) heat = oracle_heat_rate(c->heat_thick, c->heat_thin, cd_in, cd_out, vol_ph, s->normflux);   /* radiation_photoionrates.F90:142-172 */
+        if (c->heat_thick && c->xray_heat_thick && s->normflux_x > 0.0) {                                               /* :165-171 phi = phi + heat "P" */
+            heat = heat + oracle_heat_rate(c->xray_heat_thick, c->xray_heat_thin, cd_in, cd_out, vol_ph, s->normflux_x);
+            if (c->tolw_heat) c->tolw_heat[id] += (1.0 + cd_in * C2R_SIGMA_HI) * s->normflux_x * table_lookup(c->xray_heat_thick, cd_in * C2R_SIGMA_HI) / vol_ph;
+        }
         if (c->heat_thick && c->tolw_heat && s->normflux > 0.0)
             c->tolw_heat[id] += (1.0 + cd_in * C2R_SIGMA_HI) * s->normflux * table_lookup(c->heat_thick, cd_in * C2R_SIGMA_HI) / vol_ph;
         phi[0] = phi[0] / (xav0 * nd);                                         /* :262 */

@@ -28,6 +28,7 @@ class Cfg(C.Structure):
                 ("cool_mintemp", C.c_double), ("cool_dtemp", C.c_double), ("zred", C.c_double),
                 ("temper_grid", C.c_void_p), ("phiheat", C.c_void_p), ("tolw_heat", C.c_void_p),
                 ("xray_thick", C.c_void_p), ("xray_thin", C.c_void_p), ("xray_flux", C.c_void_p),
+                ("xray_heat_thick", C.c_void_p), ("xray_heat_thin", C.c_void_p),
                 ("thermal_stats", C.c_void_p)]
 
 
@@ -90,6 +91,13 @@ class Oracle:
         c.tolw = None
         c.cfg.tolw = None
         return c
+
+    def enable_xray_heat(self, heat_thick, heat_thin):
+        """The X-ray type's heating tables (non-isothermal runs: heat_lookuptable "P")."""
+        self.xray_heat_thick = np.ascontiguousarray(heat_thick, dtype=np.float64)
+        self.xray_heat_thin = np.ascontiguousarray(heat_thin, dtype=np.float64)
+        assert self.xray_heat_thick.size == 2001 and self.xray_heat_thin.size == 2001
+        self.cfg.xray_heat_thick, self.cfg.xray_heat_thin = self.xray_heat_thick.ctypes.data, self.xray_heat_thin.ctypes.data
 
     def enable_xray(self, xray_thick, xray_thin, xray_flux):
         """The second source type of photoion_rates (use_xray_SED=.true.): its two tables and NormFlux_xray per source, in the

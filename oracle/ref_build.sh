@@ -45,9 +45,10 @@ SRCS="precision.f90 mathconstants.f90 cgsconstants.f90 cgsastroconstants.f90 c2r
 #          133-137, 167-171).  The reference fills its X-ray tables from an UNINITIALISED local array (radiation_tables.F90:367,
 #          :405-425: xray_SED is never set; sed_parameters.f90:55 "not yet implemented"), so ref_driver overwrites
 #          xray_photo_thick/thin_table with tables it is handed (namelist xray_tables=) before any rate is evaluated.
-variant_file () {   # $1 = variant -> the reference file the variant rewrites
+variant_file () {   # $1 = variant -> the reference file(s) the variant rewrites
   case "$1" in
     pl|xray) echo sed_parameters.f90 ;;
+    xraythermal) echo "sed_parameters.f90 c2ray_parameters.f90" ;;     # use_xray_SED=.true. AND isothermal=.false.
     *) echo c2ray_parameters.f90 ;;
   esac
 }
@@ -60,6 +61,11 @@ params_for_variant () {   # $1 = variant, $2 = output file
     grey)   sed 's|^\( *logical,parameter :: grey = \).false.|\1.true.|' "$REF/c2ray_parameters.f90" > "$2"; grep -q "grey = .true." "$2" ;;
     pl)     sed 's|^\( *integer,parameter :: stellar_SED_type=\)1|\12|' "$REF/sed_parameters.f90" > "$2"; grep -q "stellar_SED_type=2" "$2" ;;
     xray)   sed 's|^\( *logical,parameter :: use_xray_SED=\).false.|\1.true.|' "$REF/sed_parameters.f90" > "$2"; grep -q "use_xray_SED=.true." "$2" ;;
+    xraythermal)
+      case "$(basename "$2")" in
+        sed_parameters.f90) sed 's|^\( *logical,parameter :: use_xray_SED=\).false.|\1.true.|' "$REF/sed_parameters.f90" > "$2"; grep -q "use_xray_SED=.true." "$2" ;;
+        *) sed 's|^\( *logical,parameter :: isothermal=\).true.|\1.false.|' "$REF/c2ray_parameters.f90" > "$2"; grep -q "isothermal=.false." "$2" ;;
+      esac ;;
     *) echo "unknown variant $1" >&2; exit 1 ;;
   esac
 }
@@ -72,13 +78,16 @@ build_variant () {   # $1 = mesh[:variant], $2 = subdir, $3 = extra flags
   sed "s|^\( *integer,dimension(Ndim),parameter,public :: mesh=\)(/ 300, 300, 300 /)|\1(/ $N, $N, $N /)|" \
       "$REF/sizes.f90" > "$B/sizes.f90"
   grep -q "mesh=(/ $N, $N, $N /)" "$B/sizes.f90"
-  local VF=""
-  [ -n "$V" ] && VF=$(variant_file "$V") && params_for_variant "$V" "$B/$VF"
+  local VF="" vf
+  if [ -n "$V" ]; then
+    VF=$(variant_file "$V")
+    for vf in $VF; do params_for_variant "$V" "$B/$vf"; done
+  fi
   local objs=""
   for s in $SRCS; do
     local src o
     if [ "${s#@}" != "$s" ]; then src="$B/${s#@}"; else src="$REF/$s"; fi
-    [ -n "$V" ] && [ "$s" = "$VF" ] && src="$B/$VF"
+    for vf in $VF; do [ "$s" = "$vf" ] && src="$B/$vf"; done
     o="$B/$(basename "${s#@}" | sed 's/\.[fF]90$/.o/')"
     if [ ! -f "$o" ] || [ "$src" -nt "$o" ]; then
       ( cd "$B" && $FC $FLAGS -c "$src" -o "$o" 2>>"$B/build.log" )

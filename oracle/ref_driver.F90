@@ -30,7 +30,8 @@ program ref_driver
   use sizes, only: mesh
   use grid, only: grid_ini, dr, vol
   use radiation_tables, only: rad_ini, stellar_photo_thick_table, stellar_photo_thin_table, &
-       stellar_heat_thick_table, stellar_heat_thin_table, xray_photo_thick_table, xray_photo_thin_table
+       stellar_heat_thick_table, stellar_heat_thin_table, xray_photo_thick_table, xray_photo_thin_table, &
+       xray_heat_thick_table, xray_heat_thin_table
   use sed_parameters, only: use_xray_SED
   use radiative_cooling, only: setup_cool, coolin
   use thermalevolution, only: thermal
@@ -103,6 +104,10 @@ program ref_driver
      open(newunit=u, file=trim(xray_tables), access='stream', form='unformatted', status='old')
      read(u) xray_photo_thick_table(:,1)
      read(u) xray_photo_thin_table(:,1)
+     if (.not.isothermal) then          ! ... followed by the type's heating tables (radiation_tables.F90:84-85)
+        read(u) xray_heat_thick_table(:,1)
+        read(u) xray_heat_thin_table(:,1)
+     endif
      close(u)
   endif
   if (.not.isothermal) call setup_cool()          ! C2Ray.F90:143 (reads ./tables/corocool.tab)

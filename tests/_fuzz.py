@@ -5,8 +5,8 @@ both fully and barely ionized gas, so that sub-boxes end anywhere between the fi
 row-group tiling of k_sweep_shell (three rows per thread, groups per sign class) meets every remainder; one case in
 two also draws a non-default switch: type_of_LLS 2 or 3, source-ordered (deterministic) Gamma accumulation, one
 source per batch; three in ten run in a non-isothermal context and compare the heating rates too (asserted here, within
-the Gamma tolerance with the heating weight W_heat); a quarter of the isothermal ones carry the second (X-ray) source type with
-the reference's power-law tables and a random NormFlux_xray per source (round 5)."""
+the Gamma tolerance with the heating weight W_heat); a quarter carry the second (X-ray) source type with the reference's
+power-law tables and a random NormFlux_xray per source -- with its heating tables where the context heats (round 5)."""
 import numpy as np
 
 
@@ -42,7 +42,7 @@ def make_case(seed, pkg):
     scratch = int(rng.choice([0, 0, 1]))     # 1 byte: one source per batch
     heating = bool(rng.random() < 0.3)       # a non-isothermal context: the sweep also accumulates the heating rates
     # (drawn last again, round 5) the second source type of photoion_rates: NormFlux_xray per source, some of them zero
-    xray = bool(rng.random() < 0.25) and not heating
+    xray = bool(rng.random() < 0.25)         # (with heating: the X-ray type's heating tables too)
     nfx = 10.0 ** rng.uniform(3, 9, nsrc) * (rng.random(nsrc) < 0.7)
     return dict(xray=xray, nfx=nfx, heating=heating, mesh=mesh, dr=dr, vol=dr[0] * dr[1] * dr[2], nd=nd, xh=xh, pos=pos, nf=nf, lls=lls, k=k,
                 lls_type=lls_type, lls_grid=lls_grid, r_max=r_max, deterministic=deterministic, scratch=scratch)
@@ -67,6 +67,11 @@ def run_case(seed, pkg, tables, fast):
         from tests._util import GOLDEN
         pl = np.load(os.path.join(GOLDEN, "tables_pl.npz"))
         o.enable_xray(pl["thick"], pl["thin"], c["nfx"])
+        if c["heating"]:
+            import ctypes as C
+            sed = pkg.SedParams(); pkg.load_library().c2r_default_sed_power_law(C.byref(sed))
+            xhk, xhn = pkg._capi.build_heat_tables(sed)
+            o.enable_xray_heat(xhk, xhn)
     phih_o = np.zeros(ncell)
     oloss, onb, ovis = o.pass_sources(c["nd"], c["xh"], phih_o, c["pos"], c["nf"])
     w = w.copy()
@@ -81,6 +86,8 @@ def run_case(seed, pkg, tables, fast):
         b.set_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"])
     if c["xray"]:
         b.set_xray(pl["thick"], pl["thin"], c["nfx"])
+        if c["heating"]:
+            b.set_xray_heat(xhk, xhn)
     b.begin_step(); b.zero_rates()
     loss, nbox, vis = b.pass_sources()
     phih = b.fetch("phih_grid")

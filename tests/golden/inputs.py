@@ -77,7 +77,7 @@ def run_driver(n, sources, nml, dens=None, xfield=None, extra_files=None, omp=Fa
     shutil.rmtree(d, ignore_errors=True)
     os.makedirs(d + "/results")
     os.makedirs(d + "/dump")
-    if variant == "thermal":                   # setup_cool (cooling.f90:64) opens ./tables/corocool.tab
+    if variant in ("thermal", "xraythermal"):  # setup_cool (cooling.f90:64) opens ./tables/corocool.tab
         os.makedirs(d + "/tables")
         open(d + "/tables/corocool.tab", "w").write(cooling_table(cooling)[0])
     with open(d + "/answers", "w") as f:

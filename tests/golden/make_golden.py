@@ -51,10 +51,10 @@ def xray_files(xray):
     """run_driver arguments that hand the fixture driver the X-ray tables (ref_driver.F90: namelist xray_tables)."""
     if xray is None:
         return {}, {}
-    thick, thin = xray
-    def w(p):
+    def w(p):        # thick, thin[, heat thick, heat thin]
         with open(p, "wb") as f:
-            np.ascontiguousarray(thick, dtype=np.float64).tofile(f); np.ascontiguousarray(thin, dtype=np.float64).tofile(f)
+            for t in xray:
+                np.ascontiguousarray(t, dtype=np.float64).tofile(f)
     return {"xray.f64": w}, {"xray_tables": "'xray.f64'"}
 
 
@@ -220,7 +220,7 @@ def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, kee
             arrays[tag + "_phiheat_grid"] = rd(d, tag + "_phiheat_grid.f64", n)
     if lls_grid is not None: arrays["lls_grid"] = lls_grid.astype(np.float32)
     if clump_grid is not None: arrays["clump_grid"] = clump_grid.astype(np.float32)
-    if xray is not None: arrays["xray_thick"], arrays["xray_thin"] = xray
+    if xray is not None: arrays["xray_thick"], arrays["xray_thin"] = xray[:2]
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
     json.dump(meta, open(os.path.join(HERE, name + ".json"), "w"), indent=1)
     print(name, {t: m["niter"] for t, m in meta["steps"].items()})
@@ -242,10 +242,12 @@ def case_sweep(name, n, sources, x_init=None, dens_seed=None, xfield=None, ns_du
     phih = rd(d, tag + "_phih_grid.f64", n)
     cdo = rd(d, tag + "_coldensh_out.f64", n)
     arrays = {"xh": rd(d, tag + "_xh_before.f64", n), "ndens": rd(d, tag + "_ndens.f32", n, np.float32)}
-    if variant == "thermal":
+    if variant in ("thermal", "xraythermal"):
         arrays["phiheat"] = rd(d, tag + "_phiheat_grid.f64", n)
     if xray is not None:
-        arrays["xray_thick"], arrays["xray_thin"] = xray
+        arrays["xray_thick"], arrays["xray_thin"] = xray[:2]
+        if len(xray) == 4:
+            arrays["xray_heat_thick"], arrays["xray_heat_thin"] = xray[2:]
     if full:
         arrays.update(phih=phih, coldensh_out=cdo)
     else:   # large grids: three orthogonal planes through source ns_dump + checksums
@@ -483,6 +485,22 @@ def main():
         case_sweep("sweep32_xray", 32, src, dens_seed=5, xfield=x, ns_dump=5, variant="xray", xray=xr)
         x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 6.0)
         case_evolve("evolve32_xray", 32, src, 1, [1], dens_seed=11, xfield=x, variant="xray", xray=xr)
+    if want("xraythermal"):
+        # both switches: use_xray_SED=.true. and isothermal=.false. (ref_build.sh 32:xraythermal): the X-ray type also heats
+        # (heat_lookuptable "P", radiation_photoionrates.F90:165-171).  Its four tables are inputs: the power-law photo tables of
+        # the reference (tables_pl) and the power-law heating tables of our builder (c2r_build_heat_tables, C2R_SED_POWER_LAW).
+        sys.path.insert(0, ROOT)
+        import ctypes as C
+        import __graft_entry__ as g
+        pkg = g.load_package()
+        sed = pkg.SedParams(); pkg.load_library().c2r_default_sed_power_law(C.byref(sed))
+        hk, hn = pkg._capi.build_heat_tables(sed)
+        pl = np.load(os.path.join(HERE, "tables_pl.npz"))
+        xr = (pl["thick"], pl["thin"], hk, hn)
+        src = [SRC_STD[0] + (3e6,), SRC_STD[1] + (0.0,), SRC_STD[2] + (2e7,), SRC_STD[3] + (0.0,), SRC_STD[4] + (5e8,),
+               SRC_STD[5] + (0.0,), SRC_STD[6] + (1e6,), SRC_STD[7] + (0.0,), SRC_STD[8] + (4e8,), SRC_STD[9] + (0.0,)]
+        x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 7.0)
+        case_sweep("sweep32_xraythermal", 32, src, dens_seed=5, xfield=x, ns_dump=5, variant="xraythermal", xray=xr)
     # non-isothermal run (isothermal=.false.), with the synthetic cooling table of inputs.cooling_table()
     if want("thermal"):
         case_thermal_tables_and_points()

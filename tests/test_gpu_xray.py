@@ -76,7 +76,40 @@ def test_evolve3d_with_xray_sources_vs_reference(pkg, tables):
     b.close()
 
 
-def test_xray_needs_an_isothermal_context_and_matching_lists(pkg, tables):
+def test_sweep_with_xray_heating_vs_reference(pkg, tables):
+    """Non-isothermal context with the X-ray source type (EXT = 3 kernels): rates and heating rates against the reference
+    rebuilt with both switches (fixture sweep32_xraythermal); c2r_set_xray_heat_tables is required before a pass."""
+    from tests._util import load_thermal_tables, TOL, sweep_mode
+    m, a = load_case("sweep32_xraythermal")
+    n = m["n"]
+    nd, xh = F(expand(a["ndens"], n)), F(expand(a["xh"], n))
+    tt = load_thermal_tables()
+    o = oracle_for(m, tables, n)
+    o.enable_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"], m["zred"], np.zeros((n ** 3, 3), dtype=np.float32))
+    o.enable_xray(a["xray_thick"], a["xray_thin"], m["normflux_xray"]); o.enable_xray_heat(a["xray_heat_thick"], a["xray_heat_thin"])
+    w, wh = o.enable_tolerance_weight(), o.enable_heat_tolerance_weight()
+    o.pass_sources(nd, xh, np.zeros(n ** 3), m["srcpos"], m["normflux"])
+    b = pkg.HipBackend(n, *tables, device=0)
+    b.set_step((m["dr1"], m["dr2"], m["dr3"]), m["vol"], m["coldensh_LLS"], m["clumping"])
+    b.set_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"])
+    b.set_sources(m["srcpos"], m["normflux"]); b.set_rank(0, 1)
+    b.set_xray(a["xray_thick"], a["xray_thin"], m["normflux_xray"])
+    b.load(ndens=nd, xh=xh, temperature_grid=np.full(n ** 3, 1e4, dtype=np.float32))
+    b.begin_step(); b.zero_rates()
+    with pytest.raises(pkg.C2RayHipError, match="c2r_set_xray_heat_tables"):
+        b.pass_sources()
+    b.set_xray_heat(a["xray_heat_thick"], a["xray_heat_thin"])
+    loss, nbox, vis = b.pass_sources()
+    assert nbox == m["sum_nbox"] and abs(loss - m["photon_loss"]) <= tol("loss") * abs(m["photon_loss"])
+    assert_gamma(b.fetch("phih_grid"), F(a["phih"]), w, "X-ray + heating: Gamma")
+    heat, ref = b.fetch("phiheat_grid"), F(a["phiheat"])
+    t = TOL[sweep_mode()]
+    assert np.array_equal(heat == 0, ref == 0)
+    assert (np.abs(heat - ref) - (t["gamma_rtol"] * ref + t["gamma_wtol"] * wh)).max() <= 0
+    b.close()
+
+
+def test_xray_setters_check_their_arguments(pkg, tables):
     import ctypes as C
     lib = pkg.load_library()
     p = pkg.default_params(16)

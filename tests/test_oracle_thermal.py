@@ -54,6 +54,26 @@ def test_sweep_heating_rates_vs_reference():
     assert np.count_nonzero(o.phiheat) == np.count_nonzero(phih) > 5000
 
 
+def test_sweep_with_xray_heating_vs_reference():
+    """Both switches at once -- use_xray_SED=.true. and isothermal=.false. (ref_build.sh 32:xraythermal): the X-ray source type
+    also heats (heat_lookuptable with the "P" tables, radiation_photoionrates.F90:165-171).  Rates AND heating rates of the
+    reference's sweep, bit for bit."""
+    m, a = load_case("sweep32_xraythermal")
+    n = m["n"]
+    o = thermal_oracle_for(m, TAB, np.zeros((n ** 3, 3), dtype=np.float32), n)
+    o.enable_xray(a["xray_thick"], a["xray_thin"], m["normflux_xray"])
+    o.enable_xray_heat(a["xray_heat_thick"], a["xray_heat_thin"])
+    nd, xh = F(a["ndens"]), F(a["xh"])
+    phih = np.zeros(n ** 3)
+    loss, nb, vis = o.pass_sources(nd, xh, phih, m["srcpos"], m["normflux"])
+    assert nb == m["sum_nbox"] and loss == m["photon_loss"]
+    assert np.array_equal(phih, F(a["phih"])) and np.array_equal(o.phiheat, F(a["phiheat"]))
+    # ... and the X-ray heating is in there: the stellar-only heating rates of the same field differ
+    o2 = thermal_oracle_for(m, TAB, np.zeros((n ** 3, 3), dtype=np.float32), n)
+    o2.pass_sources(nd, xh, np.zeros(n ** 3), m["srcpos"], m["normflux"])
+    assert np.max(np.abs(o2.phiheat - o.phiheat) / np.maximum(o.phiheat, 1e-300)) > 0.1
+
+
 def test_evolve3d_nonisothermal_vs_reference():
     """Whole steps 1 and 3 of a non-isothermal run: iteration history, xh, Gamma, heating rates and the three temperature
     fields, all equal to the reference's."""
