@@ -800,14 +800,18 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
 // Deterministic mode: phih(cell) += Gamma_s(cell) for the sources of a batch IN SOURCE ORDER (the order
 // of the serial reference, evolve_point.F90:283 inside master_slave.F90:85's loop).  One thread per
 // cell; a source contributes where the cell lies inside its final sub-box (evolve_source.F90:135-136).
+// A block is an 8 (x) by 32 (y) tile of one z-plane, a wave 8 by 8 cells: a source's rate sits in its x-fastest grid for cells
+// of its z / y faces and in its y-fastest grid for cells of its x faces (that is how the sweep's waves wrote them), and
+// groups of 8 consecutive cells in EITHER direction are one 64-byte sector -- both reads are sector-efficient.  (Round 5; the
+// former row-of-256-cells mapping read the y-fastest grids with a stride of a mesh row: a sector per cell, 70 ms per pass at
+// 256^3 x 1000 against ~35 now; the sums and their order are unchanged.)
 __global__ __launch_bounds__(256) void k_gamma_reduce(KParams p, int nsrc, const int *final_nbox, int subbox,
                                                       double *phih, double *heat /* phiheat_grid, or null */,
                                                       const int *gate = nullptr /* see k_transpose_xy */)
 {
     if (gate && *gate != 0) return;
-    // block = 256 cells along x of one (y,z) row: the y and z parts of the box test are block-uniform
-    const int c0 = blockIdx.x * 256 + threadIdx.x, c1 = blockIdx.y, c2 = blockIdx.z;
-    const bool live = c0 < p.n[0];
+    const int c0 = blockIdx.x * 8 + (threadIdx.x & 7), c1 = blockIdx.y * 32 + (threadIdx.x >> 3), c2 = blockIdx.z;
+    const bool live = c0 < p.n[0] && c1 < p.n[1];
     const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
     const unsigned id = (unsigned)c0 + (unsigned)p.n[0] * ((unsigned)c1 + (unsigned)p.n[1] * (unsigned)c2);
     const unsigned id_t = (unsigned)c1 + (unsigned)p.n[1] * ((unsigned)c0 + (unsigned)p.n[0] * (unsigned)c2);
@@ -817,16 +821,14 @@ __global__ __launch_bounds__(256) void k_gamma_reduce(KParams p, int nsrc, const
         const int nb = final_nbox[s];                 // uniform
         if (nb <= 0) continue;
         const int ext = subbox * nb;
-        int d1 = c1 - p.srcw[3 * s + 1], d2 = c2 - p.srcw[3 * s + 2];
-        d1 -= (d1 > p.hr[1]) ? p.n[1] : 0;  d1 += (d1 < -p.hl[1]) ? p.n[1] : 0;
+        int d2 = c2 - p.srcw[3 * s + 2];              // uniform: the whole tile lies in one z-plane
         d2 -= (d2 > p.hr[2]) ? p.n[2] : 0;  d2 += (d2 < -p.hl[2]) ? p.n[2] : 0;
-        if (d1 < -min(ext, p.hl[1]) || d1 > min(ext, p.hr[1]) || d2 < -min(ext, p.hl[2]) || d2 > min(ext, p.hr[2]))
-            continue;                                 // the whole row lies outside this source's box
-        const int m12 = max(abs(d1), abs(d2));
-        int d0 = c0 - p.srcw[3 * s + 0];
+        if (d2 < -min(ext, p.hl[2]) || d2 > min(ext, p.hr[2])) continue;
+        int d0 = c0 - p.srcw[3 * s + 0], d1 = c1 - p.srcw[3 * s + 1];
         d0 -= (d0 > p.hr[0]) ? p.n[0] : 0;  d0 += (d0 < -p.hl[0]) ? p.n[0] : 0;
-        if (live && d0 >= -min(ext, p.hl[0]) && d0 <= min(ext, p.hr[0])) {
-            const bool xf = abs(d0) > m12;            // cinterp branch priority z > y > x
+        d1 -= (d1 > p.hr[1]) ? p.n[1] : 0;  d1 += (d1 < -p.hl[1]) ? p.n[1] : 0;
+        if (live && d0 >= -min(ext, p.hl[0]) && d0 <= min(ext, p.hr[0]) && d1 >= -min(ext, p.hl[1]) && d1 <= min(ext, p.hr[1])) {
+            const bool xf = abs(d0) > max(abs(d1), abs(d2));            // cinterp branch priority z > y > x
             const double *g = p.gbox + ((size_t)s * 2 + (xf ? 1 : 0)) * ncell;
             acc = acc + g[xf ? id_t : id];
             if (heat) acc_h = acc_h + (p.gbox_h + ((size_t)s * 2 + (xf ? 1 : 0)) * ncell)[xf ? id_t : id];

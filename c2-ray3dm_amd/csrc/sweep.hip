@@ -616,7 +616,7 @@ struct BatchSweep {
     void gamma_reduce(const int *gate)
     {
         if (sc.d_gbox)
-            hipLaunchKernelGGL(k_gamma_reduce, dim3((p.mesh[0] + 255) / 256, p.mesh[1], p.mesh[2]), dim3(256), 0, st, k, count,
+            hipLaunchKernelGGL(k_gamma_reduce, dim3((p.mesh[0] + 7) / 8, (p.mesh[1] + 31) / 32, p.mesh[2]), dim3(256), 0, st, k, count,
                                sc.d_final_nbox, p.subboxsize, (double *)ctx->grid[4], ctx->thermal ? (double *)ctx->grid[5] : nullptr, gate);
     }
 
