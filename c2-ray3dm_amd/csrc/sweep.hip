@@ -782,7 +782,10 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
 // before any count of sub-box n - 1 is waited for, so the streams always hold work of every chain and the GPU overlaps one
 // chain's launch with the tail of another's.  Same launches, same arguments, same per-source results as one chain after
 // the other; only the order in which the Gamma atomics of different sources land can differ (as it may within one launch).
-constexpr int kChainAhead = 2;
+#ifndef C2R_CHAIN_AHEAD
+#define C2R_CHAIN_AHEAD 2          // (3 measured the same: profiles/r05_chains)
+#endif
+constexpr int kChainAhead = C2R_CHAIN_AHEAD;
 int run_chains(Ctx *ctx, int first, int count, bool first_of_pass, std::vector<int> *nbox_out)
 {
     const int nch = std::min(ctx->nchains, count);
