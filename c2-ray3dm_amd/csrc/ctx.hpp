@@ -158,6 +158,7 @@ struct Ctx {
     double *d_dbg = nullptr, *d_pair = nullptr;
     unsigned long long *d_seq = nullptr, seq_seen = 0;           // passes completed by fused iterations (k_pass_final counts, the host polls h_sc->seq)
     bool spin_wait = true;                                       // C2R_SPIN_WAIT=0: always hipStreamSynchronize (experiments)
+    bool poll_wait = true;                                       // C2R_POLL_WAIT=0: the sub-box counts are waited for with hipEventSynchronize alone (experiments)
     double *h_it4 = nullptr, *d_hit4 = nullptr;   // pinned [C2R_MAX_ITER_LOG][4]: per-iteration photon-statistics sums, written by the device
     // profiling
     int prof = 0;               // 0 off; 1 an event pair around every k_sweep_shell launch; 2 one pair per sub-box

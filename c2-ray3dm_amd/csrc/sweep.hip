@@ -290,6 +290,24 @@ int plane_set_before(const Ctx *ctx, int nbox, int n_active, bool pair_ok)
     return set;
 }
 
+// Wait for an event by polling it first: the wake-up of a blocking event wait is 20 - 50 us, which is what a sub-box of a few
+// dozen sources lasts; after half a millisecond the ordinary wait takes over.
+int wait_polling(Ctx *ctx, hipEvent_t ev)
+{
+    if (!ctx->poll_wait) { HIP_TRY(hipEventSynchronize(ev)); return C2R_OK; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; hipEventQuery(ev) != hipSuccess; ++spins) {
+        if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) {
+            (void)hipGetLastError();
+            HIP_TRY(hipEventSynchronize(ev));
+            return C2R_OK;
+        }
+        cpu_relax();
+    }
+    (void)hipGetLastError();                 // (hipErrorNotReady of the polls)
+    return C2R_OK;
+}
+
 // One batch of sources through the sweep -- local sources [first, first+count) of this rank's list: the staging block, the
 // launches of a sub-box (source cells, fused first sub-boxes, shells and look-ahead pairs, loss sums, the decision), the
 // captured launch sequence of a small batch and the wait behind a fused iteration, the run-ahead schedule.  sweep_batch()
@@ -756,7 +774,7 @@ int BatchSweep::run(std::vector<int> *nbox_out, std::vector<double> *loss_out)
         // (many sources: always the previous box's -- one sub-box stays in flight from the first box on)
         const int need = !few ? nbox - 1 : (nbox == hint ? nbox : (nbox > hint ? nbox - 1 : 0));
         if (need > known) {
-            HIP_TRY(hipEventSynchronize(sc.ev_box[need]));
+            { const int rc = wait_polling(ctx, sc.ev_box[need]); if (rc) return rc; }
             known = need; bound = sc.h_nactive[need];
         }
     }
@@ -822,16 +840,8 @@ int run_chains(Ctx *ctx, int first, int count, bool first_of_pass, std::vector<i
             while (b.known < nbox && hipEventQuery(b.sc.ev_box[b.known + 1]) == hipSuccess) b.bound = b.sc.h_nactive[++b.known];
             const int need = nbox - kChainAhead;
             if (need > b.known) {
-                // poll before blocking: the wake-up of an event wait is 20 - 50 us, a sub-box near the source lasts 100
-                const auto t0 = std::chrono::steady_clock::now();
-                for (unsigned spins = 0; hipEventQuery(b.sc.ev_box[need]) != hipSuccess; ++spins) {
-                    if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) {
-                        HIP_TRY(hipEventSynchronize(b.sc.ev_box[need]));
-                        break;
-                    }
-                    cpu_relax();
-                }
-                (void)hipGetLastError();                 // (hipErrorNotReady of the polls)
+                // (polling before blocking: a sub-box near the source lasts about as long as the wake-up of an event wait)
+                { const int rc = wait_polling(ctx, b.sc.ev_box[need]); if (rc) return rc; }
                 b.known = need; b.bound = b.sc.h_nactive[need];
             }
         }
