@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
-template <int MODE>      // 0: f64 atomic add   1: u64 atomic add   2: two u64 adds, two arrays   3: f64 add + u64 add, two arrays   4: two f64 adds, two arrays
+template <int MODE>      // 0: f64 atomic add   1: u64 atomic add   2: two u64 adds, two arrays   3: f64 add + u64 add, two arrays   4: two f64 adds, two arrays   5: two f64 adds, interleaved in one array (a[2 id], a[2 id + 1]; a must hold 2 n)
 __global__ __launch_bounds__(256) void k(double *a, double *b, unsigned nrows, int rounds, unsigned seed)
 {
     const unsigned wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void k(double *a, double *b, unsigned nrows, i
         if (MODE == 2) { atomicAdd(reinterpret_cast<unsigned long long *>(a) + id, 3ULL); atomicAdd(reinterpret_cast<unsigned long long *>(b) + id, 5ULL); }
         if (MODE == 3) { atomicAdd(a + id, 1.0); atomicAdd(reinterpret_cast<unsigned long long *>(b) + id, 5ULL); }
         if (MODE == 4) { atomicAdd(a + id, 1.0); atomicAdd(b + id, 1.0); }
+        if (MODE == 5) { atomicAdd(a + 2 * id, 1.0); atomicAdd(a + 2 * id + 1, 1.0); }
     }
 }
 template <int MODE>
@@ -41,10 +42,10 @@ double run(double *a, double *b, size_t n, int blocks, int rounds)
 int main()
 {
     const size_t n = (size_t)256 * 256 * 256;
-    double *a, *b; hipMalloc(&a, n * 8); hipMalloc(&b, n * 8); hipMemset(a, 0, n * 8); hipMemset(b, 0, n * 8);
+    double *a, *b; hipMalloc(&a, n * 16); hipMalloc(&b, n * 8); hipMemset(a, 0, n * 16); hipMemset(b, 0, n * 8);
     for (int blocks : {16384}) for (int rounds : {64, 512}) {
-        printf("blocks %d rounds %d, visits/s:  f64 add %.3e   u64 add %.3e   two u64 adds (two arrays) %.3e   f64 + u64 %.3e   two f64 adds %.3e\n", blocks, rounds,
-               run<0>(a, b, n, blocks, rounds), run<1>(a, b, n, blocks, rounds), run<2>(a, b, n, blocks, rounds), run<3>(a, b, n, blocks, rounds), run<4>(a, b, n, blocks, rounds));
+        printf("blocks %d rounds %d, visits/s:  f64 add %.3e   u64 add %.3e   two u64 adds (two arrays) %.3e   f64 + u64 %.3e   two f64 adds %.3e   two f64 adds interleaved %.3e\n", blocks, rounds,
+               run<0>(a, b, n, blocks, rounds), run<1>(a, b, n, blocks, rounds), run<2>(a, b, n, blocks, rounds), run<3>(a, b, n, blocks, rounds), run<4>(a, b, n, blocks, rounds), run<5>(a, b, n, blocks, rounds));
     }
     return 0;
 }
