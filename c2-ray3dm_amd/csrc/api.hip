@@ -57,6 +57,10 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     if (const char *e = getenv("C2R_FUSED_ITER")) ctx->fused_iter = atoi(e) != 0;
     if (const char *e = getenv("C2R_PAIR_SHELLS")) ctx->pair_shells = atoi(e) != 0;
     if (const char *e = getenv("C2R_SPIN_WAIT")) ctx->spin_wait = atoi(e) != 0;
+    if (const char *e = getenv("C2R_XCD_ORDER")) ctx->xcd_order = atoi(e);
+    if (const char *e = getenv("C2R_XCD_MIN_PER_PLANE")) ctx->xcd_min_per_plane = atof(e);
+    if (const char *e = getenv("C2R_XCD_MIN_ALIVE")) ctx->xcd_min_alive = atof(e);
+    if (const char *e = getenv("C2R_XCD_QMIN")) ctx->xcd_qmin = std::max(1, atoi(e));
     if (const char *e = getenv("C2R_POLL_WAIT")) ctx->poll_wait = atoi(e) != 0;
     if (const char *e = getenv("C2R_FOLD_SOURCE_CELL")) ctx->fold_source_cell = atoi(e) != 0;
     if (const char *e = getenv("C2R_SPARSE_EXCHANGE")) ctx->sparse_exchange = atoi(e) != 0;
@@ -209,6 +213,7 @@ const char *c2r_info(c2r_ctx *c)
                 "; rank " + std::to_string(ctx->rank) + " of " + std::to_string(ctx->nranks) +
                 "; chains " + std::to_string(ctx->nchains) +
                 "; exchanges overlapped with the sweep " + std::to_string(ctx->xchg_overlapped) +
+                "; plane-ordered launches " + std::to_string(ctx->xcd_launches) +
                 "; graph captures " + std::to_string(ctx->captures);
     if (!ctx->info_warn.empty()) ctx->info += "; " + ctx->info_warn;
     return ctx->info.c_str();

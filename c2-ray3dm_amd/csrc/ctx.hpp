@@ -55,6 +55,7 @@ struct SweepScratch {
     hipEvent_t ev_done = nullptr;                            // 'this chain's launches of the pass have run'
     double *d_loss_partial = nullptr, *d_loss_acc = nullptr, *d_final_loss = nullptr;
     int *d_final_nbox = nullptr;
+    int *d_perm = nullptr, *h_perm = nullptr;                // [3][cap]: the batch's traceable sources sorted by wrapped position along each axis (k_sweep_shell_xcd)
 };
 
 struct Ctx {
@@ -158,6 +159,10 @@ struct Ctx {
     double *d_dbg = nullptr, *d_pair = nullptr;
     unsigned long long *d_seq = nullptr, seq_seen = 0;           // passes completed by fused iterations (k_pass_final counts, the host polls h_sc->seq)
     bool spin_wait = true;                                       // C2R_SPIN_WAIT=0: always hipStreamSynchronize (experiments)
+    // XCD-aware, plane-ordered block mapping of the far shells (k_sweep_shell_xcd): C2R_XCD_ORDER = 0 never, 1 always where it
+    // can run, unset: where at least xcd_min_per_plane sources share a mesh plane and face sign (sources / mesh planes)
+    int xcd_order = -1; double xcd_min_per_plane = 1.5; double xcd_min_alive = 0.9; int xcd_qmin = 16;
+    long long xcd_launches = 0;
     bool poll_wait = true;                                       // C2R_POLL_WAIT=0: the sub-box counts are waited for with hipEventSynchronize alone (experiments)
     double *h_it4 = nullptr, *d_hit4 = nullptr;   // pinned [C2R_MAX_ITER_LOG][4]: per-iteration photon-statistics sums, written by the device
     // profiling

@@ -92,7 +92,7 @@ __device__ __forceinline__ unsigned plane_off8(const KParams &p, int a, int b)
 
 // XONLY: read n_HI and the LLS grid from the x-fastest arrays whatever the face (same values; the look-ahead recompute
 // calls this with a per-lane face and must not pick a buffer per lane)
-template <int LLS, bool STREAM, bool XONLY = false>
+template <int LLS, int STREAM /* 0 / 1 / 2: see shell_rows_fast_core */, bool XONLY = false>
 __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArgs &sa, const int face, const int s,
                                                 const int a, const int b, const double c1v, const double c2v,
                                                 const double c3v, const double c4v, const double r1, const double r2,
@@ -118,7 +118,7 @@ __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArg
     cs.id = ca + __umul24(na, cb + __umul24(nb, c2));
     const unsigned ncell = (unsigned)p.n[0] * (unsigned)p.n[1] * (unsigned)p.n[2];
     const __amdgpu_buffer_rsrc_t r_x = make_rsrc(xf ? p.nhi_T : p.nhi, ncell * 8u);
-    cs.nhi = buf_load_f64<STREAM ? C2R_NHI_AUX : 0>(r_x, cs.id * 8u);
+    cs.nhi = buf_load_f64<STREAM == 1 ? C2R_NHI_AUX : 0>(r_x, cs.id * 8u);
     cs.o8 = plane_off8(p, a, b);
 
     // cinterp, generic in (a,b,pd): the three branches differ only by which axes play (u,v).
@@ -262,7 +262,7 @@ constexpr int kRows = C2R_ROWS;
 #define C2R_PAIR_LDS_TABLE 0        // 1: the pair kernels fill the per-wave LDS table like the single-shell kernels (experiments)
 #endif
 constexpr int kPairRows = 1;        // rows per thread of the second shell of a look-ahead pair (k_sweep_pair, k_sweep_pair_fast)
-template <bool DET, int LLS, bool STREAM, int EXT, bool STORE = true>
+template <bool DET, int LLS, int STREAM, int EXT, bool STORE = true>
 __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                              const int face, const int s, const int a, const int b0, const int sgb,
                                              const int nvalid)
@@ -295,13 +295,13 @@ __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &
 #if C2R_ROWS >= 4
     const CellState c3 = cell_state<LLS, STREAM>(p, sa, face, s, a, b0 + 3 * sgb, vm[3], va[3], vm[4], va[4], rm[3], ra[3], rm[4], ra[4]);
 #endif
-    double loss = cell_commit<DET, LLS, STREAM, EXT, STORE>(p, sa, ltab, face, s, a, b0, c0);
-    if (nvalid > 1) loss = loss + cell_commit<DET, LLS, STREAM, EXT, STORE>(p, sa, ltab, face, s, a, b0 + sgb, c1);
+    double loss = cell_commit<DET, LLS, STREAM != 0, EXT, STORE>(p, sa, ltab, face, s, a, b0, c0);
+    if (nvalid > 1) loss = loss + cell_commit<DET, LLS, STREAM != 0, EXT, STORE>(p, sa, ltab, face, s, a, b0 + sgb, c1);
 #if C2R_ROWS >= 3
-    if (nvalid > 2) loss = loss + cell_commit<DET, LLS, STREAM, EXT, STORE>(p, sa, ltab, face, s, a, b0 + 2 * sgb, c2);
+    if (nvalid > 2) loss = loss + cell_commit<DET, LLS, STREAM != 0, EXT, STORE>(p, sa, ltab, face, s, a, b0 + 2 * sgb, c2);
 #endif
 #if C2R_ROWS >= 4
-    if (nvalid > 3) loss = loss + cell_commit<DET, LLS, STREAM, EXT, STORE>(p, sa, ltab, face, s, a, b0 + 3 * sgb, c3);
+    if (nvalid > 3) loss = loss + cell_commit<DET, LLS, STREAM != 0, EXT, STORE>(p, sa, ltab, face, s, a, b0 + 3 * sgb, c3);
 #endif
     return loss;
 }
@@ -356,9 +356,11 @@ __device__ __forceinline__ double shell_cell_look(const KParams &p, const ShellA
 
 // STREAM: the non-temporal cache policy above (the host turns it on for meshes whose n_HI array outgrows the L2s)
 // LOOK (sq = the previous shell's arguments): one row per thread (FaceRect built for kPairRows), corners recomputed
-template <bool DET, int LLS, bool STREAM, int EXT, int LOOK = 0, bool STORE = true>
+// (src < 0: the source is sa.active[sl]; else src, and sl only indexes the loss partials of a shell on the sub-box surface)
+template <bool DET, int LLS, int STREAM, int EXT, int LOOK = 0, bool STORE = true>
 __device__ __forceinline__ void sweep_tile(const KParams &p, const ShellArgs &sa, const FaceRect &fr, const v2f64 *ltab,
-                                           double *sm, const int face, const int tile, const int sl, const ShellArgs &sq)
+                                           double *sm, const int face, const int tile, const int sl, const ShellArgs &sq,
+                                           const int src = -1)
 {
     double loss = 0.0;
     const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
@@ -372,8 +374,9 @@ __device__ __forceinline__ void sweep_tile(const KParams &p, const ShellArgs &sa
         const int sgb = pos ? 1 : -1;
         const int b0 = pos ? k0 : -1 - k0;
         const int left = pos ? (fr.b_lo + fr.wb - b0) : (b0 - fr.b_lo + 1);     // rows from b0 to the end of the class
-        if (LOOK) loss = shell_cell_look<DET, LLS, STREAM, EXT>(p, sa, sq, ltab, face, sa.active[sl], a, b0);
-        else loss = shell_rows<DET, LLS, STREAM, EXT, STORE>(p, sa, ltab, face, sa.active[sl], a, b0, sgb, min(left, kRows));
+        const int s = src < 0 ? sa.active[sl] : src;
+        if (LOOK) loss = shell_cell_look<DET, LLS, STREAM != 0, EXT>(p, sa, sq, ltab, face, s, a, b0);
+        else loss = shell_rows<DET, LLS, STREAM, EXT, STORE>(p, sa, ltab, face, s, a, b0, sgb, min(left, kRows));
     }
     if (sa.has_boundary) {
         const double tot = block_sum_256(loss, sm);
@@ -534,7 +537,9 @@ __device__ __forceinline__ double lookahead_cd_out(const KParams &p, const Shell
 // Everything a thread does for its NR rows once the upstream values are known: vm[r], va_[r] = the previous shell's
 // column densities at columns am = a - sga and a of rows b0 - sgb, b0, ..., b0 + (NR-1) sgb.
 // STORE: write the column densities into the planes (off for the first shell of a look-ahead pair: nothing reads them)
-template <bool DET, int LLS, bool STREAM, int NR, int EXT, bool STORE = true>
+// STREAM (here and in shell_rows_fast / sweep_tile_fast): 0 no cache hints, 1 every stream non-temporal, 2 all but the n_HI loads
+// (the plane-ordered mapping wants them to stay in the XCD's L2)
+template <bool DET, int LLS, int STREAM, int NR, int EXT, bool STORE = true>
 __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                                        const double *__restrict__ thick, const int face, const int s, const int a,
                                                        const int b0, const int sgb, const int nvalid,
@@ -563,7 +568,7 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
     for (int k = 0; k < NR; ++k) {
         const unsigned cb = wrap_pos(p.srcw[3 * s + va], p.n[va], b0 + k * sgb);
         id[k] = ca + base_p + __umul24(stride_b, cb);
-        nhi[k] = buf_load_f64<STREAM ? C2R_NHI_AUX : 0>(r_x, id[k] * 8u);
+        nhi[k] = buf_load_f64<STREAM == 1 ? C2R_NHI_AUX : 0>(r_x, id[k] * 8u);
     }
     // column part of the interpolation and of the geometry
     const double omu = (double)abs(a) * sa.inv_q, ddu = 1.0 - omu;   // weights of columns am and a
@@ -629,7 +634,7 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
 // LOOK = 0: the upstream values are read from the previous shell's planes (sq unused: pass sa).  LOOK = 1 (sq = the previous
 // shell's arguments, by reference -- a pointer to a kernel argument would force it into scratch): they are recomputed from
 // the planes of the shell before it (lookahead_cd_out).
-template <bool DET, int LLS, bool STREAM, int NR, int EXT, int LOOK = 0, bool STORE = true>
+template <bool DET, int LLS, int STREAM, int NR, int EXT, int LOOK = 0, bool STORE = true>
 __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                                   const double *__restrict__ thick,   // p.thick, or the block's LDS copy of it
                                                   const int face, const int s, const int a, const int b0, const int sgb,
@@ -644,8 +649,8 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
         for (int r = 0; r <= NR; ++r) {                        // rows b0-sgb, b0, ..., b0+(NR-1)sgb
             // (rows beyond the thread's valid cells are computed too -- from periodic-wrapped, in-range addresses -- and unused)
             const int row = b0 + (r - 1) * sgb;
-            vm[r] = lookahead_cd_out<LLS, STREAM>(p, sq, face, s, am, row);
-            va_[r] = lookahead_cd_out<LLS, STREAM>(p, sq, face, s, a, row);
+            vm[r] = lookahead_cd_out<LLS, STREAM != 0>(p, sq, face, s, am, row);
+            va_[r] = lookahead_cd_out<LLS, STREAM != 0>(p, sq, face, s, a, row);
         }
     } else {
         const unsigned plane_bytes = (unsigned)p.PP * 8u;
@@ -669,11 +674,12 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
 #ifndef C2R_FAST_ATTR
 #define C2R_FAST_ATTR __launch_bounds__(kBlock)
 #endif
-// one (source, face, tile) block of work of k_sweep_shell_fast; sl = position in the active list
-template <bool DET, int LLS, bool STREAM, int EXT, int LOOK = 0, bool STORE = true, int NR = kRows>
+// one (source, face, tile) block of work of k_sweep_shell_fast; sl = position in the active list (src < 0: the source is
+// sa.active[sl]; else src, and sl only indexes the loss partials of a shell on the sub-box surface)
+template <bool DET, int LLS, int STREAM, int EXT, int LOOK = 0, bool STORE = true, int NR = kRows>
 __device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArgs &sa, const FaceRect &fr, const v2f64 *ltab,
                                                 const double *thick, double *sm, const int face, const int tile, const int sl,
-                                                const ShellArgs &sq)
+                                                const ShellArgs &sq, const int src = -1)
 {
     double loss = 0.0;
     const unsigned t = (unsigned)tile * kBlock + threadIdx.x;
@@ -685,7 +691,7 @@ __device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArg
         const int sgb = pos ? 1 : -1;
         const int b0 = pos ? k0 : -1 - k0;
         const int left = pos ? (fr.b_lo + fr.wb - b0) : (b0 - fr.b_lo + 1);
-        loss = shell_rows_fast<DET, LLS, STREAM, NR, EXT, LOOK, STORE>(p, sa, ltab, thick, face, sa.active[sl], a, b0, sgb,
+        loss = shell_rows_fast<DET, LLS, STREAM, NR, EXT, LOOK, STORE>(p, sa, ltab, thick, face, src < 0 ? sa.active[sl] : src, a, b0, sgb,
                                                                         min(left, NR), sq);
     }
     if (sa.has_boundary) {
@@ -708,6 +714,50 @@ __global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
     if (tile >= fr.ntiles && !sa.has_boundary) return;
     const v2f64 *ltab = wave_log_table(p.odtab, s_log);
     sweep_tile_fast<DET, LLS, STREAM, EXT>(p, sa, fr, ltab, p.thick, sm, face, tile, (int)blockIdx.z, sa);
+}
+
+// The same shell with an XCD-AWARE, MESH-PLANE-ORDERED block mapping (many sources, no cell on the sub-box surface).  Within a
+// launch a mesh cell is visited by ~14 sources (q = 100, 1000 sources), but by workgroups that run far apart in time and on
+// different XCDs, so n_HI (8 of the ~38 B per visit that leave the L2s) comes from HBM every time.  Workgroups are dealt
+// round-robin over the 8 XCDs (blocks b and b + 8 share one: MI355X_MICROARCH.md, Workgroup dispatch -- a speed assumption only),
+// each with its own 4 MB L2.  Here block b works for XCD group x = b % 8 on item b / 8 of that group's list: for every face, the
+// x-th eighth of the batch's sources SORTED BY THEIR POSITION ALONG THE FACE'S AXIS (xa.perm, made on the host once per batch),
+// source after source, tile after tile.  Sources whose faces lie on the same mesh plane are neighbours in that order: their
+// tiles run on ONE XCD at about the same time, and the plane's n_HI is fetched from HBM once for all of them.  Same cells, same
+// arithmetic, same results as k_sweep_shell / k_sweep_shell_fast (FAST); retired sources' blocks return at once (the host falls back to the compact
+// active list when many have retired).
+#ifndef C2R_XCD_STREAM
+#define C2R_XCD_STREAM 2
+#endif
+struct XcdArgs {
+    const int *perm;           // [3][cap]: the batch's traceable sources sorted by srcw[axis] (axis 0, 1, 2), stable
+    int n, cap;                // sources in each permutation; stride
+    const int *final_nbox;     // [batch]: 0 while a source is being traced
+};
+template <bool DET, int LLS, bool STREAM, int EXT, bool FAST>
+__global__ C2R_FAST_ATTR void k_sweep_shell_xcd(KParams p, ShellArgs sa, XcdArgs xa)
+{
+    __shared__ double sm[16];
+    __shared__ v2f64 s_log[kBlock];
+    const unsigned x = blockIdx.x & 7u;
+    unsigned r = blockIdx.x >> 3;
+    const unsigned start = (x * (unsigned)xa.n) >> 3, cnt = (((x + 1u) * (unsigned)xa.n) >> 3) - start;
+    int face = -1; unsigned item = 0, tile = 0;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        const unsigned nt = (unsigned)sa.face[f].ntiles, nb = cnt * nt;
+        if (face < 0) {
+            if (r < nb) { face = f; item = r / nt; tile = r - item * nt; }
+            else r -= nb;
+        }
+    }
+    if (face < 0) return;
+    const int s = xa.perm[(2 - (face >> 1)) * xa.cap + (int)(start + item)];
+    if (xa.final_nbox[s] != 0) return;
+    const FaceRect fr = sa.face[face];
+    const v2f64 *ltab = wave_log_table(p.odtab, s_log);
+    if (FAST) sweep_tile_fast<DET, LLS, STREAM ? C2R_XCD_STREAM : 0, EXT>(p, sa, fr, ltab, p.thick, sm, face, (int)tile, 0, sa, s);
+    else sweep_tile<DET, LLS, STREAM ? C2R_XCD_STREAM : 0, EXT>(p, sa, fr, ltab, sm, face, (int)tile, 0, sa, s);
 }
 
 // Look-ahead pair (few sources, no cell of either shell on the sub-box surface): shell sa.q (blockIdx.y 0..5) and shell

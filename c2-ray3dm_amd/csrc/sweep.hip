@@ -9,6 +9,8 @@ namespace {
 void free_chain(SweepScratch &sc)
 {
     hipFree(sc.d_planes); hipFree(sc.d_gbox); hipFree(sc.d_gbox_h); hipFree(sc.d_batch); hipFree(sc.d_batch_init); hipFree(sc.d_loss_partial);
+    hipFree(sc.d_perm);
+    if (sc.h_perm) hipHostFree(sc.h_perm);
     if (sc.h_batch) hipHostFree(sc.h_batch);
     if (sc.h_nactive) hipHostFree(sc.h_nactive);
     for (auto &e : sc.ev_box) hipEventDestroy(e);
@@ -67,6 +69,8 @@ int alloc_chain(Ctx *ctx, SweepScratch &sc, int cap)
         sc.d_srcpos_b = i; sc.d_srcw_b = i + 3 * (size_t)cap; sc.d_active[0] = i + 6 * (size_t)cap;
         sc.d_active[1] = i + 7 * (size_t)cap; sc.d_final_nbox = i + 8 * (size_t)cap; sc.d_nactive = i + 9 * (size_t)cap;
     }
+    HIP_TRY(hipMalloc(&sc.d_perm, (size_t)3 * cap * sizeof(int)));
+    HIP_TRY(hipHostMalloc((void **)&sc.h_perm, (size_t)3 * cap * sizeof(int)));
     HIP_TRY(hipHostMalloc((void **)&sc.h_nactive, (size_t)(ctx->nbox_max + 2) * sizeof(int), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void **)&sc.d_hnactive, sc.h_nactive, 0));
     sc.ev_box.resize(ctx->nbox_max + 2);
@@ -326,6 +330,7 @@ struct BatchSweep {
     bool chained = false;          // one of several chains in flight (run_chains): no per-launch timing events, no host waits of its own
     int launches = 0;              // shell launches enqueued so far (k_sweep_shell*, pairs)
     int bound = 0, known = 0;      // run_chains: upper bound of the device's active count; sub-boxes whose count has been read back
+    bool perm_ready = false;       // the batch's sources sorted along each axis are on the device (stage_perm): far shells may run plane-ordered
 
     BatchSweep(Ctx *c, SweepScratch &sc_, int first_, int count_, bool first_of_pass_, double *dbg_, FusedIter *fz_)
         : ctx(c), sc(sc_), p(c->prm), first(first_), count(count_), first_of_pass(first_of_pass_), dbg(dbg_), fz(fz_),
@@ -359,6 +364,22 @@ struct BatchSweep {
             else h_fl[i] = flux;                                       // loop never entered: loss = initial value
         }
         h_na[0] = n_active; h_na[1] = 0;
+    }
+
+    // Plane-ordered far shells (k_sweep_shell_xcd): atomic rates, no debug array, and enough sources that
+    // several share a mesh plane (n_active / planes per face sign); uploaded behind the staging block
+    void stage_perm()
+    {
+        perm_ready = false;
+        if (dbg || sc.d_gbox || !sc.d_perm || ctx->xcd_order == 0 || n_active < 64) return;
+        const int nmin = std::min(p.mesh[0], std::min(p.mesh[1], p.mesh[2]));
+        if (ctx->xcd_order < 0 && (double)n_active < ctx->xcd_min_per_plane * (double)nmin) return;
+        for (int d = 0; d < 3; ++d) {
+            int *perm = sc.h_perm + (size_t)d * cap;
+            for (int t = 0; t < n_active; ++t) perm[t] = h_act[t];
+            std::stable_sort(perm, perm + n_active, [&](int a, int b) { return h_posw[3 * a + d] < h_posw[3 * b + d]; });
+        }
+        perm_ready = true;
     }
 
     // ---- 2. the launches of one sub-box -----------------------------------------------------------------------------
@@ -530,6 +551,27 @@ struct BatchSweep {
             pbuf = 1 - pbuf;
             ++in_box;
             if (prof == 1) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
+            if (perm_ready && !det && !sa.has_boundary && q >= ctx->xcd_qmin && (double)bound >= ctx->xcd_min_alive * (double)n_active) {
+                // the plane-ordered mapping: 8 XCD groups x (an eighth of the sources) x (the six faces' tiles)
+                XcdArgs xa{};
+                xa.perm = sc.d_perm; xa.n = n_active; xa.cap = (int)cap; xa.final_nbox = sc.d_final_nbox;
+                int tiles6 = 0;
+                for (int f = 0; f < 6; ++f) tiles6 += sa.face[f].ntiles;
+                const dim3 grid(8u * (unsigned)((n_active + 7) / 8) * (unsigned)tiles6), blk(kBlock);
+#define C2R_LAUNCH_XCD_F(L, H, F) do { if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_shell_xcd<false, L, true, H, F>), grid, blk, 0, st, k, sa, xa); \
+                                       else hipLaunchKernelGGL((k_sweep_shell_xcd<false, L, false, H, F>), grid, blk, 0, st, k, sa, xa); } while (0)
+#define C2R_LAUNCH_XCD_H(L, H) do { if (ctx->fast) C2R_LAUNCH_XCD_F(L, H, true); else C2R_LAUNCH_XCD_F(L, H, false); } while (0)
+#define C2R_LAUNCH_XCD(L) do { if (ctx->thermal && ctx->xray) C2R_LAUNCH_XCD_H(L, 3); else if (ctx->thermal) C2R_LAUNCH_XCD_H(L, 1); else if (ctx->xray) C2R_LAUNCH_XCD_H(L, 2); else C2R_LAUNCH_XCD_H(L, 0); } while (0)
+                switch (ctx->lls_type) {
+                    case 1: C2R_LAUNCH_XCD(1); break;
+                    case 2: C2R_LAUNCH_XCD(2); break;
+                    default: C2R_LAUNCH_XCD(3); break;
+                }
+#undef C2R_LAUNCH_XCD
+#undef C2R_LAUNCH_XCD_H
+#undef C2R_LAUNCH_XCD_F
+                ++ctx->xcd_launches;
+            } else
             {
                 const dim3 grid(sa.tiles_max, 6, bound), blk(kBlock);
 #define C2R_LAUNCH_SWEEP_H(D, L, H) do { \
@@ -708,6 +750,7 @@ struct BatchSweep {
 int BatchSweep::run(std::vector<int> *nbox_out, std::vector<double> *loss_out)
 {
     stage();
+    stage_perm();
     // The active count lives on the device (d_nactive[cur]); the host only needs an upper bound to
     // size the grids.  It runs ONE sub-box ahead: box n+1 is enqueued (sized by the count known
     // after box n-1) before the count after box n is read back, so the GPU never drains while the
@@ -765,6 +808,8 @@ int BatchSweep::run(std::vector<int> *nbox_out, std::vector<double> *loss_out)
     }
     if (fz && !pre_run) { const int rc = fz->pre(); if (rc) return rc; }
     if (!uploaded) HIP_TRY(hipMemcpyAsync(sc.d_batch, sc.h_batch, sc.batch_bytes, hipMemcpyHostToDevice, st));
+    // (h_perm, like the staging block, is rewritten by the next batch only after this one's final synchronize)
+    if (perm_ready) HIP_TRY(hipMemcpyAsync(sc.d_perm, sc.h_perm, (size_t)3 * cap * sizeof(int), hipMemcpyHostToDevice, st));
     for (int nbox = first_box; nbox <= ctx->nbox_max && bound > 0; ++nbox) {
         { const int rc = enqueue_box(nbox, bound); if (rc) return rc; }
         HIP_TRY(hipEventRecord(sc.ev_box[nbox], st));
