@@ -107,11 +107,13 @@ def cpu_baseline(mesh, srcpos, normflux, xfield, gpu_nbox, box_cost, nd=None):
                       "relaxed xh_av field the timed GPU steps start from" % (nsamp, mesh)}
 
 
-def mix_ceiling_this_box(device):
+def mix_ceiling_this_box(device, mask=31):
     """Visits per second the memory system of THIS box sustains for the sweep kernel's four streams with no arithmetic at
     all (profiles/micro/trafficmix.hip as a library: one n_HI load from a pseudo-random run of a 134 MB grid, the previous
-    shell's plane rows, one plane store, one f64 atomic per visit; runs start anywhere, as the kernel's do).  Taken in the
-    bench process, after the timed region; None where the library is not built."""
+    shell's plane rows, one plane store, one f64 atomic per visit; runs start anywhere, as the kernel's do; mask 63: the same
+    with every n_HI load an L2 hit -- the plane-ordered block mapping of the far shells serves three quarters of them
+    from the L2s, the kernel's real mix lies between the two).  Taken in the bench process, after the timed region; None where the
+    library is not built."""
     import ctypes
     path = os.path.join(ROOT, "profiles", "micro", "libtrafficmix.so")
     if not os.path.exists(path):
@@ -119,7 +121,7 @@ def mix_ceiling_this_box(device):
     lib = ctypes.CDLL(path)
     lib.c2r_micro_traffic_mix.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
     v = ctypes.c_double(0.0)
-    return v.value if lib.c2r_micro_traffic_mix(int(device), 31, ctypes.byref(v)) == 0 else None
+    return v.value if lib.c2r_micro_traffic_mix(int(device), int(mask), ctypes.byref(v)) == 0 else None
 
 
 def parity_check(pkg, mesh, step, nd, xh_init, xfield, srcpos, normflux, tables, device, fast, nsub=16):
@@ -375,7 +377,7 @@ def main():
         # roofline object carries nulls instead of numbers derived from the whole step's wall time
         timed = prof_mode != 0 and sweep_s > 0
         achieved = bytes_per_visit * vis_rank / sweep_s / 1e9 if timed else None
-        traffic, traffic_note, mix_ceiling = None, None, None
+        traffic, traffic_note, mix_ceiling, mix_ceiling_l2 = None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "TRAFFIC.json")
         if os.path.exists(tpath) and timed:      # PMC counters of the same command, from the latest committed profile
             tj = json.load(open(tpath))
@@ -385,6 +387,7 @@ def main():
         if timed and world == 1 and not args.thermal and not args.no_mix_ceiling:
             torch.cuda.synchronize()
             mix_ceiling = mix_ceiling_this_box(local_rank)
+            mix_ceiling_l2 = mix_ceiling_this_box(local_rank, 63)
         out = {
             "metric": "cells-traced/sec (grid^3 x sources / wallclock) on 256^3",
             "value": value, "unit": "cells-traced/s", "n_gpus": world, "steps": args.steps,
@@ -419,6 +422,10 @@ def main():
                          # streams with no arithmetic at all, measured on THIS box after the timed region (mix_ceiling_this_box, profiles/micro/trafficmix.hip)
                          "mix_ceiling_this_box": mix_ceiling,
                          "frac_of_memory_only_mix": (vis_rank / sweep_s / mix_ceiling) if (mix_ceiling and timed and not args.thermal) else None,
+                         # ... and with every n_HI load an L2 hit: the far shells' plane-ordered block mapping serves ~3/4 of
+                         # them from the L2s, so the ceiling of the kernel's real mix lies between the two
+                         "mix_ceiling_nhi_in_l2_this_box": mix_ceiling_l2,
+                         "frac_of_memory_only_mix_nhi_in_l2": (vis_rank / sweep_s / mix_ceiling_l2) if (mix_ceiling_l2 and timed and not args.thermal) else None,
                          "algorithmic_bytes_per_launch": bytes_per_visit * vis_rank / launches if timed else None, "algorithmic_bytes_per_visit": bytes_per_visit,
                          "avg_launch_ms": prof["sweep_ms"] / launches if timed else None, "launches": prof["sweep_launches"],
                          "timing": {0: "off (few sources: launches of a few microseconds inside a hipGraph): no kernel timing, roofline fields are null", 1: "HIP events around every k_sweep_shell launch",
@@ -426,9 +433,11 @@ def main():
                          "chem_kernel_ms_per_launch": prof["chem_ms"] / max(1, prof["chem_launches"]),
                          "chem_achieved_GBs": (CHEM_BYTES_PER_CELL * float(n) ** 3 * prof["chem_launches"] /
                                                (prof["chem_ms"] * 1e-3) / 1e9) if prof["chem_ms"] > 0 else 0.0,
-                         "note": "achieved = 28 algorithmic B per visited (cell, source) / launch time; the traffic actually leaving the L2s is ~38 B per visit "
-                                 "(shell planes make a round trip through HBM between launches) and the Gamma atomics cost the memory side a "
-                                 "read and a write each: ~47 B per visit at DRAM level, ~5.2 TB/s of the ~6.3 TB/s achievable; see DESIGN.md s5"},
+                         "note": "achieved = 28 algorithmic B per visited (cell, source) / launch time; the traffic actually leaving the L2s is ~32 B per visit "
+                                 "(shell planes make a round trip through HBM between launches; n_HI is shared in the L2s by the sources of a mesh "
+                                 "plane since round 5: ~2 of its 8 B) and the Gamma atomics cost the memory side a read and a write each: ~41 B per "
+                                 "visit at DRAM level, ~4.9 TB/s of the ~6.3 TB/s achievable; the memory-side f64 atomics run at 72 % of their chip-wide "
+                                 "rate; see DESIGN.md s3e, s5"},
         }
         if world == 1 and not args.no_other_mode and not args.thermal:
             # the same steps in the other sweep mode (the library default is exact: column densities bit-identical to the

@@ -125,7 +125,8 @@ double run(const double *nhi, double *gam, const double *pin, double *pout, unsi
 // The same measurement as a function, for bench.py (ctypes): the memory-only ceiling of the sweep's traffic mix ON THE BOX
 // the bench runs on, taken in the bench process after the timed region -- so that `roofline.frac_of_memory_only_mix` does not
 // divide a number of this box by a constant measured on another one (boxes differ by +-5 %).
-//   mask: 31 = all four streams, runs starting anywhere (what the kernel does); 15 = 512-B aligned runs; see k_mix
+//   mask: 31 = all four streams, runs starting anywhere (what the kernel does); 63 = the same with the n_HI loads served by the
+//         L2s (what the plane-ordered mapping of round 5 approaches); 15 = 512-B aligned runs; see k_mix
 //   hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -DTRAFFICMIX_LIB -shared -fPIC trafficmix.hip -o libtrafficmix.so
 extern "C" int c2r_micro_traffic_mix(int device, int mask, double *visits_per_s)
 {
@@ -141,6 +142,7 @@ extern "C" int c2r_micro_traffic_mix(int device, int mask, double *visits_per_s)
     double v = 0.0;
     switch (mask) {
         case 31: v = run<31>(nhi, gam, pin, pout, nrows, plane_elems, nthreads); break;
+        case 63: v = run<63>(nhi, gam, pin, pout, nrows, plane_elems, nthreads); break;      // ... with every n_HI load an L2 hit
         case 15: v = run<15>(nhi, gam, pin, pout, nrows, plane_elems, nthreads); break;
         case 24: v = run<24>(nhi, gam, pin, pout, nrows, plane_elems, nthreads); break;
         case 6:  v = run<6>(nhi, gam, pin, pout, nrows, plane_elems, nthreads); break;

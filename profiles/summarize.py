@@ -22,9 +22,16 @@ import sys
 
 
 def kname(full):
-    """'void c2r::k_sweep_shell<false, 1>(c2r::KParams, ...)' -> 'c2r::k_sweep_shell'"""
-    k = full.split("(")[0].split("<")[0].strip()
-    return k[5:] if k.startswith("void ") else k
+    """'void c2r::k_sweep_shell<false, 1>(c2r::KParams, ...)' -> 'c2r::k_sweep_shell'.  The plane-ordered launches of a shell
+    (k_sweep_shell_xcd<..., FAST>: the same cells and arithmetic under another block mapping, round 5) count as launches of the
+    mode's shell kernel."""
+    head = full.split("(")[0]
+    k = head.split("<")[0].strip()
+    k = k[5:] if k.startswith("void ") else k
+    if k == "c2r::k_sweep_shell_xcd":
+        args = head.split("<", 1)[1].rsplit(">", 1)[0] if "<" in head else ""
+        return "c2r::k_sweep_shell_fast" if args.replace(" ", "").endswith("true") or not args else "c2r::k_sweep_shell"
+    return k
 
 
 def per_kernel(path):
@@ -45,9 +52,12 @@ def main():
     out = {"kernels": {}}
     for r in csv.DictReader(open(os.path.join(d, "kernel_stats.csv"))):
         k = kname(r["Name"])
-        if k.startswith("c2r::"):
-            out["kernels"][k] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
-                                 "total_ns": float(r["TotalDurationNs"]), "pct": float(r["Percentage"])}
+        if k.startswith("c2r::"):          # (several instantiations / block mappings of one kernel: merged)
+            e = out["kernels"].setdefault(k, {"calls": 0, "avg_ns": 0.0, "total_ns": 0.0, "pct": 0.0})
+            e["calls"] += int(r["Calls"]); e["total_ns"] += float(r["TotalDurationNs"]); e["pct"] += float(r["Percentage"])
+            e["avg_ns"] = e["total_ns"] / e["calls"]
+            if "k_sweep_shell_xcd" in r["Name"]:
+                e["plane_ordered_calls"] = e.get("plane_ordered_calls", 0) + int(r["Calls"])
     f = per_kernel(os.path.join(d, "pmc_FETCH_SIZE.csv"))
     w = per_kernel(os.path.join(d, "pmc_WRITE_SIZE.csv"))
     for k in out["kernels"]:
