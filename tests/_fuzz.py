@@ -1,6 +1,7 @@
 """Randomized GPU-vs-oracle cases shared by tests/test_gpu_fuzz.py (asserting, 25 cases per mode) and
 tests/fuzz_gpu.py (the long run by hand).  Random non-cubic meshes (every extent 3..44, odd and even), 1..12
 sources anywhere (also outside [1,N]), rates over 6 decades, density and ionization fields with structure,
+(one case in seven: 64 - 300 or 769 - 900 sources -- chains in flight, the plane-ordered block mapping),
 both fully and barely ionized gas, so that sub-boxes end anywhere between the first and the clipped last; the
 row-group tiling of k_sweep_shell (three rows per thread, groups per sign class) meets every remainder; one case in
 two also draws a non-default switch: type_of_LLS 2 or 3, source-ordered (deterministic) Gamma accumulation, one
@@ -44,6 +45,16 @@ def make_case(seed, pkg):
     # (drawn last again, round 5) the second source type of photoion_rates: NormFlux_xray per source, some of them zero
     xray = bool(rng.random() < 0.25)         # (with heating: the X-ray type's heating tables too)
     nfx = 10.0 ** rng.uniform(3, 9, nsrc) * (rng.random(nsrc) < 0.7)
+    # (drawn last, late round 5) MANY sources on the same fields: 64 - 300 run as chains in flight (sweep.hip run_chains), more than
+    # 768 as one chain whose far shells use the XCD-aware, plane-ordered block mapping (k_sweep_shell_xcd) -- the schedules of the
+    # headline workload, which 1 - 12 sources never reach
+    r = rng.random()
+    if r < 0.14:
+        nsrc = int(rng.integers(64, 301)) if r < 0.08 else int(rng.integers(769, 901))
+        pos = np.stack([rng.integers(-3, mesh[d] + 5, nsrc) for d in range(3)], axis=1).astype(np.int32)
+        nf = 10.0 ** rng.uniform(4, 10, nsrc)
+        nf[rng.random(nsrc) < 0.03] = 0.0
+        nfx = 10.0 ** rng.uniform(3, 9, nsrc) * (rng.random(nsrc) < 0.7)
     return dict(xray=xray, nfx=nfx, heating=heating, mesh=mesh, dr=dr, vol=dr[0] * dr[1] * dr[2], nd=nd, xh=xh, pos=pos, nf=nf, lls=lls, k=k,
                 lls_type=lls_type, lls_grid=lls_grid, r_max=r_max, deterministic=deterministic, scratch=scratch)
 

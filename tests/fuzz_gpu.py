@@ -26,7 +26,7 @@ def main():
             assert gamma_ok(r["dgamma"], r["gamma_ref"], r["w"], fast), (case, r["mesh"], r["gamma_rel"], r["gamma_w"])
         for k in worst:
             worst[k] = max(worst[k], r[k])
-        print("case %3d %-16s mesh %-14s nsrc %2d  sum_nbox %3d  visited %8d  dGamma/Gamma %.1e  dGamma/W %.1e  dcd %.1e  dloss %.1e" %
+        print("case %3d %-16s mesh %-14s nsrc %3d  sum_nbox %5d  visited %8d  dGamma/Gamma %.1e  dGamma/W %.1e  dcd %.1e  dloss %.1e" %
               (case, r["variant"], r["mesh"], r["nsrc"], r["nbox"], r["visited"], r["gamma_rel"], r["gamma_w"], r["cd"], r["loss"]), flush=True)
     print("FUZZ OK (%s): %d cases, worst" % ("fast" if fast else "exact", ncase), worst)
 
