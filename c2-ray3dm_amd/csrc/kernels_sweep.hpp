@@ -92,7 +92,7 @@ __device__ __forceinline__ unsigned plane_off8(const KParams &p, int a, int b)
 
 // XONLY: read n_HI and the LLS grid from the x-fastest arrays whatever the face (same values; the look-ahead recompute
 // calls this with a per-lane face and must not pick a buffer per lane)
-template <int LLS, int STREAM /* 0 / 1 / 2: see shell_rows_fast_core */, bool XONLY = false>
+template <int LLS, int STREAM /* bits: see shell_rows_fast_core */, bool XONLY = false>
 __device__ __forceinline__ CellState cell_state(const KParams &p, const ShellArgs &sa, const int face, const int s,
                                                 const int a, const int b, const double c1v, const double c2v,
                                                 const double c3v, const double c4v, const double r1, const double r2,
@@ -281,8 +281,8 @@ __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &
 #pragma unroll
     for (int r = 0; r <= kRows; ++r) {                       // rows b0-sgb, b0, ..., b0+(kRows-1)sgb
         const bool inr = abs(b0 + (r - 1) * sgb) <= qm;
-        vm[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (inam && inr) ? o - da8 : kOOB);
-        va[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (ina && inr) ? o : kOOB);
+        vm[r] = buf_load_f64<(STREAM & 1) ? C2R_PLANE_AUX : 0>(r_prev, (inam && inr) ? o - da8 : kOOB);
+        va[r] = buf_load_f64<(STREAM & 1) ? C2R_PLANE_AUX : 0>(r_prev, (ina && inr) ? o : kOOB);
         o += db8;
     }
 #pragma unroll
@@ -295,13 +295,13 @@ __device__ __forceinline__ double shell_rows(const KParams &p, const ShellArgs &
 #if C2R_ROWS >= 4
     const CellState c3 = cell_state<LLS, STREAM>(p, sa, face, s, a, b0 + 3 * sgb, vm[3], va[3], vm[4], va[4], rm[3], ra[3], rm[4], ra[4]);
 #endif
-    double loss = cell_commit<DET, LLS, STREAM != 0, EXT, STORE>(p, sa, ltab, face, s, a, b0, c0);
-    if (nvalid > 1) loss = loss + cell_commit<DET, LLS, STREAM != 0, EXT, STORE>(p, sa, ltab, face, s, a, b0 + sgb, c1);
+    double loss = cell_commit<DET, LLS, (STREAM & 1) != 0, EXT, STORE>(p, sa, ltab, face, s, a, b0, c0);
+    if (nvalid > 1) loss = loss + cell_commit<DET, LLS, (STREAM & 1) != 0, EXT, STORE>(p, sa, ltab, face, s, a, b0 + sgb, c1);
 #if C2R_ROWS >= 3
-    if (nvalid > 2) loss = loss + cell_commit<DET, LLS, STREAM != 0, EXT, STORE>(p, sa, ltab, face, s, a, b0 + 2 * sgb, c2);
+    if (nvalid > 2) loss = loss + cell_commit<DET, LLS, (STREAM & 1) != 0, EXT, STORE>(p, sa, ltab, face, s, a, b0 + 2 * sgb, c2);
 #endif
 #if C2R_ROWS >= 4
-    if (nvalid > 3) loss = loss + cell_commit<DET, LLS, STREAM != 0, EXT, STORE>(p, sa, ltab, face, s, a, b0 + 3 * sgb, c3);
+    if (nvalid > 3) loss = loss + cell_commit<DET, LLS, (STREAM & 1) != 0, EXT, STORE>(p, sa, ltab, face, s, a, b0 + 3 * sgb, c3);
 #endif
     return loss;
 }
@@ -375,7 +375,7 @@ __device__ __forceinline__ void sweep_tile(const KParams &p, const ShellArgs &sa
         const int b0 = pos ? k0 : -1 - k0;
         const int left = pos ? (fr.b_lo + fr.wb - b0) : (b0 - fr.b_lo + 1);     // rows from b0 to the end of the class
         const int s = src < 0 ? sa.active[sl] : src;
-        if (LOOK) loss = shell_cell_look<DET, LLS, STREAM != 0, EXT>(p, sa, sq, ltab, face, s, a, b0);
+        if (LOOK) loss = shell_cell_look<DET, LLS, (STREAM & 1) != 0, EXT>(p, sa, sq, ltab, face, s, a, b0);
         else loss = shell_rows<DET, LLS, STREAM, EXT, STORE>(p, sa, ltab, face, s, a, b0, sgb, min(left, kRows));
     }
     if (sa.has_boundary) {
@@ -537,8 +537,12 @@ __device__ __forceinline__ double lookahead_cd_out(const KParams &p, const Shell
 // Everything a thread does for its NR rows once the upstream values are known: vm[r], va_[r] = the previous shell's
 // column densities at columns am = a - sga and a of rows b0 - sgb, b0, ..., b0 + (NR-1) sgb.
 // STORE: write the column densities into the planes (off for the first shell of a look-ahead pair: nothing reads them)
-// STREAM (here and in shell_rows_fast / sweep_tile_fast): 0 no cache hints, 1 every stream non-temporal, 2 all but the n_HI loads
-// (the plane-ordered mapping wants them to stay in the XCD's L2)
+#ifndef C2R_XCD_KEEP_DBG
+#define C2R_XCD_KEEP_DBG 0          // 1 (experiments): keep the debug path in the plane-ordered kernel (65 VGPRs, 7 waves)
+#endif
+// STREAM (here and in shell_rows_fast / sweep_tile_fast / sweep_tile): bit 0 -- non-temporal cache hints on the streams; bit 1 -- the
+// plane-ordered mapping (k_sweep_shell_xcd): the n_HI loads keep the plain policy (they are to stay in the XCD's L2) and the
+// coldensh_out debug path, which that mapping never runs with, is compiled out (63 VGPRs instead of 65: 8 waves per SIMD)
 template <bool DET, int LLS, int STREAM, int NR, int EXT, bool STORE = true>
 __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                                        const double *__restrict__ thick, const int face, const int s, const int a,
@@ -581,7 +585,7 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
     const double nflux = p.normflux[s];
     const double nflux_x = (EXT & 2) ? p.normflux_x[s] : 0.0;
     const __amdgpu_buffer_rsrc_t r_cur = make_rsrc(p.planes + ((size_t)s * 2 + sa.buf_cur) * 6 * p.PP, 6u * plane_bytes);
-    constexpr int SA = STREAM ? C2R_STORE_AUX : 0;
+    constexpr int SA = (STREAM & 1) ? C2R_STORE_AUX : 0;
     const bool bnd_col = sa.has_boundary && (a == sa.boxR[ua] || a == -sa.boxL[ua] || pd == sa.boxR[axis] || pd == -sa.boxL[axis]);
     double loss = 0.0;
     unsigned o8 = o_first;
@@ -607,7 +611,7 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
                     buf_store_f64<SA>(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((b + p.R) * p.P + (pd + p.R)) * 8u, cd_out);
             }
             }
-            if (sa.dbg_cdout) {
+            if ((C2R_XCD_KEEP_DBG || !(STREAM & 2)) && sa.dbg_cdout) {
                 const Delta3 dl = mesh_delta(axis, pd, a, b);
                 const unsigned c0 = wrap_pos(p.srcw[3 * s + 0], p.n[0], dl.d0), c1 = wrap_pos(p.srcw[3 * s + 1], p.n[1], dl.d1),
                                c2 = wrap_pos(p.srcw[3 * s + 2], p.n[2], dl.d2);
@@ -649,8 +653,8 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
         for (int r = 0; r <= NR; ++r) {                        // rows b0-sgb, b0, ..., b0+(NR-1)sgb
             // (rows beyond the thread's valid cells are computed too -- from periodic-wrapped, in-range addresses -- and unused)
             const int row = b0 + (r - 1) * sgb;
-            vm[r] = lookahead_cd_out<LLS, STREAM != 0>(p, sq, face, s, am, row);
-            va_[r] = lookahead_cd_out<LLS, STREAM != 0>(p, sq, face, s, a, row);
+            vm[r] = lookahead_cd_out<LLS, (STREAM & 1) != 0>(p, sq, face, s, am, row);
+            va_[r] = lookahead_cd_out<LLS, (STREAM & 1) != 0>(p, sq, face, s, a, row);
         }
     } else {
         const unsigned plane_bytes = (unsigned)p.PP * 8u;
@@ -663,8 +667,8 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
 #pragma unroll
         for (int r = 0; r <= NR; ++r) {                        // rows b0-sgb, b0, ..., b0+(NR-1)sgb
             const bool inr = abs(b0 + (r - 1) * sgb) <= qm;
-            vm[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (inam && inr) ? o - da8 : kOOB);
-            va_[r] = buf_load_f64<STREAM ? C2R_PLANE_AUX : 0>(r_prev, (ina && inr) ? o : kOOB);
+            vm[r] = buf_load_f64<(STREAM & 1) ? C2R_PLANE_AUX : 0>(r_prev, (inam && inr) ? o - da8 : kOOB);
+            va_[r] = buf_load_f64<(STREAM & 1) ? C2R_PLANE_AUX : 0>(r_prev, (ina && inr) ? o : kOOB);
             o += db8;
         }
     }
@@ -726,9 +730,6 @@ __global__ C2R_FAST_ATTR void k_sweep_shell_fast(KParams p, ShellArgs sa)
 // tiles run on ONE XCD at about the same time, and the plane's n_HI is fetched from HBM once for all of them.  Same cells, same
 // arithmetic, same results as k_sweep_shell / k_sweep_shell_fast (FAST); retired sources' blocks return at once (the host falls back to the compact
 // active list when many have retired).
-#ifndef C2R_XCD_STREAM
-#define C2R_XCD_STREAM 2
-#endif
 struct XcdArgs {
     const int *perm;           // [3][cap]: the batch's traceable sources sorted by srcw[axis] (axis 0, 1, 2), stable
     int n, cap;                // sources in each permutation; stride
@@ -756,8 +757,8 @@ __global__ C2R_FAST_ATTR void k_sweep_shell_xcd(KParams p, ShellArgs sa, XcdArgs
     if (xa.final_nbox[s] != 0) return;
     const FaceRect fr = sa.face[face];
     const v2f64 *ltab = wave_log_table(p.odtab, s_log);
-    if (FAST) sweep_tile_fast<DET, LLS, STREAM ? C2R_XCD_STREAM : 0, EXT>(p, sa, fr, ltab, p.thick, sm, face, (int)tile, 0, sa, s);
-    else sweep_tile<DET, LLS, STREAM ? C2R_XCD_STREAM : 0, EXT>(p, sa, fr, ltab, sm, face, (int)tile, 0, sa, s);
+    if (FAST) sweep_tile_fast<DET, LLS, STREAM ? 3 : 2, EXT>(p, sa, fr, ltab, p.thick, sm, face, (int)tile, 0, sa, s);
+    else sweep_tile<DET, LLS, STREAM ? 3 : 2, EXT>(p, sa, fr, ltab, sm, face, (int)tile, 0, sa, s);
 }
 
 // Look-ahead pair (few sources, no cell of either shell on the sub-box surface): shell sa.q (blockIdx.y 0..5) and shell
