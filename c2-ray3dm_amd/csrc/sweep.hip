@@ -44,6 +44,11 @@ int choose_chains(const Ctx *ctx, int want)
 {
     if (ctx->chains_env > 0) return std::min(ctx->chains_env, std::max(1, want));
     if (ctx->prm.deterministic_rates || want < 64 || want > 768) return 1;
+    // meshes that outgrow the L2s (n_HI >= 64 MB): from 1.5 sources per mesh plane ONE chain whose far shells run under the
+    // plane-ordered block mapping (stage_perm) is at least as fast as two chains of half the sources (256^3, 400 / 500 / 640 / 768
+    // sources: 57.3 / 71.6 / 89.3 / 106.8 ms against 58.1 / 72.2 / 92.0 / 112.9; at 128^3 the chains win: profiles/r05_xcd/ab_mid*.txt)
+    if (ctx->stream_hint && ctx->xcd_order != 0 &&
+        (double)want >= ctx->xcd_min_per_plane * (double)std::min(ctx->prm.mesh[0], std::min(ctx->prm.mesh[1], ctx->prm.mesh[2]))) return 1;
     return (want >= 192 && want <= 384) ? 3 : 2;
 }
 
