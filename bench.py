@@ -415,7 +415,12 @@ def main():
                        "visited_cell_sources_whole_run_rank0": float(ev.visited + visited_before),
                        "mean_subboxes_per_source": [x / S for x in nbox_hist]},
             "check": check,
-            "roofline": {"bound": "hbm", "kernel": "k_sweep_shell_fast" if args.sweep_mode == "fast" else "k_sweep_shell", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_sweep_shell_fast" if args.sweep_mode == "fast" else "k_sweep_shell",
+                         # the same shell kernel under two block mappings: the plain (tile, face, source) grid and, for the far shells of many
+                         # sources, the XCD-aware plane-ordered one; a rocprofv3 --stats table lists them under two names, the launch
+                         # average below is over both (profiles/summarize.py merges them the same way)
+                         "kernel_names_in_a_trace": ["k_sweep_shell_fast", "k_sweep_shell_xcd<..., FAST = true>"] if args.sweep_mode == "fast" else ["k_sweep_shell", "k_sweep_shell_xcd<..., FAST = false>"],
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if timed else None,
                          "traffic": traffic, "traffic_source": traffic_note,
                          # informational: the kernel's visits/s against what the memory system sustains for the same four
