@@ -174,6 +174,10 @@ void c2r_destroy(c2r_ctx *c)
     if (!c) return;
     Ctx *ctx = C(c);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    // (the chains' and the exchange's streams have joined the context's stream by the end of every pass; drained once more
+    // before their arrays go)
+    for (int k = 1; k < kMaxChains; ++k) if (ctx->sc[k].stream) hipStreamSynchronize(ctx->sc[k].stream);
+    if (ctx->xstream) hipStreamSynchronize(ctx->xstream);
     for (auto &kv : ctx->graphs) { if (kv.second.exec) hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) hipGraphDestroy(kv.second.graph); }
     for (auto &kv : ctx->pinned) hipHostUnregister(const_cast<void *>(kv.first));
     free_sweep_scratch(ctx);
