@@ -371,14 +371,16 @@ struct BatchSweep {
         h_na[0] = n_active; h_na[1] = 0;
     }
 
-    // Plane-ordered far shells (k_sweep_shell_xcd): atomic rates, no debug array, and enough sources that
+    // Plane-ordered far shells (k_sweep_shell_xcd): no debug array, and enough sources that
     // several share a mesh plane (n_active / planes per face sign); uploaded behind the staging block
     void stage_perm()
     {
         perm_ready = false;
-        if (dbg || sc.d_gbox || !sc.d_perm || ctx->xcd_order == 0 || n_active < 64) return;
+        if (dbg || !sc.d_perm || ctx->xcd_order == 0 || n_active < 64) return;
         const int nmin = std::min(p.mesh[0], std::min(p.mesh[1], p.mesh[2]));
-        if (ctx->xcd_order < 0 && (double)n_active < ctx->xcd_min_per_plane * (double)nmin) return;
+        // (with ordered rates from half that count: there the mapping pays by keeping a source's per-source grid writes together --
+        // 256^3, batches of 250 sources: -7 %, 1000 sources in four batches -7 ... -20 %: profiles/r05_xcd/ab_det_counts.txt)
+        if (ctx->xcd_order < 0 && (double)n_active < ctx->xcd_min_per_plane * (double)nmin * (sc.d_gbox ? 0.5 : 1.0)) return;
         for (int d = 0; d < 3; ++d) {
             int *perm = sc.h_perm + (size_t)d * cap;
             for (int t = 0; t < n_active; ++t) perm[t] = h_act[t];
@@ -556,15 +558,16 @@ struct BatchSweep {
             pbuf = 1 - pbuf;
             ++in_box;
             if (prof == 1) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
-            if (perm_ready && !det && !sa.has_boundary && q >= ctx->xcd_qmin && (double)bound >= ctx->xcd_min_alive * (double)n_active) {
+            if (perm_ready && !sa.has_boundary && q >= ctx->xcd_qmin && (double)bound >= ctx->xcd_min_alive * (double)n_active) {
                 // the plane-ordered mapping: 8 XCD groups x (an eighth of the sources) x (the six faces' tiles)
                 XcdArgs xa{};
                 xa.perm = sc.d_perm; xa.n = n_active; xa.cap = (int)cap; xa.final_nbox = sc.d_final_nbox;
                 int tiles6 = 0;
                 for (int f = 0; f < 6; ++f) tiles6 += sa.face[f].ntiles;
                 const dim3 grid(8u * (unsigned)((n_active + 7) / 8) * (unsigned)tiles6), blk(kBlock);
-#define C2R_LAUNCH_XCD_F(L, H, F) do { if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_shell_xcd<false, L, true, H, F>), grid, blk, 0, st, k, sa, xa); \
-                                       else hipLaunchKernelGGL((k_sweep_shell_xcd<false, L, false, H, F>), grid, blk, 0, st, k, sa, xa); } while (0)
+#define C2R_LAUNCH_XCD_D(D, L, H, F) do { if (ctx->stream_hint) hipLaunchKernelGGL((k_sweep_shell_xcd<D, L, true, H, F>), grid, blk, 0, st, k, sa, xa); \
+                                          else hipLaunchKernelGGL((k_sweep_shell_xcd<D, L, false, H, F>), grid, blk, 0, st, k, sa, xa); } while (0)
+#define C2R_LAUNCH_XCD_F(L, H, F) do { if (det) C2R_LAUNCH_XCD_D(true, L, H, F); else C2R_LAUNCH_XCD_D(false, L, H, F); } while (0)
 #define C2R_LAUNCH_XCD_H(L, H) do { if (ctx->fast) C2R_LAUNCH_XCD_F(L, H, true); else C2R_LAUNCH_XCD_F(L, H, false); } while (0)
 #define C2R_LAUNCH_XCD(L) do { if (ctx->thermal && ctx->xray) C2R_LAUNCH_XCD_H(L, 3); else if (ctx->thermal) C2R_LAUNCH_XCD_H(L, 1); else if (ctx->xray) C2R_LAUNCH_XCD_H(L, 2); else C2R_LAUNCH_XCD_H(L, 0); } while (0)
                 switch (ctx->lls_type) {
@@ -575,6 +578,7 @@ struct BatchSweep {
 #undef C2R_LAUNCH_XCD
 #undef C2R_LAUNCH_XCD_H
 #undef C2R_LAUNCH_XCD_F
+#undef C2R_LAUNCH_XCD_D
                 ++ctx->xcd_launches;
             } else
             {

@@ -4,7 +4,7 @@ sorted along the face's axis -- so that sources whose faces lie on one mesh plan
 the plane's n_HI in its L2.  WHICH workgroup does a (source, face, tile) changes, nothing else: sub-box counts, visited cells and
 the photon loss are bit-identical to the plain (tile, face, source) grid, the rates equal to the order of the atomics; also with
 sources that retire early (their blocks return at once), with a source count that is no multiple of eight, with zero-flux
-sources, heating rates and X-ray sources.  C2R_XCD_ORDER / _QMIN / _MIN_ALIVE are read by c2r_create."""
+sources, heating rates, X-ray sources and ordered (deterministic) rates -- those bit-identical.  C2R_XCD_ORDER / _QMIN / _MIN_ALIVE are read by c2r_create."""
 import numpy as np
 import pytest
 from tests._util import F, oracle_for, assert_gamma, oracle_pass, tol, load_thermal_tables, load_case
@@ -38,12 +38,12 @@ def case(pkg, n, nsrc, seed, mesh=None, x_mode="ionized", dark=0):
     return s, F(nd), F(xh), pos, nf
 
 
-def run_pass(pkg, tables, s, mesh, nd, xh, pos, nf, monkeypatch, order, qmin=2, alive="0", thermal=None, xray=None):
+def run_pass(pkg, tables, s, mesh, nd, xh, pos, nf, monkeypatch, order, qmin=2, alive="0", thermal=None, xray=None, det=False):
     monkeypatch.setenv("C2R_CHAINS", "1")
     monkeypatch.setenv("C2R_XCD_ORDER", str(order))
     monkeypatch.setenv("C2R_XCD_QMIN", str(qmin))
     monkeypatch.setenv("C2R_XCD_MIN_ALIVE", alive)
-    b = pkg.HipBackend(mesh, *tables, device=0)
+    b = pkg.HipBackend(mesh, *tables, device=0, deterministic=det)
     b.set_step((s["dr1"], s["dr2"], s["dr3"]), s["vol"], s["coldensh_LLS"], s["clumping"])
     if thermal is not None:
         b.set_thermal(thermal["heat_thick"], thermal["heat_thin"], thermal["cool_logT"], thermal["cool_logL"])
@@ -141,6 +141,22 @@ def test_plane_ordered_with_heating_rates_and_xray_sources(pkg, tables, monkeypa
         if thermal is not None:
             assert (a["heat"] > 0).any()
             same_to_the_order_of_the_atomics(a, b, "heat")
+
+
+def test_plane_ordered_with_ordered_rates(pkg, tables, monkeypatch):
+    """deterministic_rates = 1: the per-source grids are written by whichever workgroup the mapping gives a tile to and summed
+    in source order afterwards -- the rates are the SAME BITS with and without the mapping (and with heating rates)."""
+    mesh = (40, 40, 40)
+    s, nd, xh, pos, nf = case(pkg, 40, 170, 29, mesh, "mixed", 4)
+    tt = load_thermal_tables()
+    for thermal in (None, tt):
+        a = run_pass(pkg, tables, s, mesh, nd, xh, pos, nf, monkeypatch, 0, det=True, thermal=thermal)
+        b = run_pass(pkg, tables, s, mesh, nd, xh, pos, nf, monkeypatch, 1, det=True, thermal=thermal)
+        assert launches(a["info"]) == 0 and launches(b["info"]) > 0
+        same_integers_and_loss(a, b)
+        assert np.array_equal(a["phih"], b["phih"])
+        if thermal is not None:
+            assert np.array_equal(a["heat"], b["heat"])
 
 
 def test_whole_steps_plane_ordered(pkg, tables, monkeypatch):
