@@ -220,6 +220,8 @@ def main():
                          "(c2r_set_exchange_overlap; off by default until an N > 1 RCCL run has measured it)")
     ap.add_argument("--deterministic", action="store_true",
                     help="per-source Gamma grids reduced in source order instead of f64 atomics")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="c2r_set_option on every context of the run (include/c2ray_hip.h has the table; A/B measurements), e.g. --option chains=3")
     ap.add_argument("--thermal", action="store_true",
                     help="time the non-isothermal variant (isothermal=.false.: heating rates in the sweep, thermal.f90 in the "
                          "global pass; synthetic cooling table, T = 1e4 K start).  Not the headline configuration; no CPU baseline")
@@ -254,6 +256,7 @@ def main():
         sys.stderr.write("bench.py: rank %d fails on purpose (C2R_BENCH_TEST_FAIL_RANK)\n" % rank)
         os._exit(3)
     n, S = args.mesh, args.sources
+    options = {kv.split("=", 1)[0]: float(kv.split("=", 1)[1]) for kv in args.option}
     tp = pkg.TestProblem(n)
     s = tp.step(1)
     nd, xh = tp.fields(1, args.x_init)
@@ -267,7 +270,7 @@ def main():
         # the file is taken to hold the slice of the step's own redshift
     srcpos, normflux = pkg.seeded_sources(n, S)
     thick, thin, _ = pkg.build_tables()          # rad_ini on the host (c2r_build_tables)
-    b = pkg.HipBackend(n, thick, thin, device=local_rank, deterministic=args.deterministic, fast=args.sweep_mode == "fast")
+    b = pkg.HipBackend(n, thick, thin, device=local_rank, deterministic=args.deterministic, fast=args.sweep_mode == "fast", options=options)
     b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], s["clumping"], s["temper"])
     b.set_sources(srcpos, normflux)
     b.load(ndens=nd, xh=xh)
@@ -333,7 +336,7 @@ def main():
             nbox_first = b.last_nbox().astype(np.int64)        # per-source sub-box counts of the first timed pass
         # (only where launches are timed: with few sources a step is a few hundred microseconds and this bookkeeping would be
         # a tenth of it)
-        if prof_mode != 0 and os.environ.get("C2R_FUSE_SMALL") != "0":
+        if prof_mode != 0 and options.get("fuse_small", 1.0) != 0.0:
             fused_visited += float(np.sum(pkg.box_cost(np.minimum(b.last_nbox(), 2), (n, n, n))))
     sync()
     dt_wall = time.perf_counter() - t0
@@ -449,7 +452,7 @@ def main():
             # Fortran; `value` above is the mode named in config.sweep_mode), outside the timed region of the headline
             b.close()
             other = "exact" if args.sweep_mode == "fast" else "fast"
-            b2 = pkg.HipBackend(n, thick, thin, device=local_rank, deterministic=args.deterministic, fast=other == "fast")
+            b2 = pkg.HipBackend(n, thick, thin, device=local_rank, deterministic=args.deterministic, fast=other == "fast", options=options)
             b2.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], s["clumping"], s["temper"])
             b2.set_sources(srcpos, normflux)
             b2.load(ndens=nd, xh=xh)
@@ -499,7 +502,7 @@ def main():
             # (DESIGN.md s3d, s6).  Informational, outside the timed region.
             b.close()
             share = pkg.static_source_share(S, 0, 8)
-            b4 = pkg.HipBackend(n, thick, thin, device=local_rank, fast=args.sweep_mode == "fast")
+            b4 = pkg.HipBackend(n, thick, thin, device=local_rank, fast=args.sweep_mode == "fast", options=options)
             b4.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], s["clumping"], s["temper"])
             b4.set_sources(srcpos[share], normflux[share])
             b4.load(ndens=nd, xh=xh)

@@ -80,6 +80,7 @@ SYMBOLS = [
     ("c2r_last_error", C.c_char_p, [_P]),
     ("c2r_info", C.c_char_p, [_P]),
     ("c2r_set_stream", C.c_int, [_P, _P]),
+    ("c2r_set_option", C.c_int, [_P, C.c_char_p, _D]),
     ("c2r_set_tables", C.c_int, [_P, _P, _P, _I32]),
     ("c2r_set_step", C.c_int, [_P, C.POINTER(_D * 3), _D, _D, C.c_float, _D]),
     ("c2r_set_lls", C.c_int, [_P, _I32, _P, _D]),

@@ -39,7 +39,7 @@ int c2r_default_params(c2r_params *p)
     p->sqrt2 = C2R_SQRT2; p->sqrt3 = C2R_SQRT3; p->pi = C2R_PI; p->abu_c = C2R_ABU_C;
     p->bh00 = C2R_BH00; p->albpow = C2R_ALBPOW; p->colh0 = C2R_COLH0; p->temph0 = C2R_TEMPH0;
     p->S_star = C2R_S_STAR;
-    p->sweep_mode = C2R_SWEEP_EXACT;
+    p->sweep_mode = C2R_SWEEP_FAST;             // (the opt-in C2R_SWEEP_EXACT: column densities bit-identical to the Fortran)
     p->scratch_bytes = 0;
     return C2R_OK;
 }
@@ -51,20 +51,6 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     if (p->mesh[0] < 1 || p->mesh[1] < 1 || p->mesh[2] < 1 || p->numtau < 1 || p->subboxsize < 1) return C2R_EINVAL;
     Ctx *ctx = new Ctx();
     ctx->prm = *p;
-    if (const char *e = getenv("C2R_FUSE_SMALL")) ctx->fuse_small = atoi(e) != 0;
-    if (const char *e = getenv("C2R_SCHED_HINT")) ctx->sched_hint = atoi(e) != 0;
-    if (const char *e = getenv("C2R_GRAPH")) ctx->use_graph = atoi(e) != 0;
-    if (const char *e = getenv("C2R_FUSED_ITER")) ctx->fused_iter = atoi(e) != 0;
-    if (const char *e = getenv("C2R_PAIR_SHELLS")) ctx->pair_shells = atoi(e) != 0;
-    if (const char *e = getenv("C2R_SPIN_WAIT")) ctx->spin_wait = atoi(e) != 0;
-    if (const char *e = getenv("C2R_XCD_ORDER")) ctx->xcd_order = atoi(e);
-    if (const char *e = getenv("C2R_XCD_MIN_PER_PLANE")) ctx->xcd_min_per_plane = atof(e);
-    if (const char *e = getenv("C2R_XCD_MIN_ALIVE")) ctx->xcd_min_alive = atof(e);
-    if (const char *e = getenv("C2R_XCD_QMIN")) ctx->xcd_qmin = std::max(1, atoi(e));
-    if (const char *e = getenv("C2R_POLL_WAIT")) ctx->poll_wait = atoi(e) != 0;
-    if (const char *e = getenv("C2R_FOLD_SOURCE_CELL")) ctx->fold_source_cell = atoi(e) != 0;
-    if (const char *e = getenv("C2R_SPARSE_EXCHANGE")) ctx->sparse_exchange = atoi(e) != 0;
-    if (const char *e = getenv("C2R_SPARSE_FRACTION")) ctx->sparse_fraction = std::max(0.0, atof(e));
     if (p->sweep_mode != C2R_SWEEP_EXACT && p->sweep_mode != C2R_SWEEP_FAST) { delete ctx; return C2R_EINVAL; }
     ctx->fast = p->sweep_mode == C2R_SWEEP_FAST;          // the caller's choice only: no environment override
     *out = reinterpret_cast<c2r_ctx *>(ctx);     // returned even on failure so c2r_last_error works
@@ -93,7 +79,6 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     ctx->own_stream = true;
     ctx->ncell = (size_t)p->mesh[0] * p->mesh[1] * p->mesh[2];
     ctx->stream_hint = ctx->ncell * sizeof(double) >= ((size_t)64 << 20);      // 8 x 4 MB of L2; neutral at 128^3, +2.8 % at 256^3
-    if (const char *e = getenv("C2R_STREAM_HINT")) ctx->stream_hint = atoi(e) != 0;
     // The sweep addresses cells through buffer descriptors with 32-bit BYTE offsets (cell id * 8 and a
     // num_records of ncell * 8, kernels.hpp cell_state / shell_rows_fast): ncell * 8 must stay below 2^32,
     // i.e. ncell < 2^29 (a cubic mesh up to 812^3).  Checked before anything is allocated.
@@ -161,9 +146,6 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_step, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_prepared, hipEventDisableTiming));
     ctx->sc[0].stream = ctx->stream;                       // chain 0 of the sweep runs on the context's stream
-    if (const char *e = getenv("C2R_EXCHANGE_OVERLAP")) ctx->exchange_overlap = atoi(e) != 0;
-    if (const char *e = getenv("C2R_EXCHANGE_OVERLAP_MIN")) ctx->overlap_min_sources = std::max(1, atoi(e));
-    if (const char *e = getenv("C2R_CHAINS")) ctx->chains_env = std::max(0, std::min(kMaxChains, atoi(e)));
     hipLaunchKernelGGL(k_load_code_object, dim3(1), dim3(1), 0, ctx->stream, (int *)nullptr);      // (loads the library's code object now)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return C2R_OK;
@@ -179,6 +161,7 @@ void c2r_destroy(c2r_ctx *c)
     for (int k = 1; k < kMaxChains; ++k) if (ctx->sc[k].stream) hipStreamSynchronize(ctx->sc[k].stream);
     if (ctx->xstream) hipStreamSynchronize(ctx->xstream);
     for (auto &kv : ctx->graphs) { if (kv.second.exec) hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) hipGraphDestroy(kv.second.graph); }
+    for (auto &kv : ctx->chain_graphs) { if (kv.second.exec) hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) hipGraphDestroy(kv.second.graph); }
     for (auto &kv : ctx->pinned) hipHostUnregister(const_cast<void *>(kv.first));
     free_sweep_scratch(ctx);
     for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
@@ -216,6 +199,7 @@ const char *c2r_info(c2r_ctx *c)
                 "; rates " + (ctx->prm.deterministic_rates ? "ordered per-source sums" : "f64 atomics") +
                 "; rank " + std::to_string(ctx->rank) + " of " + std::to_string(ctx->nranks) +
                 "; chains " + std::to_string(ctx->nchains) +
+                "; chain passes replayed " + std::to_string(ctx->chain_replays) + " (halted " + std::to_string(ctx->chain_halts) + "), launch by launch " + std::to_string(ctx->chain_eager) +
                 "; exchanges overlapped with the sweep " + std::to_string(ctx->xchg_overlapped) +
                 "; plane-ordered launches " + std::to_string(ctx->xcd_launches) +
                 "; graph captures " + std::to_string(ctx->captures);
@@ -235,6 +219,44 @@ int c2r_set_stream(c2r_ctx *c, void *s)
         ctx->stream = (hipStream_t)s;
     }
     ctx->sc[0].stream = ctx->stream;
+    ++ctx->gen;
+    return C2R_OK;
+}
+
+// The schedule's switches (include/c2ray_hip.h has the table).  None changes a result beyond the order in which the f64 atomics of
+// different sources land; every captured launch sequence is dropped, and the sweep scratch where the option shapes it.
+int c2r_set_option(c2r_ctx *c, const char *name, double value)
+{
+    if (!c || !name) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    HIP_TRY(hipSetDevice(ctx->prm.device));
+    const std::string n(name);
+    const bool on = value != 0.0;
+    const int iv = (int)value;
+    bool scratch = false;
+    if (n == "graph") ctx->use_graph = on;
+    else if (n == "chain_graph") ctx->chain_graph = on;
+    else if (n == "fused_iter") ctx->fused_iter = on;
+    else if (n == "fuse_small") ctx->fuse_small = on;
+    else if (n == "fold_source_cell") ctx->fold_source_cell = on;
+    else if (n == "pair_shells") ctx->pair_shells = on;
+    else if (n == "sched_hint") ctx->sched_hint = on;
+    else if (n == "spin_wait") ctx->spin_wait = on;
+    else if (n == "poll_wait") ctx->poll_wait = on;
+    else if (n == "stream_hint") { ctx->stream_hint = value < 0.0 ? ctx->ncell * sizeof(double) >= ((size_t)64 << 20) : on; scratch = true; }
+    else if (n == "xcd_order") { ctx->xcd_order = iv < 0 ? -1 : (iv > 0 ? 1 : 0); scratch = true; }
+    else if (n == "xcd_min_per_plane") { ctx->xcd_min_per_plane = value; scratch = true; }
+    else if (n == "xcd_min_alive") ctx->xcd_min_alive = value;
+    else if (n == "xcd_qmin") ctx->xcd_qmin = std::max(1, iv);
+    else if (n == "chains") { ctx->chains_env = std::max(0, std::min(kMaxChains, iv)); scratch = true; }
+    else if (n == "batch_cap") { ctx->batch_cap_opt = std::max(0, iv); scratch = true; }
+    else if (n == "sparse_exchange") ctx->sparse_exchange = on;
+    else if (n == "sparse_fraction") ctx->sparse_fraction = std::max(0.0, value);
+    else if (n == "exchange_overlap") ctx->exchange_overlap = on;
+    else if (n == "exchange_overlap_min") ctx->overlap_min_sources = std::max(1, iv);
+    else FAIL(C2R_EINVAL, "c2r_set_option: unknown option '" + n + "'");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (scratch) free_sweep_scratch(ctx);          // (laid out again by the next pass or c2r_set_sources)
     ++ctx->gen;
     return C2R_OK;
 }

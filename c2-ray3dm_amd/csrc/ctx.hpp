@@ -99,12 +99,22 @@ struct Ctx {
                         bool fused = false; bool stats = false; const void *acc = nullptr;   // acc: the accumulator the captured launches add into
     };
     std::map<int, BatchGraph> graphs;                            // key: 2 x (first source of the batch) + (fused iteration ? 1 : 0)
+    // A chain's launch sequence of a whole pass as ONE replayed hipGraph (sweep.hip run_chains): the sub-boxes the chain's previous
+    // pass went through, every launch sized for the count that pass left (+ a margin); the decision kernels guard the sizes on the
+    // device (k_box_decide next_bound) and the host finishes eagerly whatever the sequence did not cover.  bounds[nbox] (1..H):
+    // sources the launches of sub-box nbox were sized for.  profile[k]: sources active after sub-box k of the chain's last pass
+    // (profile[0]: the traceable sources it started with); empty: not known.
+    struct ChainGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long long gen = 0; int count = 0, n_active = 0, shape_count = 0;
+                        const void *acc = nullptr; int H = 0, launches = 0; std::vector<int> bounds, profile, profile_prev; int passes_since_capture = 0; };
+    std::map<int, ChainGraph> chain_graphs;                      // key: first local source of the chain
+    bool chain_graph = true;                                     // option chain_graph = 0: chains are always driven launch by launch
+    long long chain_replays = 0, chain_halts = 0, chain_eager = 0;   // chain passes replayed / replays the device halted (a launch too small) / driven launch by launch
     unsigned long long gen = 1;
     long long captures = 0;                                      // launch sequences captured so far (c2r_info; tests: a new time step must not add one)
-    bool use_graph = true;                                       // C2R_GRAPH=0: never (experiments)
-    bool fused_iter = true;                                      // C2R_FUSED_ITER=0: c2r_iterate always runs its three steps in turn (experiments)
-    bool fold_source_cell = true;                                // C2R_FOLD_SOURCE_CELL=0: k_source_cells is always its own launch (experiments)
-    bool pair_shells = true;                                     // C2R_PAIR_SHELLS=0: never two shells per launch (experiments)
+    bool use_graph = true;                                       // option graph = 0: never
+    bool fused_iter = true;                                      // option fused_iter = 0: c2r_iterate always runs its three steps in turn
+    bool fold_source_cell = true;                                // option fold_source_cell = 0: k_source_cells is always its own launch
+    bool pair_shells = true;                                     // option pair_shells = 0: never two shells per launch
     // cost-balanced distribution inside the library (c2r_set_balance): every rank learns every source's last
     // sub-box count through the all-reduce callback and computes the same LPT partition
     bool balance = false, auto_share = false;                    // auto_share: `share` was set by the balancer, not the caller
@@ -113,7 +123,7 @@ struct Ctx {
     c2r_allreduce_fn ar = nullptr;
     void *ar_user = nullptr;
     // sparse exchange of the rates (c2r_allreduce_rates): while the sources' final sub-boxes cover a small part of the mesh only
-    // the boxes travel (C2R_SPARSE_EXCHANGE=0: always the whole grid; C2R_SPARSE_FRACTION: the largest sum of box volumes, in
+    // the boxes travel (option sparse_exchange = 0: always the whole grid; sparse_fraction: the largest sum of box volumes, in
     // units of the mesh, that still goes packed)
     bool sparse_exchange = true; double sparse_fraction = 0.5;
     long long pass_id = 0, nbox_all_pass = -1;                   // passes swept so far; the pass nbox_all was gathered for
@@ -123,7 +133,7 @@ struct Ctx {
     long long xchg_calls = 0, xchg_sparse = 0, xchg_bytes_last = 0, xchg_bytes_total = 0, xchg_overlapped = 0;
     // the exchange overlapped with the sweep (c2r_set_exchange_overlap; sweep.hip pass_sources_impl): a pass as two halves of the
     // rank's sources into two pairs of accumulators, the first half's all-reduce on a second stream while the second is swept
-    bool exchange_overlap = false; int overlap_min_sources = 2 * kFewSources;    // (C2R_EXCHANGE_OVERLAP_MIN: experiments, tests)
+    bool exchange_overlap = false; int overlap_min_sources = 2 * kFewSources;    // (option exchange_overlap_min)
     double *d_phih2 = nullptr, *d_phih2_T = nullptr, *acc_phih = nullptr, *acc_phih_T = nullptr;   // acc_*: what the launches being enqueued add into (null: phih_grid / d_phih_T)
     hipStream_t xstream = nullptr; hipEvent_t ev_half = nullptr, ev_xdone = nullptr;
     long long rates_reduced_pass = -1;                           // the pass whose rates in phih_grid are already summed over the ranks
@@ -140,11 +150,12 @@ struct Ctx {
     int batch_cap = 0, batch_want = 0;
     SweepScratch sc[kMaxChains];
     int nchains = 1, chain_cap = 0;
-    int chains_env = 0;         // C2R_CHAINS=n: force n chains (experiments; 0: the rule of choose_chains)
+    int chains_env = 0;         // option chains = n: force n chains (0: the rule of choose_chains)
+    int batch_cap_opt = 0;      // option batch_cap = n: at most n sources in flight per round (0: what the scratch budget allows)
     hipEvent_t ev_prepared = nullptr;      // 'the pass's inputs are ready' on the context's stream, for the other chains' streams
     bool stream_hint = false;   // non-temporal cache policy of k_sweep_shell: meshes whose n_HI array outgrows the L2s
-    bool fuse_small = true;     // C2R_FUSE_SMALL=0 disables the fused first sub-boxes (experiments, A/B tests)
-    bool sched_hint = true;     // C2R_SCHED_HINT=0: always one sub-box ahead (experiments, see sweep_batch)
+    bool fuse_small = true;     // option fuse_small = 0 disables the fused first sub-boxes (A/B tests)
+    bool sched_hint = true;     // option sched_hint = 0: always one sub-box ahead (see sweep_batch)
     // the time step's scalars as the kernels read them (kernels.hpp StepBlock + ShellStep[Qmax + 1]): device copy, the image last sent
     char *d_step = nullptr, *h_step = nullptr; std::vector<char> step_image; double step_dt = 0.0;      // h_step: pinned staging of the copy
     hipEvent_t ev_step = nullptr; bool ev_step_recorded = false;                                          // ... and 'the copy has read it'
@@ -158,12 +169,12 @@ struct Ctx {
       *d_hsc = nullptr;                       // ... and its device alias: kernels store results there directly
     double *d_dbg = nullptr, *d_pair = nullptr;
     unsigned long long *d_seq = nullptr, seq_seen = 0;           // passes completed by fused iterations (k_pass_final counts, the host polls h_sc->seq)
-    bool spin_wait = true;                                       // C2R_SPIN_WAIT=0: always hipStreamSynchronize (experiments)
-    // XCD-aware, plane-ordered block mapping of the far shells (k_sweep_shell_xcd): C2R_XCD_ORDER = 0 never, 1 always where it
-    // can run, unset: where at least xcd_min_per_plane sources share a mesh plane and face sign (sources / mesh planes)
+    bool spin_wait = true;                                       // option spin_wait = 0: always hipStreamSynchronize
+    // XCD-aware, plane-ordered block mapping of the far shells (k_sweep_shell_xcd): option xcd_order = 0 never, 1 always where it
+    // can run, -1 (default): where at least xcd_min_per_plane sources share a mesh plane and face sign (sources / mesh planes)
     int xcd_order = -1; double xcd_min_per_plane = 1.5; double xcd_min_alive = 0.9; int xcd_qmin = 16;
     long long xcd_launches = 0;
-    bool poll_wait = true;                                       // C2R_POLL_WAIT=0: the sub-box counts are waited for with hipEventSynchronize alone (experiments)
+    bool poll_wait = true;                                       // option poll_wait = 0: the sub-box counts are waited for with hipEventSynchronize alone
     double *h_it4 = nullptr, *d_hit4 = nullptr;   // pinned [C2R_MAX_ITER_LOG][4]: per-iteration photon-statistics sums, written by the device
     // profiling
     int prof = 0;               // 0 off; 1 an event pair around every k_sweep_shell launch; 2 one pair per sub-box

@@ -1024,8 +1024,12 @@ __global__ __launch_bounds__(1024) void k_box_decide(const int *active_in, const
                                                      int *n_out, int *n_out_host, const double *normflux, double S_star,
                                                      double loss_fraction, int can_grow, int nbox,
                                                      double *loss_acc, double *final_loss, int *final_nbox,
-                                                     const double *loss_partial, int bps)
+                                                     const double *loss_partial, int bps, int next_bound, int *halt_host)
 {
+    // next_bound / halt_host (a replayed launch sequence, sweep.hip run_chains): the launches of the next sub-box were sized for
+    // next_bound sources when they were captured.  Should more stay active, the device count is left at ZERO -- every later launch
+    // of the sequence returns at once, the lists and planes stay as this sub-box left them -- the true count still goes to the
+    // host's slot and the sub-box number to *halt_host: the host resumes from there with launches of the right size.
     // loss_partial/bps: block partials of the sub-box's LAST shell launch (bps = 6 x tiles per source, 0: none) -- what
     // k_loss_reduce would add, folded in here to save a launch; four interleaved partial sums, then in a fixed order
     __shared__ int scan[1024];
@@ -1068,7 +1072,11 @@ __global__ __launch_bounds__(1024) void k_box_decide(const int *active_in, const
         __syncthreads();
     }
     // n_out_host: the schedule's pinned slot for this sub-box, written straight through the mapped pointer
-    if (threadIdx.x == 0) { *n_out = base; *n_out_host = base; }
+    if (threadIdx.x == 0) {
+        const bool over = base > next_bound;
+        *n_out = over ? 0 : base; *n_out_host = base;
+        if (over) *halt_host = nbox;
+    }
 }
 
 // k_box_decide for up to 64 active sources (one wave, no scan through LDS): the same sums in the same order, the same
@@ -1085,7 +1093,8 @@ __global__ __launch_bounds__(64) void k_box_decide_small(const int *active_in, c
                                                          int *n_out, int *n_out_host, const double *normflux, double S_star,
                                                          double loss_fraction, int can_grow, int nbox,
                                                          double *loss_acc, double *final_loss, int *final_nbox,
-                                                         const double *loss_partial, int bps, SmallTotals tot)
+                                                         const double *loss_partial, int bps, SmallTotals tot,
+                                                         int next_bound, int *halt_host)
 {
 #if defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
 #error "k_box_decide_small is one 64-lane wave (ballot, cross-lane reads of final_loss): build for a wave64 target (gfx950)"
@@ -1113,7 +1122,11 @@ __global__ __launch_bounds__(64) void k_box_decide_small(const int *active_in, c
     const unsigned long long mask = __ballot(keep);
     if (keep) active_out[__popcll(mask & ((1ULL << i) - 1ULL))] = s;
     const int n_keep = __popcll(mask);
-    if (i == 0) { *n_out = n_keep; *n_out_host = n_keep; }
+    if (i == 0) {                                         // (next_bound, halt_host: see k_box_decide)
+        const bool over = n_keep > next_bound;
+        *n_out = over ? 0 : n_keep; *n_out_host = n_keep;
+        if (over) *halt_host = nbox;
+    }
     if (tot.on && n_keep == 0) {
         __threadfence_block();                            // (one wave: the stores above are ordered before the loads below)
         __syncthreads();

@@ -2,6 +2,7 @@
 // (BatchSweep), the pass over all of a rank's sources, one source, one cell.  Kernels: kernels_sweep.hpp.
 #include "ctx.hpp"
 #include "kernels_sweep.hpp"
+#include <climits>
 
 namespace c2r {
 
@@ -102,7 +103,7 @@ int ensure_sweep_scratch(Ctx *ctx, int want)
         budget = fr / 4;
     }
     int cap = (int)std::min<size_t>((size_t)want, std::max<size_t>(1, budget / per_src));
-    if (const char *e = getenv("C2R_BATCH_CAP")) cap = std::max(1, std::min(cap, atoi(e)));      // experiments
+    if (ctx->batch_cap_opt > 0) cap = std::max(1, std::min(cap, ctx->batch_cap_opt));          // (option batch_cap: tests of several rounds)
     cap = std::min(cap, 65535);                 // grid.z of k_sweep_shell
     // the sources of a round, split over the chains (each chain's arrays hold its share)
     const int nch = choose_chains(ctx, cap);
@@ -335,6 +336,7 @@ struct BatchSweep {
     bool chained = false;          // one of several chains in flight (run_chains): no per-launch timing events, no host waits of its own
     int launches = 0;              // shell launches enqueued so far (k_sweep_shell*, pairs)
     int bound = 0, known = 0;      // run_chains: upper bound of the device's active count; sub-boxes whose count has been read back
+    int next = 1, last = 0;        // run_chains: the sub-box to enqueue next, the one enqueued last
     bool perm_ready = false;       // the batch's sources sorted along each axis are on the device (stage_perm): far shells may run plane-ordered
 
     BatchSweep(Ctx *c, SweepScratch &sc_, int first_, int count_, bool first_of_pass_, double *dbg_, FusedIter *fz_)
@@ -393,6 +395,7 @@ struct BatchSweep {
     // what the launches of sub-box nbox share
     struct Box {
         int nbox, bound;               // the sub-box; upper bound of the device's active count (sizes the grids)
+        int next_bound;                // what the NEXT sub-box's launches are sized for, where that is fixed already (a captured sequence); else INT_MAX
         int boxR[3], boxL[3];          // last_r / last_l - srcpos (evolve_source.F90:135-136)
         bool pair_ok, fused_box, det;
         int pbuf;                      // which plane set holds shell q0 - 1
@@ -621,6 +624,7 @@ struct BatchSweep {
     void launch_decision(const Box &bx)
     {
         const int nbox = bx.nbox;
+        int *const halt = sc.d_hnactive;                  // slot 0 of the pinned counts: the sub-box a replayed sequence halted at (0: none)
         const int can_grow = (p.subboxsize * nbox < ctx->hr[2]) && (p.subboxsize * nbox < ctx->hl[2]);
         if (n_active <= 64) {
             // one wave decides; at the sub-box a fused iteration's graph ends with it also leaves the batch's totals and
@@ -635,19 +639,19 @@ struct BatchSweep {
             hipLaunchKernelGGL(k_box_decide_small, dim3(1), dim3(64), 0, st, sc.d_active[cur], sc.d_nactive + cur,
                                sc.d_active[1 - cur], sc.d_nactive + (1 - cur), sc.d_hnactive + nbox, sc.d_nflux_b,
                                p.S_star, p.loss_fraction, can_grow, nbox, sc.d_loss_acc, sc.d_final_loss, sc.d_final_nbox,
-                               (const double *)sc.d_loss_partial, last_bps, tot);
+                               (const double *)sc.d_loss_partial, last_bps, tot, bx.next_bound, halt);
         } else
         hipLaunchKernelGGL(k_box_decide, dim3(1), dim3(1024), 0, st, sc.d_active[cur], sc.d_nactive + cur,
                            sc.d_active[1 - cur], sc.d_nactive + (1 - cur), sc.d_hnactive + nbox, sc.d_nflux_b,
                            p.S_star, p.loss_fraction, can_grow, nbox, sc.d_loss_acc, sc.d_final_loss, sc.d_final_nbox,
-                           (const double *)sc.d_loss_partial, last_bps);
+                           (const double *)sc.d_loss_partial, last_bps, bx.next_bound, halt);
     }
 
     // every launch of sub-box nbox for `bound` sources at most (no host wait, no event); flips `cur`
-    int enqueue_box(const int nbox, const int bound)
+    int enqueue_box(const int nbox, const int bound, const int next_bound = INT_MAX)
     {
         Box bx{};
-        bx.nbox = nbox; bx.bound = bound;
+        bx.nbox = nbox; bx.bound = bound; bx.next_bound = next_bound;
         for (int d = 0; d < 3; ++d) {
             bx.boxR[d] = std::min(p.subboxsize * nbox, ctx->hr[d]);
             bx.boxL[d] = std::min(p.subboxsize * nbox, ctx->hl[d]);
@@ -725,6 +729,11 @@ struct BatchSweep {
             }
         } else { (void)hipGetLastError(); ctx->use_graph = false; }
     }
+
+    // A chain's whole pass as one launch sequence (run_chains): the batch upload and sub-boxes 1..H of the chain's last pass, every
+    // launch sized by bounds_from_profile, every decision guarding the next sub-box's size.  false: not captured (the context falls
+    // back to launch-by-launch for good where the runtime cannot capture at all).
+    bool capture_chain(Ctx::ChainGraph &cg);
 
     // behind a fused iteration's graph: the last kernel of the gated tail stores the count of completed passes to pinned
     // memory as its final act -- poll it instead of blocking (bounded); true: the gate was open, the whole iteration has run
@@ -842,6 +851,35 @@ int BatchSweep::run(std::vector<int> *nbox_out, std::vector<double> *loss_out)
     return C2R_OK;
 }
 
+static void bounds_from_profile(const std::vector<int> &prof, int n_active, std::vector<int> &bounds, int &H);
+
+bool BatchSweep::capture_chain(Ctx::ChainGraph &cg)
+{
+    if (cg.exec) { hipGraphExecDestroy(cg.exec); cg.exec = nullptr; }
+    if (cg.graph) { hipGraphDestroy(cg.graph); cg.graph = nullptr; }
+    bounds_from_profile(cg.profile, n_active, cg.bounds, cg.H);
+    if (cg.H < 1) return false;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); ctx->use_graph = false; return false; }
+    ++ctx->captures;
+    int rc = (int)hipMemcpyAsync(sc.d_batch, sc.h_batch, sc.batch_bytes, hipMemcpyHostToDevice, st);
+    const int cur0 = cur, launches0 = launches;
+    cur = 0;
+    for (int nbox = 1; nbox <= cg.H && rc == C2R_OK; ++nbox) rc = enqueue_box(nbox, cg.bounds[nbox], nbox < cg.H ? cg.bounds[nbox + 1] : INT_MAX);
+    cg.launches = launches - launches0;
+    cur = cur0; launches = launches0;
+    const hipError_t e = hipStreamEndCapture(st, &cg.graph);
+    if (rc == C2R_OK && e == hipSuccess && hipGetLastError() == hipSuccess && hipGraphInstantiate(&cg.exec, cg.graph, nullptr, nullptr, 0) == hipSuccess) {
+        cg.gen = ctx->gen; cg.count = count; cg.n_active = n_active; cg.shape_count = shape_count; cg.acc = (const void *)k.phih;
+        cg.passes_since_capture = 0;
+        return true;
+    }
+    if (cg.graph) { hipGraphDestroy(cg.graph); cg.graph = nullptr; }
+    cg.exec = nullptr;
+    (void)hipGetLastError();
+    ctx->use_graph = false;            // this runtime / stream cannot capture: launch by launch from now on
+    return false;
+}
+
 int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg, std::vector<int> *nbox_out,
                 std::vector<double> *loss_out, FusedIter *fz = nullptr)
 {
@@ -850,14 +888,55 @@ int sweep_batch(Ctx *ctx, int first, int count, bool first_of_pass, double *dbg,
 }
 
 // One round of a pass as SEVERAL chains in flight: local sources [first, first + count) in nch contiguous shares, each with
-// its own scratch and stream (SweepScratch), driven in lock-step by this thread -- sub-box n of every chain is enqueued
-// before any count of sub-box n - 1 is waited for, so the streams always hold work of every chain and the GPU overlaps one
-// chain's launch with the tail of another's.  Same launches, same arguments, same per-source results as one chain after
+// its own scratch and stream (SweepScratch).  Same launches, same arguments, same per-source results as one chain after
 // the other; only the order in which the Gamma atomics of different sources land can differ (as it may within one launch).
+//
+// Two ways to drive them:
+// * REPLAYED (round 6; the steady state of an outer iteration): each chain's launch sequence -- the batch upload and every
+//   launch of the sub-boxes its previous pass went through, sized for the counts that pass left plus a margin -- is ONE
+//   hipGraph on the chain's stream.  The host launches nch graphs and waits once per chain: no host round trip per sub-box,
+//   dependent launches follow each other at the command processor's pace whatever the host is doing.  The sizes are guarded
+//   on the device (k_box_decide's next_bound: a decision that keeps more sources than the next launches were sized for
+//   leaves the device count at zero and reports the sub-box), and whatever the sequence did not cover -- sources still active
+//   behind its last sub-box, or a halt -- the host finishes launch by launch as below.
+// * LAUNCH BY LAUNCH (first pass of a source list, changing counts): this thread drives the chains in lock-step, sub-box n of
+//   every chain enqueued before any count of sub-box n - kChainAhead is waited for, so the streams always hold work of every
+//   chain and the GPU overlaps one chain's launch with the tail of another's.
 #ifndef C2R_CHAIN_AHEAD
 #define C2R_CHAIN_AHEAD 2          // (3 measured the same: profiles/r05_chains)
 #endif
 constexpr int kChainAhead = C2R_CHAIN_AHEAD;
+
+// The launch sizes a replayed sequence is captured with, from the chain's last pass: sub-box nbox for the count sub-box nbox - 1
+// left, plus a margin of an eighth (at least 2) so that a source that goes one sub-box further than last time does not halt the
+// sequence -- a surplus source costs a few hundred workgroups that return at once.  H: the sub-boxes that pass went through.
+static void bounds_from_profile(const std::vector<int> &prof, int n_active, std::vector<int> &bounds, int &H)
+{
+    H = 0;
+    while (H + 1 < (int)prof.size() && prof[H] > 0) ++H;         // prof[k] > 0 for k < H: sub-box k + 1 had sources to trace
+    bounds.assign((size_t)H + 1, 0);
+    for (int nb = 1; nb <= H; ++nb) {
+        const int c = prof[nb - 1];
+        bounds[nb] = nb == 1 ? n_active : std::min(n_active, c + std::max(2, c / 8));
+    }
+}
+
+// May the chain's pass be replayed from cg as it is?  The same batch and launch shapes, the same number of sub-boxes as the last
+// pass went through, every launch at least as large as that pass needed and the whole not much larger.
+static bool chain_graph_fits(const Ctx *ctx, const Ctx::ChainGraph &cg, const BatchSweep &b, const void *acc)
+{
+    if (!cg.exec || cg.gen != ctx->gen || cg.count != b.count || cg.n_active != b.n_active || cg.shape_count != b.shape_count || cg.acc != acc) return false;
+    std::vector<int> want; int H = 0;
+    bounds_from_profile(cg.profile, b.n_active, want, H);
+    if (H != cg.H) return false;
+    long long have = 0, need = 0;
+    for (int nb = 1; nb <= H; ++nb) {
+        if (cg.bounds[nb] < cg.profile[nb - 1]) return false;
+        have += cg.bounds[nb]; need += cg.profile[nb - 1];
+    }
+    return have <= need + need / 2 + 4LL * H;
+}
+
 int run_chains(Ctx *ctx, int first, int count, bool first_of_pass, std::vector<int> *nbox_out)
 {
     const int nch = std::min(ctx->nchains, count);
@@ -869,37 +948,83 @@ int run_chains(Ctx *ctx, int first, int count, bool first_of_pass, std::vector<i
     // the pass's inputs (n_HI, the zeroed transposed accumulators: sweep_prepare on the context's stream) before any chain starts
     HIP_TRY(hipEventRecord(ctx->ev_prepared, ctx->stream));
     if (ctx->prof) prof_begin(ctx, ctx->ev_sweep, ctx->ev_sweep_used);
-    for (auto &b : ch) {
+    std::vector<Ctx::ChainGraph *> graph_of(ch.size(), nullptr);
+    for (size_t c = 0; c < ch.size(); ++c) {
+        BatchSweep &b = ch[c];
         b.chained = true;
         b.stage();
         if (b.st != ctx->stream) HIP_TRY(hipStreamWaitEvent(b.st, ctx->ev_prepared, 0));
-        HIP_TRY(hipMemcpyAsync(b.sc.d_batch, b.sc.h_batch, b.sc.batch_bytes, hipMemcpyHostToDevice, b.st));
-        b.bound = b.n_active; b.known = 0; b.cur = 0;
-    }
-    for (int nbox = 1; nbox <= ctx->nbox_max; ++nbox) {
-        bool any = false;
-        for (auto &b : ch) {
-            if (b.bound <= 0) continue;
-            any = true;
-            { const int rc = b.enqueue_box(nbox, b.bound); if (rc) return rc; }
-            HIP_TRY(hipEventRecord(b.sc.ev_box[nbox], b.st));
+        b.bound = b.n_active; b.known = 0; b.cur = 0; b.next = 1;
+        Ctx::ChainGraph &cg = ctx->chain_graphs[b.first];
+        ++cg.passes_since_capture;
+        bool replay = false;
+        if (ctx->use_graph && ctx->chain_graph && b.n_active > 0 && !cg.profile.empty()) {
+            replay = chain_graph_fits(ctx, cg, b, (const void *)b.k.phih);
+            // (re)capture: nothing to replay yet, or the counts have settled (two passes alike), or the last capture is a while
+            // ago -- a capture costs about what it saves in one pass, so counts that move every pass are driven launch by launch
+            if (!replay && (!cg.exec || cg.gen != ctx->gen || cg.profile == cg.profile_prev || cg.passes_since_capture > 3))
+                replay = b.capture_chain(cg);
         }
-        if (!any) break;
-        // kChainAhead sub-boxes stay in flight per chain: the count after sub-box nbox - kChainAhead sizes (and ends) the next
-        // round of launches.  (One ahead, as a single chain of many sources runs, leaves the streams empty while this thread
-        // enqueues the next sub-box of every chain -- near the source a sub-box is five launches of 10 - 20 us, about what
-        // enqueueing it costs; blocks of sources that retired in between return at once: at most 512 sources here.)
-        for (auto &b : ch) {
-            if (b.bound <= 0) continue;
-            while (b.known < nbox && hipEventQuery(b.sc.ev_box[b.known + 1]) == hipSuccess) b.bound = b.sc.h_nactive[++b.known];
-            const int need = nbox - kChainAhead;
-            if (need > b.known) {
-                // (polling before blocking: a sub-box near the source lasts about as long as the wake-up of an event wait)
-                { const int rc = wait_polling(ctx, b.sc.ev_box[need]); if (rc) return rc; }
-                b.known = need; b.bound = b.sc.h_nactive[need];
+        if (replay) {
+            b.sc.h_nactive[0] = 0;                                                  // (the halt slot)
+            HIP_TRY(hipGraphLaunch(cg.exec, b.st));
+            HIP_TRY(hipEventRecord(b.sc.ev_done, b.st));
+            graph_of[c] = &cg;
+            b.bound = 0;                                                            // (not driven below until the replay has been looked at)
+            ++ctx->chain_replays;
+        } else {
+            HIP_TRY(hipMemcpyAsync(b.sc.d_batch, b.sc.h_batch, b.sc.batch_bytes, hipMemcpyHostToDevice, b.st));
+            ++ctx->chain_eager;
+        }
+    }
+    // launch by launch, in lock-step: every chain that has sources to trace gets its next sub-box, then the counts are looked at
+    auto lockstep = [&]() -> int {
+        for (;;) {
+            bool any = false;
+            for (auto &b : ch) {
+                if (b.bound <= 0 || b.next > ctx->nbox_max) continue;
+                any = true;
+                { const int rc = b.enqueue_box(b.next, b.bound); if (rc) return rc; }
+                HIP_TRY(hipEventRecord(b.sc.ev_box[b.next], b.st));
+                b.last = b.next++;
+            }
+            if (!any) return C2R_OK;
+            // kChainAhead sub-boxes stay in flight per chain: the count after sub-box last - kChainAhead sizes (and ends) the next
+            // round of launches.  (One ahead, as a single chain of many sources runs, leaves the streams empty while this thread
+            // enqueues the next sub-box of every chain -- near the source a sub-box is five launches of 10 - 20 us, about what
+            // enqueueing it costs; blocks of sources that retired in between return at once: at most 512 sources here.)
+            for (auto &b : ch) {
+                if (b.bound <= 0) continue;
+                while (b.known < b.last && hipEventQuery(b.sc.ev_box[b.known + 1]) == hipSuccess) b.bound = b.sc.h_nactive[++b.known];
+                const int need = b.last - kChainAhead;
+                if (need > b.known) {
+                    // (polling before blocking: a sub-box near the source lasts about as long as the wake-up of an event wait)
+                    { const int rc = wait_polling(ctx, b.sc.ev_box[need]); if (rc) return rc; }
+                    b.known = need; b.bound = b.sc.h_nactive[need];
+                }
             }
         }
+    };
+    { const int rc = lockstep(); if (rc) return rc; }
+    // the replayed chains: one wait each; where the sequence ended with sources still active, or halted, the rest launch by launch
+    bool more = false;
+    for (size_t c = 0; c < ch.size(); ++c) {
+        if (!graph_of[c]) continue;
+        BatchSweep &b = ch[c];
+        { const int rc = wait_polling(ctx, b.sc.ev_done); if (rc) return rc; }
+        const int halt = b.sc.h_nactive[0];
+        const int at = halt > 0 ? halt : graph_of[c]->H;           // the last sub-box whose decision stands
+        b.launches += graph_of[c]->launches;
+        b.known = at; b.cur = at & 1; b.next = at + 1; b.bound = b.sc.h_nactive[at];
+        if (halt > 0) {
+            // the decision of sub-box `halt` kept more sources than the next launches were sized for: it left the device count at
+            // zero (the rest of the sequence did nothing) and the true count in the host's slot -- put it back, go on from there
+            HIP_TRY(hipMemcpyAsync(b.sc.d_nactive + b.cur, &b.sc.h_nactive[at], sizeof(int), hipMemcpyHostToDevice, b.st));
+            ++ctx->chain_halts;
+        }
+        if (b.bound > 0 && b.next <= ctx->nbox_max) more = true;
     }
+    if (more) { const int rc = lockstep(); if (rc) return rc; }
     // the chains join the context's stream; their totals follow in chain order = source order
     int launches = 0;
     for (auto &b : ch) {
@@ -912,6 +1037,15 @@ int run_chains(Ctx *ctx, int first, int count, bool first_of_pass, std::vector<i
     if (ctx->prof) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(launches); }
     for (auto &b : ch) { const int rc = b.enqueue_totals(nbox_out ? nbox_out : nullptr, nullptr, ctx->stream, b.first_of_pass); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // what the next pass's sequence is sized by: the counts this pass left, sub-box by sub-box (every slot up to the last
+    // sub-box enqueued has been written; beyond the first zero nothing is looked at)
+    for (auto &b : ch) {
+        Ctx::ChainGraph &cg = ctx->chain_graphs[b.first];
+        cg.profile_prev.swap(cg.profile);
+        cg.profile.assign(1, b.n_active);
+        for (int nb = 1; nb < b.next && cg.profile.back() > 0; ++nb) cg.profile.push_back(b.sc.h_nactive[nb]);
+        if (cg.profile.back() > 0) cg.profile.push_back(0);       // (ended at the last sub-box there is)
+    }
     if (nbox_out) {
         nbox_out->clear();
         for (auto &b : ch) nbox_out->insert(nbox_out->end(), b.h_fnb, b.h_fnb + b.count);

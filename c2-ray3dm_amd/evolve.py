@@ -61,7 +61,7 @@ def balanced_source_shares(cost, npr):
 class HipBackend:
     """The HIP path: owns a c2r context on one GPU and the device-resident arrays."""
 
-    def __init__(self, mesh, thick, thin, device=0, scratch_bytes=0, deterministic=False, fast=None):
+    def __init__(self, mesh, thick, thin, device=0, scratch_bytes=0, deterministic=False, fast=None, options=None):
         import torch
         self.torch = torch
         self.lib = _capi.load_library()
@@ -75,8 +75,8 @@ class HipBackend:
         p.scratch_bytes = scratch_bytes
         p.deterministic_rates = 1 if deterministic else 0
         # fast=None: this HOST's switch -- the environment variable C2R_SWEEP_MODE (0/1; how the GPU tests run every case
-        # in both modes), else the library default C2R_SWEEP_EXACT.  The library itself reads no environment variable:
-        # an explicit fast=True/False is what the context gets.
+        # in both modes), else the library default (c2r_default_params: C2R_SWEEP_FAST).  The library itself reads no
+        # environment variable: an explicit fast=True/False is what the context gets.
         if fast is None and os.environ.get("C2R_SWEEP_MODE") is not None:
             fast = os.environ["C2R_SWEEP_MODE"] not in ("0", "")
         if fast is not None:
@@ -108,6 +108,12 @@ class HipBackend:
         self.nsrc = 0
         self.rank, self.npr = 0, 1
         self._cb = None
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
+
+    def set_option(self, name, value):
+        """c2r_set_option: a switch of the launch schedule (include/c2ray_hip.h has the table), for A/B runs and tests."""
+        self._check(self.lib.c2r_set_option(self.ctx, str(name).encode(), float(value)), "c2r_set_option(%s)" % name)
 
     # -- plumbing -----------------------------------------------------------------------------
     def _check(self, rc, what):

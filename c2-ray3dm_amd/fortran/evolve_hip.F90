@@ -403,10 +403,11 @@ contains
     p%bh00 = bh00; p%albpow = albpow; p%colh0 = colh0; p%temph0 = temph0
     p%S_star = S_star
     ! Sweep arithmetic: the reference has no such parameter, so this drop-in takes it from its own run-time switch, the
-    ! environment variable C2R_SWEEP_MODE (unset or 0: C2R_SWEEP_EXACT, column densities bit-identical to the Fortran;
-    ! 1: C2R_SWEEP_FAST).  The library reads no environment: what is set here is what runs, and it is logged below.
+    ! environment variable C2R_SWEEP_MODE (unset or 1: C2R_SWEEP_FAST, the library default -- xh within 1e-9 of the Fortran where
+    ! the task asks for 1e-5; 0: C2R_SWEEP_EXACT, column densities bit-identical to the Fortran, ~20 % slower).  The library
+    ! reads no environment: what is set here is what runs, and it is logged below.
     call get_environment_variable("C2R_SWEEP_MODE", envval, status=envstat)
-    if (envstat == 0 .and. len_trim(envval) > 0 .and. trim(envval) /= "0") p%sweep_mode = 1_c_int32_t
+    if (envstat == 0 .and. len_trim(envval) > 0) p%sweep_mode = merge(0_c_int32_t, 1_c_int32_t, trim(envval) == "0")
     call get_environment_variable("C2R_SHIM_SYNC_WORK_ARRAYS", envval, status=envstat)
     sync_work_arrays = envstat == 0 .and. len_trim(envval) > 0 .and. trim(envval) /= "0"
     call check(c2r_create(ctx, p), "c2r_create")

@@ -62,7 +62,7 @@ typedef struct c2r_params {
                                       * 1: per-source Gamma grids reduced in source order: bit-reproducible, and
                                       *    the summation order of the serial reference (evolve_point.F90:283);
                                       *    costs 16 B x N^3 of scratch per source in flight */
-    int32_t sweep_mode;              /* C2R_SWEEP_EXACT (0, default): every f64 operation of evolve0D's geometry and of cinterp
+    int32_t sweep_mode;              /* C2R_SWEEP_EXACT (0; opt-in since round 6): every f64 operation of evolve0D's geometry and of cinterp
                                       *    (column_density.f90:29-271) in the reference's order, IEEE-exact division and
                                       *    sqrt: column densities bit-identical to the Fortran.  The RATE of a cell
                                       *    (photoion_rates, radiation_photoionrates.F90:71-317) is evaluated by the routine both
@@ -74,7 +74,8 @@ typedef struct c2r_params {
                                       *    compares a loss good to ~1e-13 with loss_fraction x flux: the integer results (sub-box
                                       *    counts, visited cells) are tolerance-bound in BOTH modes -- equal to the reference's on
                                       *    every fixture and in every fuzz run so far, not equal by construction;
-                                      * C2R_SWEEP_FAST (1): the interpolation and the geometry re-associated as well (factored
+                                      * C2R_SWEEP_FAST (1; what c2r_default_params sets, what the Fortran shim and the Python host run
+                                      *    unless told otherwise, and what bench.py's headline times): the interpolation and the geometry re-associated as well (factored
                                       *    weights, 2^-48 reciprocals): same integer results, column densities within 1e-11 and
                                       *    rates within |dGamma| <= 1e-12 Gamma + 2e-14 W of the oracle (W = sum_s (1+tau_in)
                                       *    photo_in / (vol_ph n_HI): the rate that passes THROUGH the cell; worst plain relative
@@ -151,6 +152,29 @@ const char *c2r_last_error(const c2r_ctx *ctx);
 const char *c2r_info(c2r_ctx *ctx);
 /* Run on a caller-provided hipStream_t (NULL = the context's own stream). */
 int  c2r_set_stream(c2r_ctx *ctx, void *hip_stream);
+/* Switches of the launch schedule, for A/B measurements and tests.  The library reads NO environment variable for any of them
+ * (nor for anything else but the device of C2R_DEVICE_AUTO): a host that wants one calls this.  None changes a result beyond the
+ * order in which the f64 atomics of different sources land in the rate arrays; sub-box counts, visited cells and the photon loss are
+ * the same bits under every setting (tests/test_gpu_chains.py, test_gpu_few_sources.py, test_gpu_xcd_order.py).  Setting one drops
+ * every captured launch sequence.  C2R_EINVAL for an unknown name.
+ *   name                  default   meaning
+ *   graph                 1         0: no launch sequence is ever captured and replayed (hipGraph)
+ *   chain_graph           1         0: chains in flight (64 - 768 sources per round) are driven launch by launch in every pass;
+ *                                      1: from the second pass on a chain's launch sequence is one replayed hipGraph (sweep.hip run_chains)
+ *   fused_iter            1         0: c2r_iterate always runs its three steps in turn (no whole-iteration graph for <= 32 sources)
+ *   fuse_small            1         0: the first sub-boxes run shell by shell instead of in k_sweep_box_fused
+ *   fold_source_cell      1         0: k_source_cells is always its own launch
+ *   pair_shells           1         0: never two shells per launch (look-ahead pairs of <= 32 sources)
+ *   sched_hint            1         0: the host always runs exactly one sub-box ahead of the device
+ *   spin_wait, poll_wait  1         0: host waits block (hipStreamSynchronize / hipEventSynchronize) instead of polling first
+ *   stream_hint           -1        non-temporal cache policy of the shell kernels: -1 by mesh size (n_HI >= 64 MB), 0 off, 1 on
+ *   xcd_order             -1        plane-ordered block mapping of the far shells: -1 from xcd_min_per_plane sources per mesh plane, 0 never, 1 always
+ *   xcd_min_per_plane     1.5       ... that threshold;   xcd_min_alive 0.9: ... while this share of the batch is still traced;   xcd_qmin 16: ... from this shell
+ *   chains                0         n > 0: a pass runs as n chains in flight (1 - 4) whatever its source count; 0: the library's rule
+ *   batch_cap             0         n > 0: at most n sources in flight per round (tests of passes cut into several rounds)
+ *   sparse_exchange       1         0: c2r_allreduce_rates always reduces the whole grid;   sparse_fraction 0.5: largest packed volume (units of the mesh)
+ *   exchange_overlap      0         = c2r_set_exchange_overlap;   exchange_overlap_min 64: fewest sources per rank it applies to */
+int  c2r_set_option(c2r_ctx *ctx, const char *name, double value);
 
 /* ---- inputs the driver owns ------------------------------------------------------------ */
 /* stellar_photo_thick_table / _thin_table (0:NumTau,1), built once by rad_ini
@@ -299,8 +323,7 @@ int  c2r_pass_sources(c2r_ctx *ctx, double *photon_loss, int64_t *sum_nbox, int6
  * hands the first half's rates to the all-reduce callback -- on a second stream -- while the second half is swept; both
  * reduced halves are then added.  c2r_allreduce_rates after such a pass only refreshes the per-source sub-box list.  The
  * result is the plain path's up to the association of the sums (1e-16 relative).  Every rank must make the same choice, and
- * the callback must honour its stream argument (the RCCL binding and the torch.distributed host do).  Off by default; the
- * environment variable C2R_EXCHANGE_OVERLAP=1 (read by c2r_create) switches it on as well. */
+ * the callback must honour its stream argument (the RCCL binding and the torch.distributed host do).  Off by default. */
 int  c2r_set_exchange_overlap(c2r_ctx *ctx, int32_t on);
 
 /* mpi_accumulate_grid_quantities (evolve.F90:577-616) through the callback; no-op for 1 rank.

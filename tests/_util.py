@@ -90,7 +90,7 @@ def gamma_ok(dgamma, gamma_ref, w, fast):
 def sweep_mode():
     """Mode the GPU tests run the sweep in: the `sweep_mode` fixture (conftest.py) sets C2R_SWEEP_MODE, which
     c2r_create reads, so every context a test creates -- through Python, C or the Fortran shim -- follows it."""
-    return "fast" if os.environ.get("C2R_SWEEP_MODE") == "1" else "exact"
+    return "exact" if os.environ.get("C2R_SWEEP_MODE") == "0" else "fast"       # (unset: the library default, C2R_SWEEP_FAST)
 
 
 def tol(key):

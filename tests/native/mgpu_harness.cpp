@@ -140,6 +140,12 @@ static void *rank_main(void *p)
         if (const char *e = getenv("C2R_SWEEP_MODE")) prm.sweep_mode = atoi(e) ? C2R_SWEEP_FAST : C2R_SWEEP_EXACT;
         if (const char *e = getenv("C2R_HARNESS_DETERMINISTIC")) prm.deterministic_rates = atoi(e) ? 1 : 0;   // ordered per-source sums: runs comparable bit for bit
         TRY(c2r_create(&ctx, &prm));
+        // the library reads no environment variable for its schedule switches: this harness (test code) hands its own over
+        static const char *const opts[][2] = {{"C2R_EXCHANGE_OVERLAP", "exchange_overlap"}, {"C2R_EXCHANGE_OVERLAP_MIN", "exchange_overlap_min"},
+                                              {"C2R_SPARSE_EXCHANGE", "sparse_exchange"}, {"C2R_SPARSE_FRACTION", "sparse_fraction"},
+                                              {"C2R_CHAINS", "chains"}, {"C2R_CHAIN_GRAPH", "chain_graph"}};
+        for (const auto &o : opts)
+            if (const char *e = getenv(o[0])) TRY(c2r_set_option(ctx, o[1], atof(e)));
         TRY(c2r_set_tables(ctx, pb.thick.data(), pb.thin.data(), (int32_t)pb.thick.size()));
         const double dr[3] = {pb.dr, pb.dr, pb.dr};
         TRY(c2r_set_step(ctx, dr, pb.vol, pb.lls, 1.0f, 1.0e4));

@@ -108,8 +108,8 @@ def test_bench_two_ranks_with_the_exchange_overlapped():
                          timeout=900, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(C2R_BENCH_TEST_ONE_GPU="1", C2R_SPARSE_EXCHANGE="0")
-    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--overlap-exchange"] + args, capture_output=True,
+    env.update(C2R_BENCH_TEST_ONE_GPU="1")
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--overlap-exchange", "--option", "sparse_exchange=0"] + args, capture_output=True,
                          text=True, timeout=900, cwd=ROOT, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     a, b = line(one.stdout), line(two.stdout)

@@ -125,3 +125,104 @@ def test_whole_steps_with_and_without_chains(pkg, tables, monkeypatch):
         assert r[0] == reps[0][0] and r[1] == reps[0][1] and r[2] == reps[0][2]
         assert abs(r[3] - reps[0][3]) <= 1e-12 * abs(reps[0][3])
         assert np.max(np.abs(r[4] - reps[0][4])) < 1e-11
+
+
+# ---- round 6: a chain's pass as ONE replayed launch sequence (csrc/sweep.hip run_chains, include/c2ray_hip.h option chain_graph) --------
+
+def _info_counts(b):
+    """(replayed, halted, launch by launch) chain passes so far, from c2r_info."""
+    import re
+    m = re.search(r"chain passes replayed (\d+) \(halted (\d+)\), launch by launch (\d+)", b.info())
+    return tuple(int(v) for v in m.groups())
+
+
+def _passes(pkg, tables, monkeypatch, chain_graph, n, s, nd, fields, pos, nf, chains=None):
+    """One context, one pass per entry of `fields` (each loaded as xh_av before its pass): per pass (loss, sum_nbox, visited,
+    per-source sub-boxes, Gamma), and the context's chain counters at the end."""
+    monkeypatch.setenv("C2R_CHAIN_GRAPH", "1" if chain_graph else "0")
+    if chains is None:
+        monkeypatch.delenv("C2R_CHAINS", raising=False)
+    else:
+        monkeypatch.setenv("C2R_CHAINS", str(chains))
+    b = pkg.HipBackend(n, *tables, device=0)
+    b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], 1.0)
+    b.set_sources(pos, nf); b.set_rank(0, 1); b.load(ndens=nd, xh=fields[0]); b.begin_step()
+    out = []
+    for x in fields:
+        b.load(xh_av=x)
+        b.zero_rates()
+        loss, nbox, vis = b.pass_sources()
+        out.append((loss, nbox, vis, b.last_nbox().copy(), b.fetch("phih_grid")))
+    counts = _info_counts(b)
+    b.close()
+    return out, counts
+
+
+def _same(r, ref, what):
+    assert r[0] == ref[0], (what, r[0], ref[0])                                  # photon loss: the same bits
+    assert r[1:3] == ref[1:3] and np.array_equal(r[3], ref[3]), what             # sum of sub-boxes, visited pairs, per-source sub-boxes
+    live = ref[4] > 0
+    assert np.array_equal(r[4] > 0, live), what
+    assert np.max(np.abs(r[4][live] - ref[4][live]) / ref[4][live]) < 1e-13, what      # atomics in another order
+
+
+@pytest.mark.parametrize("S,chains", [(96, None), (130, None), (200, None), (130, 4)])
+def test_replayed_chain_passes_equal_launch_by_launch(pkg, tables, monkeypatch, S, chains):
+    """Four passes over the same field: the first is driven launch by launch (nothing is known about the counts), the others are
+    replays of the captured sequence -- per-source sub-box counts, visited cells and the photon loss of every pass are the bits
+    of the launch-by-launch schedule, no replay halts, and one capture serves them all."""
+    n = 64
+    s, nd, xh, pos, nf = _case(pkg, n, S, 77)
+    ref, c0 = _passes(pkg, tables, monkeypatch, False, n, s, nd, [xh] * 4, pos, nf, chains)
+    got, c1 = _passes(pkg, tables, monkeypatch, True, n, s, nd, [xh] * 4, pos, nf, chains)
+    assert len(set(int(v) for v in ref[0][3])) > 2                               # sources retire at different sub-boxes
+    assert c0[0] == 0 and c0[2] > 0
+    nch = c1[2]                                                                  # the first pass: every chain launch by launch
+    assert c1 == (3 * nch, 0, nch), c1
+    for k in range(4):
+        _same(got[k], ref[k], (S, chains, k))
+        _same(got[k], ref[0], (S, chains, k))
+
+
+def test_replay_when_the_counts_move(pkg, tables, monkeypatch):
+    """The field changes between passes: sources trace further than the captured sequence was sized for (the device halts the
+    replay at the first decision that keeps more sources than the next launches hold, the host goes on from there), go beyond its
+    last sub-box (the host continues launch by launch), or retire earlier (surplus launches return at once).  Every pass: the bits
+    of a fresh launch-by-launch context on that field."""
+    from tests.golden.inputs import bubble_xfield
+    n, S = 64, 130
+    s, nd, xh, pos, nf = _case(pkg, n, S, 77)
+    centres = [tuple(int(v) for v in q) for q in pos[:40]]
+    more = F(bubble_xfield(n, [tuple(int(v) for v in q) for q in pos], 14.0))            # every source in a large bubble: all trace further
+    less = F(bubble_xfield(n, centres[:10], 5.0))                                         # nearly neutral: all retire in the first sub-boxes
+    fields = [xh, xh, more, more, less, xh, xh, more]
+    got, c = _passes(pkg, tables, monkeypatch, True, n, s, nd, fields, pos, nf)
+    assert c[0] > 0 and c[1] > 0, c                                                       # replays happened, and at least one was halted
+    for k, x in enumerate(fields):
+        ref, _ = _passes(pkg, tables, monkeypatch, False, n, s, nd, [x], pos, nf)
+        _same(got[k], ref[0], k)
+    assert len({tuple(g[3]) for g in got}) >= 3                                           # the fields do move the sub-box counts
+
+
+def test_whole_steps_replayed_and_launch_by_launch(pkg, tables, monkeypatch):
+    """evolve3D over a cold start with 80 sources: the counts change from iteration to iteration (captures, halts, continuations
+    all occur); iteration count, non-converged-cell history, sub-box history equal, xh to the order of the atomics."""
+    n, S = 32, 80
+    tp = pkg.TestProblem(n); s = tp.step(1)
+    nd, xh = tp.fields(1)
+    pos, nf = pkg.seeded_sources(n, S, seed=3)
+    reps = []
+    for cg in ("0", "1"):
+        monkeypatch.setenv("C2R_CHAIN_GRAPH", cg)
+        monkeypatch.setenv("C2R_CHAINS", "2")
+        b = pkg.HipBackend(n, *tables, device=0)
+        b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], 1.0)
+        b.set_sources(pos, nf); b.load(ndens=nd, xh=xh)
+        rep = b.evolve3d_native(s["dt"])
+        reps.append((rep.niter, list(rep.it_conv_flag[:rep.niter]), list(rep.it_sum_nbox[:rep.niter]), rep.photon_loss_all, b.fetch("xh"), _info_counts(b)))
+        b.close()
+    a, r = reps
+    assert a[5][0] == 0 and r[5][0] > 0, (a[5], r[5])
+    assert r[0] == a[0] and r[1] == a[1] and r[2] == a[2]
+    assert abs(r[3] - a[3]) <= 1e-12 * abs(a[3])
+    assert np.max(np.abs(r[4] - a[4])) < 1e-11
