@@ -77,7 +77,8 @@ def cpu_baseline(mesh, srcpos, normflux, xfield, gpu_nbox, box_cost, nd=None):
             # the octant scheme is memory-bound and synchronises per plane)
             nt = int(max(1, min(len(normflux), round(12.0 * 1.2 * (s_vis / s_sec) / full))))
             o_sec, o_nbox, o_vis = _run_reference(os.path.join(ref, "omp", "ref_driver"), mesh, srcpos[:nt], normflux[:nt], xfield, threads, box_cost)
-            return {"value": full * nt / o_sec, "unit": "cells-traced/s", "cores": threads, "kind": "reference",
+            return {"value": full * nt / o_sec, "unit": "cells-traced/s", "cores": threads, "host_cores": ncores, "kind": "reference",
+                    "openmp_speedup_over_serial": (o_vis / o_sec) / (s_vis / s_sec),
                     "seconds": o_sec, "sources": nt, "visited": o_vis, "visited_per_s": o_vis / o_sec,
                     "sum_nbox": int(o_nbox.sum()), "gpu_sum_nbox_same_sources": int(np.sum(gpu_nbox[:nt])),
                     "serial": {"value": full * n1 / s_sec, "cores": 1, "seconds": s_sec, "sources": n1, "visited": s_vis,
@@ -86,7 +87,8 @@ def cpu_baseline(mesh, srcpos, normflux, xfield, gpu_nbox, box_cost, nd=None):
                     "sample": "compiled Fortran reference (oracle/_ref, amdflang -O2), do_source over the first %d (OpenMP build, "
                               "%d threads) / %d (serial build) of the bench's sources on the same %d^3 mesh and on the relaxed "
                               "xh_av field the timed GPU steps start from; `value` = nominal N^3 x sources / s of the OpenMP leg, "
-                              "`visited` = (cell, source) pairs it actually traced" % (nt, threads, n1, mesh)}
+                              "`visited` = (cell, source) pairs it actually traced; `cores` = OpenMP threads used (the reference's scheme "
+                              "is at most 8-way), `host_cores` = what this host has" % (nt, threads, n1, mesh)}
         except Exception as exc:          # fall through to the port
             sys.stderr.write("cpu_baseline: reference run failed (%r), using the C port\n" % (exc,))
     from oracle.oracle import Oracle
@@ -101,7 +103,7 @@ def cpu_baseline(mesh, srcpos, normflux, xfield, gpu_nbox, box_cost, nd=None):
     t0 = time.perf_counter()
     loss, nb, vis = o.pass_sources(nd, xfield, phih, srcpos[:nsamp], normflux[:nsamp])
     sec = time.perf_counter() - t0
-    return {"value": full * nsamp / sec, "unit": "cells-traced/s", "cores": 1, "kind": "port",
+    return {"value": full * nsamp / sec, "unit": "cells-traced/s", "cores": 1, "host_cores": ncores, "kind": "port",
             "seconds": sec, "sources": nsamp, "visited": int(vis), "visited_per_s": vis / sec, "sum_nbox": int(nb),
             "sample": "serial C oracle, pass over the first %d of the bench's sources on the same %d^3 mesh and on the "
                       "relaxed xh_av field the timed GPU steps start from" % (nsamp, mesh)}
@@ -124,17 +126,18 @@ def mix_ceiling_this_box(device, mask=31):
     return v.value if lib.c2r_micro_traffic_mix(int(device), int(mask), ctypes.byref(v)) == 0 else None
 
 
-def parity_check(pkg, mesh, step, nd, xh_init, xfield, srcpos, normflux, tables, device, fast, nsub=16):
+def parity_check(pkg, mesh, step, nd, xh_init, xfield, srcpos, normflux, tables, device, fast, nsub=64):
     """The second half of BASELINE.json's metric -- "xh L-inf error vs Fortran ref" -- for THIS workload, outside the timed
-    region: one pass over the first `nsub` sources of the bench's list plus one global pass (evolve0D_global over the mesh,
+    region: one pass over `nsub` sources drawn evenly ACROSS the bench's list plus one global pass (evolve0D_global over the mesh,
     evolve_point.F90:305-406) on the relaxed field the timed steps start from, on the GPU and in the oracle (the pinned C
     restatement of the reference, the checker).  Reports max |dxh| over the mesh, the worst rate error in units of the
     tolerance weight W (tests/_util.py: |dGamma| <= rtol Gamma + wtol W) and whether the integer results agree."""
     from oracle.oracle import Oracle
-    from tests._util import oracle_pass                       # (the oracle's pass with its source chunks in threads)
+    from tests._util import oracle_pass, gamma_plain_rel, GAMMA_PLAIN_RTOL, GAMMA_PLAIN_FLOOR     # (the oracle's pass with its source chunks in threads)
     thick, thin = tables
     o = Oracle(mesh, step["dr1"], step["vol"], step["coldensh_LLS"], thick, thin)
-    pos, nf = srcpos[:nsub], normflux[:nsub]
+    sel = np.unique(np.linspace(0, len(normflux) - 1, min(nsub, len(normflux))).astype(np.int64))
+    pos, nf = srcpos[sel], normflux[sel]
     t0 = time.perf_counter()
     oloss, onb, ovis, phih_o, w = oracle_pass(o, nd, xfield, pos, nf)
     xav, xint = xfield.copy(), xh_init.copy()
@@ -154,14 +157,85 @@ def parity_check(pkg, mesh, step, nd, xh_init, xfield, srcpos, normflux, tables,
     dxav = float(np.max(np.abs(b.fetch("xh_av") - xav)))
     b.close()
     live = w > 0
+    plain = gamma_plain_rel(phih - phih_o, phih_o, w)
     return {"xh_linf": max(dx, dxav), "gamma_max_over_W": float(np.max(np.abs(phih - phih_o)[live] / w[live])),
             "gamma_max_rel": float(np.max(np.abs(phih - phih_o)[live] / np.maximum(phih_o[live], 1e-300))),
+            # the plain bound the tests assert (tests/_util.py): relative error wherever a cell's own rate is >= 1e-6 of the rate passing through it
+            "gamma_max_rel_significant_cells": plain, "gamma_plain_bound": GAMMA_PLAIN_RTOL, "gamma_plain_floor_over_W": GAMMA_PLAIN_FLOOR,
+            "gamma_plain_ok": bool(plain <= GAMMA_PLAIN_RTOL),
+            "source_indices": [int(sel[0]), int(sel[1]) if len(sel) > 1 else None, "...", int(sel[-1])],
             "photon_loss_rel": abs(loss - oloss) / abs(oloss) if oloss else 0.0,
             "integers_equal": bool((nbox, vis, conv) == (onb, ovis, oconv)), "sum_nbox": int(nbox), "nonconverged_cells": int(conv),
             "sources": int(len(nf)), "checker": "oracle", "oracle_seconds": sec,
-            "what": "one pass over the first %d sources + one global pass on the relaxed xh_av field of the timed steps, GPU vs the "
+            "what": "one pass over %d sources drawn evenly across the list + one global pass on the relaxed xh_av field of the timed steps, GPU vs the "
                     "pinned C restatement of the reference (oracle/c2ray_oracle.c); xh_linf = max |xh_intermed, xh_av difference| "
                     "(north_star: 1e-5), gamma_max_over_W in units of the tolerance weight (stated bound 2e-14)" % len(nf)}
+
+
+def timed_leg(pkg, torch, n, S, nd, xh, srcpos, normflux, step, tables, device, fast, options, steps, warm=1, prof_mode=1,
+              deterministic=False):
+    """A short run of the same kind as the headline -- its own context; one relaxing iteration, `warm` warm-up steps, `steps`
+    timed ones (set_rates_to_zero + pass over all sources + global pass each) -- with the sweep launches timed by HIP events on the
+    context's stream (c2r_profile, as the headline's roofline is): ms per step, the nominal metric and the roofline of the shell
+    kernel (28 algorithmic bytes per visited pair outside the fused first sub-boxes / launch time)."""
+    thick, thin = tables
+    b = pkg.HipBackend(n, thick, thin, device=device, deterministic=deterministic, fast=fast, options=options)
+    b.set_step(step["dr1"], step["vol"], step["coldensh_LLS"], step["clumping"], step["temper"])
+    b.set_sources(srcpos, normflux)
+    b.load(ndens=nd, xh=xh)
+    ev = pkg.Evolve(b)
+    b.begin_step()
+    for k in range(-1, warm):
+        ev.iteration(k, step["dt"])
+    torch.cuda.synchronize()
+    b.profile(prof_mode)
+    ev.visited = 0
+    fused = 0.0
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev.iteration(k, step["dt"])
+        if prof_mode != 0 and options.get("fuse_small", 1.0) != 0.0:
+            fused += float(np.sum(pkg.box_cost(np.minimum(b.last_nbox(), 2), (n, n, n))))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = b.profile_read()
+    out = {"mesh": n, "sources": int(len(normflux)), "sweep_mode": "fast" if fast else "exact", "steps": steps, "ms_per_step": 1e3 * dt / steps,
+           "value": float(n) ** 3 * len(normflux) * steps / dt, "unit": "cells-traced/s", "sum_nbox_last_step": int(ev.sum_nbox_all),
+           "visited_per_step": float(ev.visited) / steps, "schedule": b.info().split("; chains ")[1].split("; exchanges")[0]}
+    if prof_mode != 0 and prof["sweep_ms"] > 0:
+        vis = max(0.0, float(ev.visited) - fused)
+        ach = SWEEP_BYTES_PER_VISIT * vis / (prof["sweep_ms"] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_sweep_shell_fast" if fast else "k_sweep_shell", "achieved": ach, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": prof["sweep_ms"] / max(1, prof["sweep_launches"]),
+                           "launches": prof["sweep_launches"],
+                           "timing": {1: "HIP events around every shell launch", 2: "HIP events around every sub-box (chained passes: around the round)"}[prof_mode]}
+    b.close()
+    return out
+
+
+def share_leg(pkg, torch, n, share, nd, xh, srcpos, normflux, step, tables, device, fast, options, eighth_ms):
+    """`share` (indices into the bench's source list: what ONE of eight GPUs sweeps) on its own context: four relaxing / warm-up
+    steps (the first pass is driven launch by launch, the second captures the chains' launch sequences), then ten steps timed one
+    by one -- the median, next to an eighth of the headline step."""
+    thick, thin = tables
+    b = pkg.HipBackend(n, thick, thin, device=device, fast=fast, options=options)
+    b.set_step(step["dr1"], step["vol"], step["coldensh_LLS"], step["clumping"], step["temper"])
+    b.set_sources(srcpos[share], normflux[share])
+    b.load(ndens=nd, xh=xh)
+    ev = pkg.Evolve(b)
+    b.begin_step()
+    t_steps = []
+    for k in range(-5, 10):
+        torch.cuda.synchronize(); t4 = time.perf_counter()
+        ev.iteration(k, step["dt"])
+        torch.cuda.synchronize()
+        if k >= 0:
+            t_steps.append(1e3 * (time.perf_counter() - t4))
+    ms = float(np.median(t_steps))
+    out = {"sources": int(len(share)), "ms_per_step": ms, "ms_per_step_min_max": [min(t_steps), max(t_steps)], "eighth_of_headline_ms": eighth_ms,
+           "ratio": ms / eighth_ms, "schedule": b.info().split("; chains ")[1].split("; exchanges")[0], "sum_nbox_last_step": int(ev.sum_nbox_all)}
+    b.close()
+    return out
 
 
 def self_launch(ngpus):
@@ -213,6 +287,9 @@ def main():
     ap.add_argument("--no-small-leg", action="store_true",
                     help="skip the short leg that times BASELINE configs[1] (128^3, one source: the launch-bound regime; reported "
                          "as `configs1_128_1src`; only the default workload runs it)")
+    ap.add_argument("--no-configs-leg", action="store_true",
+                    help="skip the short legs that time BASELINE configs[2] (256^3 x 100 sources) and one GPU's share of configs[4] "
+                         "(504^3, 1250 of 10 000 sources, log-normal density; needs ~45 GB of HBM and ~10 s)")
     ap.add_argument("--balance", action="store_true",
                     help="cost-balanced source shares (by the previous pass) instead of the static stride")
     ap.add_argument("--overlap-exchange", action="store_true",
@@ -243,6 +320,15 @@ def main():
     if world != args.gpus:                     # started by a launcher with another rank count: the launcher wins
         args.gpus = world
     one_gpu_test = os.environ.get("C2R_BENCH_TEST_ONE_GPU") == "1"    # CI only: every rank on cuda:0, gloo
+    if world > 1 and not one_gpu_test:
+        # preflight, before any rendezvous (so that a bad launch FAILS, on every rank by itself, instead of hanging in a collective):
+        # one process per GPU needs as many visible devices as there are ranks on this node (device_count() does not initialise the GPU)
+        ndev = torch.cuda.device_count()
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        if ndev < local_world or local_rank >= ndev:
+            sys.stderr.write("bench.py: rank %d (local rank %d): %d rank(s) on this node but %d GPU(s) visible -- one process per GPU "
+                             "needs one device each (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)\n" % (rank, local_rank, local_world, ndev))
+            sys.exit(4)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_gpu_test:
@@ -283,6 +369,28 @@ def main():
         args.no_cpu_baseline = True
     bytes_per_visit = SWEEP_BYTES_PER_VISIT + (16 if args.thermal else 0)      # + phiheat_grid read-modify-write
     ev = pkg.Evolve(b, comm=dist if world > 1 else None, balance=args.balance)
+    rank_devices = None
+    if world > 1:
+        # which physical device every rank's context resolved to: two ranks on one GPU would "scale" by time-slicing it -- fail loudly
+        import socket
+        pr = torch.cuda.get_device_properties(local_rank)
+        ident = str(getattr(pr, "uuid", "")) or ":".join(str(getattr(pr, k, "?")) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        mine = {"rank": rank, "host": socket.gethostname(), "local_rank": local_rank, "c2r_device": int(b.get_device()), "device_id": ident,
+                "info": b.info().split(";")[0]}
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, mine)
+        seen = {}
+        for d in rank_devices:
+            seen.setdefault((d["host"], d["device_id"], d["c2r_device"]), []).append(d["rank"])
+        shared = [r for r in seen.values() if len(r) > 1]
+        if shared and not one_gpu_test:
+            sys.stderr.write("bench.py: ranks %s resolved to the SAME device: one process per GPU is the contract (rank %d: %s)\n" % (shared, rank, mine["info"]))
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(5)
+        if dist.get_world_size() != world:
+            sys.stderr.write("bench.py: the communicator has %d ranks, the launcher announced %d\n" % (dist.get_world_size(), world))
+            sys.exit(6)
     if args.overlap_exchange and world > 1:
         b.set_exchange_overlap(True)
     b.begin_step()
@@ -402,6 +510,10 @@ def main():
                        "mesh": n, "sources": S, "sweep_mode": args.sweep_mode, "isothermal": not args.thermal, "gamma_accumulation": "ordered" if args.deterministic else "atomic", "sources_per_gpu": len(pkg.static_source_share(S, 0, world)),
                        "parallelism": "sources sharded over %d GPU(s), RCCL all-reduce of Gamma" % world,
                        "ranks": dist.get_world_size() if world > 1 else 1,
+                       # first contact with a real multi-GPU node: the communicator's own rank count and the device every rank's context
+                       # runs on (checked above: distinct devices, or the run has failed) -- one_gpu_test: every rank on cuda:0 on purpose
+                       "communicator_ranks": dist.get_world_size() if world > 1 else 1, "rank_devices": rank_devices,
+                       "ranks_on_distinct_devices": (len({(d["host"], d["device_id"], d["c2r_device"]) for d in rank_devices}) == world) if rank_devices else True,
                        # evolve.F90:599 through c2r_allreduce_rates: the whole grid, or the sources' packed sub-boxes while those are few
                        "gamma_exchange": {"calls": xchg1["calls"] - xchg0["calls"], "packed_calls": xchg1["sparse_calls"] - xchg0["sparse_calls"],
                                           "bytes_per_step": (xchg1["bytes_total"] - xchg0["bytes_total"]) / max(1, args.steps),
@@ -426,6 +538,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if timed else None,
                          "traffic": traffic, "traffic_source": traffic_note,
+                         "traffic_measured_in_this_run": False,     # bytes per visit from the committed PMC profile (builder's box) x this run's visits per launch
                          # informational: the kernel's visits/s against what the memory system sustains for the same four
                          # streams with no arithmetic at all, measured on THIS box after the timed region (mix_ceiling_this_box, profiles/micro/trafficmix.hip)
                          "mix_ceiling_this_box": mix_ceiling,
@@ -448,28 +561,13 @@ def main():
                                  "rate; see DESIGN.md s3e, s5"},
         }
         if world == 1 and not args.no_other_mode and not args.thermal:
-            # the same steps in the other sweep mode (the library default is exact: column densities bit-identical to the
-            # Fortran; `value` above is the mode named in config.sweep_mode), outside the timed region of the headline
+            # the same steps in the OTHER sweep mode (`value` above is the mode named in config.sweep_mode: fast, the library and
+            # drop-in default; exact is the opt-in with column densities bit-identical to the Fortran), outside the timed region of
+            # the headline, its shell kernel timed the same way
             b.close()
             other = "exact" if args.sweep_mode == "fast" else "fast"
-            b2 = pkg.HipBackend(n, thick, thin, device=local_rank, deterministic=args.deterministic, fast=other == "fast", options=options)
-            b2.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], s["clumping"], s["temper"])
-            b2.set_sources(srcpos, normflux)
-            b2.load(ndens=nd, xh=xh)
-            ev2 = pkg.Evolve(b2, balance=args.balance)
-            b2.begin_step()
-            k2 = min(args.steps, 3)
-            for k in range(-1, k2 + 1):             # relax + one warm-up, then k2 timed steps
-                if k == 1:
-                    torch.cuda.synchronize(); t2 = time.perf_counter()
-                ev2.set_rates_to_zero(); ev2.pass_all_sources(k, s["dt"]); ev2.global_pass(s["dt"])
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t2
-            out["other_sweep_mode"] = {"sweep_mode": other, "steps": k2, "ms_per_step": 1e3 * dt2 / k2,
-                                       "value": float(n) ** 3 * S * k2 / dt2, "unit": "cells-traced/s",
-                                       "sum_nbox_last_step": int(ev2.sum_nbox_all),
-                                       "xh_av_sum": float(b2.xh_av.sum(dtype=torch.float64))}
-            b2.close()
+            out["other_sweep_mode"] = timed_leg(pkg, torch, n, S, nd, xh, srcpos, normflux, s, (thick, thin), local_rank, other == "fast", options,
+                                                min(args.steps, 3), deterministic=args.deterministic, prof_mode=prof_mode)
         if world == 1 and not args.no_small_leg and (n, S) == (256, 1000) and not args.thermal and not args.density_file:
             # BASELINE configs[1] -- 128^3, one source, the reference's own CPU-runnable case -- is bound by the number of
             # dependent launches, not by bytes: informational, outside the timed region of the headline
@@ -499,29 +597,35 @@ def main():
         if world == 1 and not args.no_small_leg and (n, S) == (256, 1000) and not args.thermal and not args.density_file:
             # What one GPU's share of the 8-GPU strong-scaling run costs, on THIS box: 125 of the 1000 sources (the static share of
             # rank 0), same field, next to an eighth of the headline step -- the ratio bounds the 8-GPU speed-up before the exchange
-            # (DESIGN.md s3d, s6).  Informational, outside the timed region.
+            # (DESIGN.md s3d, s6).  Informational, outside the timed region.  From its second pass on each chain of the share replays
+            # its launch sequence as one hipGraph (no host round trip per sub-box).
             b.close()
-            share = pkg.static_source_share(S, 0, 8)
-            b4 = pkg.HipBackend(n, thick, thin, device=local_rank, fast=args.sweep_mode == "fast", options=options)
-            b4.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], s["clumping"], s["temper"])
-            b4.set_sources(srcpos[share], normflux[share])
-            b4.load(ndens=nd, xh=xh)
-            ev4 = pkg.Evolve(b4)
-            b4.begin_step()
-            t_steps = []
-            for k in range(-3, 10):            # three relaxing / warm-up steps, ten timed one by one
-                torch.cuda.synchronize(); t4 = time.perf_counter()
-                ev4.iteration(k, s["dt"])
-                torch.cuda.synchronize()
-                if k >= 0:
-                    t_steps.append(1e3 * (time.perf_counter() - t4))
-            # the median: with launches of 10 - 200 us this regime feels what else runs on the node's host cores
-            ms4 = float(np.median(t_steps))
-            out["one_gpu_share_of_8"] = {"sources": int(len(share)), "ms_per_step": ms4, "ms_per_step_min_max": [min(t_steps), max(t_steps)], "eighth_of_headline_ms": 1e3 * dt_wall / args.steps / 8.0,
-                                         "ratio": ms4 / (1e3 * dt_wall / args.steps / 8.0), "chains": b4.info().split("chains ")[1].split(";")[0],
-                                         "note": "its own field relaxes from x = %.3f with 125 sources only: sub-box counts as in the headline" % args.x_init,
-                                         "sum_nbox_last_step": int(ev4.sum_nbox_all)}
-            b4.close()
+            out["one_gpu_share_of_8"] = share_leg(pkg, torch, n, pkg.static_source_share(S, 0, 8), nd, xh, srcpos, normflux, s, (thick, thin), local_rank,
+                                                  args.sweep_mode == "fast", options, 1e3 * dt_wall / args.steps / 8.0)
+            out["one_gpu_share_of_8"]["note"] = "its own field relaxes from x = %.3f with 125 sources only: sub-box counts as in the headline" % args.x_init
+        if world == 1 and not args.no_configs_leg and (n, S) == (256, 1000) and not args.thermal and not args.density_file:
+            # The other BASELINE configs at HEAD, bounded (outside the timed region): configs[2] = 256^3 x 100 sources, and one GPU's
+            # share of configs[4] = 504^3, 1250 of 10 000 sources, log-normal density, everything resident in HBM -- each with its
+            # shell kernel's roofline from the same HIP-event path as the headline's.
+            b.close()
+            pos100, nf100 = pkg.seeded_sources(n, 100)
+            out["configs"] = {"256_100src": timed_leg(pkg, torch, n, 100, nd, xh, pos100, nf100, s, (thick, thin), local_rank, args.sweep_mode == "fast", options, 5, warm=2, prof_mode=2)}
+            out["configs"]["256_100src"]["what"] = "BASELINE configs[2]: 256^3, 100 seeded sources, same field and pre-ionisation; chained pass (2 chains), timed around the round"
+            try:
+                n5, S5 = 504, 10000
+                tp5 = pkg.TestProblem(n5); s5 = tp5.step(1)
+                nd5, xh5 = tp5.fields(1, args.x_init)
+                rng = np.random.default_rng(20261003)
+                nd5 = (nd5 * np.exp(rng.standard_normal(nd5.size, dtype=np.float32) - 0.5)).astype(np.float32)
+                pos5, nf5 = pkg.seeded_sources(n5, S5)
+                sh5 = pkg.static_source_share(S5, 0, 8)
+                leg = timed_leg(pkg, torch, n5, len(sh5), nd5, xh5, pos5[sh5], nf5[sh5], s5, (thick, thin), local_rank, args.sweep_mode == "fast", options, 2, warm=1, prof_mode=1)
+                leg["what"] = ("one GPU's share of BASELINE configs[4]: 504^3, log-normal density (sigma_ln = 1), the 1250 sources rank 0 of 8 sweeps of the "
+                               "10 000 seeded ones, all in flight at once (30 GB of shell planes); `value` counts these 1250 sources")
+                out["configs"]["504_share_of_8"] = leg
+                del nd5, xh5
+            except Exception as exc:                    # (e.g. a GPU shared with another job: not enough free HBM)
+                out["configs"]["504_share_of_8"] = {"skipped": repr(exc)}
         if world == 1 and not args.no_dropin_leg and (n, S) == (256, 1000) and not args.thermal and not args.density_file:
             # The boundary north_star names, end to end: the reference's OWN program (C2Ray.F90 and every set-up module,
             # unmodified) with its evolve modules replaced by the Fortran shim + this library, on its own test problem

@@ -118,6 +118,7 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
     HIP_TRY(hipMalloc(&ctx->d_conv, sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&ctx->d_chemfail, sizeof(unsigned int)));
     HIP_TRY(hipMalloc(&ctx->d_pair, 2 * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_gate, sizeof(int)));
     HIP_TRY(hipMalloc(&ctx->d_seq, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(ctx->d_seq, 0, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(ctx->d_conv, 0, sizeof(unsigned long long)));     // k_pass_final leaves them at zero again
@@ -179,7 +180,7 @@ void c2r_destroy(c2r_ctx *c)
     if (ctx->h_step) hipHostFree(ctx->h_step);
     if (ctx->ev_step) hipEventDestroy(ctx->ev_step);
     hipFree(ctx->d_photon_loss); hipFree(ctx->d_sum_nbox); hipFree(ctx->d_sum_partial); hipFree(ctx->d_sum_out); hipFree(ctx->d_stat_partial);
-    hipFree(ctx->d_conv); hipFree(ctx->d_chemfail); hipFree(ctx->d_dbg); hipFree(ctx->d_pair); hipFree(ctx->d_seq); hipFree(ctx->d_nbox_all);
+    hipFree(ctx->d_conv); hipFree(ctx->d_chemfail); hipFree(ctx->d_dbg); hipFree(ctx->d_pair); hipFree(ctx->d_seq); hipFree(ctx->d_gate); hipFree(ctx->d_nbox_all);
     if (ctx->h_nbox_all) hipHostFree(ctx->h_nbox_all);
     if (ctx->h_sc) hipHostFree(ctx->h_sc);
     if (ctx->h_it4) hipHostFree(ctx->h_it4);
@@ -199,7 +200,7 @@ const char *c2r_info(c2r_ctx *c)
                 "; rates " + (ctx->prm.deterministic_rates ? "ordered per-source sums" : "f64 atomics") +
                 "; rank " + std::to_string(ctx->rank) + " of " + std::to_string(ctx->nranks) +
                 "; chains " + std::to_string(ctx->nchains) +
-                "; chain passes replayed " + std::to_string(ctx->chain_replays) + " (halted " + std::to_string(ctx->chain_halts) + "), launch by launch " + std::to_string(ctx->chain_eager) +
+                "; chain passes replayed " + std::to_string(ctx->chain_replays) + " (halted " + std::to_string(ctx->chain_halts) + "), launch by launch " + std::to_string(ctx->chain_eager) + ", iterations with a device-gated tail " + std::to_string(ctx->chain_tails) +
                 "; exchanges overlapped with the sweep " + std::to_string(ctx->xchg_overlapped) +
                 "; plane-ordered launches " + std::to_string(ctx->xcd_launches) +
                 "; graph captures " + std::to_string(ctx->captures);
@@ -248,6 +249,7 @@ int c2r_set_option(c2r_ctx *c, const char *name, double value)
     else if (n == "xcd_min_per_plane") { ctx->xcd_min_per_plane = value; scratch = true; }
     else if (n == "xcd_min_alive") ctx->xcd_min_alive = value;
     else if (n == "xcd_qmin") ctx->xcd_qmin = std::max(1, iv);
+    else if (n == "xcd_min_sources") ctx->xcd_min_sources = std::max(8, iv);
     else if (n == "chains") { ctx->chains_env = std::max(0, std::min(kMaxChains, iv)); scratch = true; }
     else if (n == "batch_cap") { ctx->batch_cap_opt = std::max(0, iv); scratch = true; }
     else if (n == "sparse_exchange") ctx->sparse_exchange = on;
@@ -438,6 +440,7 @@ int c2r_set_sources(c2r_ctx *c, const int32_t *srcpos, const double *normflux, i
     ctx->sparse_valid = false;                    // (nbox_all / last_nbox no longer describe what is in phih_grid)
     ctx->nflux_x.clear();                         // (NormFlux_xray belongs to the list: c2r_set_xray_sources follows a new one)
     ctx->explicit_share = false; ctx->auto_share = false; ctx->share.clear(); ctx->last_nbox.clear(); ctx->nbox_all.clear(); ctx->box_hint = 0;
+    for (auto &kv : ctx->chain_graphs) { kv.second.profile.clear(); kv.second.profile_prev.clear(); }      // (what the old list's passes left says nothing about this one)
     // set-up belongs here, not in the first evolve3D of a run (the reference allocates in evolve_ini, evolve_data.F90:75-90): the
     // sweep scratch of this rank's share -- device planes, the pinned staging block -- is a few milliseconds of allocation calls
     if (nsrc > 0 && n_local_sources(ctx) > 0) {

@@ -105,7 +105,7 @@ struct Ctx {
     // sources the launches of sub-box nbox were sized for.  profile[k]: sources active after sub-box k of the chain's last pass
     // (profile[0]: the traceable sources it started with); empty: not known.
     struct ChainGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long long gen = 0; int count = 0, n_active = 0, shape_count = 0;
-                        const void *acc = nullptr; int H = 0, launches = 0; std::vector<int> bounds, profile, profile_prev; int passes_since_capture = 0; };
+                        const void *acc = nullptr; bool perm = false; int H = 0, launches = 0; std::vector<int> bounds, profile, profile_prev; int passes_since_capture = 0; };
     std::map<int, ChainGraph> chain_graphs;                      // key: first local source of the chain
     bool chain_graph = true;                                     // option chain_graph = 0: chains are always driven launch by launch
     long long chain_replays = 0, chain_halts = 0, chain_eager = 0;   // chain passes replayed / replays the device halted (a launch too small) / driven launch by launch
@@ -168,11 +168,13 @@ struct Ctx {
                          unsigned long long seq; double before[4], after[4]; } *h_sc = nullptr,  // pinned
       *d_hsc = nullptr;                       // ... and its device alias: kernels store results there directly
     double *d_dbg = nullptr, *d_pair = nullptr;
+    int *d_gate = nullptr;                                       // run_chains: 0 iff the replayed chains of a pass have all run to their end (k_chain_gate)
+    long long chain_tails = 0;                                   // iterations whose tail (totals, fold, global pass) ran behind that gate: one host wait
     unsigned long long *d_seq = nullptr, seq_seen = 0;           // passes completed by fused iterations (k_pass_final counts, the host polls h_sc->seq)
     bool spin_wait = true;                                       // option spin_wait = 0: always hipStreamSynchronize
     // XCD-aware, plane-ordered block mapping of the far shells (k_sweep_shell_xcd): option xcd_order = 0 never, 1 always where it
     // can run, -1 (default): where at least xcd_min_per_plane sources share a mesh plane and face sign (sources / mesh planes)
-    int xcd_order = -1; double xcd_min_per_plane = 1.5; double xcd_min_alive = 0.9; int xcd_qmin = 16;
+    int xcd_order = -1; double xcd_min_per_plane = 1.5; double xcd_min_alive = 0.9; int xcd_qmin = 16; int xcd_min_sources = 64;
     long long xcd_launches = 0;
     bool poll_wait = true;                                       // option poll_wait = 0: the sub-box counts are waited for with hipEventSynchronize alone
     double *h_it4 = nullptr, *d_hit4 = nullptr;   // pinned [C2R_MAX_ITER_LOG][4]: per-iteration photon-statistics sums, written by the device
@@ -248,7 +250,7 @@ int sweep_finish(Ctx *ctx, const int *gate = nullptr);
 long long visited_for_nbox(const Ctx *ctx, int nbox);
 int upload_lls_grid(Ctx *ctx, const float *lls_grid);          // LLS_grid and its (x,y)-transposed replica
 // do_grid over this rank's sources (c2r_pass_sources; iterate_impl: fz / no_wait)
-int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64_t *sum_nbox, int64_t *visited, bool no_wait = false);
+int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64_t *sum_nbox, int64_t *visited, bool no_wait = false, FusedIter *chain_tail = nullptr);
 // ---- exchange.hip ------------------------------------------------------------------------------------------------
 void slab_of(const Ctx *ctx, int r, int P, size_t *off, size_t *cnt);
 void balance_before_pass(Ctx *ctx);

@@ -31,10 +31,23 @@ static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, i
     };
     double *four = stats_host ? ctx->d_hsc->four : nullptr;
     if (!can_fuse) {
-        // the three steps, with one wait behind the global pass instead of one behind each of the last two
+        // the three steps, with one wait behind the global pass instead of one behind each of the last two -- and where the pass
+        // runs as replayed chains (64 - 768 sources: sweep.hip run_chains) the fold and the global pass are enqueued behind them
+        // gated on the device, so that the whole iteration is one host wait
+        FusedIter tail;
+        tail.dt = dt; tail.stats = stats_host != nullptr;
+        tail.post = [ctx, dt, four](const int *gate) -> int {
+            const int r = sweep_finish(ctx, gate);
+            return r ? r : global_pass_enqueue(ctx, dt, four, 0, ctx->ncell, gate, gate != nullptr);
+        };
+        const bool use_tail = ctx->nranks == 1 && !ctx->balance && ctx->use_graph && ctx->chain_graph && ctx->prof == 0 &&
+                              !(ctx->thermal && ctx->tprm.cosmological && !ctx->have_zred);
         if ((rc = zero_rates())) return rc;
-        if ((rc = pass_sources_impl(ctx, nullptr, nullptr, nullptr, vis, ctx->nranks == 1 && !ctx->balance))) return rc;
-        if ((rc = global_pass_impl(ctx, dt, conv, sum1, four, 0, (size_t)-1))) return rc;
+        if ((rc = pass_sources_impl(ctx, nullptr, nullptr, nullptr, vis, ctx->nranks == 1 && !ctx->balance, use_tail ? &tail : nullptr))) return rc;
+        if (tail.tail_done) {
+            if (conv) *conv = (int64_t)ctx->h_sc->conv;
+            if (sum1) *sum1 = ctx->h_sc->sum;
+        } else if ((rc = global_pass_impl(ctx, dt, conv, sum1, four, 0, (size_t)-1))) return rc;
         if (loss) *loss = ctx->h_sc->photon_loss;
         if (nb) *nb = ctx->h_sc->sum_nbox;
     } else {

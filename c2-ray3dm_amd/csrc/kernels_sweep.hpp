@@ -1140,13 +1140,27 @@ __global__ __launch_bounds__(64) void k_box_decide_small(const int *active_in, c
     }
 }
 
+// Behind the replayed launch sequences of a pass's chains (sweep.hip run_chains): *gate = 0 iff every chain's sequence ran to its
+// end with no source left to trace and none was halted -- what the launches behind the pass (totals, the fold of the transposed
+// rates, the global pass) wait for on the device instead of the host.
+constexpr int kGateChains = 4;
+struct ChainGateArgs { const int *n_active[kGateChains]; const int *halt[kGateChains]; int nch; };
+__global__ void k_chain_gate(ChainGateArgs a, int *gate)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int g = 0;
+    for (int c = 0; c < a.nch; ++c) g += *a.n_active[c] + (*a.halt[c] != 0 ? 1 : 0);
+    *gate = g;
+}
+
 // photon_loss(1) += photon_loss_src, in source order (evolve_source.F90:216); sum_nbox (:219).
 // first: first batch of a pass (the running totals restart from zero).  The totals so far are also
 // written to the host's pinned scalars through their mapped pointers.
 __global__ __launch_bounds__(1024) void k_batch_totals(int nsrc, const double *final_loss, const int *final_nbox,
                                                        double *photon_loss, long long *sum_nbox, int first,
-                                                       double *host_loss, long long *host_nbox)
+                                                       double *host_loss, long long *host_nbox, const int *gate = nullptr /* see k_transpose_xy */)
 {
+    if (gate && *gate != 0) return;
     // thread t sums the contiguous run [t*c, (t+1)*c) in order, thread 0 the runs in order: for up to 1024
     // sources (c = 1) that IS the sequential source-order sum of the reference; beyond, a fixed two-level order
     __shared__ double sl[1024];

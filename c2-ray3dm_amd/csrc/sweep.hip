@@ -378,7 +378,7 @@ struct BatchSweep {
     void stage_perm()
     {
         perm_ready = false;
-        if (dbg || !sc.d_perm || ctx->xcd_order == 0 || n_active < 64) return;
+        if (dbg || !sc.d_perm || ctx->xcd_order == 0 || n_active < ctx->xcd_min_sources) return;
         const int nmin = std::min(p.mesh[0], std::min(p.mesh[1], p.mesh[2]));
         // (with ordered rates from half that count: there the mapping pays by keeping a source's per-source grid writes together --
         // 256^3, batches of 250 sources: -7 %, 1000 sources in four batches -7 ... -20 %: profiles/r05_xcd/ab_det_counts.txt)
@@ -675,11 +675,11 @@ struct BatchSweep {
 
     // the batch's share of photon_loss / sum_nbox, added to the pass's running totals in source order -- on stream `on`: the
     // chain's own, or the context's when several chains were in flight (run_chains: chain after chain, i.e. in source order)
-    int enqueue_totals(std::vector<int> *nbox_out, std::vector<double> *loss_out, hipStream_t on, bool first_batch)
+    int enqueue_totals(std::vector<int> *nbox_out, std::vector<double> *loss_out, hipStream_t on, bool first_batch, const int *gate = nullptr)
     {
         hipLaunchKernelGGL(k_batch_totals, dim3(1), dim3(1024), 0, on, count, sc.d_final_loss, sc.d_final_nbox,
                            ctx->d_photon_loss, ctx->d_sum_nbox, first_batch ? 1 : 0, &ctx->d_hsc->photon_loss,
-                           &ctx->d_hsc->sum_nbox);
+                           &ctx->d_hsc->sum_nbox, gate);
         HIP_TRY(hipGetLastError());
         if (nbox_out) HIP_TRY(hipMemcpyAsync(h_fnb, sc.d_final_nbox, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, on));
         if (loss_out) HIP_TRY(hipMemcpyAsync(h_fl, sc.d_final_loss, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, on));
@@ -862,6 +862,7 @@ bool BatchSweep::capture_chain(Ctx::ChainGraph &cg)
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); ctx->use_graph = false; return false; }
     ++ctx->captures;
     int rc = (int)hipMemcpyAsync(sc.d_batch, sc.h_batch, sc.batch_bytes, hipMemcpyHostToDevice, st);
+    if (rc == C2R_OK && perm_ready) rc = (int)hipMemcpyAsync(sc.d_perm, sc.h_perm, (size_t)3 * cap * sizeof(int), hipMemcpyHostToDevice, st);
     const int cur0 = cur, launches0 = launches;
     cur = 0;
     for (int nbox = 1; nbox <= cg.H && rc == C2R_OK; ++nbox) rc = enqueue_box(nbox, cg.bounds[nbox], nbox < cg.H ? cg.bounds[nbox + 1] : INT_MAX);
@@ -870,6 +871,7 @@ bool BatchSweep::capture_chain(Ctx::ChainGraph &cg)
     const hipError_t e = hipStreamEndCapture(st, &cg.graph);
     if (rc == C2R_OK && e == hipSuccess && hipGetLastError() == hipSuccess && hipGraphInstantiate(&cg.exec, cg.graph, nullptr, nullptr, 0) == hipSuccess) {
         cg.gen = ctx->gen; cg.count = count; cg.n_active = n_active; cg.shape_count = shape_count; cg.acc = (const void *)k.phih;
+        cg.perm = perm_ready;
         cg.passes_since_capture = 0;
         return true;
     }
@@ -925,7 +927,8 @@ static void bounds_from_profile(const std::vector<int> &prof, int n_active, std:
 // pass went through, every launch at least as large as that pass needed and the whole not much larger.
 static bool chain_graph_fits(const Ctx *ctx, const Ctx::ChainGraph &cg, const BatchSweep &b, const void *acc)
 {
-    if (!cg.exec || cg.gen != ctx->gen || cg.count != b.count || cg.n_active != b.n_active || cg.shape_count != b.shape_count || cg.acc != acc) return false;
+    if (!cg.exec || cg.gen != ctx->gen || cg.count != b.count || cg.n_active != b.n_active || cg.shape_count != b.shape_count || cg.acc != acc ||
+        cg.perm != b.perm_ready) return false;
     std::vector<int> want; int H = 0;
     bounds_from_profile(cg.profile, b.n_active, want, H);
     if (H != cg.H) return false;
@@ -937,7 +940,8 @@ static bool chain_graph_fits(const Ctx *ctx, const Ctx::ChainGraph &cg, const Ba
     return have <= need + need / 2 + 4LL * H;
 }
 
-int run_chains(Ctx *ctx, int first, int count, bool first_of_pass, std::vector<int> *nbox_out)
+static_assert(kGateChains >= kMaxChains, "k_chain_gate holds every chain's pointers");
+int run_chains(Ctx *ctx, int first, int count, bool first_of_pass, std::vector<int> *nbox_out, FusedIter *tail)
 {
     const int nch = std::min(ctx->nchains, count);
     const int per = (count + nch - 1) / nch;
@@ -953,6 +957,7 @@ int run_chains(Ctx *ctx, int first, int count, bool first_of_pass, std::vector<i
         BatchSweep &b = ch[c];
         b.chained = true;
         b.stage();
+        if (ctx->xcd_order > 0) b.stage_perm();       // (chains take the plane-ordered mapping only where it is forced: measured, not adopted -- DESIGN 3d)
         if (b.st != ctx->stream) HIP_TRY(hipStreamWaitEvent(b.st, ctx->ev_prepared, 0));
         b.bound = b.n_active; b.known = 0; b.cur = 0; b.next = 1;
         Ctx::ChainGraph &cg = ctx->chain_graphs[b.first];
@@ -974,6 +979,7 @@ int run_chains(Ctx *ctx, int first, int count, bool first_of_pass, std::vector<i
             ++ctx->chain_replays;
         } else {
             HIP_TRY(hipMemcpyAsync(b.sc.d_batch, b.sc.h_batch, b.sc.batch_bytes, hipMemcpyHostToDevice, b.st));
+            if (b.perm_ready) HIP_TRY(hipMemcpyAsync(b.sc.d_perm, b.sc.h_perm, (size_t)3 * b.cap * sizeof(int), hipMemcpyHostToDevice, b.st));
             ++ctx->chain_eager;
         }
     }
@@ -1006,15 +1012,39 @@ int run_chains(Ctx *ctx, int first, int count, bool first_of_pass, std::vector<i
         }
     };
     { const int rc = lockstep(); if (rc) return rc; }
+    // Every chain replays and the caller has handed over what follows the pass (iterate_impl: the fold of the transposed rates, the
+    // global pass): the chains join the context's stream, k_chain_gate says on the device whether every sequence ran to its end, the
+    // totals and the tail follow GATED by it, and the host waits ONCE for the whole iteration.  A closed gate (a halt, or sources
+    // still active behind a sequence's last sub-box) leaves the gated launches undone: the chains are finished launch by launch
+    // below and the caller runs the tail the ordinary way.
+    bool all_replay = !ch.empty();
+    for (size_t c = 0; c < ch.size(); ++c) all_replay = all_replay && graph_of[c] != nullptr;
+    if (tail && all_replay && !ctx->prof) {
+        ChainGateArgs ga{};
+        ga.nch = (int)ch.size();
+        for (size_t c = 0; c < ch.size(); ++c) {
+            BatchSweep &b = ch[c];
+            ga.n_active[c] = b.sc.d_nactive + (graph_of[c]->H & 1); ga.halt[c] = b.sc.d_hnactive;
+            if (b.st != ctx->stream) HIP_TRY(hipStreamWaitEvent(ctx->stream, b.sc.ev_done, 0));
+        }
+        hipLaunchKernelGGL(k_chain_gate, dim3(1), dim3(64), 0, ctx->stream, ga, ctx->d_gate);
+        for (auto &b : ch) { const int rc = b.enqueue_totals(nbox_out, nullptr, ctx->stream, b.first_of_pass, ctx->d_gate); if (rc) return rc; }
+        { const int rc = tail->post(ctx->d_gate); if (rc) return rc; }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (__atomic_load_n(&ctx->h_sc->seq, __ATOMIC_ACQUIRE) == ctx->seq_seen + 1) {       // the gate was open: the whole iteration has run
+            ctx->seq_seen += 1; tail->tail_done = true; ++ctx->chain_tails;
+        }
+    }
     // the replayed chains: one wait each; where the sequence ended with sources still active, or halted, the rest launch by launch
     bool more = false;
     for (size_t c = 0; c < ch.size(); ++c) {
         if (!graph_of[c]) continue;
         BatchSweep &b = ch[c];
+        b.launches += graph_of[c]->launches;
+        if (tail && tail->tail_done) { b.next = graph_of[c]->H + 1; continue; }
         { const int rc = wait_polling(ctx, b.sc.ev_done); if (rc) return rc; }
         const int halt = b.sc.h_nactive[0];
         const int at = halt > 0 ? halt : graph_of[c]->H;           // the last sub-box whose decision stands
-        b.launches += graph_of[c]->launches;
         b.known = at; b.cur = at & 1; b.next = at + 1; b.bound = b.sc.h_nactive[at];
         if (halt > 0) {
             // the decision of sub-box `halt` kept more sources than the next launches were sized for: it left the device count at
@@ -1027,16 +1057,18 @@ int run_chains(Ctx *ctx, int first, int count, bool first_of_pass, std::vector<i
     if (more) { const int rc = lockstep(); if (rc) return rc; }
     // the chains join the context's stream; their totals follow in chain order = source order
     int launches = 0;
-    for (auto &b : ch) {
-        launches += b.launches;
-        if (b.st != ctx->stream) {
-            HIP_TRY(hipEventRecord(b.sc.ev_done, b.st));
-            HIP_TRY(hipStreamWaitEvent(ctx->stream, b.sc.ev_done, 0));
+    for (auto &b : ch) launches += b.launches;
+    if (!(tail && tail->tail_done)) {
+        for (auto &b : ch) {
+            if (b.st != ctx->stream) {
+                HIP_TRY(hipEventRecord(b.sc.ev_done, b.st));
+                HIP_TRY(hipStreamWaitEvent(ctx->stream, b.sc.ev_done, 0));
+            }
         }
+        if (ctx->prof) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(launches); }
+        for (auto &b : ch) { const int rc = b.enqueue_totals(nbox_out ? nbox_out : nullptr, nullptr, ctx->stream, b.first_of_pass); if (rc) return rc; }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
-    if (ctx->prof) { prof_end(ctx, ctx->ev_sweep, ctx->ev_sweep_used); ctx->ev_sweep_cnt.push_back(launches); }
-    for (auto &b : ch) { const int rc = b.enqueue_totals(nbox_out ? nbox_out : nullptr, nullptr, ctx->stream, b.first_of_pass); if (rc) return rc; }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
     // what the next pass's sequence is sized by: the counts this pass left, sub-box by sub-box (every slot up to the last
     // sub-box enqueued has been written; beyond the first zero nothing is looked at)
     for (auto &b : ch) {
@@ -1178,7 +1210,7 @@ int overlap_end(Ctx *ctx)
 }
 }  // namespace
 
-int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64_t *sum_nbox, int64_t *visited, bool no_wait)
+int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64_t *sum_nbox, int64_t *visited, bool no_wait, FusedIter *chain_tail)
 {
     int rc;
     if ((rc = sync_step(ctx))) return rc;
@@ -1216,7 +1248,8 @@ int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64_t *sum
                 // several chains in flight where the scratch was laid out for it (ensure_sweep_scratch: 64 - 768 sources per round)
                 if (ctx->nchains > 1 && !fz && h1 - first >= 2 * kFewSources) {
                     count = std::min(ctx->batch_cap, h1 - first);
-                    rc = run_chains(ctx, first, count, first == 0, &nb);
+                    // (chain_tail: only where this round is the whole pass -- every local source, no overlapped halves)
+                    rc = run_chains(ctx, first, count, first == 0, &nb, (!overlap && first == 0 && count == nloc) ? chain_tail : nullptr);
                 } else {
                     count = std::min(ctx->sc[0].cap, h1 - first);
                     rc = sweep_batch(ctx, first, count, first == 0, nullptr, &nb, nullptr, fz);
@@ -1224,7 +1257,7 @@ int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64_t *sum
                 if (rc) { ctx->acc_phih = ctx->acc_phih_T = nullptr; return rc; }
                 for (int v : nb) { vis += visited_for_nbox(ctx, v); ctx->last_nbox.push_back(v); }
             }
-            if (!fz && (rc = sweep_finish(ctx))) { ctx->acc_phih = ctx->acc_phih_T = nullptr; return rc; }
+            if (!fz && !(chain_tail && chain_tail->tail_done) && (rc = sweep_finish(ctx))) { ctx->acc_phih = ctx->acc_phih_T = nullptr; return rc; }
             if (overlap && (rc = overlap_exchange_half(ctx, half))) { ctx->acc_phih = ctx->acc_phih_T = nullptr; return rc; }
         }
         ctx->acc_phih = ctx->acc_phih_T = nullptr;

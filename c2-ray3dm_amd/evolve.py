@@ -121,6 +121,12 @@ class HipBackend:
             msg = self.lib.c2r_last_error(self.ctx) if self.ctx else b""
             raise C2RayHipError("%s failed (%d): %s" % (what, rc, (msg or b"").decode()))
 
+    def get_device(self):
+        """c2r_get_device: the HIP device ordinal the context runs on (C2R_DEVICE_AUTO resolved)."""
+        d = C.c_int32()
+        self._check(self.lib.c2r_get_device(self.ctx, C.byref(d)), "c2r_get_device")
+        return d.value
+
     def info(self):
         """c2r_info: device (and how C2R_DEVICE_AUTO resolved it), sweep mode, rate accumulation, rank."""
         return (self.lib.c2r_info(self.ctx) or b"").decode()

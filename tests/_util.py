@@ -82,9 +82,25 @@ TOL = {
 }
 
 
+# ... and a PLAIN relative bound that no weight can hide a regression under: wherever a cell's own rate is at least
+# GAMMA_PLAIN_FLOOR of the rate passing through it (W), |dGamma| <= GAMMA_PLAIN_RTOL * Gamma, in both modes (the weighted
+# criterion allows 2e-8 there; below the floor a cell's rate is the difference of two table values ~1e6 times larger and only
+# the weighted criterion is meaningful -- the reference's own libm moves those cells by as much).  evolve_point.F90:262.
+GAMMA_PLAIN_RTOL = 2e-7
+GAMMA_PLAIN_FLOOR = 1e-6
+
+
+def gamma_plain_rel(dgamma, gamma_ref, w):
+    """max |dGamma| / Gamma over the cells with Gamma >= GAMMA_PLAIN_FLOOR x W (0.0 when there is none)."""
+    dgamma, gamma_ref, w = (np.asarray(v, dtype=np.float64) for v in (dgamma, gamma_ref, w))
+    sig = (gamma_ref > 0) & (gamma_ref >= GAMMA_PLAIN_FLOOR * w)
+    return float(np.max(np.abs(dgamma[sig]) / gamma_ref[sig])) if sig.any() else 0.0
+
+
 def gamma_ok(dgamma, gamma_ref, w, fast):
     t = TOL["fast" if fast else "exact"]
-    return bool(np.all(np.abs(dgamma) <= t["gamma_rtol"] * np.abs(gamma_ref) + t["gamma_wtol"] * w))
+    return bool(np.all(np.abs(dgamma) <= t["gamma_rtol"] * np.abs(gamma_ref) + t["gamma_wtol"] * w)) and \
+        gamma_plain_rel(dgamma, gamma_ref, w) <= GAMMA_PLAIN_RTOL
 
 
 def sweep_mode():
@@ -116,6 +132,10 @@ def assert_gamma(got, ref, w, what="", state_rtol=0.0):
         pytest.fail("%s Gamma out of tolerance at flat index %d: got %.17g ref %.17g W %.3g (rel %.2e, /W %.2e)" %
                     (what, i, got.flat[i], ref.flat[i], w.flat[i], abs(got.flat[i] / ref.flat[i] - 1),
                      abs(got.flat[i] - ref.flat[i]) / w.flat[i]))
+    # the plain bound (GAMMA_PLAIN_RTOL wherever Gamma >= GAMMA_PLAIN_FLOOR x W), whatever the weight says
+    plain = gamma_plain_rel(got - ref, ref, w)
+    assert plain <= GAMMA_PLAIN_RTOL + state_rtol, "%s plain relative Gamma error %.2e in a cell with Gamma >= %.0e W (bound %.0e)" % (
+        what, plain, GAMMA_PLAIN_FLOOR, GAMMA_PLAIN_RTOL + state_rtol)
 
 
 def oracle_pass(o, nd, xh, srcpos, normflux):

@@ -238,6 +238,39 @@ def test_failing_allreduce_callback_surfaces_as_ecallback_and_the_context_surviv
     lib.c2r_destroy(ctx)
 
 
+def test_set_option_is_the_only_way_to_the_schedule_switches(pkg, tables, monkeypatch):
+    """c2r_set_option: known names are accepted (and show in c2r_info where it reports them), an unknown name is C2R_EINVAL with a
+    message; the library itself ignores the variables the tests' conftest translates (a raw c2r_create under C2R_CHAINS=3 keeps
+    the library's own rule)."""
+    lib = pkg.load_library()
+    monkeypatch.setenv("C2R_CHAINS", "3"); monkeypatch.setenv("C2R_GRAPH", "0")
+    p = pkg.default_params(32)
+    ctx = C.c_void_p()
+    assert lib.c2r_create(C.byref(ctx), C.byref(p)) == 0
+    assert p.sweep_mode == 1 and b"sweep_mode fast" in lib.c2r_info(ctx)            # the default mode
+    assert lib.c2r_set_option(ctx, b"no_such_switch", 1.0) == -1 and b"no_such_switch" in lib.c2r_last_error(ctx)
+    for name, v in ((b"graph", 0.0), (b"chain_graph", 0.0), (b"chains", 3.0), (b"xcd_order", -1.0), (b"stream_hint", -1.0), (b"batch_cap", 0.0),
+                    (b"sparse_fraction", 0.25), (b"exchange_overlap_min", 16.0)):
+        assert lib.c2r_set_option(ctx, name, v) == 0, name
+    lib.c2r_destroy(ctx)
+    # 96 sources under the library's own rule are two chains whatever C2R_CHAINS says in the environment of a raw context
+    monkeypatch.delenv("C2R_GRAPH")
+    tp = pkg.TestProblem(32); s = tp.step(1)
+    pos, nf = pkg.seeded_sources(32, 96, seed=1)
+    ctx = C.c_void_p()
+    assert lib.c2r_create(C.byref(ctx), C.byref(p)) == 0
+    thick, thin = (np.ascontiguousarray(t) for t in tables)
+    assert lib.c2r_set_tables(ctx, thick.ctypes.data, thin.ctypes.data, thick.size) == 0
+    dr = (C.c_double * 3)(s["dr1"], s["dr1"], s["dr1"])
+    assert lib.c2r_set_step(ctx, C.byref(dr), s["vol"], s["coldensh_LLS"], 1.0, 1e4) == 0
+    posc = np.ascontiguousarray(pos, dtype=np.int32); nfc = np.ascontiguousarray(nf)
+    assert lib.c2r_set_sources(ctx, posc.ctypes.data, nfc.ctypes.data, 96) == 0
+    assert b"; chains 2;" in lib.c2r_info(ctx)
+    assert lib.c2r_set_option(ctx, b"chains", 3.0) == 0 and lib.c2r_set_sources(ctx, posc.ctypes.data, nfc.ctypes.data, 96) == 0
+    assert b"; chains 3;" in lib.c2r_info(ctx)
+    lib.c2r_destroy(ctx)
+
+
 def test_info_reports_device_mode_and_rank_and_the_library_ignores_the_environment(pkg, tables, monkeypatch):
     """c2r_info: how the device was chosen, the sweep mode that RUNS, rank/nranks.  c2r_params.sweep_mode is the only
     switch of the mode: C2R_SWEEP_MODE in the environment is a host-side convention (HipBackend(fast=None), the Fortran shim),

@@ -97,6 +97,25 @@ def test_bench_eight_ranks_equal_one_rank(form, balance):
         assert 0.0 < ph[k]["min_s_per_step"] <= ph[k]["max_s_per_step"]
     assert sum(ph[k]["max_s_per_step"] for k in ph) >= 0.5 * b["ms_per_step"] * 1e-3
     assert b["config"]["gamma_exchange"]["ring_over_xgmi_s_per_step"] > 0.0 and a["config"]["rank_phases"] is None
+    # first contact with a multi-GPU node: the communicator's own rank count, and the device every rank's context resolved to (all
+    # eight on the one GPU here, on purpose -- which the line must SAY; without C2R_BENCH_TEST_ONE_GPU that fails the run, below)
+    assert b["config"]["communicator_ranks"] == 8 and a["config"]["communicator_ranks"] == 1
+    rd = b["config"]["rank_devices"]
+    assert [d["rank"] for d in rd] == list(range(8)) and all(d["c2r_device"] == 0 and d["device_id"] for d in rd)
+    assert b["config"]["ranks_on_distinct_devices"] is False and a["config"]["ranks_on_distinct_devices"] is True
+
+
+def test_bench_more_ranks_than_devices_fails_loudly():
+    """`bench.py --gpus 2` on a box with ONE GPU and no test override: every rank finds fewer visible devices than ranks before any
+    rendezvous and exits non-zero with a message -- no hang in a collective, no JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "C2R_BENCH_TEST_ONE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + ARGS8, capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=env)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs: the launch is legitimate")
+    assert r.returncode != 0
+    assert "GPU(s) visible" in r.stderr and not [l for l in r.stdout.split("\n") if l.startswith("{")]
 
 
 def test_bench_two_ranks_with_the_exchange_overlapped():

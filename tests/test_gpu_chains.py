@@ -204,6 +204,37 @@ def test_replay_when_the_counts_move(pkg, tables, monkeypatch):
     assert len({tuple(g[3]) for g in got}) >= 3                                           # the fields do move the sub-box counts
 
 
+def test_iterations_with_a_device_gated_tail(pkg, tables, monkeypatch):
+    """c2r_iterate over replayed chains: from the iteration whose chains all replay, the totals, the fold of the transposed rates and
+    the global pass are enqueued behind them gated on the device (k_chain_gate) and the host waits once.  Iteration by iteration:
+    the same photon loss, sub-box sum, visited pairs and non-converged count as with chains driven launch by launch, xh_av to the
+    order of the atomics -- on a field that stays put (the gate opens) and after it has been changed (the gate stays shut for an
+    iteration, the tail runs the ordinary way)."""
+    import re
+    from tests.golden.inputs import bubble_xfield
+    n, S = 64, 130
+    s, nd, xh, pos, nf = _case(pkg, n, S, 77)
+    more = F(bubble_xfield(n, [tuple(int(v) for v in q) for q in pos], 14.0))
+    hist = {}
+    for cg in ("0", "1"):
+        monkeypatch.setenv("C2R_CHAIN_GRAPH", cg)
+        b = pkg.HipBackend(n, *tables, device=0)
+        b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], 1.0)
+        b.set_sources(pos, nf); b.set_rank(0, 1); b.load(ndens=nd, xh=xh); b.begin_step()
+        out = []
+        for k in range(9):
+            b.load(xh_av=more if k >= 4 else xh)                    # from k = 4 every source traces further: halts, a shut gate
+            b.load(xh_intermed=xh)                                  # (so that every iteration starts from the same chemistry state)
+            out.append(tuple(b.iterate(s["dt"])) + (b.fetch("xh_av"),))
+        hist[cg] = out
+        tails = int(re.search(r"device-gated tail (\d+)", b.info()).group(1))
+        assert (tails == 0) if cg == "0" else (3 <= tails <= 8), (cg, b.info())
+        b.close()
+    for k, (a, r) in enumerate(zip(hist["0"], hist["1"])):
+        assert r[0] == a[0] and r[1:4] == a[1:4], (k, r[:5], a[:5])       # loss (bits), sum_nbox, visited, conv_flag
+        assert abs(r[4] - a[4]) <= 1e-9 * abs(a[4]) and np.max(np.abs(r[5] - a[5])) < 1e-11, k
+
+
 def test_whole_steps_replayed_and_launch_by_launch(pkg, tables, monkeypatch):
     """evolve3D over a cold start with 80 sources: the counts change from iteration to iteration (captures, halts, continuations
     all occur); iteration count, non-converged-cell history, sub-box history equal, xh to the order of the atomics."""

@@ -77,6 +77,7 @@ def test_default_params_are_the_reference_constants(pkg):
     assert p.subboxsize == 5 and p.max_subbox == 1000 and p.numtau == 2000
     assert p.sigma_HI == float(np.float32(6.30e-18)) and p.pi == float(np.float32(3.141592654))
     assert p.loss_fraction == 1e-2 and p.epsilon == 1e-14
+    assert p.sweep_mode == 1          # C2R_SWEEP_FAST: the library (and drop-in) default since round 6; 0 = C2R_SWEEP_EXACT is the opt-in
 
 
 def test_no_gpu_fails_loudly(pkg):
@@ -294,4 +295,5 @@ def test_bench_plain_multi_gpu_form_is_a_launcher():
     assert r.returncode != 0
     assert "2-rank child run failed" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert "No HIP GPUs are available" in r.stderr or "no GPU visible" in r.stderr or "no HIP device" in r.stderr
+    # (since round 6 the ranks' own preflight -- fewer visible devices than ranks -- stops them before anything else does)
+    assert "GPU(s) visible" in r.stderr or "No HIP GPUs are available" in r.stderr or "no GPU visible" in r.stderr or "no HIP device" in r.stderr
