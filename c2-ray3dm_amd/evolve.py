@@ -25,8 +25,6 @@ import numpy as np
 from . import _capi
 from ._capi import C2RayHipError
 
-CONVERGENCE_FRACTION = 9.99999974737875164e-05     # c2ray_parameters.f90:25 (f32 literal, widened)
-MAX_OUTER_ITER = 100                               # evolve.F90:228
 
 
 def static_source_share(nsrc, rank, npr):
@@ -651,79 +649,42 @@ class Evolve:
 
     # evolve.F90:83
     def evolve3D(self, time, dt, restart=0):
-        if self.slab:
-            raise ValueError("slab chemistry runs in the native loop: use backend.evolve3d_native(dt)")
+        """evolve3D(time,dt,restart) (evolve.F90:83-281): a thin host of the ONE outer loop there is -- the library's
+        (c2r_evolve3d_dev / c2r_evolve3d_restart_dev, csrc/evolve_loop.hip: the convergence tests, the all-reduce through
+        this process's callback, the global pass, the photon statistics).  What stays here is what the reference does
+        outside that arithmetic: restart=1/2/3 reads the iteration dump first (start_from_dump), and rank 0 writes
+        iterdump1/2.bin alternately when dump_interval_s of wall clock have passed, from the loop's iteration hook.
+        Returns the step's report as a dict (per-iteration history in `log`).  The piecewise entries above (iteration,
+        pass_all_sources, global_pass, ...) remain for hosts that drive the steps themselves (bench.py, tests)."""
         b = self.b
-        n = b.mesh
-        ncell = n[0] * n[1] * n[2]
-        niter = 0
-        conv_flag = ncell
-        prev1 = float(np.float32(2.0) * np.float32(n[0]) * np.float32(n[1]) * np.float32(n[2]))
-        prev0 = prev1
-        if restart == 0:
-            b.begin_step()
-        else:
-            niter = self.start_from_dump(restart)                        # :156
-            prev1 = prev0 = 0.0                                          # saved module variables, zero in a new run
-        conv_criterion = min(int(CONVERGENCE_FRACTION * n[0] * n[1] * n[2]), (b.nsrc - 1) // 3)
-        self.log = []
+        if not hasattr(b, "evolve3d_native"):
+            raise TypeError("Evolve.evolve3D is a host of the library's loop: this backend has none (drive it piecewise)")
         self.visited = 0
-        t_sweep = t_chem = 0.0
-        stats = hasattr(b, "photon_sums")
-        before = b.photon_sums("xh", "xh") if stats else None          # evolve.F90:136 state_before
-        if restart == 0:
-            sum1 = b.sum_xh_intermed()
-        else:
-            conv_flag, sum1 = self.global_pass(dt)                       # :157
-            self.log.append(dict(conv_flag=conv_flag, sum_nbox=0, photon_loss=self.photon_loss_all))
-        converged = False
-        t_last_dump = _time.perf_counter()
-        while True:
-            sum0 = float(np.float32(ncell)) - sum1
-            rel1 = abs(sum1 - prev1) / sum1 if sum1 > 0.0 else 1.0
-            rel0 = abs(sum0 - prev0) / sum0 if sum0 > 0.0 else 1.0
-            if self.log:
-                self.log[-1].update(rel_change_xh1=rel1, rel_change_xh0=rel0, sum_xh1=sum1)
-            if conv_flag < conv_criterion or (rel1 < CONVERGENCE_FRACTION and rel0 < CONVERGENCE_FRACTION):
-                b.accept()
-                converged = True
-                break
-            if niter > MAX_OUTER_ITER:
-                break
-            prev1, prev0 = sum1, sum0
-            niter += 1
-            t0 = _time.perf_counter()
-            # evolve.F90:253-266: rank 0 writes iterdump1/2.bin alternately when the interval has passed -- between the
-            # pass and the global pass, so an iteration in which a dump is due runs as its three steps
-            dump_due = self.rank == 0 and self.dump_interval_s is not None and \
-                _time.perf_counter() - t_last_dump > self.dump_interval_s
-            if not dump_due and self.npr == 1:
-                conv_flag, sum1 = self.iteration(niter, dt)
-                t1 = t2 = _time.perf_counter()
+        t_last = [_time.perf_counter()]
+
+        def hook(niter, loss):                                           # evolve.F90:253-266
+            if self.rank == 0 and self.dump_interval_s is not None and _time.perf_counter() - t_last[0] > self.dump_interval_s:
+                self.photon_loss_all = loss
+                self.write_iteration_dump(niter)
+                t_last[0] = _time.perf_counter()
+        b.set_iteration_hook(hook if self.dump_interval_s is not None else None)
+        try:
+            if restart == 0:
+                rep = b.evolve3d_native(dt)
             else:
-                self.set_rates_to_zero()
-                self.pass_all_sources(niter, dt)
-                t1 = _time.perf_counter()
-                if dump_due:
-                    self.write_iteration_dump(niter)
-                    t_last_dump = _time.perf_counter()
-                conv_flag, sum1 = self.global_pass(dt)
-                t2 = _time.perf_counter()
-            t_sweep += t1 - t0
-            t_chem += t2 - t1
-            self.log.append(dict(conv_flag=conv_flag, sum_nbox=self.sum_nbox_all,
-                                 photon_loss=self.photon_loss_all))
-        phot = {}
-        if stats:                                                        # evolve.F90:277-279
-            after = b.photon_sums("xh", "xh_av")
-            vol = b.vol
-            totrec, totcol = after[2] * vol * dt, after[3] * vol * dt
-            dh0 = before[0] * vol - after[0] * vol
-            totalsrc = b.normflux_sum * b.params.S_star * dt
-            phot = dict(totrec=totrec, totcollisions=totcol, dh0=dh0, total_ion=totrec + dh0, totalsrc=totalsrc,
-                        photcons=(totrec + dh0 - totcol) / totalsrc if totalsrc > 0 else 0.0,
-                        h1_before=before[1] * vol, h1_after=after[1] * vol)
-        return dict(photon_statistics=phot,
-                    niter=niter, converged=converged, conv_flag=conv_flag, conv_criterion=conv_criterion,
-                    sum_nbox_all=self.sum_nbox_all, photon_loss_all=self.photon_loss_all,
-                    visited=self.visited, seconds_sweep=t_sweep, seconds_chem=t_chem, log=self.log)
+                niter0 = self.start_from_dump(restart)                   # :156
+                rep = b.evolve3d_native(dt, restart_niter=niter0, restart_photon_loss=self.photon_loss_all)
+        finally:
+            b.set_iteration_hook(None)
+        self.sum_nbox = self.sum_nbox_all = int(rep.sum_nbox_all)
+        self.photon_loss = self.photon_loss_all = float(rep.photon_loss_all)
+        self.visited = int(rep.visited)
+        first = niter0 - 1 if restart != 0 and niter0 >= 1 else 0        # (a restart logs the repeated global pass in the dump's slot)
+        self.log = [dict(conv_flag=int(rep.it_conv_flag[k]), sum_nbox=int(rep.it_sum_nbox[k]), rel_change_xh1=float(rep.it_rel_change_xh1[k]),
+                         rel_change_xh0=float(rep.it_rel_change_xh0[k]), sum_xh1=float(rep.it_sum_xh1[k]), photcons=float(rep.it_photcons[k]))
+                    for k in range(first, min(int(rep.niter), _capi.MAX_ITER_LOG))]
+        phot = dict(totrec=rep.totrec, totcollisions=rep.totcollisions, dh0=rep.dh0, total_ion=rep.total_ion, totalsrc=rep.totalsrc,
+                    photcons=rep.photcons, h1_before=rep.h1_before, h1_after=rep.h1_after)
+        return dict(photon_statistics=phot, niter=int(rep.niter), converged=bool(rep.converged), conv_flag=int(rep.conv_flag),
+                    conv_criterion=int(rep.conv_criterion), sum_nbox_all=self.sum_nbox_all, photon_loss_all=self.photon_loss_all,
+                    visited=self.visited, seconds_sweep=float(rep.seconds_sweep), seconds_chem=float(rep.seconds_chem), log=self.log)

@@ -64,6 +64,11 @@ typedef struct {
     const double *xray_thin;  /* xray_photo_thin_table(0:NumTau,1)  */
     const double *xray_flux;  /* NormFlux_xray(1:NumSrc): column 5 of the source list / S_star_xray (sourceprops.F90:381, 631) */
     const double *xray_heat_thick, *xray_heat_thin;   /* xray_heat_thick/thin_table(0:NumTau,1): non-isothermal runs (heat_lookuptable "P", :165-171) */
+    /* Builds of the reference with -DALLFRAC (ionfractions_module.F90:19-50; no shipped makefile defines it): xh, xh_av, xh_intermed are
+     * (mesh,0:1) and the NEUTRAL fraction is stored, not derived as 1 - x.  xh0 == NULL: the shipped build.  Pinned against the reference
+     * compiled with that one flag (oracle/ref_build.sh 32:allfrac).  The three arrays below are the (:,:,:,0) halves; the pointers every
+     * routine already takes are the (:,:,:,1) halves. */
+    double *xh0, *xh_av0, *xh_intermed0;
     long   *thermal_stats;    /* checker diagnostic (NULL = off): [0] thermal() calls, [1] of them left untouched because T_initial <=
                                * minitemp (thermal.f90:83), [2] of them ended by the sub-step cap i_heating > 10000 (:163), [3] sub-steps
                                * in all -- what the fixtures exercise; the reference has no such counters */
@@ -300,7 +305,8 @@ static void evolve0d(sweep_t *s, const int rt[3])
     if (s->cdout[id] != 0.0) return;                                           /* :128 */
     s->visited++;
     const double xav1 = dmax(s->xh_av[id], C2R_EPSILON);                       /* :137 */
-    const double xav0 = dmax(1.0 - xav1, C2R_EPSILON);                         /* :140 */
+    const double xav0 = c->xh_av0 ? dmax(c->xh_av0[id], C2R_EPSILON)           /* ALLFRAC :131-132: the stored neutral fraction */
+                                  : dmax(1.0 - xav1, C2R_EPSILON);             /* :140 */
     const double nd = (double)s->ndens[id];
     double cd_in, path, vol_ph;
     int stop_far = 0;
@@ -446,6 +452,10 @@ long oracle_global_pass(const oracle_cfg *c, double dt, const float *ndens, cons
         h_av[1] = dmax(C2R_EPSILON, xh_av[id]);
         h_old[0] = 1.0 - h_old[1];
         h_av[0] = 1.0 - h_av[1];
+        if (c->xh0) {                                                          /* ALLFRAC :341-346: both stored, both floored */
+            h_old[0] = dmax(C2R_EPSILON, c->xh0[id]);
+            h_av[0] = dmax(C2R_EPSILON, c->xh_av0[id]);
+        }
         const double nd = (double)ndens[id];
         const double gamma = phih[id];
         const int thermal = c->heat_thick != NULL;
@@ -477,7 +487,7 @@ long oracle_global_pass(const oracle_cfg *c, double dt, const float *ndens, cons
             t_new_avg = (double)tg[1];                                         /* :381 get_temperature_point again */
         }
         const double yh1_av_old = dmax(C2R_EPSILON, xh_av[id]);                /* :378 */
-        const double yh0_av_old = 1.0 - yh1_av_old;
+        const double yh0_av_old = c->xh0 ? c->xh_av0[id] : 1.0 - yh1_av_old;   /* ALLFRAC :375: as stored, not floored */
         if ((fabs(h_av[0] - yh0_av_old) > C2R_MIN_FRACTIONAL_CHANGE &&
              fabs((h_av[0] - yh0_av_old) / h_av[0]) > C2R_MIN_FRACTIONAL_CHANGE &&
              h_av[0] > C2R_MIN_FRACTION_OF_ATOMS) ||
@@ -485,6 +495,7 @@ long oracle_global_pass(const oracle_cfg *c, double dt, const float *ndens, cons
              fabs(t_start_avg - t_new_avg) > C2R_TEMP_CONV_ABS)) conv_flag++;  /* :384-391 (.or. binds looser than .and.) */
         xh_intermed[id] = h[1];
         xh_av[id] = h_av[1];
+        if (c->xh0) { c->xh_intermed0[id] = h[0]; c->xh_av0[id] = h_av[0]; }   /* ALLFRAC :395-398 */
     }
     return conv_flag;
 }
@@ -503,17 +514,26 @@ double oracle_sum(const double *a, size_t n)
 /* photonstatistics.F90:104-217  state_before / state_after / total_rates: the four mesh sums
  * (sequential, k-j-i order) before scaling.  out = { h0, h1, totrec, totcollisions } where
  * h0,h1 use xh_l and the rate sums use xh_r. */
+/* ALLFRAC (photonstatistics.F90:106-119, :158-160, :204-206): the stored neutral fractions of xh_l / xh_r (xl0 / xr0: the (:,:,:,0)
+ * halves; NULL: derived as 1 - x) */
+void oracle_photon_sums_x(const oracle_cfg *c, const float *ndens, const double *xh_l, const double *xh_r,
+                          const double *xl0, const double *xr0, double out[4]);
 void oracle_photon_sums(const oracle_cfg *c, const float *ndens, const double *xh_l, const double *xh_r,
                         double out[4])
+{
+    oracle_photon_sums_x(c, ndens, xh_l, xh_r, NULL, NULL, out);
+}
+void oracle_photon_sums_x(const oracle_cfg *c, const float *ndens, const double *xh_l, const double *xh_r,
+                          const double *xl0, const double *xr0, double out[4])
 {
     const size_t ncell = (size_t)c->n[0] * c->n[1] * c->n[2];
     double h0 = 0.0, h1 = 0.0, totrec = 0.0, totcoll = 0.0;
     const double rec = pow(c->temper / 1e4, C2R_ALBPOW), sq = sqrt(c->temper), ex = exp(-C2R_TEMPH0 / c->temper);
     for (size_t id = 0; id < ncell; ++id) {
         const double nd = (double)ndens[id];
-        h0 = h0 + nd * (1.0 - xh_l[id]);
+        h0 = h0 + nd * (xl0 ? xl0[id] : 1.0 - xh_l[id]);
         h1 = h1 + nd * xh_l[id];
-        const double y1 = xh_r[id], y0 = 1.0 - xh_r[id];
+        const double y1 = xh_r[id], y0 = xr0 ? xr0[id] : 1.0 - xh_r[id];
         const double de = nd * (y1 + C2R_ABU_C);
         if (c->heat_thick) {                                                   /* :167 get_temperature_point: %average */
             const double t = (double)c->temper_grid[3 * id + 1];
@@ -561,6 +581,10 @@ void oracle_evolve3d_x(const oracle_cfg *c, double dt, const float *ndens, doubl
     if (restart_niter < 0) {
         memcpy(xh_av, xh, ncell * sizeof(double));                             /* :145-146 */
         memcpy(xh_intermed, xh, ncell * sizeof(double));
+        if (c->xh0) {                                                          /* ALLFRAC :142-143: all of (:,:,:,:) */
+            memcpy(c->xh_av0, c->xh0, ncell * sizeof(double));
+            memcpy(c->xh_intermed0, c->xh0, ncell * sizeof(double));
+        }
     } else {
         niter = restart_niter;
         prev1 = prev0 = 0.0;
@@ -571,10 +595,11 @@ void oracle_evolve3d_x(const oracle_cfg *c, double dt, const float *ndens, doubl
     const long conv_criterion = c1 < c2 ? c1 : c2;
     memset(rep, 0, sizeof(*rep));
     double before[4], after[4];
-    oracle_photon_sums(c, ndens, xh, xh, before);                              /* state_before, evolve.F90:136 */
+    oracle_photon_sums_x(c, ndens, xh, xh, c->xh0, c->xh0, before);            /* state_before, evolve.F90:136 */
     for (;;) {
         const double sum1 = oracle_sum(xh_intermed, ncell);                    /* :183 */
-        const double sum0 = (double)(float)ncell - sum1;                       /* :184 */
+        const double sum0 = c->xh0 ? oracle_sum(c->xh_intermed0, ncell)        /* ALLFRAC :180-181 */
+                                   : (double)(float)ncell - sum1;              /* :184 */
         rel1 = sum1 > 0.0 ? fabs(sum1 - prev1) / sum1 : 1.0;
         rel0 = sum0 > 0.0 ? fabs(sum0 - prev0) / sum0 : 1.0;
         if (niter > 0 && niter <= 128) { rep->it_rel1[niter - 1] = rel1; rep->it_rel0[niter - 1] = rel0;
@@ -582,6 +607,7 @@ void oracle_evolve3d_x(const oracle_cfg *c, double dt, const float *ndens, doubl
         if (conv_flag < conv_criterion ||
             (rel1 < C2R_CONVERGENCE_FRACTION && rel0 < C2R_CONVERGENCE_FRACTION)) {   /* :212 */
             memcpy(xh, xh_intermed, ncell * sizeof(double));
+            if (c->xh0) memcpy(c->xh0, c->xh_intermed0, ncell * sizeof(double));   /* ALLFRAC :216 */
             if (c->heat_thick)                                                 /* :220 set_final_temperature_point */
                 for (size_t id = 0; id < ncell; ++id) c->temper_grid[3 * id] = c->temper_grid[3 * id + 2];
             rep->converged = 1;
@@ -603,7 +629,7 @@ void oracle_evolve3d_x(const oracle_cfg *c, double dt, const float *ndens, doubl
         if (niter <= 128) { rep->it_conv_flag[niter - 1] = conv_flag; rep->it_sum_nbox[niter - 1] = nb; }
     }
     rep->niter = niter; rep->conv_flag = conv_flag;
-    oracle_photon_sums(c, ndens, xh, xh_av, after);                            /* evolve.F90:277 */
+    oracle_photon_sums_x(c, ndens, xh, xh_av, c->xh0, c->xh_av0, after);       /* evolve.F90:277 */
     rep->totrec = after[2] * c->vol * dt;
     rep->totcollisions = after[3] * c->vol * dt;
     rep->dh0 = before[0] * c->vol - after[0] * c->vol;

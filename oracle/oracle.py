@@ -29,6 +29,7 @@ class Cfg(C.Structure):
                 ("temper_grid", C.c_void_p), ("phiheat", C.c_void_p), ("tolw_heat", C.c_void_p),
                 ("xray_thick", C.c_void_p), ("xray_thin", C.c_void_p), ("xray_flux", C.c_void_p),
                 ("xray_heat_thick", C.c_void_p), ("xray_heat_thin", C.c_void_p),
+                ("xh0", C.c_void_p), ("xh_av0", C.c_void_p), ("xh_intermed0", C.c_void_p),
                 ("thermal_stats", C.c_void_p)]
 
 
@@ -108,6 +109,15 @@ class Oracle:
         assert self.xray_thick.size == 2001 and self.xray_thin.size == 2001
         self.cfg.xray_thick, self.cfg.xray_thin = self.xray_thick.ctypes.data, self.xray_thin.ctypes.data
         self.cfg.xray_flux = self.xray_flux.ctypes.data
+
+    def enable_allfrac(self, xh0):
+        """A build of the reference with -DALLFRAC: the stored neutral fractions.  xh0 (ncell f64) is the (:,:,:,0) half of xh and
+        is updated in place like xh; xh_av0 / xh_intermed0 are allocated here (evolve3d fills them; a lone pass reads xh_av0)."""
+        assert xh0.dtype == np.float64 and xh0.size == self.ncell and xh0.flags.c_contiguous
+        self.xh0 = xh0
+        self.xh_av0 = xh0.copy()
+        self.xh_intermed0 = xh0.copy()
+        self.cfg.xh0, self.cfg.xh_av0, self.cfg.xh_intermed0 = xh0.ctypes.data, self.xh_av0.ctypes.data, self.xh_intermed0.ctypes.data
 
     def enable_thermal(self, heat_thick, heat_thin, cool_logT, cool_logL, zred, temper_grid=None):
         """Non-isothermal run (isothermal=.false.): heating tables, the cooling table as setup_cool (cooling.f90:64-87)

@@ -45,9 +45,14 @@ SRCS="precision.f90 mathconstants.f90 cgsconstants.f90 cgsastroconstants.f90 c2r
 #          133-137, 167-171).  The reference fills its X-ray tables from an UNINITIALISED local array (radiation_tables.F90:367,
 #          :405-425: xray_SED is never set; sed_parameters.f90:55 "not yet implemented"), so ref_driver overwrites
 #          xray_photo_thick/thin_table with tables it is handed (namelist xray_tables=) before any rate is evaluated.
+# And the one PREPROCESSOR variant of the path's files (round 6):
+#   allfrac  -DALLFRAC on every file (no parameter file rewritten): xh / xh_av / xh_intermed carry both fractions (:,:,:,0:1) and
+#          the NEUTRAL fraction is stored, not derived as 1 - x (ionfractions_module.F90:19-50, evolve_point.F90:130-142, :341-350,
+#          :394-399, evolve.F90:141-150, :179, :215, photonstatistics.F90).  No shipped makefile defines it; it compiles as it lies.
 variant_file () {   # $1 = variant -> the reference file(s) the variant rewrites
   case "$1" in
     pl|xray) echo sed_parameters.f90 ;;
+    allfrac) echo "" ;;
     xraythermal) echo "sed_parameters.f90 c2ray_parameters.f90" ;;     # use_xray_SED=.true. AND isothermal=.false.
     *) echo c2ray_parameters.f90 ;;
   esac
@@ -73,6 +78,7 @@ params_for_variant () {   # $1 = variant, $2 = output file
 build_variant () {   # $1 = mesh[:variant], $2 = subdir, $3 = extra flags
   local N=${1%%:*} V="" FLAGS="-DGFORT -O2 $3"
   [ "$1" != "$N" ] && V=${1#*:}
+  [ "$V" = allfrac ] && FLAGS="$FLAGS -DALLFRAC"
   local B=$HERE/_ref/N$N${V:+_$V}/$2
   mkdir -p "$B"
   sed "s|^\( *integer,dimension(Ndim),parameter,public :: mesh=\)(/ 300, 300, 300 /)|\1(/ $N, $N, $N /)|" \
@@ -105,6 +111,7 @@ build_variant () {   # $1 = mesh[:variant], $2 = subdir, $3 = extra flags
 build_hip_dropin () {   # $1 = mesh[:variant]
   local N=${1%%:*} V="" FLAGS="-DGFORT -O2"
   [ "$1" != "$N" ] && V=${1#*:}
+  [ "$V" = allfrac ] && FLAGS="$FLAGS -DALLFRAC"
   local D=$HERE/_ref/N$N${V:+_$V}
   local S=$D/serial B=$D/hip PKG=$HERE/../c2-ray3dm_amd
   [ -f "$PKG/libc2ray_hip.so" ] || { echo "libc2ray_hip.so not built: skipping drop-in program" >&2; return 0; }

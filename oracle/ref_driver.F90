@@ -70,9 +70,9 @@ program ref_driver
   integer            :: nsteps = 1, dump_first = 1, dump_last = 1, ns_dump = 1, nrep = 1
   real(kind=dp)      :: x_init = -1.0_dp
   character(len=512) :: dens_file = 'none', x_file = 'none', out_dir = './dump/'
-  character(len=512) :: lls_file = 'none', clump_file = 'none', t_file = 'none', xray_tables = 'none'
+  character(len=512) :: lls_file = 'none', clump_file = 'none', t_file = 'none', xray_tables = 'none', x0_file = 'none'
   namelist /ctl/ mode, nsteps, x_init, dens_file, x_file, dump_first, dump_last, &
-       ns_dump, nrep, out_dir, lls_file, clump_file, t_file, xray_tables
+       ns_dump, nrep, out_dir, lls_file, clump_file, t_file, xray_tables, x0_file
 
   character(len=512) :: answers
   integer :: restart = 0, nz0 = 1, ierror = 0, nz, u, istep, ns, irep, gi, gj, gk, conv_flag
@@ -177,12 +177,30 @@ program ref_driver
         endif
 
         if (istep == 1) then
+#ifdef ALLFRAC
+           ! builds with -DALLFRAC (ionfractions_module.F90:19-50): the ionized fraction comes in as before, the stored neutral
+           ! fraction is set the way xfrac_restart_init does (:97-100) -- or read from x0_file where a test wants the two to
+           ! be inconsistent on purpose (what distinguishes the build: evolve0D reads the STORED neutral fraction)
+           if (x_init >= 0.0_dp) xh(:,:,:,1) = x_init
+           if (trim(x_file) /= 'none') then
+              open(newunit=u, file=trim(x_file), access='stream', form='unformatted', status='old')
+              read(u) xh(:,:,:,1)
+              close(u)
+           endif
+           xh(:,:,:,0) = 1.0_dp - xh(:,:,:,1)
+           if (trim(x0_file) /= 'none') then
+              open(newunit=u, file=trim(x0_file), access='stream', form='unformatted', status='old')
+              read(u) xh(:,:,:,0)
+              close(u)
+           endif
+#else
            if (x_init >= 0.0_dp) xh = x_init
            if (trim(x_file) /= 'none') then
               open(newunit=u, file=trim(x_file), access='stream', form='unformatted', status='old')
               read(u) xh
               close(u)
            endif
+#endif
            ! non-isothermal builds: an initial temperature field (K, f32) instead of the uniform
            ! initial_temperature that temperature_array_init (temperature_module.F90:43) fills in
            if (.not.isothermal .and. trim(t_file) /= 'none') then
@@ -280,8 +298,8 @@ program ref_driver
                  enddo
               enddo
            enddo
-           call dump_r8(trim(tag)//'_xh_av', xh_av)
-           call dump_r8(trim(tag)//'_xh_intermed', xh_intermed)
+           call dump_x(trim(tag)//'_xh_av', xh_av)
+           call dump_x(trim(tag)//'_xh_intermed', xh_intermed)
            open(newunit=u, file=trim(out_dir)//trim(tag)//'_cells.txt', status='replace')
            write(u,'(A,1X,ES26.17E3)') 'photon_loss_src', photon_loss_src_thread(1)
            write(u,'(A,1X,I12)') 'evolve0D_calls', ncall
@@ -315,8 +333,8 @@ program ref_driver
               enddo
            enddo
 #endif
-           call dump_r8(trim(tag)//'_xh_av', xh_av)
-           call dump_r8(trim(tag)//'_xh_intermed', xh_intermed)
+           call dump_x(trim(tag)//'_xh_av', xh_av)
+           call dump_x(trim(tag)//'_xh_intermed', xh_intermed)
            open(newunit=u, file=trim(out_dir)//trim(tag)//'_grid.txt', status='replace')
            write(u,'(A,1X,ES26.17E3)') 'photon_loss', photon_loss(1)
            write(u,'(A,1X,I12)') 'sum_nbox', sum_nbox
@@ -339,9 +357,9 @@ program ref_driver
            call evolve3D(sim_time, actual_dt, 0)
         endif
         if (istep >= dump_first .and. istep <= dump_last) then
-           call dump_r8(trim(tag)//'_xh_after', xh)
-           call dump_r8(trim(tag)//'_xh_av', xh_av)
-           call dump_r8(trim(tag)//'_xh_intermed', xh_intermed)
+           call dump_x(trim(tag)//'_xh_after', xh)
+           call dump_x(trim(tag)//'_xh_av', xh_av)
+           call dump_x(trim(tag)//'_xh_intermed', xh_intermed)
            call dump_r8(trim(tag)//'_phih_grid', phih_grid)
            if (.not.isothermal) then
               call dump_r8(trim(tag)//'_phiheat_grid', phiheat_grid)
@@ -379,6 +397,23 @@ contains
     close(uu)
   end subroutine dump_r8
 
+  !> one of the ionization-fraction arrays: <name>.f64 holds the ionized fraction; builds with -DALLFRAC also leave the stored
+  !! neutral fraction in <name>0.f64
+#ifdef ALLFRAC
+  subroutine dump_x(name, a)
+    character(len=*), intent(in) :: name
+    real(kind=dp), intent(in) :: a(:,:,:,0:)
+    call dump_r8(name, a(:,:,:,1))
+    call dump_r8(trim(name)//'0', a(:,:,:,0))
+  end subroutine dump_x
+#else
+  subroutine dump_x(name, a)
+    character(len=*), intent(in) :: name
+    real(kind=dp), intent(in) :: a(:,:,:)
+    call dump_r8(name, a)
+  end subroutine dump_x
+#endif
+
   !> temperature_grid as it lies in memory: (current, average, intermed) f32 per cell
   subroutine dump_temper(name)
     character(len=*), intent(in) :: name
@@ -404,7 +439,7 @@ contains
   subroutine dump_inputs(tag)
     character(len=*), intent(in) :: tag
     integer :: uu, is
-    call dump_r8(trim(tag)//'_xh_before', xh)
+    call dump_x(trim(tag)//'_xh_before', xh)
     open(newunit=uu, file=trim(out_dir)//trim(tag)//'_ndens.f32', access='stream', &
          form='unformatted', status='replace')
     write(uu) ndens

@@ -88,3 +88,92 @@ class OracleBackend:
     def scalars_tensor(self, values):
         import torch
         return torch.tensor(values, dtype=torch.float64)
+
+
+# ---- the piecewise outer loop of a time step, for THIS double (test infrastructure) -----------------------------------------
+# The product has one outer loop: the library's (c2r_evolve3d_dev; Evolve.evolve3D is its thin host).  A backend without it --
+# this CPU double -- is driven step by step through Evolve's piecewise entries (set_rates_to_zero, pass_all_sources / iteration,
+# global_pass, the dump reader and writer) by the loop below, which restates evolve.F90:83-281 the way the oracle restates the
+# kernels: the CPU tests of the host logic (source shares, the all-reduce over gloo, dumps and restarts) run through it.
+CONVERGENCE_FRACTION = 9.99999974737875164e-05     # c2ray_parameters.f90:25 (f32 literal, widened)
+MAX_OUTER_ITER = 100                               # evolve.F90:228
+
+
+def evolve3d_piecewise(ev, time_, dt, restart=0):
+    import time
+    if ev.slab:
+        raise ValueError("slab chemistry runs in the native loop: use backend.evolve3d_native(dt)")
+    b = ev.b
+    n = b.mesh
+    ncell = n[0] * n[1] * n[2]
+    niter = 0
+    conv_flag = ncell
+    prev1 = float(np.float32(2.0) * np.float32(n[0]) * np.float32(n[1]) * np.float32(n[2]))
+    prev0 = prev1
+    if restart == 0:
+        b.begin_step()
+    else:
+        niter = ev.start_from_dump(restart)                        # :156
+        prev1 = prev0 = 0.0                                          # saved module variables, zero in a new run
+    conv_criterion = min(int(CONVERGENCE_FRACTION * n[0] * n[1] * n[2]), (b.nsrc - 1) // 3)
+    ev.log = []
+    ev.visited = 0
+    t_sweep = t_chem = 0.0
+    stats = hasattr(b, "photon_sums")
+    before = b.photon_sums("xh", "xh") if stats else None          # evolve.F90:136 state_before
+    if restart == 0:
+        sum1 = b.sum_xh_intermed()
+    else:
+        conv_flag, sum1 = ev.global_pass(dt)                       # :157
+        ev.log.append(dict(conv_flag=conv_flag, sum_nbox=0, photon_loss=ev.photon_loss_all))
+    converged = False
+    t_last_dump = time.perf_counter()
+    while True:
+        sum0 = float(np.float32(ncell)) - sum1
+        rel1 = abs(sum1 - prev1) / sum1 if sum1 > 0.0 else 1.0
+        rel0 = abs(sum0 - prev0) / sum0 if sum0 > 0.0 else 1.0
+        if ev.log:
+            ev.log[-1].update(rel_change_xh1=rel1, rel_change_xh0=rel0, sum_xh1=sum1)
+        if conv_flag < conv_criterion or (rel1 < CONVERGENCE_FRACTION and rel0 < CONVERGENCE_FRACTION):
+            b.accept()
+            converged = True
+            break
+        if niter > MAX_OUTER_ITER:
+            break
+        prev1, prev0 = sum1, sum0
+        niter += 1
+        t0 = time.perf_counter()
+        # evolve.F90:253-266: rank 0 writes iterdump1/2.bin alternately when the interval has passed -- between the
+        # pass and the global pass, so an iteration in which a dump is due runs as its three steps
+        dump_due = ev.rank == 0 and ev.dump_interval_s is not None and \
+            time.perf_counter() - t_last_dump > ev.dump_interval_s
+        if not dump_due and ev.npr == 1:
+            conv_flag, sum1 = ev.iteration(niter, dt)
+            t1 = t2 = time.perf_counter()
+        else:
+            ev.set_rates_to_zero()
+            ev.pass_all_sources(niter, dt)
+            t1 = time.perf_counter()
+            if dump_due:
+                ev.write_iteration_dump(niter)
+                t_last_dump = time.perf_counter()
+            conv_flag, sum1 = ev.global_pass(dt)
+            t2 = time.perf_counter()
+        t_sweep += t1 - t0
+        t_chem += t2 - t1
+        ev.log.append(dict(conv_flag=conv_flag, sum_nbox=ev.sum_nbox_all,
+                             photon_loss=ev.photon_loss_all))
+    phot = {}
+    if stats:                                                        # evolve.F90:277-279
+        after = b.photon_sums("xh", "xh_av")
+        vol = b.vol
+        totrec, totcol = after[2] * vol * dt, after[3] * vol * dt
+        dh0 = before[0] * vol - after[0] * vol
+        totalsrc = b.normflux_sum * b.params.S_star * dt
+        phot = dict(totrec=totrec, totcollisions=totcol, dh0=dh0, total_ion=totrec + dh0, totalsrc=totalsrc,
+                    photcons=(totrec + dh0 - totcol) / totalsrc if totalsrc > 0 else 0.0,
+                    h1_before=before[1] * vol, h1_after=after[1] * vol)
+    return dict(photon_statistics=phot,
+                niter=niter, converged=converged, conv_flag=conv_flag, conv_criterion=conv_criterion,
+                sum_nbox_all=ev.sum_nbox_all, photon_loss_all=ev.photon_loss_all,
+                visited=ev.visited, seconds_sweep=t_sweep, seconds_chem=t_chem, log=ev.log)

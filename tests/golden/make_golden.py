@@ -191,11 +191,13 @@ def case_thermal_points_steep():
 
 
 def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, keep=("xh_after", "phih_grid", "xh_av"),
-                variant=None, lls_grid=None, clump_grid=None, tfield=None, cooling="primordial", dens_sigma=0.6, xray=None):
+                variant=None, lls_grid=None, clump_grid=None, tfield=None, cooling="primordial", dens_sigma=0.6, xray=None, x0field=None):
     dens = density_factor(n, dens_seed, dens_sigma) if dens_seed is not None else None
     nml = {"mode": "'evolve'", "nsteps": nsteps, "dump_first": dump[0], "dump_last": dump[-1]}
     extra, xn = xray_files(xray)
     nml.update(xn)
+    if x0field is not None:            # -DALLFRAC builds: the stored neutral fraction the run starts from (ref_driver.F90 x0_file)
+        extra["x0.f64"] = lambda p: x0field.T.tofile(p); nml["x0_file"] = "'x0.f64'"
     if lls_grid is not None:
         extra["lls.f32"] = lambda p: lls_grid.astype(np.float32).T.tofile(p); nml["lls_file"] = "'lls.f32'"
     if clump_grid is not None:
@@ -211,6 +213,8 @@ def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, kee
         kv["niter"] = len(log[s - 1]["nonconv"])
         meta["steps"][tag] = kv
         arrays[tag + "_xh_before"] = rd(d, tag + "_xh_before.f64", n)
+        if variant == "allfrac":
+            arrays[tag + "_xh_before0"] = rd(d, tag + "_xh_before0.f64", n)
         arrays[tag + "_ndens"] = rd(d, tag + "_ndens.f32", n, np.float32)
         for k in keep:
             arrays[tag + "_" + k] = rd(d, "%s_%s.f64" % (tag, k), n)
@@ -226,13 +230,15 @@ def case_evolve(name, n, sources, nsteps, dump, dens_seed=None, xfield=None, kee
     print(name, {t: m["niter"] for t, m in meta["steps"].items()})
 
 
-def case_sweep(name, n, sources, x_init=None, dens_seed=None, xfield=None, ns_dump=1, full=True, variant=None, xray=None):
+def case_sweep(name, n, sources, x_init=None, dens_seed=None, xfield=None, ns_dump=1, full=True, variant=None, xray=None, x0field=None):
     dens = density_factor(n, dens_seed) if dens_seed is not None else None
     nml = {"mode": "'sweep'", "ns_dump": ns_dump}
     if x_init is not None:
         nml["x_init"] = "%.17g" % x_init
     extra, xn = xray_files(xray)
     nml.update(xn)
+    if x0field is not None:
+        extra["x0.f64"] = lambda p: x0field.T.tofile(p); nml["x0_file"] = "'x0.f64'"
     d = run_driver(n, sources, nml, dens=dens, xfield=xfield, variant=variant, extra_files=extra)
     tag = "step001"
     kv = read_kv("%s/dump/%s_in.txt" % (d, tag))
@@ -242,6 +248,8 @@ def case_sweep(name, n, sources, x_init=None, dens_seed=None, xfield=None, ns_du
     phih = rd(d, tag + "_phih_grid.f64", n)
     cdo = rd(d, tag + "_coldensh_out.f64", n)
     arrays = {"xh": rd(d, tag + "_xh_before.f64", n), "ndens": rd(d, tag + "_ndens.f32", n, np.float32)}
+    if variant == "allfrac":
+        arrays["xh0"] = rd(d, tag + "_xh_before0.f64", n)
     if variant in ("thermal", "xraythermal"):
         arrays["phiheat"] = rd(d, tag + "_phiheat_grid.f64", n)
     if xray is not None:
@@ -501,6 +509,18 @@ def main():
                SRC_STD[5] + (0.0,), SRC_STD[6] + (1e6,), SRC_STD[7] + (0.0,), SRC_STD[8] + (4e8,), SRC_STD[9] + (0.0,)]
         x = bubble_xfield(32, [(18, 18, 18), (20, 10, 10), (6, 6, 18)], 7.0)
         case_sweep("sweep32_xraythermal", 32, src, dens_seed=5, xfield=x, ns_dump=5, variant="xraythermal", xray=xr)
+    # the reference compiled with -DALLFRAC (ref_build.sh 32:allfrac): both fractions stored.  The run starts from a neutral
+    # fraction that is NOT 1 - x (2e-3 of noise on it, one cell in fifty with a stored zero, which evolve0D raises to epsilon):
+    # a path that derived it from x would not reproduce these rates.  After its first global pass the code keeps the two
+    # consistent itself (doric).
+    if want("allfrac"):
+        rng = np.random.default_rng(606)
+        x = bubble_xfield(32, [(16, 16, 16), (5, 27, 9), (24, 8, 20)], 7.0)
+        x0 = (1.0 - x) * (1.0 + 2e-3 * rng.standard_normal(x.shape))
+        x0[rng.random(x.shape) < 0.02] = 0.0
+        case_sweep("sweep32_allfrac", 32, SRC_STD, dens_seed=5, xfield=x, ns_dump=5, variant="allfrac", x0field=x0)
+        case_evolve("evolve32_allfrac", 32, SRC_STD, 2, [1, 2], dens_seed=11, xfield=x, variant="allfrac", x0field=x0,
+                    keep=("xh_after", "xh_after0", "phih_grid", "xh_av", "xh_av0", "xh_intermed", "xh_intermed0"))
     # non-isothermal run (isothermal=.false.), with the synthetic cooling table of inputs.cooling_table()
     if want("thermal"):
         case_thermal_tables_and_points()

@@ -81,7 +81,8 @@ def test_sweep64_planes_vs_reference_fixture(pkg, tables):
 def test_evolve3d_vs_reference_fixture(pkg, tables, name, native):
     """Whole time steps: same outer-iteration count, same non-converged-cell sequence, xh within
     tol("x") of the Fortran.  native=True runs the loop inside the C ABI (c2r_evolve3d_dev, what the
-    Fortran shim calls), native=False the Python host mirror (Evolve.evolve3D)."""
+    Fortran shim calls) through the backend, native=False through the Python host (Evolve.evolve3D: since round 6 a thin host
+    of the SAME C loop -- its report as a dict, dumps from the iteration hook, restarts through start_from_dump)."""
     m, a = load_case(name)
     n = m["n"]
     for tag, s in m["steps"].items():

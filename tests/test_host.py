@@ -118,15 +118,16 @@ def test_seeded_sources_are_reproducible_and_distinct(pkg):
 
 
 def test_evolve_loop_on_cpu_double_matches_reference(pkg):
-    """The Python outer loop (Evolve.evolve3D) driven by the oracle-backed test double reproduces
-    the reference's iteration history exactly: the loop logic is right independently of the GPU."""
-    from tests._cpu_backend import OracleBackend
+    """The host mirror's piecewise entries (Evolve.iteration / pass_all_sources / global_pass ...) driven through a whole step
+    by the oracle-backed test double and its loop (tests/_cpu_backend.py evolve3d_piecewise; the product's one outer loop is the
+    library's, which needs a GPU) reproduce the reference's iteration history exactly."""
+    from tests._cpu_backend import OracleBackend, evolve3d_piecewise
     tables = load_tables()
     m, a = load_case("evolve32_std_bubbles")
     for tag, s in m["steps"].items():
         b = OracleBackend(oracle_for(s, tables, m["n"]), F(a[tag + "_ndens"]), F(a[tag + "_xh_before"]),
                           s["srcpos"], s["normflux"])
-        r = pkg.Evolve(b).evolve3D(0.0, s["dt"], 0)
+        r = evolve3d_piecewise(pkg.Evolve(b), 0.0, s["dt"], 0)
         assert r["niter"] == s["niter"] and r["converged"]
         assert [e["conv_flag"] for e in r["log"]] == s["log"]["nonconv"]
         assert np.array_equal(b.xh, F(a[tag + "_xh_after"]))
@@ -135,9 +136,9 @@ def test_evolve_loop_on_cpu_double_matches_reference(pkg):
 
 @pytest.mark.parametrize("name", ["restart32_std_bubbles", "restart32_onesrc"])
 def test_restart_from_iteration_dump_on_cpu_double(pkg, tmp_path, name):
-    """Evolve.evolve3D(restart=3) reads iterdump.bin (the reference's record layout) and resumes exactly
+    """restart=3: Evolve.start_from_dump reads iterdump.bin (the reference's record layout) and the step resumes exactly
     as the reference did from the same file (fixture generated by the reference reading OUR dump)."""
-    from tests._cpu_backend import OracleBackend
+    from tests._cpu_backend import OracleBackend, evolve3d_piecewise
     tables = load_tables()
     m, a = load_case(name)
     b = OracleBackend(oracle_for(m, tables, m["n"]), F(a["ndens"]), F(a["xh_before"]), m["srcpos"], m["normflux"])
@@ -145,7 +146,7 @@ def test_restart_from_iteration_dump_on_cpu_double(pkg, tmp_path, name):
                                     a["dump_phih"], a["dump_xh_av"], a["dump_xh_intermed"])
     ev = pkg.Evolve(b)
     ev.dump_dir = str(tmp_path)
-    r = ev.evolve3D(0.0, m["dt"], 3)
+    r = evolve3d_piecewise(ev, 0.0, m["dt"], 3)
     assert r["converged"] and [e["conv_flag"] for e in r["log"]] == m["log"]["nonconv"]
     assert np.array_equal(b.xh, F(a["xh_after"])) and np.array_equal(b.phih_grid, F(a["phih_grid"]))
 
@@ -154,13 +155,13 @@ def test_iteration_dump_then_restart_reproduces_the_rest_of_the_step(pkg, tmp_pa
     """Dumps written by the loop itself (dump interval 0: after every pass) alternate between
     iterdump1.bin and iterdump2.bin (evolve.F90:296-301) and a restart from the last one finishes the step
     with the same answer as the reference's restart semantics predict (one extra global pass)."""
-    from tests._cpu_backend import OracleBackend
+    from tests._cpu_backend import OracleBackend, evolve3d_piecewise
     tables = load_tables()
     m, a = load_case("restart32_onesrc")
     o = oracle_for(m, tables, m["n"])
     b = OracleBackend(o, F(a["ndens"]), F(a["xh_before"]), m["srcpos"], m["normflux"])
     ev = pkg.Evolve(b); ev.dump_dir = str(tmp_path); ev.dump_interval_s = 0.0
-    r = ev.evolve3D(0.0, m["dt"], 0)
+    r = evolve3d_piecewise(ev, 0.0, m["dt"], 0)
     assert os.path.exists(tmp_path / "iterdump1.bin") and os.path.exists(tmp_path / "iterdump2.bin")
     last = 2 if r["niter"] % 2 == 0 else 1
     niter, loss, phih, xav, xint = pkg.fileio.read_iteration_dump(str(tmp_path / ("iterdump%d.bin" % last)), m["n"])
@@ -169,7 +170,7 @@ def test_iteration_dump_then_restart_reproduces_the_rest_of_the_step(pkg, tmp_pa
     # from it redoes that global pass and must land on the same converged state
     b2 = OracleBackend(o, F(a["ndens"]), F(a["xh_before"]), m["srcpos"], m["normflux"])
     ev2 = pkg.Evolve(b2); ev2.dump_dir = str(tmp_path); ev2.dump_interval_s = None
-    r2 = ev2.evolve3D(0.0, m["dt"], last)
+    r2 = evolve3d_piecewise(ev2, 0.0, m["dt"], last)
     assert r2["converged"]
     # not bitwise: after a restart the previous-sum variables are zero, so at least one more pass is
     # forced and the loop stops at a different point of the same 1e-4 convergence criterion
@@ -227,13 +228,13 @@ def test_two_ranks_gloo_equals_one_rank(pkg, tmp_path, mode):
                            "--master-addr", "127.0.0.1", "--master-port", "29731", script, str(out), mode],
                           env=env, cwd=ROOT, timeout=280)
     got = np.load(out)
-    from tests._cpu_backend import OracleBackend
+    from tests._cpu_backend import OracleBackend, evolve3d_piecewise
     tables = load_tables()
     m, a = load_case("evolve32_std_bubbles")
     s = m["steps"]["step001"]
     b = OracleBackend(oracle_for(s, tables, m["n"]), F(a["step001_ndens"]), F(a["step001_xh_before"]),
                       s["srcpos"], s["normflux"])
-    r = pkg.Evolve(b).evolve3D(0.0, s["dt"], 0)
+    r = evolve3d_piecewise(pkg.Evolve(b), 0.0, s["dt"], 0)
     assert int(got["niter"]) == r["niter"]
     assert int(got["sum_nbox_all"]) == r["sum_nbox_all"]
     assert abs(float(got["photon_loss_all"]) / r["photon_loss_all"] - 1) < 1e-14

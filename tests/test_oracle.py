@@ -299,3 +299,50 @@ def test_do_grid_then_global_pass_module_surface(tables):
     xav, xint = xh.copy(), xh.copy()
     assert o.global_pass(m["dt"], nd, xh, xav, xint, phih) == m["conv_flag"]
     assert np.array_equal(xav, F(a["xh_av"])) and np.array_equal(xint, F(a["xh_intermed"]))
+
+
+# ---- the reference compiled with -DALLFRAC (oracle/ref_build.sh 32:allfrac): both fractions stored ----------------------------
+
+def test_allfrac_sweep_reads_the_stored_neutral_fraction(tables):
+    """One pass on a field whose stored neutral fraction is NOT 1 - x (2e-3 of noise, 2 % stored zeros that evolve0D raises to
+    epsilon, evolve_point.F90:131-134): column densities, rates and the photon loss of the -DALLFRAC reference, bit for bit --
+    and not what the shipped build's derived neutral fraction gives."""
+    m, a = load_case("sweep32_allfrac")
+    n = m["n"]
+    nd, xh, xh0 = F(a["ndens"]), F(a["xh"]), F(a["xh0"])
+    o = oracle_for(m, tables, n)
+    o.enable_allfrac(xh0)
+    phih = np.zeros(o.ncell)
+    loss, nb, vis = o.pass_sources(nd, xh, phih, m["srcpos"], m["normflux"])
+    assert nb == m["sum_nbox"] and loss == m["photon_loss"]
+    assert np.array_equal(phih, F(a["phih"]))
+    ns = m["ns_dump"]
+    _, _, _, cd = o.do_source(nd, xh, np.zeros(o.ncell), m["srcpos"][ns - 1], m["normflux"][ns - 1])
+    assert np.array_equal(cd, F(a["coldensh_out"]))
+    plain = oracle_for(m, tables, n)
+    g = np.zeros(o.ncell)
+    plain.pass_sources(nd, xh, g, m["srcpos"], m["normflux"])
+    assert relerr(g, phih, floor=1e-60) > 1e-4            # the fixture does tell the two builds apart
+
+
+def test_allfrac_evolve3d_steps(tables):
+    """Whole steps of the -DALLFRAC reference: evolve0D_global reads and writes both fractions (evolve_point.F90:341-346, :394-399),
+    Test 2 sums the stored neutral fraction (evolve.F90:179-181), the photon statistics count it (photonstatistics.F90)."""
+    m, a = load_case("evolve32_allfrac")
+    n = m["n"]
+    for tag, s in m["steps"].items():
+        o = oracle_for(s, tables, n)
+        xh, xh0, nd = F(a[tag + "_xh_before"]), F(a[tag + "_xh_before0"]), F(a[tag + "_ndens"])
+        o.enable_allfrac(xh0)
+        rep, xav, xint, phih = o.evolve3d(s["dt"], nd, xh, s["srcpos"], s["normflux"])
+        assert rep.niter == s["niter"] and rep.converged == 1
+        assert list(rep.it_conv_flag[:rep.niter]) == s["log"]["nonconv"]
+        assert np.array_equal(xh, F(a[tag + "_xh_after"])) and np.array_equal(xh0, F(a[tag + "_xh_after0"]))
+        assert np.array_equal(phih, F(a[tag + "_phih_grid"]))
+        assert np.array_equal(xav, F(a[tag + "_xh_av"])) and np.array_equal(o.xh_av0, F(a[tag + "_xh_av0"]))
+        assert np.array_equal(xint, F(a[tag + "_xh_intermed"])) and np.array_equal(o.xh_intermed0, F(a[tag + "_xh_intermed0"]))
+        assert rep.sum_nbox_all == s["sum_nbox_all"] and rep.photon_loss_all == s["photon_loss_all"]
+        for k in ("totrec", "totcollisions", "dh0", "total_ion"):
+            assert getattr(rep, k) == s[k], k
+        t2 = np.array(s["log"]["test2"][1:])
+        assert relerr(np.array([rep.it_rel1[:rep.niter], rep.it_rel0[:rep.niter]]).T, t2) < 1e-13
