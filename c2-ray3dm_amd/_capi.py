@@ -10,14 +10,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libc2ray_hip.so")
 MAX_ITER_LOG = 128
 
-GRID_NDENS, GRID_XH, GRID_XH_AV, GRID_XH_INTERMED, GRID_PHIH, GRID_PHIHEAT, GRID_TEMPER = range(7)
+GRID_NDENS, GRID_XH, GRID_XH_AV, GRID_XH_INTERMED, GRID_PHIH, GRID_PHIHEAT, GRID_TEMPER, GRID_XH0, GRID_XH_AV0, GRID_XH_INTERMED0 = range(10)
 
 
 class Params(C.Structure):
     _fields_ = [("mesh", C.c_int32 * 3), ("device", C.c_int32), ("subboxsize", C.c_int32),
                 ("max_subbox", C.c_int32), ("numtau", C.c_int32), ("max_outer_iter", C.c_int32),
                 ("max_chem_iter", C.c_int32), ("deterministic_rates", C.c_int32),
-                ("sweep_mode", C.c_int32), ("reserved1", C.c_int32),
+                ("sweep_mode", C.c_int32), ("allfrac", C.c_int32),
                 ("epsilon", C.c_double), ("convergence_fraction", C.c_double),
                 ("minimum_fractional_change", C.c_double), ("minimum_fraction_of_atoms", C.c_double),
                 ("loss_fraction", C.c_double), ("max_coldensh", C.c_double),

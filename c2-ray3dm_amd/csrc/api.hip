@@ -5,6 +5,30 @@
 
 namespace c2r {
 
+int copy_in(Ctx *ctx, int which, const void *host)
+{
+    if (ctx->allfrac && which >= 1 && which <= 3) {
+        const double *h = static_cast<const double *>(host);
+        HIP_TRY(hipMemcpyAsync(ctx->grid[which + 6], h, grid_bytes(ctx, which), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->grid[which], h + ctx->ncell, grid_bytes(ctx, which), hipMemcpyHostToDevice, ctx->stream));
+        return C2R_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->grid[which], host, grid_bytes(ctx, which), hipMemcpyHostToDevice, ctx->stream));
+    return C2R_OK;
+}
+
+int copy_out(Ctx *ctx, int which, void *host)
+{
+    if (ctx->allfrac && which >= 1 && which <= 3) {
+        double *h = static_cast<double *>(host);
+        HIP_TRY(hipMemcpyAsync(h, ctx->grid[which + 6], grid_bytes(ctx, which), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h + ctx->ncell, ctx->grid[which], grid_bytes(ctx, which), hipMemcpyDeviceToHost, ctx->stream));
+        return C2R_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(host, ctx->grid[which], grid_bytes(ctx, which), hipMemcpyDeviceToHost, ctx->stream));
+    return C2R_OK;
+}
+
 int check_ready(Ctx *ctx)
 {
     // the context's allocations and launches belong to its device, whatever the caller made current since
@@ -89,6 +113,9 @@ int c2r_create(c2r_ctx **out, const c2r_params *p)
                          "(812^3) and every pair product < 2^24");
     for (int w = 0; w < 5; ++w) { HIP_TRY(hipMalloc(&ctx->grid[w], grid_bytes(ctx, w))); ctx->own[w] = true; }
     HIP_TRY(hipMemset(ctx->grid[4], 0, grid_bytes(ctx, 4)));      // evolve_data.F90:76 phih_grid=0.0
+    ctx->allfrac = p->allfrac != 0;
+    if (ctx->allfrac)      // ionfractions_module.F90:36-38, evolve_data.F90:80-84: the (:,:,:,0) halves
+        for (int w = 7; w <= 9; ++w) { HIP_TRY(hipMalloc(&ctx->grid[w], grid_bytes(ctx, w))); HIP_TRY(hipMemset(ctx->grid[w], 0, grid_bytes(ctx, w))); }
     HIP_TRY(hipMalloc(&ctx->d_nhi, grid_bytes(ctx, 2)));
     HIP_TRY(hipMalloc(&ctx->d_nhi_T, grid_bytes(ctx, 2)));
     HIP_TRY(hipMalloc(&ctx->d_phih_T, grid_bytes(ctx, 4)));
@@ -166,7 +193,7 @@ void c2r_destroy(c2r_ctx *c)
     for (auto &kv : ctx->pinned) hipHostUnregister(const_cast<void *>(kv.first));
     free_sweep_scratch(ctx);
     for (int w = 0; w < 5; ++w) if (ctx->own[w]) hipFree(ctx->grid[w]);
-    hipFree(ctx->grid[5]); hipFree(ctx->grid[6]); hipFree(ctx->d_hthick); hipFree(ctx->d_hthin); hipFree(ctx->d_cool); hipFree(ctx->d_heat_T);
+    hipFree(ctx->grid[5]); hipFree(ctx->grid[6]); hipFree(ctx->grid[7]); hipFree(ctx->grid[8]); hipFree(ctx->grid[9]); hipFree(ctx->d_hthick); hipFree(ctx->d_hthin); hipFree(ctx->d_cool); hipFree(ctx->d_heat_T);
     hipFree(ctx->d_thick); hipFree(ctx->d_thin); hipFree(ctx->d_xthick); hipFree(ctx->d_xthin); hipFree(ctx->d_xhthick); hipFree(ctx->d_xhthin); hipFree(ctx->d_logtab); hipFree(ctx->d_odtab);
     hipFree(ctx->d_nhi); hipFree(ctx->d_nhi_T); hipFree(ctx->d_phih_T); hipFree(ctx->d_step); hipFree(ctx->d_pack); hipFree(ctx->d_boxdesc);
     if (ctx->h_boxdesc) hipHostFree(ctx->h_boxdesc);
@@ -469,17 +496,19 @@ int c2r_bind_device_buffers(c2r_ctx *c, void *ndens, void *xh, void *xh_av, void
 
 int c2r_device_ptr(c2r_ctx *c, int32_t which, void **ptr)
 {
-    if (!c || !ptr || which < 0 || which > 6) return C2R_EINVAL;
-    if (which > 4 && !C(c)->thermal) return C2R_ESTATE;
+    if (!c || !ptr || which < 0 || which > 9) return C2R_EINVAL;
+    if (which > 4 && which < 7 && !C(c)->thermal) return C2R_ESTATE;
+    if (which >= 7 && !C(c)->allfrac) return C2R_ESTATE;
     *ptr = C(c)->grid[which];
     return C2R_OK;
 }
 
 int c2r_upload(c2r_ctx *c, int32_t which, const void *host)
 {
-    if (!c || !host || which < 0 || which > 6) return C2R_EINVAL;
+    if (!c || !host || which < 0 || which > 9) return C2R_EINVAL;
     Ctx *ctx = C(c);
-    if (which > 4 && !ctx->thermal) FAIL(C2R_ESTATE, "arrays 5 and 6 exist in non-isothermal runs only (c2r_set_thermal)");
+    if (which > 4 && which < 7 && !ctx->thermal) FAIL(C2R_ESTATE, "arrays 5 and 6 exist in non-isothermal runs only (c2r_set_thermal)");
+    if (which >= 7 && !ctx->allfrac) FAIL(C2R_ESTATE, "arrays 7 - 9 (the stored neutral fractions) exist with c2r_params.allfrac only");
     HIP_TRY(hipMemcpyAsync(ctx->grid[which], host, grid_bytes(ctx, which), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (which == 4 || which == 5) { ctx->rates_clean = false; ctx->sparse_valid = false; }     // the caller's rates: not a pass over zeroed ones
@@ -488,9 +517,10 @@ int c2r_upload(c2r_ctx *c, int32_t which, const void *host)
 
 int c2r_download(c2r_ctx *c, int32_t which, void *host)
 {
-    if (!c || !host || which < 0 || which > 6) return C2R_EINVAL;
+    if (!c || !host || which < 0 || which > 9) return C2R_EINVAL;
     Ctx *ctx = C(c);
-    if (which > 4 && !ctx->thermal) FAIL(C2R_ESTATE, "arrays 5 and 6 exist in non-isothermal runs only (c2r_set_thermal)");
+    if (which > 4 && which < 7 && !ctx->thermal) FAIL(C2R_ESTATE, "arrays 5 and 6 exist in non-isothermal runs only (c2r_set_thermal)");
+    if (which >= 7 && !ctx->allfrac) FAIL(C2R_ESTATE, "arrays 7 - 9 (the stored neutral fractions) exist with c2r_params.allfrac only");
     HIP_TRY(hipMemcpyAsync(host, ctx->grid[which], grid_bytes(ctx, which), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return C2R_OK;
@@ -513,7 +543,7 @@ int c2r_do_source_host(c2r_ctx *c, int32_t ns, const float *ndens, const double 
     Ctx *ctx = C(c);
     int rc;
     if ((rc = c2r_upload(c, 0, ndens))) return rc;
-    if ((rc = c2r_upload(c, 2, xh_av))) return rc;
+    if ((rc = copy_in(ctx, 2, xh_av))) return rc;              // (-DALLFRAC drivers: both halves of the (mesh,0:1) array)
     if ((rc = c2r_zero_rates(c))) return rc;
     if ((rc = c2r_do_source(c, ns, coldensh_out, photon_loss_src, nbox, nullptr))) return rc;
     // phih_grid(pos) = phih_grid(pos) + this source's rate (evolve_point.F90:283), on the host array
@@ -531,7 +561,7 @@ int c2r_do_grid_host(c2r_ctx *c, const float *ndens, const double *xh_av, double
     if (ctx->thermal && !phiheat_grid) FAIL(C2R_EINVAL, "non-isothermal run: do_grid needs phiheat_grid");
     int rc;
     if ((rc = c2r_upload(c, 0, ndens))) return rc;
-    if ((rc = c2r_upload(c, 2, xh_av))) return rc;
+    if ((rc = copy_in(ctx, 2, xh_av))) return rc;
     if ((rc = c2r_zero_rates(c))) return rc;
     double loss = 0.0; int64_t nb = 0;
     if ((rc = c2r_pass_sources(c, &loss, &nb, nullptr))) return rc;

@@ -15,7 +15,8 @@ int photon_sums_launch(Ctx *ctx, int which_l, int which_r, double *dst)
                        (const double *)ctx->grid[which_r], p.abu_c, (double)ctx->clumping, (const float *)ctx->d_clump,
                        p.bh00, pow(ctx->temper / 1e4, p.albpow), p.colh0, sqrt(ctx->temper),
                        exp(-p.temph0 / ctx->temper), ctx->d_sum_partial, ctx->thermal ? (const float *)ctx->grid[6] : nullptr,
-                       p.albpow, p.temph0);
+                       p.albpow, p.temph0, ctx->allfrac ? (const double *)ctx->grid[which_l + 6] : nullptr,
+                       ctx->allfrac ? (const double *)ctx->grid[which_r + 6] : nullptr);
     hipLaunchKernelGGL(k_sum_final, dim3(4), dim3(256), 0, ctx->stream, kSumBlocks, ctx->d_sum_partial, dst);
     HIP_TRY(hipGetLastError());
     return C2R_OK;
@@ -37,6 +38,9 @@ int global_pass_enqueue(Ctx *ctx, double dt, double *stats_dst, size_t cell_off,
     cp.bh00 = p.bh00; cp.clump = ctx->d_clump ? ctx->d_clump + cell_off : nullptr;
     cp.colh0 = p.colh0;
     cp.stat_partial = ctx->d_stat_partial;
+    if (ctx->allfrac) {      // the (:,:,:,0) halves (evolve_point.F90:341-346, :394-399)
+        cp.xh0 = (const double *)ctx->grid[7] + cell_off; cp.xh_av0 = (double *)ctx->grid[8] + cell_off; cp.xh_intermed0 = (double *)ctx->grid[9] + cell_off;
+    }
     if (ctx->thermal) {
         const c2r_thermal_params &t = ctx->tprm;
         if (t.cosmological && !ctx->have_zred) FAIL(C2R_ESTATE, "non-isothermal run: c2r_set_redshift has not been called (cosmo_cool needs zred)");
@@ -125,9 +129,15 @@ int c2r_global_pass_cell_host(c2r_ctx *c, double dt, const int32_t pos[3], const
     if (ctx->thermal && (!phiheat_grid || !temperature_grid)) FAIL(C2R_EINVAL, "non-isothermal run: evolve0D_global needs phiheat_grid and temperature_grid");
     const size_t idx = (size_t)(pos[0] - 1) + (size_t)p.mesh[0] * ((size_t)(pos[1] - 1) + (size_t)p.mesh[1] * (size_t)(pos[2] - 1));
     hipStream_t st = ctx->stream;
+    // (-DALLFRAC drivers: xh / xh_av / xh_intermed are (mesh,0:1) -- the neutral half first, the ionized half ncell further on)
+    const size_t ion = ctx->allfrac ? ctx->ncell : 0;
     HIP_TRY(hipMemcpyAsync((float *)ctx->grid[0] + idx, ndens + idx, sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync((double *)ctx->grid[1] + idx, xh + idx, sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync((double *)ctx->grid[2] + idx, xh_av + idx, sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync((double *)ctx->grid[1] + idx, xh + ion + idx, sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync((double *)ctx->grid[2] + idx, xh_av + ion + idx, sizeof(double), hipMemcpyHostToDevice, st));
+    if (ctx->allfrac) {
+        HIP_TRY(hipMemcpyAsync((double *)ctx->grid[7] + idx, xh + idx, sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((double *)ctx->grid[8] + idx, xh_av + idx, sizeof(double), hipMemcpyHostToDevice, st));
+    }
     HIP_TRY(hipMemcpyAsync((double *)ctx->grid[4] + idx, phih_grid + idx, sizeof(double), hipMemcpyHostToDevice, st));
     if (ctx->thermal) {
         HIP_TRY(hipMemcpyAsync((double *)ctx->grid[5] + idx, phiheat_grid + idx, sizeof(double), hipMemcpyHostToDevice, st));
@@ -135,8 +145,12 @@ int c2r_global_pass_cell_host(c2r_ctx *c, double dt, const int32_t pos[3], const
     }
     int64_t nonconv = 0;
     if ((rc = global_pass_impl(ctx, dt, &nonconv, nullptr, nullptr, idx, 1))) return rc;
-    HIP_TRY(hipMemcpyAsync(xh_av + idx, (double *)ctx->grid[2] + idx, sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(xh_intermed + idx, (double *)ctx->grid[3] + idx, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(xh_av + ion + idx, (double *)ctx->grid[2] + idx, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(xh_intermed + ion + idx, (double *)ctx->grid[3] + idx, sizeof(double), hipMemcpyDeviceToHost, st));
+    if (ctx->allfrac) {
+        HIP_TRY(hipMemcpyAsync(xh_av + idx, (double *)ctx->grid[8] + idx, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(xh_intermed + idx, (double *)ctx->grid[9] + idx, sizeof(double), hipMemcpyDeviceToHost, st));
+    }
     if (ctx->thermal)
         HIP_TRY(hipMemcpyAsync(temperature_grid + 3 * idx, (float *)ctx->grid[6] + 3 * idx, 3 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -149,19 +163,23 @@ int c2r_global_pass_host(c2r_ctx *c, double dt, const float *ndens, const double
 {
     if (!c || !ndens || !xh || !xh_av || !xh_intermed || !phih_grid) return C2R_EINVAL;
     int rc;
+    Ctx *ctx = C(c);
     if ((rc = c2r_upload(c, 0, ndens))) return rc;
-    if ((rc = c2r_upload(c, 1, xh))) return rc;
-    if ((rc = c2r_upload(c, 2, xh_av))) return rc;
+    if ((rc = copy_in(ctx, 1, xh))) return rc;                 // (-DALLFRAC drivers: both halves of the (mesh,0:1) arrays)
+    if ((rc = copy_in(ctx, 2, xh_av))) return rc;
     if ((rc = c2r_upload(c, 4, phih_grid))) return rc;
     if ((rc = c2r_global_pass(c, dt, conv_flag, nullptr))) return rc;
-    if ((rc = c2r_download(c, 2, xh_av))) return rc;
-    return c2r_download(c, 3, xh_intermed);
+    if ((rc = copy_out(ctx, 2, xh_av))) return rc;
+    if ((rc = copy_out(ctx, 3, xh_intermed))) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return C2R_OK;
 }
 
 int c2r_sum(c2r_ctx *c, int32_t which, double *sum)
 {
-    if (!c || !sum || which < 1 || which > 4) return C2R_EINVAL;
+    if (!c || !sum || which < 1 || which > 9 || which == 5 || which == 6) return C2R_EINVAL;
     Ctx *ctx = C(c);
+    if (which >= 7 && !ctx->allfrac) FAIL(C2R_ESTATE, "arrays 7 - 9 (the stored neutral fractions) exist with c2r_params.allfrac only");
     HIP_TRY(hipSetDevice(ctx->prm.device));
     hipLaunchKernelGGL(k_sum_partial, dim3(kSumBlocks), dim3(256), 0, ctx->stream, ctx->ncell,
                        (const double *)ctx->grid[which], ctx->d_sum_partial);
@@ -174,7 +192,7 @@ int c2r_sum(c2r_ctx *c, int32_t which, double *sum)
 
 int c2r_photon_sums(c2r_ctx *c, int32_t which_l, int32_t which_r, double out[4])
 {
-    if (!c || !out || which_l < 1 || which_l > 3 || which_r < 1 || which_r > 3) return C2R_EINVAL;
+    if (!c || !out || which_l < 1 || which_l > 3 || which_r < 1 || which_r > 3) return C2R_EINVAL;     // (-DALLFRAC drivers: the arrays' stored neutral halves are used too)
     Ctx *ctx = C(c);
     int rc = check_ready(ctx);
     if (rc) return rc;

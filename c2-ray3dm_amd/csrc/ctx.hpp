@@ -64,7 +64,9 @@ struct Ctx {
     bool own_stream = false;
     size_t ncell = 0;
     // grids: 0 ndens(f32) 1 xh 2 xh_av 3 xh_intermed 4 phih_grid; non-isothermal runs: 5 phiheat_grid 6 temperature_grid (3 x f32 per cell)
-    void *grid[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // drivers built with -DALLFRAC (c2r_params.allfrac): 7 xh0, 8 xh_av0, 9 xh_intermed0 -- the stored neutral fractions, the (:,:,:,0) halves
+    void *grid[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool allfrac = false;
     // non-isothermal runs (c2r_set_thermal): heating tables, cooling curve, transposed heating accumulator
     bool thermal = false;
     c2r_thermal_params tprm{};
@@ -262,5 +264,9 @@ int global_pass_impl(Ctx *ctx, double dt, int64_t *conv_flag, double *sum_xh1, d
 int final_temperature_enqueue(Ctx *ctx);                       // set_final_temperature_point (temperature_module.F90:172-183)
 // ---- api.hip -----------------------------------------------------------------------------------------------------
 int check_ready(Ctx *ctx);
+// host array `host` of the driver <-> device array `which` (1 xh, 2 xh_av, 3 xh_intermed: with -DALLFRAC drivers the host array is
+// (mesh,0:1) -- its first half goes to / comes from array which + 6; everything else: one plain copy), on the context's stream, no wait
+int copy_in(Ctx *ctx, int which, const void *host);
+int copy_out(Ctx *ctx, int which, void *host);
 
 }  // namespace c2r

@@ -16,7 +16,7 @@ static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, i
     ctx->step_dt = dt;
     if ((rc = sync_step(ctx))) return rc;
     const int nloc = n_local_sources(ctx);
-    bool can_fuse = ctx->fused_iter && ctx->nranks == 1 && !ctx->balance && ctx->use_graph && ctx->sched_hint && ctx->prof == 0 && nloc > 0 &&
+    bool can_fuse = ctx->fused_iter && !ctx->allfrac && ctx->nranks == 1 && !ctx->balance && ctx->use_graph && ctx->sched_hint && ctx->prof == 0 && nloc > 0 &&
                     nloc <= kFewSources && ctx->box_hint >= 1 &&
                     !(ctx->thermal && ctx->tprm.cosmological && !ctx->have_zred);
     if (can_fuse) {
@@ -40,7 +40,7 @@ static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, i
             const int r = sweep_finish(ctx, gate);
             return r ? r : global_pass_enqueue(ctx, dt, four, 0, ctx->ncell, gate, gate != nullptr);
         };
-        const bool use_tail = ctx->nranks == 1 && !ctx->balance && ctx->use_graph && ctx->chain_graph && ctx->prof == 0 &&
+        const bool use_tail = !ctx->allfrac && ctx->nranks == 1 && !ctx->balance && ctx->use_graph && ctx->chain_graph && ctx->prof == 0 &&
                               !(ctx->thermal && ctx->tprm.cosmological && !ctx->have_zred);
         if ((rc = zero_rates())) return rc;
         if ((rc = pass_sources_impl(ctx, nullptr, nullptr, nullptr, vis, ctx->nranks == 1 && !ctx->balance, use_tail ? &tail : nullptr))) return rc;
@@ -106,6 +106,10 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
         // evolve.F90:145-146  xh_av = xh ; xh_intermed = xh
         HIP_TRY(hipMemcpyAsync(ctx->grid[2], ctx->grid[1], grid_bytes(ctx, 1), hipMemcpyDeviceToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(ctx->grid[3], ctx->grid[1], grid_bytes(ctx, 1), hipMemcpyDeviceToDevice, ctx->stream));
+        if (ctx->allfrac) {      // :142-143 (ALLFRAC): all of (:,:,:,:)
+            HIP_TRY(hipMemcpyAsync(ctx->grid[8], ctx->grid[7], grid_bytes(ctx, 7), hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(ctx->grid[9], ctx->grid[7], grid_bytes(ctx, 7), hipMemcpyDeviceToDevice, ctx->stream));
+        }
     }
     const int64_t c1 = (int64_t)(p.convergence_fraction * p.mesh[0] * p.mesh[1] * p.mesh[2]);    // :162
     const int64_t c2 = (ctx->nsrc - 1) / 3;
@@ -133,7 +137,8 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
     }
     if (rc) return rc;
     for (;;) {
-        const double sum0 = (double)(float)ctx->ncell - sum1;                          // :184
+        double sum0 = (double)(float)ctx->ncell - sum1;                                // :184
+        if (ctx->allfrac && (rc = c2r_sum(c, 9, &sum0))) return rc;                    // :180-181 (ALLFRAC): sum(xh_intermed(:,:,:,0))
         const double rel1 = sum1 > 0.0 ? fabs(sum1 - prev1) / sum1 : 1.0;
         const double rel0 = sum0 > 0.0 ? fabs(sum0 - prev0) / sum0 : 1.0;
         if (niter > 0 && niter <= C2R_MAX_ITER_LOG) {
@@ -142,6 +147,7 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
         }
         if (conv_flag < conv_criterion || (rel1 < p.convergence_fraction && rel0 < p.convergence_fraction)) {   // :212
             HIP_TRY(hipMemcpyAsync(ctx->grid[1], ctx->grid[3], grid_bytes(ctx, 1), hipMemcpyDeviceToDevice, ctx->stream));   // :218
+            if (ctx->allfrac) HIP_TRY(hipMemcpyAsync(ctx->grid[7], ctx->grid[9], grid_bytes(ctx, 7), hipMemcpyDeviceToDevice, ctx->stream));   // :216
             if (ctx->thermal && (rc = final_temperature_enqueue(ctx))) return rc;       // :220 set_final_temperature_point
             rep->converged = 1;
             break;
@@ -307,17 +313,18 @@ struct HostCopies {
     ~HostCopies() { for (auto &e : ev) if (e) hipEventDestroy(e); }
     int up(int which, const void *host)
     {
-        pin_host_array(ctx, host, grid_bytes(ctx, which));
-        HIP_TRY(hipMemcpyAsync(ctx->grid[which], host, grid_bytes(ctx, which), hipMemcpyHostToDevice, ctx->stream));
+        // (-DALLFRAC drivers: xh / xh_av / xh_intermed are (mesh,0:1) arrays -- copy_in / copy_out move both halves)
+        pin_host_array(ctx, host, grid_bytes(ctx, which) * ((ctx->allfrac && which >= 1 && which <= 3) ? 2 : 1));
+        const int rc = copy_in(ctx, which, host);
+        if (rc) return rc;
         if (which == 4 || which == 5) { ctx->rates_clean = false; ctx->sparse_valid = false; }
         return C2R_OK;
     }
     int down(int which, void *host)
     {
         if (!host) return C2R_OK;
-        pin_host_array(ctx, host, grid_bytes(ctx, which));
-        HIP_TRY(hipMemcpyAsync(host, ctx->grid[which], grid_bytes(ctx, which), hipMemcpyDeviceToHost, ctx->stream));
-        return C2R_OK;
+        pin_host_array(ctx, host, grid_bytes(ctx, which) * ((ctx->allfrac && which >= 1 && which <= 3) ? 2 : 1));
+        return copy_out(ctx, which, host);
     }
     int mark(int i) { HIP_TRY(hipEventRecord(ev[i], ctx->stream)); return C2R_OK; }
     void finish(c2r_report *rep)       // after the step's final wait

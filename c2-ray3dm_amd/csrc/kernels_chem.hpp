@@ -26,6 +26,9 @@ struct ChemParams {
     double zp, dzdt;              // cosmology.F90:198-225 cosmo_cool = e*2/(1+zred)*dzdt (dzdt = 0: not cosmological)
     double temph0, albpow;        // doric.f90:73-78 at the cell's own temperature
     double tconv_rel, tconv_abs;  // evolve_point.F90:387-388
+    // drivers built with -DALLFRAC (c2r_params.allfrac): the stored neutral fractions, the (:,:,:,0) halves of xh / xh_av / xh_intermed
+    // (null: the shipped build, neutral = 1 - ionized)
+    const double *xh0; double *xh_av0, *xh_intermed0;
 };
 
 // cooling.f90:38-59 coolin
@@ -103,8 +106,11 @@ __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell,
         const double h_old1 = fmax(c.eps, xh[id]);
         const double xav_in = xh_av[id];
         double hav1 = fmax(c.eps, xav_in);
-        const double h_old0 = 1.0 - h_old1;
-        double hav0 = 1.0 - hav1;
+        const bool allfrac = c.xh0 != nullptr;                      // (block-uniform)
+        const double xav0_in = allfrac ? c.xh_av0[id] : 0.0;
+        // evolve_point.F90:341-346 (ALLFRAC: both stored, both floored) / :347-353
+        const double h_old0 = allfrac ? fmax(c.eps, c.xh0[id]) : 1.0 - h_old1;
+        double hav0 = allfrac ? fmax(c.eps, xav0_in) : 1.0 - hav1;
         const double nd = (double)ndens[id];
         const double gamma = phih[id];
         double brech0 = c.clump ? (double)c.clump[id] * c.bh00 * c.recpow : c.brech0;   // evolve_point.F90:443-445
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell,
             if (fabs((hav0 - yh0_av_old) / hav0) < c.min_frac_change || hav0 < c.min_frac_atoms) break;
             if (nit > c.max_iter) { nfail++; break; }
         }
-        const double yh0_old = 1.0 - fmax(c.eps, xav_in);           // evolve_point.F90:378-379
+        const double yh0_old = allfrac ? xav0_in : 1.0 - fmax(c.eps, xav_in);   // evolve_point.F90:375 (ALLFRAC: as stored) / :378-379
         bool notconv = fabs(hav0 - yh0_old) > c.min_frac_change && fabs((hav0 - yh0_old) / hav0) > c.min_frac_change &&
                        hav0 > c.min_frac_atoms;
         double t_stat = 0.0;
@@ -160,11 +166,12 @@ __global__ __launch_bounds__(256) void k_global_pass(ChemParams c, size_t ncell,
         if (notconv) nconv++;
         xh_intermed[id] = h1;
         xh_av[id] = hav1;
+        if (allfrac) { c.xh_intermed0[id] = h0; c.xh_av0[id] = hav0; }   // :395-398
         lsum += h1;
         if (STATS) {                                           // k_photon_sums with xl = xh_intermed, xr = xh_av, same expressions
-            st_h0 += nd * (1.0 - h1);
+            st_h0 += nd * (allfrac ? h0 : 1.0 - h1);
             st_h1 += nd * h1;
-            const double y1 = hav1, y0 = 1.0 - y1;
+            const double y1 = hav1, y0 = allfrac ? hav0 : 1.0 - y1;
             const double de = nd * (y1 + c.abu_c);
             const double cl = c.clump ? (double)c.clump[id] : c.clumping;
             if (THERMAL) {                                         // photonstatistics.F90:167-177 at temperature%average
@@ -202,16 +209,17 @@ __global__ __launch_bounds__(256) void k_photon_sums(size_t ncell, const float *
                                                      double abu_c, double clumping, const float *__restrict__ clump,
                                                      double bh00, double recpow, double colh0, double sqrtt, double expt,
                                                      double *partial, const float *__restrict__ temper, double albpow,
-                                                     double temph0)
+                                                     double temph0, const double *__restrict__ xl0, const double *__restrict__ xr0)
 {   // temper != null: non-isothermal run, the rate coefficients at every cell's temperature%average (:167)
+    // xl0 / xr0 != null: -DALLFRAC drivers, the stored neutral fractions of xl / xr (photonstatistics.F90:117-118, :158-159)
     __shared__ double sm[4];
     double h0 = 0.0, h1 = 0.0, tr = 0.0, tc = 0.0;
     for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < ncell; id += (size_t)gridDim.x * 256) {
         const double nd = (double)ndens[id];
         const double x = xl[id];
-        h0 += nd * (1.0 - x);
+        h0 += nd * (xl0 ? xl0[id] : 1.0 - x);
         h1 += nd * x;
-        const double y1 = xr[id], y0 = 1.0 - y1;
+        const double y1 = xr[id], y0 = xr0 ? xr0[id] : 1.0 - y1;
         const double de = nd * (y1 + abu_c);
         const double cl = clump ? (double)clump[id] : clumping;
         if (temper) {

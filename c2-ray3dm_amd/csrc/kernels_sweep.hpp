@@ -899,7 +899,8 @@ struct ZeroGrids { double *g[4]; };
 struct WordCopy { const unsigned *src; unsigned *dst; unsigned n; };
 __global__ __launch_bounds__(256) void k_prepare_nhi(int n0, int n1, int n2, double eps, const float *__restrict__ ndens,
                                                      const double *__restrict__ xh_av, double *__restrict__ nhi,
-                                                     double *__restrict__ nhi_T, ZeroGrids zero, WordCopy copy)
+                                                     double *__restrict__ nhi_T, ZeroGrids zero, WordCopy copy,
+                                                     const double *__restrict__ xh_av0 = nullptr /* -DALLFRAC drivers: the stored neutral fraction */)
 {
     __shared__ double tile[32][33];
     const int k = blockIdx.z;
@@ -912,7 +913,8 @@ __global__ __launch_bounds__(256) void k_prepare_nhi(int n0, int n1, int n2, dou
         if (i < n0 && j < n1) {
             const size_t id = (size_t)i + (size_t)n0 * ((size_t)j + (size_t)n1 * k);
             const double xav1 = fmax(xh_av[id], eps);
-            const double xav0 = fmax(1.0 - xav1, eps);
+            const double xav0 = xh_av0 ? fmax(xh_av0[id], eps)       // evolve_point.F90:131-132 (ALLFRAC)
+                                       : fmax(1.0 - xav1, eps);      // :140
             const double v = xav0 * (double)ndens[id];
             nhi[id] = v;
             tile[r][tx] = v;

@@ -1103,7 +1103,8 @@ int sweep_prepare(Ctx *ctx, bool zero_rates, bool copy_batch)
     WordCopy wc{};
     if (copy_batch) { const SweepScratch &sc = ctx->sc[0]; wc.src = (const unsigned *)sc.d_batch_init; wc.dst = (unsigned *)sc.d_batch; wc.n = (unsigned)(sc.batch_bytes / 4); }
     hipLaunchKernelGGL(k_prepare_nhi, g, dim3(256), 0, ctx->stream, p.mesh[0], p.mesh[1], p.mesh[2], p.epsilon,
-                       (const float *)ctx->grid[0], (const double *)ctx->grid[2], ctx->d_nhi, ctx->d_nhi_T, z, wc);
+                       (const float *)ctx->grid[0], (const double *)ctx->grid[2], ctx->d_nhi, ctx->d_nhi_T, z, wc,
+                       ctx->allfrac ? (const double *)ctx->grid[8] : nullptr);
     HIP_TRY(hipGetLastError());
     if (!zero_rates) {
         HIP_TRY(hipMemsetAsync(ctx->d_phih_T, 0, grid_bytes(ctx, 4), ctx->stream));
@@ -1362,7 +1363,9 @@ int c2r_evolve0d_host(c2r_ctx *c, int32_t ns, const int32_t rtpos[3], const int3
     // the source in slot 0 of the batch arrays; n_HI of the cell (evolve_point.F90:137-146) where the kernels read it.  The
     // small inputs travel through the context's pinned staging block (true async copies; the call ends with a stream wait)
     const double nflux = ctx->nflux[ns - 1];
-    const double xav1 = std::max(xh_av[idx], p.epsilon), xav0 = std::max(1.0 - xav1, p.epsilon);
+    // (-DALLFRAC drivers: xh_av is the (mesh,0:1) array -- the stored neutral fraction comes first, evolve_point.F90:131-132)
+    const double xav1 = std::max(xh_av[ctx->allfrac ? ctx->ncell + idx : idx], p.epsilon);
+    const double xav0 = ctx->allfrac ? std::max(xh_av[idx], p.epsilon) : std::max(1.0 - xav1, p.epsilon);
     const double nhi = xav0 * (double)ndens[idx];
     const size_t idt = (size_t)pos[1] + (size_t)p.mesh[1] * ((size_t)pos[0] + (size_t)p.mesh[0] * (size_t)pos[2]);
     {

@@ -59,7 +59,7 @@ def balanced_source_shares(cost, npr):
 class HipBackend:
     """The HIP path: owns a c2r context on one GPU and the device-resident arrays."""
 
-    def __init__(self, mesh, thick, thin, device=0, scratch_bytes=0, deterministic=False, fast=None, options=None):
+    def __init__(self, mesh, thick, thin, device=0, scratch_bytes=0, deterministic=False, fast=None, options=None, allfrac=False):
         import torch
         self.torch = torch
         self.lib = _capi.load_library()
@@ -72,6 +72,10 @@ class HipBackend:
         p = _capi.default_params(self.mesh, device)
         p.scratch_bytes = scratch_bytes
         p.deterministic_rates = 1 if deterministic else 0
+        # allfrac: the driver this host stands in for was built with -DALLFRAC -- the neutral fractions are stored (arrays
+        # xh0, xh_av0, xh_intermed0: context-owned, load()/fetch() by those names), not derived as 1 - x
+        p.allfrac = 1 if allfrac else 0
+        self.allfrac = bool(allfrac)
         # fast=None: this HOST's switch -- the environment variable C2R_SWEEP_MODE (0/1; how the GPU tests run every case
         # in both modes), else the library default (c2r_default_params: C2R_SWEEP_FAST).  The library itself reads no
         # environment variable: an explicit fast=True/False is what the context gets.
@@ -303,10 +307,24 @@ class HipBackend:
         self._check(self.lib.c2r_set_slab_chemistry(self.ctx, C.cast(self._rs, C.c_void_p), C.cast(self._ag, C.c_void_p),
                                                     None), "c2r_set_slab_chemistry")
 
-    def load(self, ndens=None, xh=None, xh_av=None, xh_intermed=None, phih_grid=None, phiheat_grid=None, temperature_grid=None):
+    _NEUTRAL = {"xh0": _capi.GRID_XH0, "xh_av0": _capi.GRID_XH_AV0, "xh_intermed0": _capi.GRID_XH_INTERMED0}
+
+    def _neutral_tensor(self, name):
+        """One of the stored neutral-fraction arrays (allfrac contexts; context-owned) as a torch tensor sharing the device memory."""
+        ptr = C.c_void_p()
+        self._check(self.lib.c2r_device_ptr(self.ctx, self._NEUTRAL[name], C.byref(ptr)), "c2r_device_ptr")
+        return self.torch.as_tensor(_DevView(ptr.value, self.ncell), device=self.device)
+
+    def load(self, ndens=None, xh=None, xh_av=None, xh_intermed=None, phih_grid=None, phiheat_grid=None, temperature_grid=None,
+             xh0=None, xh_av0=None, xh_intermed0=None):
         """Host (numpy, Fortran-order flat or (N,N,N) with i fastest when ravelled 'F') -> HBM.
-        temperature_grid: (ncell, 3) f32 as temperature_module.F90:35 lays it out, or one field (K) for all three."""
+        temperature_grid: (ncell, 3) f32 as temperature_module.F90:35 lays it out, or one field (K) for all three.
+        xh0 / xh_av0 / xh_intermed0: the stored neutral fractions of an allfrac context."""
         torch = self.torch
+        for name, a in (("xh0", xh0), ("xh_av0", xh_av0), ("xh_intermed0", xh_intermed0)):
+            if a is not None:
+                h = _flat(a, np.float64)
+                self._check(self.lib.c2r_upload(self.ctx, self._NEUTRAL[name], h.ctypes.data), "c2r_upload")
         if phiheat_grid is not None:
             a = _flat(phiheat_grid, np.float64)
             self._check(self.lib.c2r_upload(self.ctx, _capi.GRID_PHIHEAT, a.ctypes.data), "c2r_upload")
@@ -331,15 +349,24 @@ class HipBackend:
             a = np.empty((self.ncell, 3), dtype=np.float32)
             self._check(self.lib.c2r_download(self.ctx, _capi.GRID_TEMPER, a.ctypes.data), "c2r_download")
             return a
+        if name in self._NEUTRAL:
+            a = np.empty(self.ncell, dtype=np.float64)
+            self._check(self.lib.c2r_download(self.ctx, self._NEUTRAL[name], a.ctypes.data), "c2r_download")
+            return a
         return getattr(self, name).cpu().numpy()
 
     # -- backend interface used by Evolve ---------------------------------------------------------
     def begin_step(self):
         self.xh_av.copy_(self.xh)                 # evolve.F90:145
         self.xh_intermed.copy_(self.xh)           # evolve.F90:146
+        if self.allfrac:                          # :142-143: all of (:,:,:,:)
+            x0 = self._neutral_tensor("xh0")
+            self._neutral_tensor("xh_av0").copy_(x0); self._neutral_tensor("xh_intermed0").copy_(x0)
 
     def accept(self):
         self.xh.copy_(self.xh_intermed)           # evolve.F90:218
+        if self.allfrac:                          # :216
+            self._neutral_tensor("xh0").copy_(self._neutral_tensor("xh_intermed0"))
         self._check(self.lib.c2r_set_final_temperature(self.ctx), "c2r_set_final_temperature")     # :220 (no-op when isothermal)
 
     def sum_xh_intermed(self):

@@ -68,7 +68,7 @@ module c2ray_hip
   !> mirror of struct c2r_params (include/c2ray_hip.h)
   type, bind(C) :: c2r_params
      integer(c_int32_t) :: mesh(3), device, subboxsize, max_subbox, numtau, max_outer_iter, &
-          max_chem_iter, deterministic_rates, sweep_mode, reserved1
+          max_chem_iter, deterministic_rates, sweep_mode, allfrac
      real(c_double) :: epsilon, convergence_fraction, minimum_fractional_change, &
           minimum_fraction_of_atoms, loss_fraction, max_coldensh, tau_photo_limit, sigma_HI, &
           minlogtau, dlogtau, weight_floor, sqrt2, sqrt3, pi, abu_c, bh00, albpow, colh0, temph0, S_star
@@ -352,6 +352,22 @@ contains
     if (allocated(g)) p = c_loc(g)
   end function dp_address
 
+#ifdef ALLFRAC
+  !> ... and of the (mesh,0:1) ionization-fraction arrays of a -DALLFRAC build (the library is told: c2r_params%allfrac)
+  function xfrac_address(g) result(p)
+    real(kind=dp), dimension(:,:,:,:), allocatable, target, intent(in) :: g
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(g)) p = c_loc(g)
+  end function xfrac_address
+#else
+  function xfrac_address(g) result(p)
+    real(kind=dp), dimension(:,:,:), allocatable, target, intent(in) :: g
+    type(c_ptr) :: p
+    p = dp_address(g)
+  end function xfrac_address
+#endif
+
   subroutine check(rc, what)
     integer(c_int), intent(in) :: rc
     character(len=*), intent(in) :: what
@@ -408,6 +424,11 @@ contains
     ! reads no environment: what is set here is what runs, and it is logged below.
     call get_environment_variable("C2R_SWEEP_MODE", envval, status=envstat)
     if (envstat == 0 .and. len_trim(envval) > 0) p%sweep_mode = merge(0_c_int32_t, 1_c_int32_t, trim(envval) == "0")
+#ifdef ALLFRAC
+    ! this build stores both fractions (ionfractions_module.F90:19-50): every xh / xh_av / xh_intermed handed to the library is the
+    ! whole (mesh,0:1) array, and the library keeps the stored neutral fraction instead of deriving it
+    p%allfrac = 1_c_int32_t
+#endif
     call get_environment_variable("C2R_SHIM_SYNC_WORK_ARRAYS", envval, status=envstat)
     sync_work_arrays = envstat == 0 .and. len_trim(envval) > 0 .and. trim(envval) /= "0"
     call check(c2r_create(ctx, p), "c2r_create")
@@ -577,7 +598,11 @@ contains
   !> One walk over the mesh for any subset of the sums (host arrays; callers outside evolve3D).  Same expressions and the
   !! same left-to-right order per sum as photonstatistics.F90:113-127, :153-180.
   subroutine mesh_sums (x_state, x_rates, h0, h1, rec, col)
+#ifdef ALLFRAC
+    real(kind=dp),dimension(mesh(1),mesh(2),mesh(3),0:1),intent(in),optional :: x_state, x_rates
+#else
     real(kind=dp),dimension(mesh(1),mesh(2),mesh(3)),intent(in),optional :: x_state, x_rates
+#endif
     real(kind=dp),intent(out) :: h0, h1, rec, col
     integer :: i, j, k
     real(kind=dp) :: nd, y0, y1, de
@@ -588,11 +613,20 @@ contains
           do i = 1, mesh(1)
              nd = ndens(i,j,k)
              if (present(x_state)) then
+#ifdef ALLFRAC
+                h0 = h0 + ndens(i,j,k)*x_state(i,j,k,0)
+                h1 = h1 + ndens(i,j,k)*x_state(i,j,k,1)
+#else
                 h0 = h0 + ndens(i,j,k)*(1.0_dp - x_state(i,j,k))
                 h1 = h1 + ndens(i,j,k)*x_state(i,j,k)
+#endif
              endif
              if (present(x_rates)) then
+#ifdef ALLFRAC
+                y1 = x_rates(i,j,k,1); y0 = x_rates(i,j,k,0)
+#else
                 y1 = x_rates(i,j,k); y0 = 1.0_dp - y1
+#endif
                 de = nd*(y1 + abu_c)                                   ! tped.f90:81
                 call get_temperature_point (i,j,k,t)
                 if (type_of_clumping >= 3 .and. type_of_clumping <= 5) call clumping_point (i,j,k)
@@ -605,14 +639,22 @@ contains
   end subroutine mesh_sums
 
   subroutine state_before (xh_l)
+#ifdef ALLFRAC
+    real(kind=dp),dimension(mesh(1),mesh(2),mesh(3),0:1),intent(in) :: xh_l
+#else
     real(kind=dp),dimension(mesh(1),mesh(2),mesh(3)),intent(in) :: xh_l
+#endif
     real(kind=dp) :: r, c
     call mesh_sums (x_state=xh_l, h0=h0_before, h1=h1_before, rec=r, col=c)
     h0_before = h0_before*vol; h1_before = h1_before*vol
   end subroutine state_before
 
   subroutine state_after (xh_l)
+#ifdef ALLFRAC
+    real(kind=dp),dimension(mesh(1),mesh(2),mesh(3),0:1),intent(in) :: xh_l
+#else
     real(kind=dp),dimension(mesh(1),mesh(2),mesh(3)),intent(in) :: xh_l
+#endif
     real(kind=dp) :: r, c
     call mesh_sums (x_state=xh_l, h0=h0_after, h1=h1_after, rec=r, col=c)
     h0_after = h0_after*vol; h1_after = h1_after*vol
@@ -620,7 +662,11 @@ contains
 
   subroutine total_rates (dt,xh_l)
     real(kind=dp),intent(in) :: dt
+#ifdef ALLFRAC
+    real(kind=dp),dimension(mesh(1),mesh(2),mesh(3),0:1),intent(in) :: xh_l
+#else
     real(kind=dp),dimension(mesh(1),mesh(2),mesh(3)),intent(in) :: xh_l
+#endif
     real(kind=dp) :: a, b
     call mesh_sums (x_rates=xh_l, h0=a, h1=b, rec=totrec, col=totcollisions)
     totrec = totrec*vol*dt; totcollisions = totcollisions*vol*dt
@@ -629,7 +675,11 @@ contains
   !> photonstatistics.F90:82-99 for host arrays: neutrals after the step from xh_l, rates from xh_r, one walk over the mesh
   subroutine calculate_photon_statistics (dt,xh_l,xh_r)
     real(kind=dp),intent(in) :: dt
+#ifdef ALLFRAC
+    real(kind=dp),dimension(mesh(1),mesh(2),mesh(3),0:1),intent(in) :: xh_l, xh_r
+#else
     real(kind=dp),dimension(mesh(1),mesh(2),mesh(3)),intent(in) :: xh_l, xh_r
+#endif
     call mesh_sums (xh_l, xh_r, h0_after, h1_after, totrec, totcollisions)
     h0_after = h0_after*vol; h1_after = h1_after*vol
     totrec = totrec*vol*dt; totcollisions = totcollisions*vol*dt
@@ -975,10 +1025,10 @@ contains
     ! what comes back after the step: xh and phih_grid (output.F90 writes them); the work arrays only on request
     p_av = c_null_ptr; p_int = c_null_ptr
     if (sync_work_arrays) then
-       p_av = dp_address(xh_av); p_int = dp_address(xh_intermed)
+       p_av = xfrac_address(xh_av); p_int = xfrac_address(xh_intermed)
     endif
 #ifdef C2R_REFERENCE_PHOTONSTATISTICS
-    p_av = dp_address(xh_av)                                          ! calculate_photon_statistics(dt,xh,xh_av) below reads it
+    p_av = xfrac_address(xh_av)                                       ! calculate_photon_statistics(dt,xh,xh_av) below reads it
 #endif
 
     niter0 = 0
@@ -986,7 +1036,7 @@ contains
        ! heating and cooling: also phiheat_grid and temperature_grid (evolve_point.F90:285, :553; evolve.F90:220)
        if (restart /= 0) then
           call start_from_dump(restart, niter0)
-          p_av = dp_address(xh_av); p_int = dp_address(xh_intermed)   ! (uploaded from the dump)
+          p_av = xfrac_address(xh_av); p_int = xfrac_address(xh_intermed)   ! (uploaded from the dump)
        endif
        call check(c2r_evolve3d_thermal(ctx, dt, int(merge(niter0, -1, restart /= 0), c_int32_t), photon_loss_all(1), &
             ndens, xh, p_av, p_int, phih_grid, phiheat_grid, temperature_grid, last_report), &
@@ -1070,8 +1120,16 @@ contains
        wallclock_last_dump = now
        photon_loss_all(1) = loss_all
        rc = c2r_download(ctx, 4_c_int32_t, phih_grid)
+#ifdef ALLFRAC
+       ! (c2r_download moves ONE N^3 array: arrays 8 / 9 are the stored neutral halves, 2 / 3 the ionized ones)
+       if (rc == 0) rc = c2r_download(ctx, 8_c_int32_t, xh_av(:,:,:,0))
+       if (rc == 0) rc = c2r_download(ctx, 2_c_int32_t, xh_av(:,:,:,1))
+       if (rc == 0) rc = c2r_download(ctx, 9_c_int32_t, xh_intermed(:,:,:,0))
+       if (rc == 0) rc = c2r_download(ctx, 3_c_int32_t, xh_intermed(:,:,:,1))
+#else
        if (rc == 0) rc = c2r_download(ctx, 2_c_int32_t, xh_av)
        if (rc == 0) rc = c2r_download(ctx, 3_c_int32_t, xh_intermed)
+#endif
        if (.not.isothermal) then
           if (rc == 0) rc = c2r_download(ctx, 5_c_int32_t, phiheat_grid)
           if (rc == 0) rc = c2r_download(ctx, 6_c_int32_t, temperature_grid)
@@ -1147,8 +1205,13 @@ contains
     call dump_records (dump_path(restart), .false., niter)
     write(logf,*) "Read iteration ",niter," from dump file"
     write(logf,*) "photon loss counter: ",photon_loss_all
+#ifdef ALLFRAC
+    write(logf,*) "Intermediate result for mean ionization fraction: ", &
+         sum(xh_intermed(:,:,:,1))/real(mesh(1)*mesh(2)*mesh(3))
+#else
     write(logf,*) "Intermediate result for mean ionization fraction: ", &
          sum(xh_intermed(:,:,:))/real(mesh(1)*mesh(2)*mesh(3))
+#endif
     write(timefile,"(A,F8.1)") "Time after reading iterdump: ", timestamp_wallclock ()
   end subroutine start_from_dump
 

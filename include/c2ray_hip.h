@@ -83,7 +83,14 @@ typedef struct c2r_params {
                                       *    tests apply live in tests/_util.py (TOL); ~1.2x the throughput.  Only this field
                                       *    selects the mode: the library reads no environment variable for it (the Fortran shim
                                       *    and the Python host have their own switches) */
-    int32_t reserved1;
+    int32_t allfrac;                 /* 1: the driver was built with -DALLFRAC (ionfractions_module.F90:19-50; no shipped makefile defines it):
+                                      *    xh, xh_av, xh_intermed are (mesh,0:1) and the NEUTRAL fraction is stored, not derived as
+                                      *    1 - x.  evolve0D then takes n_HI from the stored neutral fraction (evolve_point.F90:131-134),
+                                      *    evolve0D_global reads and writes both (:341-346, :394-399), Test 2 sums the stored one
+                                      *    (evolve.F90:179-181), the photon statistics count it.  The device holds the (:,:,:,0) halves
+                                      *    as arrays 7 (xh), 8 (xh_av), 9 (xh_intermed); arrays 1 - 3 stay the (:,:,:,1) halves; every
+                                      *    HOST pointer named xh / xh_av / xh_intermed below is then the driver's whole (mesh,0:1)
+                                      *    array (neutral half first).  0 (default): the shipped build */
     double  epsilon;                 /* c2ray_parameters.f90:31 */
     double  convergence_fraction;    /* :25 */
     double  minimum_fractional_change; /* :34 */
@@ -303,7 +310,9 @@ int  c2r_get_device(const c2r_ctx *ctx, int32_t *device);
 int  c2r_bind_device_buffers(c2r_ctx *ctx, void *ndens, void *xh, void *xh_av,
                              void *xh_intermed, void *phih_grid);
 /* which: 0 ndens, 1 xh, 2 xh_av, 3 xh_intermed, 4 phih_grid; non-isothermal runs (context-owned, C2R_ESTATE otherwise):
- * 5 phiheat_grid (f64), 6 temperature_grid (3 x f32 per cell: current, average, intermed) */
+ * 5 phiheat_grid (f64), 6 temperature_grid (3 x f32 per cell: current, average, intermed); c2r_params.allfrac (context-owned,
+ * C2R_ESTATE otherwise): 7, 8, 9 = the stored neutral fractions of xh, xh_av, xh_intermed (N^3 f64 each; 1 - 3 are then the ionized
+ * halves).  These three entries move ONE N^3 array per call in every build. */
 int  c2r_device_ptr(c2r_ctx *ctx, int32_t which, void **ptr);
 int  c2r_upload(c2r_ctx *ctx, int32_t which, const void *host);
 int  c2r_download(c2r_ctx *ctx, int32_t which, void *host);

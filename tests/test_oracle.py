@@ -303,11 +303,12 @@ def test_do_grid_then_global_pass_module_surface(tables):
 
 # ---- the reference compiled with -DALLFRAC (oracle/ref_build.sh 32:allfrac): both fractions stored ----------------------------
 
-def test_allfrac_sweep_reads_the_stored_neutral_fraction(tables):
-    """One pass on a field whose stored neutral fraction is NOT 1 - x (2e-3 of noise, 2 % stored zeros that evolve0D raises to
-    epsilon, evolve_point.F90:131-134): column densities, rates and the photon loss of the -DALLFRAC reference, bit for bit --
-    and not what the shipped build's derived neutral fraction gives."""
-    m, a = load_case("sweep32_allfrac")
+@pytest.mark.parametrize("name", ["sweep32_allfrac", "sweep32_allfrac_zeros"])
+def test_allfrac_sweep_reads_the_stored_neutral_fraction(tables, name):
+    """One pass on a field whose stored neutral fraction is NOT 1 - x (2e-3 of noise; `_zeros`: also 2 % stored zeros that evolve0D
+    raises to epsilon, evolve_point.F90:131-134): column densities, rates and the photon loss of the -DALLFRAC reference, bit for
+    bit -- and not what the shipped build's derived neutral fraction gives."""
+    m, a = load_case(name)
     n = m["n"]
     nd, xh, xh0 = F(a["ndens"]), F(a["xh"]), F(a["xh0"])
     o = oracle_for(m, tables, n)
