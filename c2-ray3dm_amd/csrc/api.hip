@@ -264,6 +264,7 @@ int c2r_set_option(c2r_ctx *c, const char *name, double value)
     bool scratch = false;
     if (n == "graph") ctx->use_graph = on;
     else if (n == "chain_graph") ctx->chain_graph = on;
+    else if (n == "chain_tail") ctx->chain_tail = on;
     else if (n == "fused_iter") ctx->fused_iter = on;
     else if (n == "fuse_small") ctx->fuse_small = on;
     else if (n == "fold_source_cell") ctx->fold_source_cell = on;

@@ -109,6 +109,7 @@ struct Ctx {
     struct ChainGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long long gen = 0; int count = 0, n_active = 0, shape_count = 0;
                         const void *acc = nullptr; bool perm = false; int H = 0, launches = 0; std::vector<int> bounds, profile, profile_prev; int passes_since_capture = 0; };
     std::map<int, ChainGraph> chain_graphs;                      // key: first local source of the chain
+    bool chain_tail = true;                                      // option chain_tail = 0: the iteration's tail is never enqueued behind the replayed chains' gate (A/B)
     bool chain_graph = true;                                     // option chain_graph = 0: chains are always driven launch by launch
     long long chain_replays = 0, chain_halts = 0, chain_eager = 0;   // chain passes replayed / replays the device halted (a launch too small) / driven launch by launch
     unsigned long long gen = 1;

@@ -40,7 +40,7 @@ static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, i
             const int r = sweep_finish(ctx, gate);
             return r ? r : global_pass_enqueue(ctx, dt, four, 0, ctx->ncell, gate, gate != nullptr);
         };
-        const bool use_tail = !ctx->allfrac && ctx->nranks == 1 && !ctx->balance && ctx->use_graph && ctx->chain_graph && ctx->prof == 0 &&
+        const bool use_tail = !ctx->allfrac && ctx->nranks == 1 && !ctx->balance && ctx->use_graph && ctx->chain_graph && ctx->chain_tail && ctx->prof == 0 &&
                               !(ctx->thermal && ctx->tprm.cosmological && !ctx->have_zred);
         if ((rc = zero_rates())) return rc;
         if ((rc = pass_sources_impl(ctx, nullptr, nullptr, nullptr, vis, ctx->nranks == 1 && !ctx->balance, use_tail ? &tail : nullptr))) return rc;

@@ -168,6 +168,8 @@ int  c2r_set_stream(c2r_ctx *ctx, void *hip_stream);
  *   graph                 1         0: no launch sequence is ever captured and replayed (hipGraph)
  *   chain_graph           1         0: chains in flight (64 - 768 sources per round) are driven launch by launch in every pass;
  *                                      1: from the second pass on a chain's launch sequence is one replayed hipGraph (sweep.hip run_chains)
+ *   chain_tail            1         0: the tail of an iteration (totals, fold of the transposed rates, global pass) is never enqueued behind
+ *                                      the replayed chains' device-side gate: the host waits for the chains first
  *   fused_iter            1         0: c2r_iterate always runs its three steps in turn (no whole-iteration graph for <= 32 sources)
  *   fuse_small            1         0: the first sub-boxes run shell by shell instead of in k_sweep_box_fused
  *   fold_source_cell      1         0: k_source_cells is always its own launch

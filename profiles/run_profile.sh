@@ -10,12 +10,12 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 W=/tmp/prof_$NAME; rm -rf "$W"; mkdir -p "$W"
 python3 bench.py --steps 3 --warmup 1 "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$W/kt" -o kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-mode --no-small-leg --no-dropin-leg --no-mix-ceiling "$@" > "$OUT/kt_bench.json" 2> "$OUT/kt.err"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$W/kt" -o kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-mode --no-small-leg --no-configs-leg --no-dropin-leg --no-mix-ceiling "$@" > "$OUT/kt_bench.json" 2> "$OUT/kt.err"
 cp "$(find "$W/kt" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
 cp "$(find "$W/kt" -name '*kernel_trace.csv' | head -1)" "$OUT/kernel_trace.csv"
 pmc () {   # $1 = tag, rest = counters
   local tag=$1; shift
-  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$W/$tag" -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-mode --no-small-leg --no-dropin-leg --no-mix-ceiling $BENCH_FLAGS > "$OUT/pmc_bench.json" 2> "$OUT/pmc_$tag.err"
+  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$W/$tag" -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-mode --no-small-leg --no-configs-leg --no-dropin-leg --no-mix-ceiling $BENCH_FLAGS > "$OUT/pmc_bench.json" 2> "$OUT/pmc_$tag.err"
   cp "$(find "$W/$tag" -name '*counter_collection.csv' | head -1)" "$OUT/pmc_$tag.csv"
 }
 BENCH_FLAGS="$*"
