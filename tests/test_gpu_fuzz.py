@@ -39,3 +39,13 @@ def test_random_whole_step_vs_oracle(pkg, tables, sweep_mode, seed):
     # a few units in the last place of the f32 temperature_grid: one per global pass at most, and a step that does not
     # converge repeats the pass 101 times (worst of 51 non-isothermal cases in 150: 2.1e-7, such a step)
     assert r["dtemp"] <= 5e-7, (seed, r["mesh"], r["dtemp"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_replayed_chains_fuzz(pkg, tables, sweep_mode, seed):
+    """64 - 400 sources on random meshes, six outer iterations with the field changed in between: chains replayed (captured launch
+    sequences, device-gated tail) against chains driven launch by launch -- photon loss (bits), sub-box sums, visited pairs and
+    non-converged counts equal in every iteration (tests/_fuzz_chains.py; 200 cases per mode by hand: profiles/r06_chain_graph)."""
+    from tests._fuzz_chains import run_chain_case
+    r = run_chain_case(seed, pkg, tables, sweep_mode == "fast")
+    assert r["counts"] is not None
