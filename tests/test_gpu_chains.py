@@ -257,3 +257,36 @@ def test_whole_steps_replayed_and_launch_by_launch(pkg, tables, monkeypatch):
     assert r[0] == a[0] and r[1] == a[1] and r[2] == a[2]
     assert abs(r[3] - a[3]) <= 1e-12 * abs(a[3])
     assert np.max(np.abs(r[4] - a[4])) < 1e-11
+
+
+def test_replayed_chains_and_gated_tail_in_a_non_isothermal_context(pkg, tables, monkeypatch):
+    """The HEAT kernels under replayed chains with the gated tail (the fold of BOTH transposed accumulators, the thermal global
+    pass): 90 sources, five iterations of c2r_iterate -- integers and photon loss as launch by launch, xh_av / temperatures to the
+    order of the atomics."""
+    from tests._util import load_thermal_tables
+    n, S = 48, 90
+    s, nd, xh, pos, nf = _case(pkg, n, S, 11)
+    tt = load_thermal_tables()
+    res = {}
+    for cg in ("0", "1"):
+        monkeypatch.setenv("C2R_CHAIN_GRAPH", cg)
+        b = pkg.HipBackend(n, *tables, device=0)
+        b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], 1.0)
+        b.set_sources(pos, nf); b.set_rank(0, 1); b.load(ndens=nd, xh=xh)
+        b.set_thermal(tt["heat_thick"], tt["heat_thin"], tt["cool_logT"], tt["cool_logL"])
+        b.set_redshift(9.0)
+        b.load(temperature_grid=np.full(n ** 3, 1e4, dtype=np.float32))
+        b.begin_step()
+        out = []
+        for _ in range(5):                       # (every iteration from the same state: the counts settle, the gate opens)
+            b.load(xh_av=xh, xh_intermed=xh, temperature_grid=np.full(n ** 3, 1e4, dtype=np.float32))
+            out.append(tuple(b.iterate(s["dt"])[:4]))
+        res[cg] = (out, b.fetch("xh_av"), b.fetch("temperature_grid"), b.fetch("phiheat_grid"), _info_counts(b), b.info())
+        b.close()
+    a, r = res["0"], res["1"]
+    assert r[4][0] > 0 and "device-gated tail 0" not in r[5], r[5]
+    assert r[0] == a[0], (r[0], a[0])
+    assert np.max(np.abs(r[1] - a[1])) < 1e-11
+    assert np.max(np.abs(r[2] - a[2]) / a[2]) < 1e-5                    # f32 temperatures: a last-bit difference at most
+    live = a[3] > 0
+    assert np.array_equal(r[3] > 0, live) and np.max(np.abs(r[3][live] - a[3][live]) / a[3][live]) < 1e-12
