@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--mesh", type=int, default=256)
     ap.add_argument("--sources", type=int, default=1000)
     ap.add_argument("--steps", type=int, default=14)
+    ap.add_argument("--share-of", type=int, default=1, help="sweep only rank 0's static share of the sources among this many ranks (what one GPU of a multi-GPU run does)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="c2r_set_option (include/c2ray_hip.h)")
     a = ap.parse_args()
     import torch
     import __graft_entry__ as g
@@ -28,8 +30,12 @@ def main():
     tp = pkg.TestProblem(n)
     nd, xh = tp.fields(1)
     srcpos, normflux = pkg.seeded_sources(n, S)
+    if a.share_of > 1:
+        sh = pkg.static_source_share(S, 0, a.share_of)
+        srcpos, normflux = srcpos[sh], normflux[sh]
+        S = len(normflux)
     thick, thin, _ = pkg.build_tables()
-    b = pkg.HipBackend(n, thick, thin, device=0)
+    b = pkg.HipBackend(n, thick, thin, device=0, options={kv.split("=", 1)[0]: float(kv.split("=", 1)[1]) for kv in a.option})
     b.set_sources(srcpos, normflux)
     b.load(ndens=nd, xh=xh)
     rows = []
@@ -46,7 +52,7 @@ def main():
         row = {"step": step, "outer_iterations": rep.niter, "converged": rep.converged, "wall_s": wall,
                "visited": int(rep.visited), "mean_subboxes_last": rep.sum_nbox_all / S,
                "seconds_sweep": rep.seconds_sweep, "seconds_chem": rep.seconds_chem,
-               "mean_x": float(b.fetch("xh").mean()), "photcons": rep.photcons, "info": b.info().split("; ")[-1]}
+               "mean_x": float(b.fetch("xh").mean()), "photcons": rep.photcons, "info": b.info().split("; chains ")[1].split("; exchanges")[0] + "; " + b.info().split("; ")[-1]}
         rows.append(row)
         print(json.dumps(row), flush=True)
     print(json.dumps({"mesh": n, "sources": S, "total_wall_s": sum(r["wall_s"] for r in rows),
