@@ -21,6 +21,7 @@ namespace c2r {
 #ifndef C2R_BLOCK
 #define C2R_BLOCK 256
 #endif
+constexpr int kFusedQmaxK = 10;    // (= kFusedQmax of ctx.hpp, static_assert in sweep.hip) the fused first sub-boxes reach shell q <= this: their LDS planes are (2 q + 1)^2
 constexpr int kBlock = C2R_BLOCK;   // threads per block of the sweep; a face's owned rectangle is flattened into tiles of kBlock
 
 typedef double v2f64 __attribute__((ext_vector_type(2)));

@@ -543,11 +543,14 @@ __device__ __forceinline__ double lookahead_cd_out(const KParams &p, const Shell
 // STREAM (here and in shell_rows_fast / sweep_tile_fast / sweep_tile): bit 0 -- non-temporal cache hints on the streams; bit 1 -- the
 // plane-ordered mapping (k_sweep_shell_xcd): the n_HI loads keep the plain policy (they are to stay in the XCD's L2) and the
 // coldensh_out debug path, which that mapping never runs with, is compiled out (63 VGPRs instead of 65: 8 waves per SIMD)
-template <bool DET, int LLS, int STREAM, int NR, int EXT, bool STORE = true>
+// STORE: 0 nothing, 1 the source's global planes, 2 the workgroup's LDS planes (k_sweep_box_fused: lds_cur, pitch kLdsP)
+constexpr int kLdsR = kFusedQmaxK, kLdsP = 2 * kFusedQmaxK + 1, kLdsPP = kLdsP * kLdsP;
+template <bool DET, int LLS, int STREAM, int NR, int EXT, int STORE = 1>
 __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                                        const double *__restrict__ thick, const int face, const int s, const int a,
                                                        const int b0, const int sgb, const int nvalid,
-                                                       const double (&vm)[NR + 1], const double (&va_)[NR + 1])
+                                                       const double (&vm)[NR + 1], const double (&va_)[NR + 1],
+                                                       double *__restrict__ lds_cur = nullptr)
 {
     const int q = sa.q;
     const int axis = 2 - (face >> 1);            // 2:z 1:y 0:x  (block-uniform)
@@ -599,7 +602,7 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
             const double dist2 = __builtin_fma(step_of(p).dr2[va], (double)(b * b), du2 + shell_step(p, q).d2axis[axis]);
             const bool stop = (LLS == 3) && dist2 > p.R_max2;
             // the cell's column density, also into the planes of the faces sharing the cell
-            if (STORE) {
+            if (STORE == 1) {
             buf_store_f64<SA>(r_cur, (unsigned)face * plane_bytes + o8, cd_out);
             if (axis == 2) {
                 if (abs(a) == q)
@@ -610,6 +613,15 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
                 if (abs(a) == q)
                     buf_store_f64<SA>(r_cur, (a > 0 ? 4u : 5u) * plane_bytes + (unsigned)((b + p.R) * p.P + (pd + p.R)) * 8u, cd_out);
             }
+            }
+            if (STORE == 2) {            // the same entries of the workgroup's LDS planes (the next shell of this launch reads them)
+                lds_cur[face * kLdsPP + (b + kLdsR) * kLdsP + (a + kLdsR)] = cd_out;
+                if (axis == 2) {
+                    if (abs(a) == q) lds_cur[(a > 0 ? 4 : 5) * kLdsPP + (pd + kLdsR) * kLdsP + (b + kLdsR)] = cd_out;
+                    if (abs(b) == q) lds_cur[(b > 0 ? 2 : 3) * kLdsPP + (pd + kLdsR) * kLdsP + (a + kLdsR)] = cd_out;
+                } else if (axis == 1) {
+                    if (abs(a) == q) lds_cur[(a > 0 ? 4 : 5) * kLdsPP + (b + kLdsR) * kLdsP + (pd + kLdsR)] = cd_out;
+                }
             }
             if ((C2R_XCD_KEEP_DBG || !(STREAM & 2)) && sa.dbg_cdout) {
                 const Delta3 dl = mesh_delta(axis, pd, a, b);
@@ -638,17 +650,30 @@ __device__ __forceinline__ double shell_rows_fast_core(const KParams &p, const S
 // LOOK = 0: the upstream values are read from the previous shell's planes (sq unused: pass sa).  LOOK = 1 (sq = the previous
 // shell's arguments, by reference -- a pointer to a kernel argument would force it into scratch): they are recomputed from
 // the planes of the shell before it (lookahead_cd_out).
-template <bool DET, int LLS, int STREAM, int NR, int EXT, int LOOK = 0, bool STORE = true>
+// LOOK = 2 (k_sweep_box_fused, shells after the launch's first): the four upstream column densities of every cell are read from
+// the workgroup's LDS planes of the previous shell (lds_prev) -- the shell-to-shell hand-off stays on chip.
+template <bool DET, int LLS, int STREAM, int NR, int EXT, int LOOK = 0, int STORE = 1>
 __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellArgs &sa, const v2f64 *__restrict__ ltab,
                                                   const double *__restrict__ thick,   // p.thick, or the block's LDS copy of it
                                                   const int face, const int s, const int a, const int b0, const int sgb,
-                                                  const int nvalid, const ShellArgs &sq)
+                                                  const int nvalid, const ShellArgs &sq,
+                                                  const double *__restrict__ lds_prev = nullptr, double *__restrict__ lds_cur = nullptr)
 {
     const int q = sa.q, qm = q - 1;
     const int sga = a < 0 ? -1 : 1;
     const int am = a - sga;
     double vm[NR + 1], va_[NR + 1];
-    if (LOOK) {
+    if (LOOK == 2) {
+        const bool ina = abs(a) <= qm, inam = abs(am) <= qm;
+        const double *pl = lds_prev + face * kLdsPP + kLdsR * kLdsP + kLdsR;
+#pragma unroll
+        for (int r = 0; r <= NR; ++r) {                        // rows b0-sgb, b0, ..., b0+(NR-1)sgb
+            const int row = b0 + (r - 1) * sgb;
+            const bool inr = abs(row) <= qm;                   // (a corner outside the previous shell: weight 0, value 0, as an OOB load)
+            vm[r] = (inam && inr) ? pl[row * kLdsP + am] : 0.0;
+            va_[r] = (ina && inr) ? pl[row * kLdsP + a] : 0.0;
+        }
+    } else if (LOOK) {
 #pragma unroll
         for (int r = 0; r <= NR; ++r) {                        // rows b0-sgb, b0, ..., b0+(NR-1)sgb
             // (rows beyond the thread's valid cells are computed too -- from periodic-wrapped, in-range addresses -- and unused)
@@ -672,7 +697,7 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
             o += db8;
         }
     }
-    return shell_rows_fast_core<DET, LLS, STREAM, NR, EXT, STORE>(p, sa, ltab, thick, face, s, a, b0, sgb, nvalid, vm, va_);
+    return shell_rows_fast_core<DET, LLS, STREAM, NR, EXT, STORE>(p, sa, ltab, thick, face, s, a, b0, sgb, nvalid, vm, va_, lds_cur);
 }
 
 #ifndef C2R_FAST_ATTR
@@ -680,7 +705,7 @@ __device__ __forceinline__ double shell_rows_fast(const KParams &p, const ShellA
 #endif
 // one (source, face, tile) block of work of k_sweep_shell_fast; sl = position in the active list (src < 0: the source is
 // sa.active[sl]; else src, and sl only indexes the loss partials of a shell on the sub-box surface)
-template <bool DET, int LLS, int STREAM, int EXT, int LOOK = 0, bool STORE = true, int NR = kRows>
+template <bool DET, int LLS, int STREAM, int EXT, int LOOK = 0, int STORE = 1, int NR = kRows>
 __device__ __forceinline__ void sweep_tile_fast(const KParams &p, const ShellArgs &sa, const FaceRect &fr, const v2f64 *ltab,
                                                 const double *thick, double *sm, const int face, const int tile, const int sl,
                                                 const ShellArgs &sq, const int src = -1)
@@ -813,6 +838,15 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
 {
     __shared__ double sm[16];
     __shared__ v2f64 s_log[1024];
+    // FAST: the shells of this sub-box hand their column densities on through LDS -- two plane sets [6][kLdsP][kLdsP] (q <= 10: 21 KB
+    // each), ping-ponged; only the launch's first shell reads the source's global planes and only its last writes them (the next
+    // sub-box's launches read those).  The exact mode keeps the global planes (cell_state's buffer loads).
+#ifdef C2R_FUSED_NO_LDS                  // (A/B builds: the shells of a fused sub-box hand over through the global planes, as before round 6)
+    constexpr bool kLdsPlanes = false;
+#else
+    constexpr bool kLdsPlanes = FAST;
+#endif
+    __shared__ double s_planes[kLdsPlanes ? 2 * 6 * kLdsPP : 1];
     const int sl = blockIdx.x;
     if (sl >= *ba.n_active) return;
     const int s = ba.active[sl];
@@ -837,8 +871,20 @@ __global__ __launch_bounds__(1024) void k_sweep_box_fused(KParams p, BoxArgs ba)
             const unsigned bi = fr.magic ? __umulhi(lt, fr.magic) : lt;
             const int a = fr.a_lo + (int)(lt - __umul24(bi, (unsigned)fr.wa));
             const int b = fr.b_lo + (int)bi;
-            if (FAST) loss = loss + shell_rows_fast<DET, LLS, false, 1, EXT>(p, sa, ltab, p.thick, f, s, a, b, b < 0 ? -1 : 1, 1, sa);
-            else loss = loss + shell_cell<DET, LLS, 0, EXT>(p, sa, ltab, f, s, a, b);
+            if (FAST && !kLdsPlanes) loss = loss + shell_rows_fast<DET, LLS, false, 1, EXT>(p, sa, ltab, p.thick, f, s, a, b, b < 0 ? -1 : 1, 1, sa);
+            else if (FAST) {
+                // (block-uniform choices: the launch's first shell reads the global planes, its last one writes them)
+                const double *lp = s_planes + ((k - 1) & 1) * 6 * kLdsPP;
+                double *lc = s_planes + (k & 1) * 6 * kLdsPP;
+                const int sg = b < 0 ? -1 : 1;
+                if (k == 0) {
+                    if (k + 1 < ba.nshell) loss = loss + shell_rows_fast<DET, LLS, false, 1, EXT, 0, 2>(p, sa, ltab, p.thick, f, s, a, b, sg, 1, sa, nullptr, lc);
+                    else loss = loss + shell_rows_fast<DET, LLS, false, 1, EXT, 0, 1>(p, sa, ltab, p.thick, f, s, a, b, sg, 1, sa);
+                } else {
+                    if (k + 1 < ba.nshell) loss = loss + shell_rows_fast<DET, LLS, false, 1, EXT, 2, 2>(p, sa, ltab, p.thick, f, s, a, b, sg, 1, sa, lp, lc);
+                    else loss = loss + shell_rows_fast<DET, LLS, false, 1, EXT, 2, 1>(p, sa, ltab, p.thick, f, s, a, b, sg, 1, sa, lp, nullptr);
+                }
+            } else loss = loss + shell_cell<DET, LLS, 0, EXT>(p, sa, ltab, f, s, a, b);
         }
         if (sa.has_boundary) {
             const double tot = block_sum_256(loss, sm);       // contains a barrier

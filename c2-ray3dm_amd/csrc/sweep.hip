@@ -940,6 +940,7 @@ static bool chain_graph_fits(const Ctx *ctx, const Ctx::ChainGraph &cg, const Ba
     return have <= need + need / 2 + 4LL * H;
 }
 
+static_assert(kFusedQmaxK == kFusedQmax, "the fused kernel's LDS planes are sized for kFusedQmax");
 static_assert(kGateChains >= kMaxChains, "k_chain_gate holds every chain's pointers");
 int run_chains(Ctx *ctx, int first, int count, bool first_of_pass, std::vector<int> *nbox_out, FusedIter *tail)
 {
