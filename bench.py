@@ -546,6 +546,9 @@ def main():
                          # ... and with every n_HI load an L2 hit: the far shells' plane-ordered block mapping serves ~3/4 of
                          # them from the L2s, so the ceiling of the kernel's real mix lies between the two
                          "mix_ceiling_nhi_in_l2_this_box": mix_ceiling_l2,
+                         "mix_ceiling_note": "the first micro-benchmark (every n_HI load from HBM) is what the kernel's traffic looked like BEFORE the plane-ordered "
+                                             "mapping: the kernel now reaches ~1.0 of it while also doing 170 VALU instructions per visit, so it is not a ceiling of "
+                                             "today's kernel; the second (n_HI in the L2s) is an upper bound of today's mix -- the kernel's real mix lies between",
                          "frac_of_memory_only_mix_nhi_in_l2": (vis_rank / sweep_s / mix_ceiling_l2) if (mix_ceiling_l2 and timed and not args.thermal) else None,
                          "algorithmic_bytes_per_launch": bytes_per_visit * vis_rank / launches if timed else None, "algorithmic_bytes_per_visit": bytes_per_visit,
                          "avg_launch_ms": prof["sweep_ms"] / launches if timed else None, "launches": prof["sweep_launches"],
