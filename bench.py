@@ -626,6 +626,9 @@ def main():
                 leg["what"] = ("one GPU's share of BASELINE configs[4]: 504^3, log-normal density (sigma_ln = 1), the 1250 sources rank 0 of 8 sweeps of the "
                                "10 000 seeded ones, all in flight at once (30 GB of shell planes); `value` counts these 1250 sources")
                 out["configs"]["504_share_of_8"] = leg
+                # (the review's name for this leg; the 10 000-source step it is an eighth of takes ~11 s and is not timed in the default run:
+                # `bench.py --mesh 504 --sources 10000 --density lognormal --no-cpu-baseline` does)
+                out["share_504"] = {"see": "configs.504_share_of_8", "ms_per_step": leg["ms_per_step"], "frac": leg.get("roofline", {}).get("frac")}
                 del nd5, xh5
             except Exception as exc:                    # (e.g. a GPU shared with another job: not enough free HBM)
                 out["configs"]["504_share_of_8"] = {"skipped": repr(exc)}
