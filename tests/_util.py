@@ -105,7 +105,7 @@ def gamma_ok(dgamma, gamma_ref, w, fast):
 
 def sweep_mode():
     """Mode the GPU tests run the sweep in: the `sweep_mode` fixture (conftest.py) sets C2R_SWEEP_MODE, which
-    c2r_create reads, so every context a test creates -- through Python, C or the Fortran shim -- follows it."""
+    the HOSTS above the C ABI read (HipBackend(fast=None), the Fortran shim, the native harness), so every context a test creates follows it."""
     return "exact" if os.environ.get("C2R_SWEEP_MODE") == "0" else "fast"       # (unset: the library default, C2R_SWEEP_FAST)
 
 

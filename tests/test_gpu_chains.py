@@ -2,7 +2,7 @@
 each with its own stream and scratch, driven in lock-step) -- what one GPU's share of a multi-GPU run looks like.  The chains
 change WHEN launches run, not what they compute: per-source sub-box counts, visited cells, the photon loss (bit for bit: the
 shape of its sums is chosen by the pass's source count, not by the batch's) are those of one chain; Gamma differs only by the
-order in which the f64 atomics of different sources land.  C2R_CHAINS=n forces n chains (read by c2r_create)."""
+order in which the f64 atomics of different sources land.  C2R_CHAINS=n forces n chains (tests/conftest.py hands it to c2r_set_option "chains": the library reads no environment)."""
 import numpy as np
 import pytest
 from tests._util import F, tol, assert_gamma, oracle_pass

@@ -18,7 +18,7 @@ def pkg():
 
 
 def _backend(pkg, n, S, seed, x, fast, det, monkeypatch, env, lls=1, thermal=False):
-    """A context over a seeded test problem; env: experiment switches read by c2r_create (C2R_PAIR_SHELLS, C2R_FUSED_ITER)."""
+    """A context over a seeded test problem; env: schedule switches (C2R_PAIR_SHELLS, C2R_FUSED_ITER) that tests/conftest.py hands to c2r_set_option."""
     for k in ("C2R_PAIR_SHELLS", "C2R_FUSED_ITER", "C2R_GRAPH"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():

@@ -185,7 +185,7 @@ def test_fused_first_subboxes_equal_per_shell_launches(pkg, tables, monkeypatch)
     s, nd, xh, pos, nf = _random_case(n, nsrc, 21, pkg)
     res = []
     for fuse in ("1", "0"):
-        monkeypatch.setenv("C2R_FUSE_SMALL", fuse)          # read by c2r_create
+        monkeypatch.setenv("C2R_FUSE_SMALL", fuse)          # -> c2r_set_option "fuse_small" (tests/conftest.py)
         b = make_backend(pkg, tables, dict(s, srcpos=pos, normflux=nf), n, nd, xh)
         b.begin_step(); b.zero_rates()
         out = b.pass_sources()

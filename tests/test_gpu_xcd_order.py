@@ -4,7 +4,7 @@ sorted along the face's axis -- so that sources whose faces lie on one mesh plan
 the plane's n_HI in its L2.  WHICH workgroup does a (source, face, tile) changes, nothing else: sub-box counts, visited cells and
 the photon loss are bit-identical to the plain (tile, face, source) grid, the rates equal to the order of the atomics; also with
 sources that retire early (their blocks return at once), with a source count that is no multiple of eight, with zero-flux
-sources, heating rates, X-ray sources and ordered (deterministic) rates -- those bit-identical.  C2R_XCD_ORDER / _QMIN / _MIN_ALIVE are read by c2r_create."""
+sources, heating rates, X-ray sources and ordered (deterministic) rates -- those bit-identical.  C2R_XCD_ORDER / _QMIN / _MIN_ALIVE reach the library as c2r_set_option calls (tests/conftest.py)."""
 import numpy as np
 import pytest
 from tests._util import F, oracle_for, assert_gamma, oracle_pass, tol, load_thermal_tables, load_case
