@@ -222,6 +222,8 @@ static int evolve3d_worker(c2r_ctx *c, double dt, int restart_niter, double rest
             for (int w = 2; w <= 3; ++w) {
                 for (int r = 0; r < ctx->nranks; ++r) { bo[r] = so[r] * sizeof(double); bc[r] = sc[r] * sizeof(double); }
                 if (ctx->ag(ctx->slab_user, ctx->grid[w], bo, bc, ctx->nranks, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-gather callback failed");
+                // (-DALLFRAC drivers: the pass also wrote the stored neutral halves of its slab, arrays 8 and 9)
+                if (ctx->allfrac && ctx->ag(ctx->slab_user, ctx->grid[w + 6], bo, bc, ctx->nranks, (void *)ctx->stream) != 0) FAIL(C2R_ECALLBACK, "all-gather callback failed");
             }
             if (ctx->thermal) {
                 for (int r = 0; r < ctx->nranks; ++r) { bo[r] = so[r] * 3 * sizeof(float); bc[r] = sc[r] * 3 * sizeof(float); }
