@@ -22,7 +22,7 @@
 
 struct Problem {
     int32_t mesh, nsrc; double dr, vol, lls, dt;
-    std::vector<float> ndens; std::vector<double> xh, normflux; std::vector<int32_t> srcpos;
+    std::vector<float> ndens; std::vector<double> xh, xh0 /* allfrac: the stored neutral fraction, or empty */, normflux; std::vector<int32_t> srcpos;
     std::vector<double> thick, thin;
 };
 struct Shared {
@@ -31,7 +31,7 @@ struct Shared {
     std::vector<double *> stage; std::vector<size_t> stage_cap;   // host all-reduce: one PINNED staging buffer per rank
     unsigned char uid[C2R_RCCL_ID_BYTES];
     std::vector<int> rc; std::vector<std::string> err;
-    c2r_report rep0; std::vector<double> xh0, phih0;
+    c2r_report rep0; std::vector<double> xh0, xh0n, phih0;
     int64_t xchg[4] = {0, 0, 0, 0};                               // rank 0's c2r_exchange_stats: calls, packed calls, bytes of the last call, bytes in all
     bool rotate = false;                                          // C2R_HARNESS_ROTATE_SUM=1: the host all-reduce sums element i starting at rank i mod nranks
     std::vector<unsigned long long> hash;                         // per rank: a hash of the bits of xh and phih_grid the step left (replicas must agree)
@@ -130,7 +130,14 @@ static void *rank_main(void *p)
     const size_t ncell = (size_t)pb.mesh * pb.mesh * pb.mesh;
     // every rank owns its arrays, as every MPI process does (the library page-locks the arrays it is handed)
     std::vector<float> ndens = pb.ndens;
-    std::vector<double> xh = pb.xh, xh_av(ncell), xh_int(ncell), phih(ncell);
+    // C2R_HARNESS_ALLFRAC=1: a driver built with -DALLFRAC -- xh / xh_av / xh_intermed are (mesh,0:1) arrays, the stored neutral
+    // half first; it comes from <in.bin>.x0 (ncell doubles) or, without that file, is 1 - x as xfrac_restart_init sets it
+    const bool allfrac = getenv("C2R_HARNESS_ALLFRAC") && atoi(getenv("C2R_HARNESS_ALLFRAC")) != 0;
+    std::vector<double> xh = pb.xh, xh_av(allfrac ? 2 * ncell : ncell), xh_int(allfrac ? 2 * ncell : ncell), phih(ncell);
+    if (allfrac) {
+        xh.resize(2 * ncell);
+        for (size_t i = 0; i < ncell; ++i) { xh[ncell + i] = pb.xh[i]; xh[i] = pb.xh0.empty() ? 1.0 - pb.xh[i] : pb.xh0[i]; }
+    }
     c2r_report rep;
     {
         c2r_params prm;
@@ -139,6 +146,7 @@ static void *rank_main(void *p)
         prm.device = rank % ndev;
         if (const char *e = getenv("C2R_SWEEP_MODE")) prm.sweep_mode = atoi(e) ? C2R_SWEEP_FAST : C2R_SWEEP_EXACT;
         if (const char *e = getenv("C2R_HARNESS_DETERMINISTIC")) prm.deterministic_rates = atoi(e) ? 1 : 0;   // ordered per-source sums: runs comparable bit for bit
+        prm.allfrac = allfrac ? 1 : 0;
         TRY(c2r_create(&ctx, &prm));
         // the library reads no environment variable for its schedule switches: this harness (test code) hands its own over
         static const char *const opts[][2] = {{"C2R_EXCHANGE_OVERLAP", "exchange_overlap"}, {"C2R_EXCHANGE_OVERLAP_MIN", "exchange_overlap_min"},
@@ -174,7 +182,9 @@ static void *rank_main(void *p)
         }
         if (rank == 0) {
             sh->info0 = c2r_info(ctx);
-            sh->rep0 = rep; sh->xh0 = xh; sh->phih0 = phih;
+            sh->rep0 = rep; sh->phih0 = phih;
+            sh->xh0.assign(xh.begin() + (allfrac ? (long)ncell : 0), xh.end());      // the ionized half
+            if (allfrac) sh->xh0n.assign(xh.begin(), xh.begin() + (long)ncell);     // ... and the stored neutral half
             (void)c2r_exchange_stats(ctx, &sh->xchg[0], &sh->xchg[1], &sh->xchg[2], &sh->xchg[3]);
         }
         if (sh->rccl && sh->nranks > 1) c2r_rccl_detach(ctx);
@@ -197,6 +207,7 @@ int main(int argc, char **argv)
     pb.ndens.resize(ncell); pb.xh.resize(ncell); pb.srcpos.resize(3 * (size_t)pb.nsrc); pb.normflux.resize(pb.nsrc);
     rd(f, pb.ndens.data(), ncell); rd(f, pb.xh.data(), ncell); rd(f, pb.srcpos.data(), pb.srcpos.size()); rd(f, pb.normflux.data(), pb.normflux.size());
     fclose(f);
+    if (FILE *f0 = fopen((std::string(argv[1]) + ".x0").c_str(), "rb")) { pb.xh0.resize(ncell); rd(f0, pb.xh0.data(), ncell); fclose(f0); }
     c2r_sed_params sed;
     c2r_default_sed(&sed);
     pb.thick.resize(sed.numtau + 1); pb.thin.resize(sed.numtau + 1);
@@ -225,6 +236,7 @@ int main(int argc, char **argv)
     fwrite(&sh.rep0.photon_loss_all, sizeof(double), 1, f);
     fwrite(sh.xh0.data(), sizeof(double), ncell, f);
     fwrite(sh.phih0.data(), sizeof(double), ncell, f);
+    if (!sh.xh0n.empty()) fwrite(sh.xh0n.data(), sizeof(double), ncell, f);      // (C2R_HARNESS_ALLFRAC: the neutral half of xh behind everything else)
     fclose(f);
     printf("ok: %d rank(s) on %d device(s), %s %s, balance %d: niter %d sum_nbox %lld\n", sh.nranks, ndev < sh.nranks ? ndev : sh.nranks,
            sh.rccl ? "rccl" : "host", sh.slab ? "reduce-scatter + slab chemistry + all-gather" : "all-reduce", (int)sh.balance, sh.rep0.niter,

@@ -186,3 +186,37 @@ def test_two_ranks_over_rccl(tmp_path):
     # the same over grouped ncclReduce / ncclBroadcast (slab chemistry)
     r2 = read_output(run(tmp_path, "rccl_slab", 2, "rccl", 1, 1), n)
     assert r2["niter"] == r["niter"] and r2["conv"] == r["conv"] and np.max(np.abs(r2["xh"] - r["xh"])) < 1e-12
+
+
+def test_allfrac_ranks_slabs_and_packed_exchange(tmp_path, monkeypatch):
+    """A driver built with -DALLFRAC over several ranks (the harness hands c2r_evolve3d its (mesh,0:1) arrays, c2r_params.allfrac):
+    the step of the -DALLFRAC reference fixture on 1 rank, on 2 and 3 ranks with the all-reduce, and with slab chemistry (the stored
+    neutral halves of xh_av / xh_intermed are gathered with the ionized ones) -- iteration history of the reference, both halves of
+    xh within tol("x") of it, and with ordered rates the same bits with slab chemistry as with the replicated pass."""
+    assert os.path.exists(HARNESS)
+    monkeypatch.setenv("C2R_HARNESS_ALLFRAC", "1")
+    monkeypatch.setenv("C2R_HARNESS_DETERMINISTIC", "1")
+    m, a = load_case("evolve32_allfrac")
+    n, s = m["n"], m["steps"]["step001"]
+    write_input(str(tmp_path / "in.bin"), n, s, F(a["step001_ndens"]), F(a["step001_xh_before"]))
+    F(a["step001_xh_before0"]).tofile(str(tmp_path / "in.bin.x0"))
+
+    def read_allfrac(path):
+        r = read_output(path, n)
+        with open(path, "rb") as f:
+            f.seek(-8 * n ** 3, 2)
+            r["xh_neutral"] = np.fromfile(f, np.float64, n ** 3)
+        return r
+    res = {}
+    for tag, nranks, slab in (("1", 1, 0), ("2", 2, 0), ("3", 3, 0), ("2s", 2, 1), ("3s", 3, 1)):
+        r = read_allfrac(run(tmp_path, tag, nranks, "host", 0, slab))
+        assert r["converged"] and r["niter"] == s["niter"] and r["conv"] == s["log"]["nonconv"], tag
+        assert r["sum_nbox"] == s["sum_nbox_all"], tag
+        assert np.max(np.abs(r["xh"] - F(a["step001_xh_after"]))) < tol("x"), tag
+        assert np.max(np.abs(r["xh_neutral"] - F(a["step001_xh_after0"]))) < tol("x"), tag
+        res[tag] = r
+    for tag in ("2", "3"):        # slab chemistry against the replicated pass at the same rank count: the same bits
+        for k in ("xh", "xh_neutral", "phih"):
+            assert np.array_equal(res[tag + "s"][k], res[tag][k]), (tag, k)
+        # ... and against one rank: the partition changes only the association of the sums over ranks
+        assert np.max(np.abs(res[tag]["xh"] - res["1"]["xh"])) < 1e-12 and np.max(np.abs(res[tag]["xh_neutral"] - res["1"]["xh_neutral"])) < 1e-12
