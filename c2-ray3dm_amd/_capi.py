@@ -70,6 +70,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 # c2r_reduce_scatter_fn / c2r_allgather_fn: (user, dev_buf, offsets[nranks], counts[nranks], nranks, hip_stream)
 SLAB_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int32, C.c_void_p)
 ITERATION_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_double)
+# c2r_next_sources_fn: (user, pass, want, *first, *count)
+NEXT_SOURCES_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32))
 
 # every symbol include/c2ray_hip.h declares: (name, restype, argtypes)
 _P, _I32, _I64, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
@@ -102,6 +104,7 @@ SYMBOLS = [
     ("c2r_set_balance", C.c_int, [_P, _I32]),
     ("c2r_source_share", C.c_int, [_P, _P, _I32, C.POINTER(_I32)]),
     ("c2r_balanced_shares", C.c_int, [_P, _I32, _I32, _I32, _P, C.POINTER(_I32)]),
+    ("c2r_set_source_queue", C.c_int, [_P, _P, _P, _I32]),
     ("c2r_get_device", C.c_int, [_P, C.POINTER(_I32)]),
     ("c2r_bind_device_buffers", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("c2r_device_ptr", C.c_int, [_P, _I32, C.POINTER(_P)]),

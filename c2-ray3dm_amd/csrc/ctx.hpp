@@ -143,6 +143,8 @@ struct Ctx {
     // slab chemistry (c2r_set_slab_chemistry): reduce-scatter of the rates by z-slabs, the global pass on the own slab,
     // all-gather of its outputs -- instead of the all-reduce and a replicated global pass
     c2r_reduce_scatter_fn rs = nullptr; c2r_allgather_fn ag = nullptr; void *slab_user = nullptr;
+    // sources handed out on request (c2r_set_source_queue: do_grid_master / do_grid_slave, master_slave.F90:124-330)
+    c2r_next_sources_fn queue_next = nullptr; void *queue_user = nullptr; int queue_chunk = 0;
     c2r_iteration_fn iter_hook = nullptr;
     void *iter_user = nullptr;
     // sweep geometry

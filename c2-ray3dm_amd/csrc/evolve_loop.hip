@@ -16,7 +16,7 @@ static int iterate_impl(Ctx *ctx, double dt, double *stats_host, double *loss, i
     ctx->step_dt = dt;
     if ((rc = sync_step(ctx))) return rc;
     const int nloc = n_local_sources(ctx);
-    bool can_fuse = ctx->fused_iter && !ctx->allfrac && ctx->nranks == 1 && !ctx->balance && ctx->use_graph && ctx->sched_hint && ctx->prof == 0 && nloc > 0 &&
+    bool can_fuse = ctx->fused_iter && !ctx->allfrac && !ctx->queue_next && ctx->nranks == 1 && !ctx->balance && ctx->use_graph && ctx->sched_hint && ctx->prof == 0 && nloc > 0 &&
                     nloc <= kFewSources && ctx->box_hint >= 1 &&
                     !(ctx->thermal && ctx->tprm.cosmological && !ctx->have_zred);
     if (can_fuse) {

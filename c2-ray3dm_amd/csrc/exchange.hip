@@ -139,6 +139,21 @@ int c2r_set_slab_chemistry(c2r_ctx *c, c2r_reduce_scatter_fn rs, c2r_allgather_f
     return C2R_OK;
 }
 
+int c2r_set_source_queue(c2r_ctx *c, c2r_next_sources_fn next, void *user, int32_t chunk)
+{
+    if (!c) return C2R_EINVAL;
+    Ctx *ctx = C(c);
+    if (next && chunk < 1) FAIL(C2R_EINVAL, "c2r_set_source_queue: chunk must be >= 1");
+    if (next && ctx->prm.deterministic_rates) FAIL(C2R_ESTATE, "sources on request and ordered rates exclude each other: the order of a rank's sources is not fixed");
+    ctx->queue_next = next; ctx->queue_user = user; ctx->queue_chunk = next ? chunk : 0;
+    if (ctx->auto_share) { ctx->explicit_share = false; ctx->auto_share = false; ctx->share.clear(); }
+    HIP_TRY(hipSetDevice(ctx->prm.device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    free_sweep_scratch(ctx);               // (sized for a chunk from now on / for the rank's share again)
+    ++ctx->gen;
+    return C2R_OK;
+}
+
 int c2r_slab(const c2r_ctx *c, int32_t rank, int32_t nranks, size_t *cell_offset, size_t *cell_count)
 {
     if (!c || nranks < 1 || rank < 0 || rank >= nranks || !cell_offset || !cell_count) return C2R_EINVAL;

@@ -341,7 +341,7 @@ struct BatchSweep {
 
     BatchSweep(Ctx *c, SweepScratch &sc_, int first_, int count_, bool first_of_pass_, double *dbg_, FusedIter *fz_)
         : ctx(c), sc(sc_), p(c->prm), first(first_), count(count_), first_of_pass(first_of_pass_), dbg(dbg_), fz(fz_),
-          cap((size_t)sc_.cap), st(sc_.stream), k(make_kparams(c, sc_)), shape_count(n_local_sources(c))
+          cap((size_t)sc_.cap), st(sc_.stream), k(make_kparams(c, sc_)), shape_count(c->queue_next ? c->nsrc : n_local_sources(c))
     {
         h_nf = reinterpret_cast<double *>(sc.h_batch); h_fl = h_nf + cap; h_nfx = h_nf + 3 * cap;
         h_pos = reinterpret_cast<int *>(h_nf + 4 * cap); h_posw = h_pos + 3 * cap; h_act = h_pos + 6 * cap; h_na = h_pos + 9 * cap;
@@ -1216,15 +1216,49 @@ int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64_t *sum
 {
     int rc;
     if ((rc = sync_step(ctx))) return rc;
-    balance_before_pass(ctx);
-    const int nloc = n_local_sources(ctx);
+    // do_grid_master / do_grid_slave (master_slave.F90:124-330; c2r_set_source_queue): this rank's sources of the pass are not known
+    // in advance -- it asks the host's queue for `queue_chunk` more whenever it has swept what it had
+    const bool queued = ctx->queue_next != nullptr && fz == nullptr;
+    if (queued) { ctx->share.clear(); ctx->explicit_share = true; ctx->auto_share = true; }
+    else balance_before_pass(ctx);
+    int nloc = queued ? 0 : n_local_sources(ctx);
     long long vis = 0;
     // the sparse exchange (c2r_allreduce_rates) is only right for ONE pass over rates the library itself had zeroed: everything
     // outside this pass's sub-boxes is then zero on every rank.  fz: the fused iteration zeroes them itself (fz->pre)
     ++ctx->pass_id; ctx->sparse_valid = ctx->rates_clean || fz != nullptr; ctx->rates_clean = false;
     ctx->last_nbox.clear();
     ctx->h_sc->photon_loss = 0.0; ctx->h_sc->sum_nbox = 0;      // (the stream is idle between calls)
-    const bool overlap = exchange_overlap_applies(ctx, fz);
+    const bool overlap = !queued && exchange_overlap_applies(ctx, fz);
+    if (queued) {
+        // rounds of one chunk each: ask, sweep, ask again (the chunk's launches end with a host wait, as every round does)
+        bool prepared = false;
+        std::vector<int> nb;
+        for (;;) {
+            int32_t qf = 0, qc = 0;
+            if (ctx->queue_next(ctx->queue_user, (int64_t)ctx->pass_id, ctx->queue_chunk, &qf, &qc) != 0) FAIL(C2R_ECALLBACK, "source queue callback failed");
+            if (qc <= 0) break;
+            if (qf < 0 || qc > ctx->queue_chunk || qf + qc > ctx->nsrc) FAIL(C2R_ECALLBACK, "source queue handed out sources beyond the list");
+            const int first = (int)ctx->share.size();
+            for (int i = 0; i < qc; ++i) ctx->share.push_back(qf + i);
+            if ((rc = ensure_sweep_scratch(ctx, ctx->queue_chunk))) return rc;
+            if (!prepared) { if ((rc = sweep_prepare(ctx))) return rc; prepared = true; }
+            for (int f = first, count = 0; f < first + qc; f += count) {
+                if (ctx->nchains > 1 && first + qc - f >= 2 * kFewSources) {
+                    count = std::min(ctx->batch_cap, first + qc - f);
+                    rc = run_chains(ctx, f, count, f == 0, &nb, nullptr);
+                } else {
+                    count = std::min(ctx->sc[0].cap, first + qc - f);
+                    rc = sweep_batch(ctx, f, count, f == 0, nullptr, &nb, nullptr, nullptr);
+                }
+                if (rc) return rc;
+                for (int v : nb) { vis += visited_for_nbox(ctx, v); ctx->last_nbox.push_back(v); }
+            }
+        }
+        if (prepared && (rc = sweep_finish(ctx))) return rc;
+        ctx->box_hint = 0;
+        for (int v : ctx->last_nbox) ctx->box_hint = std::max(ctx->box_hint, v);
+        nloc = 0;                                   // (everything below that sweeps is skipped)
+    }
     if (nloc == 0 && overlap) {
         // a rank without sources (more ranks than sources in its share) still takes part in both exchanges
         if ((rc = overlap_begin(ctx)) || (rc = overlap_exchange_half(ctx, 0)) || (rc = overlap_exchange_half(ctx, 1)) || (rc = overlap_end(ctx))) return rc;
@@ -1268,10 +1302,10 @@ int pass_sources_impl(Ctx *ctx, FusedIter *fz, double *photon_loss, int64_t *sum
         for (int v : ctx->last_nbox) ctx->box_hint = std::max(ctx->box_hint, v);
     } else if (fz && (rc = fz->pre())) return rc;
     if (visited) *visited = vis;
-    if (no_wait) return C2R_OK;
+    if (no_wait && !queued) return C2R_OK;
     if (!fz) HIP_TRY(hipStreamSynchronize(ctx->stream));        // k_batch_totals stored the totals in h_sc
     prof_collect(ctx);
-    if ((rc = balance_after_pass(ctx))) return rc;
+    if (!queued && (rc = balance_after_pass(ctx))) return rc;
     if (photon_loss) *photon_loss = ctx->h_sc->photon_loss;
     if (sum_nbox) *sum_nbox = ctx->h_sc->sum_nbox;
     if (visited) *visited = vis;

@@ -269,6 +269,17 @@ class HipBackend:
             self._cb = _capi.ALLREDUCE_FN(0)
         self._check(self.lib.c2r_set_rank(self.ctx, rank, npr, self._cb, None), "c2r_set_rank")
 
+    def set_source_queue(self, next_sources=None, chunk=64):
+        """c2r_set_source_queue (do_grid_master / do_grid_slave, master_slave.F90:124-330): the pass asks
+        next_sources(user, pass_id, want, first, count) -- first[0], count[0] are the outputs -- for `chunk` more sources whenever it
+        has swept what it had; None returns to the fixed rules."""
+        if next_sources is None:
+            self._queue_cb = None
+            self._check(self.lib.c2r_set_source_queue(self.ctx, None, None, 0), "c2r_set_source_queue")
+            return
+        self._queue_cb = _capi.NEXT_SOURCES_FN(next_sources)
+        self._check(self.lib.c2r_set_source_queue(self.ctx, C.cast(self._queue_cb, C.c_void_p), None, int(chunk)), "c2r_set_source_queue")
+
     def set_exchange_overlap(self, on=True):
         """c2r_set_exchange_overlap: passes that are followed by an all-reduce of the whole grid run as two halves, the first
         half's all-reduce travelling while the second is swept (allreduce_rates afterwards only refreshes the sub-box list)."""

@@ -303,6 +303,20 @@ int  c2r_source_share(c2r_ctx *ctx, int32_t *idx, int32_t cap, int32_t *n);
 /* The partition c2r_set_balance uses, as a pure host function (no context, no GPU): rank `rank`'s share of
  * nsrc sources with the given costs over nranks ranks; idx has room for nsrc entries. */
 int  c2r_balanced_shares(const int64_t *cost, int32_t nsrc, int32_t nranks, int32_t rank, int32_t *idx, int32_t *n);
+/* do_grid_master / do_grid_slave (master_slave.F90:124-330: what do_grid selects when npr > min_numproc_master_slave = 10) -- the
+ * sources of a pass are handed out ON REQUEST instead of by a fixed rule: a rank that has swept what it had asks for more, so a
+ * rank whose sources end early takes more of them.  next(user, pass, want, &first, &count) is the host's queue: it hands the
+ * calling rank the next count <= want sources [first, first + count) (0-based) of pass number `pass` and count = 0 once none are
+ * left (the reference's master answers a worker's request with the next source number, :170-230; an MPI host implements the queue
+ * with MPI_Fetch_and_op on a counter in rank 0's window, a thread host with an atomic; one counter per parity of `pass`, the other
+ * one reset when a pass starts, needs no extra synchronisation because a collective follows every pass).  chunk: how many sources
+ * a rank asks for at a time (the reference: 1); a chunk is swept as one round of launches, so chunks of 64 and more keep the GPU
+ * busy and smaller ones balance finer.  Unlike the reference's master, every rank sweeps.  The shape of the photon-loss sums
+ * follows the whole list's size, so per-source results do not depend on who swept what; Gamma differs from the static rule's
+ * by the association of the sums over ranks.  c2r_source_share / c2r_last_nbox describe what the rank swept in the last pass.
+ * Excludes deterministic_rates (C2R_ESTATE), takes precedence over c2r_set_balance and c2r_set_source_share.  NULL: off. */
+typedef int (*c2r_next_sources_fn)(void *user, int64_t pass, int32_t want, int32_t *first, int32_t *count);
+int  c2r_set_source_queue(c2r_ctx *ctx, c2r_next_sources_fn next, void *user, int32_t chunk);
 /* The device the context runs on (resolves C2R_DEVICE_AUTO). */
 int  c2r_get_device(const c2r_ctx *ctx, int32_t *device);
 

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <vector>
 #include "../../include/c2ray_hip.h"
 #include "../../include/c2ray_rccl.h"
@@ -32,6 +33,8 @@ struct Shared {
     unsigned char uid[C2R_RCCL_ID_BYTES];
     std::vector<int> rc; std::vector<std::string> err;
     c2r_report rep0; std::vector<double> xh0, xh0n, phih0;
+    // C2R_HARNESS_QUEUE=chunk: sources handed out on request (c2r_set_source_queue) from these two counters, one per parity of the pass
+    int queue_chunk = 0; std::atomic<int> queue[2]; std::vector<long long> swept;      // swept[rank]: sources the rank took, all passes
     int64_t xchg[4] = {0, 0, 0, 0};                               // rank 0's c2r_exchange_stats: calls, packed calls, bytes of the last call, bytes in all
     bool rotate = false;                                          // C2R_HARNESS_ROTATE_SUM=1: the host all-reduce sums element i starting at rank i mod nranks
     std::vector<unsigned long long> hash;                         // per rank: a hash of the bits of xh and phih_grid the step left (replicas must agree)
@@ -116,6 +119,22 @@ static int host_allgather(void *user, void *dev_buf, const size_t *off, const si
     return 0;
 }
 
+// the harness's source queue: first come, first served (what do_grid_master does with MPI_Send / MPI_Recv, master_slave.F90:124-230)
+struct QueueArg { Shared *sh; int rank; long long last_pass = -1; };
+static int next_sources(void *user, int64_t pass, int32_t want, int32_t *first, int32_t *count)
+{
+    QueueArg *q = static_cast<QueueArg *>(user);
+    Shared *sh = q->sh;
+    const int p = (int)(pass & 1);
+    if (q->last_pass != pass) { q->last_pass = pass; sh->queue[p ^ 1].store(0); }     // (nobody uses the other counter during this pass)
+    const int v = sh->queue[p].fetch_add(want);
+    const int n = sh->pb->nsrc;
+    if (v >= n) { *first = 0; *count = 0; return 0; }
+    *first = v; *count = std::min<int>(want, n - v);
+    sh->swept[q->rank] += *count;
+    return 0;
+}
+
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != 0) { sh->rc[rank] = rc_; sh->err[rank] = std::string(#expr) + ": " + (ctx ? c2r_last_error(ctx) : ""); goto done; } } while (0)
 
 static void *rank_main(void *p)
@@ -139,6 +158,7 @@ static void *rank_main(void *p)
         for (size_t i = 0; i < ncell; ++i) { xh[ncell + i] = pb.xh[i]; xh[i] = pb.xh0.empty() ? 1.0 - pb.xh[i] : pb.xh0[i]; }
     }
     c2r_report rep;
+    QueueArg qarg{sh, rank};
     {
         c2r_params prm;
         c2r_default_params(&prm);
@@ -172,6 +192,7 @@ static void *rank_main(void *p)
                 else TRY(c2r_set_slab_chemistry(ctx, host_reduce_scatter, host_allgather, a));
             }
         }
+        if (sh->queue_chunk > 0) TRY(c2r_set_source_queue(ctx, next_sources, &qarg, sh->queue_chunk));
         TRY(c2r_evolve3d(ctx, pb.dt, ndens.data(), xh.data(), xh_av.data(), xh_int.data(), phih.data(), &rep));
         {   // FNV-1a over the bits of the replicated results
             unsigned long long h = 1469598103934665603ULL;
@@ -216,6 +237,8 @@ int main(int argc, char **argv)
     sh.nranks = atoi(argv[3]); sh.rccl = strcmp(argv[4], "rccl") == 0; sh.balance = atoi(argv[5]) != 0; sh.pb = &pb;
     sh.slab = argc > 6 && atoi(argv[6]) != 0;
     if (const char *e = getenv("C2R_HARNESS_ROTATE_SUM")) sh.rotate = atoi(e) != 0;
+    if (const char *e = getenv("C2R_HARNESS_QUEUE")) sh.queue_chunk = atoi(e);
+    sh.queue[0].store(0); sh.queue[1].store(0); sh.swept.assign(sh.nranks, 0);
     sh.hash.assign(sh.nranks, 0ULL);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { fprintf(stderr, "no HIP device\n"); return 1; }
@@ -241,6 +264,7 @@ int main(int argc, char **argv)
     printf("ok: %d rank(s) on %d device(s), %s %s, balance %d: niter %d sum_nbox %lld\n", sh.nranks, ndev < sh.nranks ? ndev : sh.nranks,
            sh.rccl ? "rccl" : "host", sh.slab ? "reduce-scatter + slab chemistry + all-gather" : "all-reduce", (int)sh.balance, sh.rep0.niter,
            (long long)sh.rep0.sum_nbox_all);
+    if (sh.queue_chunk > 0) { printf("queue: chunk %d, sources taken per rank over all passes:", sh.queue_chunk); for (long long v : sh.swept) printf(" %lld", v); printf("\n"); }
     bool same = true;
     for (int r = 1; r < sh.nranks; ++r) same = same && sh.hash[r] == sh.hash[0];
     printf("replicas identical: %s\n", same ? "yes" : "NO");

@@ -290,3 +290,44 @@ def test_replayed_chains_and_gated_tail_in_a_non_isothermal_context(pkg, tables,
     assert np.max(np.abs(r[2] - a[2]) / a[2]) < 1e-5                    # f32 temperatures: a last-bit difference at most
     live = a[3] > 0
     assert np.array_equal(r[3] > 0, live) and np.max(np.abs(r[3][live] - a[3][live]) / a[3][live]) < 1e-12
+
+
+def test_sources_on_request_in_chunks_of_chains(pkg, tables, monkeypatch):
+    """c2r_set_source_queue on one rank with 200 sources handed out 70 at a time (rounds of 70 / 70 / 60: two chains, two chains,
+    one chain below 64): per-source sub-box counts, visited cells and the photon loss of the static pass, bit for bit; three passes,
+    every source taken once per pass."""
+    import ctypes as C
+    from c2ray3dm_amd import _capi
+    n, S = 64, 200
+    s, nd, xh, pos, nf = _case(pkg, n, S, 77)
+    monkeypatch.delenv("C2R_CHAINS", raising=False)
+    ref = _pass(pkg, tables, monkeypatch, None, n, s, nd, xh, pos, nf)
+    b = pkg.HipBackend(n, *tables, device=0)
+    b.set_step(s["dr1"], s["vol"], s["coldensh_LLS"], 1.0)
+    b.set_sources(pos, nf); b.set_rank(0, 1); b.load(ndens=nd, xh=xh); b.begin_step()
+    state = {"pass": None, "next": 0, "asked": []}
+
+    def nxt(user, pass_id, want, first, count):
+        if state["pass"] != pass_id:
+            state["pass"], state["next"] = pass_id, 0
+        k = min(want, S - state["next"])
+        first[0], count[0] = state["next"], max(0, k)
+        state["next"] += max(0, k)
+        state["asked"].append((int(pass_id), int(first[0]), int(count[0])))
+        return 0
+    b.set_source_queue(nxt, 70)
+    for _ in range(3):
+        b.zero_rates()
+        loss, nbox, vis = b.pass_sources()
+        assert loss == ref[0] and (nbox, vis) == ref[1:3] and np.array_equal(b.last_nbox(), ref[3])
+        assert np.array_equal(b.local_sources(), np.arange(S))
+        g = b.fetch("phih_grid"); live = ref[4] > 0
+        assert np.array_equal(g > 0, live) and np.max(np.abs(g[live] - ref[4][live]) / ref[4][live]) < 1e-13
+    per_pass = {}
+    for p_, f_, c_ in state["asked"]:
+        per_pass.setdefault(p_, []).append((f_, c_))
+    assert len(per_pass) == 3 and all(v[:3] == [(0, 70), (70, 70), (140, 60)] and len(v) == 4 and v[3][1] == 0 for v in per_pass.values()), per_pass
+    b.set_source_queue(None)                                                 # off again: the static rule
+    b.zero_rates()
+    assert b.pass_sources()[1:] == ref[1:3]
+    b.close()

@@ -220,3 +220,31 @@ def test_allfrac_ranks_slabs_and_packed_exchange(tmp_path, monkeypatch):
             assert np.array_equal(res[tag + "s"][k], res[tag][k]), (tag, k)
         # ... and against one rank: the partition changes only the association of the sums over ranks
         assert np.max(np.abs(res[tag]["xh"] - res["1"]["xh"])) < 1e-12 and np.max(np.abs(res[tag]["xh_neutral"] - res["1"]["xh_neutral"])) < 1e-12
+
+
+@pytest.mark.parametrize("chunk", ["1", "3", "64"])
+def test_sources_handed_out_on_request(tmp_path, chunk, monkeypatch):
+    """c2r_set_source_queue -- do_grid_master / do_grid_slave of master_slave.F90:124-330: every rank asks a first-come-first-served
+    queue (two atomics in the harness; MPI_Send / MPI_Recv with rank 0 in the reference) for `chunk` more sources whenever it has
+    swept what it had.  Whoever sweeps what: the step's iteration history, sub-box sums and photon loss are the reference's, xh
+    within tol("x"); against the static rule xh to the association of the sums over ranks; every source is taken exactly once per
+    pass (chunk 1 = the reference's one source per request; chunk 64 > the list: one rank takes everything)."""
+    assert os.path.exists(HARNESS)
+    m, a = load_case("evolve32_std_bubbles")
+    n, s = m["n"], m["steps"]["step001"]
+    write_input(str(tmp_path / "in.bin"), n, s, F(a["step001_ndens"]), F(a["step001_xh_before"]))
+    static = read_output(run(tmp_path, "static", 3, "host", 0), n)
+    monkeypatch.setenv("C2R_HARNESS_QUEUE", chunk)
+    for nranks in (1, 3, 4):
+        out = str(tmp_path / ("out_q%d.bin" % nranks))
+        p = subprocess.run([HARNESS, str(tmp_path / "in.bin"), out, str(nranks), "host", "0", "0"], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout + p.stderr
+        taken = [int(v) for v in [l for l in p.stdout.split("\n") if l.startswith("queue:")][0].split(":")[-1].split()]
+        r = read_output(out, n)
+        assert r["converged"] and r["niter"] == s["niter"] and r["conv"] == s["log"]["nonconv"], nranks
+        assert len(taken) == nranks and sum(taken) == len(s["normflux"]) * r["niter"], (taken, r["niter"])
+        assert r["sum_nbox"] == s["sum_nbox_all"]
+        assert abs(r["loss"] - s["photon_loss_all"]) <= tol("loss") * abs(s["photon_loss_all"]) + 1e-300
+        assert np.max(np.abs(r["xh"] - F(a["step001_xh_after"]))) < tol("x")
+        assert np.max(np.abs(r["xh"] - static["xh"])) < 1e-12
+        assert "replicas identical: yes" in p.stdout
