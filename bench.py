@@ -214,27 +214,36 @@ def timed_leg(pkg, torch, n, S, nd, xh, srcpos, normflux, step, tables, device, 
 
 
 def share_leg(pkg, torch, n, share, nd, xh, srcpos, normflux, step, tables, device, fast, options, eighth_ms):
-    """`share` (indices into the bench's source list: what ONE of eight GPUs sweeps) on its own context: four relaxing / warm-up
+    """`share` (indices into the bench's source list: what ONE of eight GPUs sweeps) on its own context: five relaxing / warm-up
     steps (the first pass is driven launch by launch, the second captures the chains' launch sequences), then ten steps timed one
-    by one -- the median, next to an eighth of the headline step."""
+    by one -- the median, next to an eighth of the headline step; and the same once more with the chains driven launch by launch
+    (option chain_graph = 0: a host round trip per sub-box and chain, the schedule of round 5) -- what the replay buys on THIS box."""
     thick, thin = tables
-    b = pkg.HipBackend(n, thick, thin, device=device, fast=fast, options=options)
-    b.set_step(step["dr1"], step["vol"], step["coldensh_LLS"], step["clumping"], step["temper"])
-    b.set_sources(srcpos[share], normflux[share])
-    b.load(ndens=nd, xh=xh)
-    ev = pkg.Evolve(b)
-    b.begin_step()
-    t_steps = []
-    for k in range(-5, 10):
-        torch.cuda.synchronize(); t4 = time.perf_counter()
-        ev.iteration(k, step["dt"])
-        torch.cuda.synchronize()
-        if k >= 0:
-            t_steps.append(1e3 * (time.perf_counter() - t4))
-    ms = float(np.median(t_steps))
-    out = {"sources": int(len(share)), "ms_per_step": ms, "ms_per_step_min_max": [min(t_steps), max(t_steps)], "eighth_of_headline_ms": eighth_ms,
-           "ratio": ms / eighth_ms, "schedule": b.info().split("; chains ")[1].split("; exchanges")[0], "sum_nbox_last_step": int(ev.sum_nbox_all)}
-    b.close()
+
+    def run(opts):
+        b = pkg.HipBackend(n, thick, thin, device=device, fast=fast, options=opts)
+        b.set_step(step["dr1"], step["vol"], step["coldensh_LLS"], step["clumping"], step["temper"])
+        b.set_sources(srcpos[share], normflux[share])
+        b.load(ndens=nd, xh=xh)
+        ev = pkg.Evolve(b)
+        b.begin_step()
+        t_steps = []
+        for k in range(-5, 10):
+            torch.cuda.synchronize(); t4 = time.perf_counter()
+            ev.iteration(k, step["dt"])
+            torch.cuda.synchronize()
+            if k >= 0:
+                t_steps.append(1e3 * (time.perf_counter() - t4))
+        r = (float(np.median(t_steps)), [min(t_steps), max(t_steps)], b.info().split("; chains ")[1].split("; exchanges")[0], int(ev.sum_nbox_all))
+        b.close()
+        return r
+    ms, mm, sched, nbox = run(options)
+    out = {"sources": int(len(share)), "ms_per_step": ms, "ms_per_step_min_max": mm, "eighth_of_headline_ms": eighth_ms,
+           "ratio": ms / eighth_ms, "schedule": sched, "sum_nbox_last_step": nbox}
+    if "chain_graph" not in options:
+        ms0, mm0, sched0, nbox0 = run(dict(options, chain_graph=0.0))
+        out["launch_by_launch"] = {"ms_per_step": ms0, "ms_per_step_min_max": mm0, "ratio": ms0 / eighth_ms, "schedule": sched0,
+                                   "sum_nbox_last_step": nbox0}
     return out
 
 
